@@ -1,0 +1,143 @@
+"""ctypes loader for oracle/_build/liboracle.so (built by oracle/Makefile).
+
+The functions mirror the reference kernels' argument lists (reference grid_eval.cl:2-4,
+23-25; subdivision.cl:12-16; mass_properties.cl:7-12) with numpy arrays for buffers.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+_lib = None
+
+__all__ = ["build", "lib", "evaluate_points", "grid_eval", "grid_eval_pymcubes",
+           "subdivision_step", "mass_properties", "det_math"]
+
+_f32p = ctypes.POINTER(ctypes.c_float)
+_u32p = ctypes.POINTER(ctypes.c_uint32)
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+
+
+def build(force=False):
+    """Compile the oracle with gcc (a few seconds).  Building the checker is not using it."""
+    src = [os.path.join(_HERE, f) for f in ("sdf_oracle.c", "det_math.h", "Makefile")]
+    if (not force and os.path.exists(_LIB_PATH)
+            and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in src)):
+        return _LIB_PATH
+    subprocess.run(["make", "-C", _HERE, "-B"], check=True, capture_output=True)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+        for name in ("oracle_evaluate_points", "oracle_grid_eval", "oracle_grid_eval_pymcubes",
+                     "oracle_subdivision_step", "oracle_mass_properties", "oracle_det_math"):
+            getattr(_lib, name).restype = ctypes.c_int
+    return _lib
+
+
+def _tape(tape):
+    t = np.ascontiguousarray(tape, dtype=np.float32)
+    return t, t.ctypes.data_as(_f32p), ctypes.c_int(t.size)
+
+
+def _corner(corner):
+    c = np.zeros(4, dtype=np.float32)
+    c[:3] = np.asarray(corner, dtype=np.float32).reshape(-1)[:3]
+    return c
+
+
+def _dims(dims):
+    d = np.ones(3, dtype=np.uint32)
+    dims = tuple(int(x) for x in dims)
+    d[:len(dims)] = dims
+    return d
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError("oracle %s failed with code %d (malformed tape?)" % (what, rc))
+
+
+def evaluate_points(tape, points):
+    """evaluate() at each row of `points` (n,3) -> (n,4) float32 (nx, ny, nz, distance)."""
+    t, tp, tn = _tape(tape)
+    pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
+    out = np.empty((pts.shape[0], 4), dtype=np.float32)
+    _check(lib().oracle_evaluate_points(tp, tn, pts.ctypes.data_as(_f32p),
+                                        ctypes.c_int(pts.shape[0]),
+                                        out.ctypes.data_as(_f32p)), "evaluate_points")
+    return out
+
+
+def grid_eval(tape, corner, step, dims, threads=1):
+    """Reference kernel grid_eval: float4 per voxel, shape dims+(4,), index z + sz*(y + sy*x)."""
+    t, tp, tn = _tape(tape)
+    c, d = _corner(corner), _dims(dims)
+    out = np.empty(tuple(int(x) for x in d) + (4,), dtype=np.float32)
+    _check(lib().oracle_grid_eval(tp, tn, c.ctypes.data_as(_f32p), ctypes.c_float(step),
+                                  d.ctypes.data_as(_u32p), out.ctypes.data_as(_f32p),
+                                  ctypes.c_int(threads)), "grid_eval")
+    return out
+
+
+def grid_eval_pymcubes(tape, corner, step, dims, threads=1):
+    """Reference kernel grid_eval_pymcubes: flat float array, index z + (x + (sy-1-y)*sx)*sz."""
+    t, tp, tn = _tape(tape)
+    c, d = _corner(corner), _dims(dims)
+    out = np.empty(int(d[0]) * int(d[1]) * int(d[2]), dtype=np.float32)
+    _check(lib().oracle_grid_eval_pymcubes(tp, tn, c.ctypes.data_as(_f32p), ctypes.c_float(step),
+                                           d.ctypes.data_as(_u32p), out.ctypes.data_as(_f32p),
+                                           ctypes.c_int(threads)), "grid_eval_pymcubes")
+    return out
+
+
+def subdivision_step(tape, corner, step, thr, dims):
+    """Reference kernel subdivision_step -> (count, uchar4 list[:count]) in gid order."""
+    t, tp, tn = _tape(tape)
+    c, d = _corner(corner), _dims(dims)
+    n = int(d[0]) * int(d[1]) * int(d[2])
+    counter = np.zeros(1, dtype=np.uint32)
+    lst = np.zeros((n, 4), dtype=np.uint8)
+    _check(lib().oracle_subdivision_step(tp, tn, c.ctypes.data_as(_f32p), ctypes.c_float(step),
+                                         ctypes.c_float(thr), d.ctypes.data_as(_u32p),
+                                         counter.ctypes.data_as(_u32p),
+                                         lst.ctypes.data_as(_u8p)), "subdivision_step")
+    return int(counter[0]), lst[:int(counter[0])]
+
+
+def mass_properties(tape, corner, step, thr, dims):
+    """Reference kernel mass_properties -> (sum[10] uint32, count, uchar4 list[:count])."""
+    t, tp, tn = _tape(tape)
+    c, d = _corner(corner), _dims(dims)
+    n = int(d[0]) * int(d[1]) * int(d[2])
+    sums = np.zeros(10, dtype=np.uint32)
+    counter = np.zeros(1, dtype=np.uint32)
+    lst = np.zeros((n, 4), dtype=np.uint8)
+    _check(lib().oracle_mass_properties(tp, tn, c.ctypes.data_as(_f32p), ctypes.c_float(step),
+                                        ctypes.c_float(thr), d.ctypes.data_as(_u32p),
+                                        sums.ctypes.data_as(_u32p),
+                                        counter.ctypes.data_as(_u32p),
+                                        lst.ctypes.data_as(_u8p)), "mass_properties")
+    return sums, int(counter[0]), lst[:int(counter[0])]
+
+
+_DET_OPS = {"atan2": 0, "sincos": 1, "tan": 2, "acos": 3, "fmod": 4, "remainder": 5, "hypot": 6}
+
+
+def det_math(op, a, b=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(a if b is None else b, dtype=np.float32)
+    out = np.empty_like(a)
+    out2 = np.empty_like(a)
+    _check(lib().oracle_det_math(ctypes.c_int(_DET_OPS[op]), a.ctypes.data_as(_f32p),
+                                 b.ctypes.data_as(_f32p), ctypes.c_int(a.size),
+                                 out.ctypes.data_as(_f32p), out2.ctypes.data_as(_f32p)), "det_math")
+    return (out, out2) if op == "sincos" else out

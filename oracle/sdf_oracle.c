@@ -1,0 +1,558 @@
+/* oracle/sdf_oracle.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C CPU restatement of the reference's hot path (bluecube/codecad): the tape
+ * interpreter evaluate(), the 26 *_op device functions and the four kernels around
+ * them.  Every function cites the reference file:line it follows (paths relative to
+ * /root/reference/codecad/).  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this library; the product (codecad_amd/) never does.
+ *
+ * Pinning: the reference's OpenCL device code cannot be built in this image (it needs
+ * an OpenCL runtime + its builtin library, both absent; we do not fake them), so this
+ * restatement is pinned by the reference's OWN tests and fixtures restated in tests/:
+ * analytic mass properties (reference tests/test_mass_properties.py:16-108), leaf-block
+ * known answers (tests/test_subdivision.py:110-161), DSDF validity properties
+ * (tests/test_dsdf.py:113-190), and by golden tapes / block tables produced by the
+ * reference's pure-Python half (tests/golden/gen/make_golden.py).
+ *
+ * Canonical arithmetic (DESIGN.md section "Canonical arithmetic"): IEEE-754 binary32,
+ * round-to-nearest-even, no implicit contraction (-ffp-contract=off), explicit fmaf()
+ * exactly where written, IEEE sqrt and divide, elementary functions from det_math.h.
+ * The reference is compiled with -cl-fast-relaxed-math (cl_util/opencl_manager.py:
+ * 12-18), which permits exactly these liberties (fused multiply-add, x/u -> x*(1/u)
+ * for a tape-constant u); the HIP kernels perform the same operation sequence.
+ */
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "det_math.h"
+
+#define EVAL_REGISTER_COUNT 512 /* nodes/__init__.py:6 */
+
+typedef struct { float x, y, z, w; } f4;
+
+static inline f4 mk4(float x, float y, float z, float w) { f4 r = { x, y, z, w }; return r; }
+static inline f4 neg4(f4 a) { return mk4(-a.x, -a.y, -a.z, -a.w); }
+static inline float dot3(f4 a, f4 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+static inline float dot2(float ax, float ay, float bx, float by) { return fmaf(ay, by, ax * bx); }
+
+/* shapes/common.cl:1-6 quaternion_transform:
+ *   (v*dot(v,p) + cross(v,p)*w)*2 + p*(w*w - dot(v,v)) */
+static inline f4 quaternion_transform(f4 q, f4 p)
+{
+    float d = dot3(q, p);
+    float cx = fmaf(q.y, p.z, -(q.z * p.y));
+    float cy = fmaf(q.z, p.x, -(q.x * p.z));
+    float cz = fmaf(q.x, p.y, -(q.y * p.x));
+    float k = fmaf(q.w, q.w, -dot3(q, q));
+    float tx = fmaf(cx, q.w, q.x * d);
+    float ty = fmaf(cy, q.w, q.y * d);
+    float tz = fmaf(cz, q.w, q.z * d);
+    return mk4(fmaf(p.x, k, tx + tx), fmaf(p.y, k, ty + ty), fmaf(p.z, k, tz + tz), 0.0f);
+}
+
+/* shapes/common.cl:8-11 */
+static inline float quaternion_scale(f4 q)
+{
+    return fmaf(q.w, q.w, fmaf(q.z, q.z, fmaf(q.y, q.y, q.x * q.x)));
+}
+
+/* shapes/common.cl:15-31 perpendicular_intersection */
+static inline f4 perpendicular_intersection(f4 a, f4 b)
+{
+    if (a.w > 0.0f && b.w > 0.0f) {
+        float dist = dm_hypot(a.w, b.w);
+        float inv = 1.0f / dist;
+        float m1 = a.w * inv;
+        float m2 = b.w * inv;
+        return mk4(fmaf(b.x, m2, a.x * m1), fmaf(b.y, m2, a.y * m1), fmaf(b.z, m2, a.z * m1), dist);
+    } else if (a.w > b.w) {
+        return a;
+    } else {
+        return b;
+    }
+}
+
+/* shapes/common.cl:33-43 */
+static inline f4 slab_x(float h, f4 p) { return mk4(copysignf(1.0f, p.x), 0, 0, fabsf(p.x) - h); }
+static inline f4 slab_y(float h, f4 p) { return mk4(0, copysignf(1.0f, p.y), 0, fabsf(p.y) - h); }
+static inline f4 slab_z(float h, f4 p) { return mk4(0, 0, copysignf(1.0f, p.z), fabsf(p.z) - h); }
+
+/* shapes/common.cl:45-64 rounded_union */
+static inline f4 rounded_union(float r, f4 a, f4 b)
+{
+    if (r >= 0.0f) {
+        float cos_alpha = dot3(a, b);
+        float x1 = r - a.w;
+        float x2 = r - b.w;
+        if (cos_alpha * x1 < x2 && cos_alpha * x2 < x1) {
+            float num = fmaf(-((2.0f * cos_alpha) * x1), x2, fmaf(x2, x2, x1 * x1));
+            float den = fmaf(-cos_alpha, cos_alpha, 1.0f);
+            float d = r - sqrtf(num / den);
+            return mk4(0, 0, 0, d);
+        }
+    }
+    return (a.w < b.w) ? a : b;
+}
+
+/* shapes/common.cl:66-76 */
+static inline f4 union_op(float r, f4 a, f4 b) { return rounded_union(r, a, b); }
+static inline f4 intersection_op(float r, f4 a, f4 b) { return neg4(rounded_union(r, neg4(a), neg4(b))); }
+static inline f4 subtraction_op(float r, f4 a, f4 b) { return neg4(rounded_union(r, neg4(a), b)); }
+
+/* shapes/common.cl:78-98 (initial_)transformation_to_op */
+static inline f4 transformation_to_op(const float *p, f4 point)
+{
+    f4 q = mk4(p[0], p[1], p[2], p[3]);
+    f4 t = quaternion_transform(q, point);
+    return mk4(t.x + p[4], t.y + p[5], t.z + p[6], 0.0f);
+}
+
+/* shapes/common.cl:100-110 transformation_from_op */
+static inline f4 transformation_from_op(const float *p, f4 in)
+{
+    f4 q = mk4(p[0], p[1], p[2], p[3]);
+    float scale = quaternion_scale(q);
+    float inv = 1.0f / scale;
+    f4 t = quaternion_transform(q, in);
+    return mk4(t.x * inv, t.y * inv, t.z * inv, in.w * scale);
+}
+
+/* shapes/common.cl:112-131 */
+static inline f4 mirror_op(f4 in) { return mk4(-in.x, in.y, in.z, in.w); }
+static inline f4 symmetrical_to_op(f4 p) { return mk4(fabsf(p.x), p.y, p.z, p.w); }
+static inline f4 symmetrical_from_op(f4 in, f4 point)
+{
+    return mk4(point.x < 0.0f ? -in.x : in.x, in.y, in.z, in.w);
+}
+static inline f4 offset_op(float d, f4 in) { return mk4(in.x, in.y, in.z, in.w - d); }
+static inline f4 shell_op(float h, f4 in)
+{
+    f4 s = (in.w >= 0.0f) ? in : neg4(in);
+    return offset_op(h, s);
+}
+
+/* shapes/simple2d.cl:1-4 */
+static inline f4 rectangle_op(float hw, float hh, f4 c)
+{
+    return perpendicular_intersection(slab_x(hw, c), slab_y(hh, c));
+}
+
+/* shapes/simple2d.cl:6-14 */
+static inline f4 circle_op(float r, f4 c)
+{
+    float a = dm_length2(c.x, c.y);
+    float fx, fy;
+    if (a == 0.0f) {
+        fx = 1.0f; fy = 0.0f;
+    } else {
+        float inv = 1.0f / a;
+        fx = c.x * inv; fy = c.y * inv;
+    }
+    return mk4(fx, fy, 0.0f, a - r);
+}
+
+static inline float sign_f(float s) { return (s > 0.0f) ? 1.0f : ((s < 0.0f) ? -1.0f : 0.0f); }
+
+/* the "which sector" prologue shared by simple2d.cl:18-20 and unsafe.cl:10-12,18-19 */
+static inline float sector_alpha(float y, float x, float pi_over_n)
+{
+    return (dm_atan2(y, x) + 2.0f * DM_PI_F) + pi_over_n;
+}
+
+/* shapes/simple2d.cl:16-46 */
+static inline f4 regular_polygon2d_op(float pi_over_n, float r, f4 c)
+{
+    float len = dm_hypot(c.x, c.y);
+    float alpha = sector_alpha(c.y, c.x, pi_over_n);
+    int side = (int)floorf(alpha / (2.0f * pi_over_n));
+    float side2 = (float)(side * 2);
+    float mod_alpha = (alpha - side2 * pi_over_n) - pi_over_n;
+    float s, co;
+    dm_sincos(mod_alpha, &s, &co);
+    if (fabsf(s * len) > r * dm_sin(pi_over_n)) {
+        float ny, nx;
+        dm_sincos(fmaf(sign_f(s), pi_over_n, side2 * pi_over_n), &ny, &nx);
+        nx = nx * r; ny = ny * r;
+        float dx = c.x - nx, dy = c.y - ny;
+        float dist = dm_length2(dx, dy);
+        if (dist > 0.0f) {
+            float inv = 1.0f / dist;
+            return mk4(dx * inv, dy * inv, 0.0f, dist);
+        }
+    }
+    float dy, dx;
+    dm_sincos(side2 * pi_over_n, &dy, &dx);
+    return mk4(dx, dy, 0.0f, fmaf(len, co, -(r * dm_cos(pi_over_n))));
+}
+
+/* shapes/polygons2d.cl:1-74; *pp points at [n, x0,y0, ...] and is advanced past it */
+static inline f4 polygon2d_op(const float **pp, f4 coords)
+{
+    const float *params = *pp;
+    uint32_t n = (uint32_t)params[0];
+    const float *pts = params + 1;
+    float qx = coords.x, qy = coords.y;
+    float nnx = 0.0f, nny = 0.0f;
+    float nearest_d2 = INFINITY;
+    int nearest_is_vertex = 0;
+    float outside = 1.0f;
+    float cx = pts[2 * (n - 1)], cy = pts[2 * (n - 1) + 1];
+    for (uint32_t i = 0; i < n; ++i) {
+        float px = cx, py = cy;
+        cx = pts[2 * i]; cy = pts[2 * i + 1];
+        float dx = cx - px, dy = cy - py;
+        float tqx = qx - px, tqy = qy - py;
+        float snx = -dy, sny = dx;
+        if (((py < qy) != (cy < qy)) && (dy * dot2(snx, sny, tqx, tqy) > 0.0f))
+            outside = -outside;
+        float t = dot2(dx, dy, tqx, tqy) / dot2(dx, dy, dx, dy);
+        if (t > 1.0f)
+            continue;
+        float cnx, cny, cd2;
+        int cvert;
+        if (t >= 0.0f) {
+            float tcx = fmaf(-t, dx, tqx), tcy = fmaf(-t, dy, tqy);
+            cd2 = dot2(tcx, tcy, tcx, tcy);
+            cnx = snx; cny = sny;
+            cvert = 0;
+        } else {
+            cnx = tqx; cny = tqy;
+            cd2 = dot2(cnx, cny, cnx, cny);
+            cvert = cd2 > FLT_EPSILON;
+            if (!cvert) { cnx = snx; cny = sny; }
+        }
+        if (cd2 < nearest_d2) {
+            nearest_d2 = cd2; nnx = cnx; nny = cny; nearest_is_vertex = cvert;
+        }
+    }
+    float distance = outside * sqrtf(nearest_d2);
+    float inv;
+    if (nearest_is_vertex)
+        inv = 1.0f / distance;
+    else
+        inv = 1.0f / dm_length2(nnx, nny);
+    *pp = pts + 2 * n;
+    return mk4(nnx * inv, nny * inv, 0.0f, distance);
+}
+
+/* shapes/simple3d.cl:1-12 */
+static inline f4 sphere_op(float r, f4 c)
+{
+    float a = dm_length3(c.x, c.y, c.z);
+    float dist = a - r;
+    if (a == 0.0f)
+        return mk4(1, 0, 0, dist);
+    float inv = 1.0f / a;
+    return mk4(c.x * inv, c.y * inv, c.z * inv, dist);
+}
+
+/* shapes/simple3d.cl:14-16 */
+static inline f4 half_space_op(f4 c) { return mk4(0, -1, 0, -c.y); }
+
+/* shapes/simple3d.cl:18-21 */
+static inline f4 extrusion_op(float hh, f4 in, f4 coords)
+{
+    return perpendicular_intersection(slab_z(hh, coords), in);
+}
+
+/* shapes/simple3d.cl:23-26 */
+static inline f4 revolution_to_op(f4 c) { return mk4(dm_hypot(c.x, c.z), c.y, 0, 0); }
+
+/* shapes/simple3d.cl:28-39 */
+static inline f4 revolution_from_op(f4 flat, f4 coords)
+{
+    float len = dm_hypot(coords.x, coords.z);
+    float m;
+    if (len == 0.0f) { coords.x = 1.0f; m = flat.x; }
+    else m = flat.x / len;
+    return mk4(coords.x * m, flat.y, coords.z * m, flat.w);
+}
+
+/* cl_util/util.cl:11-15 rotated2d with (c, s) already known */
+static inline void rot2(float c, float s, float px, float py, float *ox, float *oy)
+{
+    *ox = fmaf(c, px, -(s * py));
+    *oy = fmaf(s, px, c * py);
+}
+
+/* shapes/simple3d.cl:42-51 */
+static inline f4 twist_revolution_to_op(float r, float twist, f4 c)
+{
+    float alpha = dm_fmod(dm_atan2(c.z, c.x) + DM_PI_F, DM_2PI_F);
+    float beta = (twist * alpha) / DM_2PI_F;
+    float axis = dm_length2(c.x, c.z);
+    float s, co, ox, oy;
+    dm_sincos(-beta, &s, &co);
+    rot2(co, s, axis - r, c.y, &ox, &oy);
+    return mk4(ox, oy, 0, 0);
+}
+
+/* shapes/simple3d.cl:53-97 */
+static inline f4 twist_revolution_from_op(float minor_r, float r, float twist, f4 res, f4 c)
+{
+    float axis = dm_length2(c.x, c.z);
+    float ipx = axis - r, ipy = c.y;
+    float center = dm_length2(ipx, ipy);
+    float wrapper = center - minor_r;
+    float padding = 0.05f * r;
+    float bound, dx, dy;
+    if (axis == 0.0f)
+        return mk4(1, 0, 0, r - minor_r);
+    else if (wrapper > padding) {
+        bound = wrapper;
+        float inv = 1.0f / center;
+        dx = ipx * inv; dy = ipy * inv;
+    } else {
+        float alpha = dm_fmod(dm_atan2(c.z, c.x) + DM_PI_F, DM_2PI_F);
+        float beta = (twist * alpha) / DM_2PI_F;
+        float lip = (((r - minor_r) * 2.0f) *
+                     dm_sin(fminf(DM_PI_F, (DM_PI_2_F * DM_PI_2_F) / fabsf(twist)))) / minor_r;
+        bound = res.w * fminf(1.0f, lip);
+        float s, co;
+        dm_sincos(beta, &s, &co);
+        rot2(co, s, res.x, res.y, &dx, &dy);
+    }
+    float m = dx / axis;
+    return mk4(c.x * m, dy, c.z * m, bound);
+}
+
+/* shapes/unsafe.cl:1-6; the tape carries (ox, oy, oz); the reciprocals are rounded once */
+static inline f4 repetition_op(float ox, float oy, float oz, f4 c)
+{
+    return mk4(dm_remainder_inv(c.x, ox, 1.0f / ox), dm_remainder_inv(c.y, oy, 1.0f / oy),
+               dm_remainder_inv(c.z, oz, 1.0f / oz), 0.0f);
+}
+
+/* shapes/unsafe.cl:8-15 */
+static inline f4 circular_repetition_to_op(float pi_over_n, f4 c)
+{
+    float len = dm_length2(c.x, c.y);
+    float alpha = sector_alpha(c.y, c.x, pi_over_n);
+    int side = (int)floorf(alpha / (2.0f * pi_over_n));
+    float mod_alpha = (alpha - (float)(side * 2) * pi_over_n) - pi_over_n;
+    float s, co;
+    dm_sincos(mod_alpha, &s, &co);
+    return mk4(len * co, len * s, c.z, 0.0f);
+}
+
+/* shapes/unsafe.cl:17-23 */
+static inline f4 circular_repetition_from_op(float pi_over_n, f4 dist, f4 c)
+{
+    float alpha = sector_alpha(c.y, c.x, pi_over_n);
+    int side = (int)floorf(alpha / (2.0f * pi_over_n));
+    float s, co, ox, oy;
+    dm_sincos((float)(side * 2) * pi_over_n, &s, &co);
+    rot2(co, s, dist.x, dist.y, &ox, &oy);
+    return mk4(ox, oy, dist.z, dist.w);
+}
+
+/* shapes/gears.cl:1-42 */
+static inline f4 involute_gear_op(float tooth_count, float pressure_angle, f4 c)
+{
+    float base_radius = dm_cos(pressure_angle);
+    float tooth_angle = DM_PI_F / tooth_count;
+    float half_tooth_base = (tooth_angle / 2.0f + dm_tan(pressure_angle)) - pressure_angle;
+    float len = dm_hypot(c.x, c.y);
+    float alpha = dm_atan2(c.y, c.x);
+    float wrapped = dm_fmod(alpha + 2.0f * DM_PI_F, 2.0f * tooth_angle);
+    float involute_alpha = half_tooth_base - fabsf(wrapped - tooth_angle);
+    if (len < base_radius) {
+        float nx = c.y / len, ny = -c.x / len;
+        if (wrapped > tooth_angle) { nx = -nx; ny = -ny; }
+        float angular = fabsf(wrapped - tooth_angle) - half_tooth_base;
+        return mk4(nx, ny, 0.0f, angular * len);
+    } else {
+        float phi = involute_alpha + dm_acos(base_radius / len);
+        float normal_angle;
+        if (wrapped < tooth_angle)
+            normal_angle = (DM_PI_F - phi) - (alpha - involute_alpha);
+        else
+            normal_angle = phi - (alpha - involute_alpha);
+        float nx, ny;
+        dm_sincos(normal_angle, &nx, &ny); /* normal = (sin, cos), gears.cl:33-36 */
+        float distance = sqrtf(fmaf(len, len, -(base_radius * base_radius))) - base_radius * phi;
+        return mk4(nx, ny, 0.0f, distance);
+    }
+}
+
+/* The interpreter generated by nodes/codegen.py:5-63 (handlers :91-134), opcode table
+ * nodes/node.py:12-56.  Returns 0 on success, <0 on a malformed tape. */
+static int evaluate(const float *program, const float *end, f4 point, f4 *result)
+{
+    f4 registers[EVAL_REGISTER_COUNT];
+    f4 last = mk4(0, 0, 0, 0);
+    f4 pt = mk4(point.x, point.y, point.z, 0.0f);
+    while (program < end) {
+        uint32_t instruction = (uint32_t)(*program++);
+        uint32_t opcode = instruction / EVAL_REGISTER_COUNT;
+        uint32_t reg = instruction % EVAL_REGISTER_COUNT;
+        const float *p = program;
+        switch (opcode) {
+        case 0: *result = last; return 0;                                   /* _return */
+        case 1: registers[reg] = last; break;                               /* _store */
+        case 2: last = registers[reg]; break;                               /* _load */
+        case 3: last = rectangle_op(p[0], p[1], last); program += 2; break;
+        case 4: last = circle_op(p[0], last); program += 1; break;
+        case 5: last = regular_polygon2d_op(p[0], p[1], last); program += 2; break;
+        case 6: last = polygon2d_op(&program, last); break;
+        case 7: last = sphere_op(p[0], last); program += 1; break;
+        case 8: last = half_space_op(last); break;
+        case 9: last = revolution_to_op(last); break;
+        case 10: last = twist_revolution_to_op(p[0], p[1], last); program += 2; break;
+        case 11: last = transformation_to_op(p, pt); program += 7; break;    /* initial_: arity 0 reads `point` */
+        case 12: last = transformation_to_op(p, last); program += 7; break;
+        case 13: last = transformation_from_op(p, last); program += 4; break;
+        case 14: last = mirror_op(last); break;
+        case 15: last = symmetrical_to_op(last); break;
+        case 16: last = offset_op(p[0], last); program += 1; break;
+        case 17: last = shell_op(p[0], last); program += 1; break;
+        case 18: last = repetition_op(p[0], p[1], p[2], last); program += 3; break;
+        case 19: last = circular_repetition_to_op(p[0], last); program += 1; break;
+        case 20: last = circular_repetition_from_op(p[0], last, registers[reg]); program += 1; break;
+        case 21: last = involute_gear_op(p[0], p[1], last); program += 2; break;
+        case 22: last = extrusion_op(p[0], last, registers[reg]); program += 1; break;
+        case 23: last = revolution_from_op(last, registers[reg]); break;
+        case 24: last = twist_revolution_from_op(p[0], p[1], p[2], last, registers[reg]); program += 3; break;
+        case 25: last = symmetrical_from_op(last, registers[reg]); break;
+        case 26: last = union_op(p[0], last, registers[reg]); program += 1; break;
+        case 27: last = intersection_op(p[0], last, registers[reg]); program += 1; break;
+        case 28: last = subtraction_op(p[0], last, registers[reg]); program += 1; break;
+        default: return -1;
+        }
+    }
+    return -2; /* ran off the end without _return */
+}
+
+/* ------------------------------------------------------------------------------------
+ * Exported entry points (ctypes).  `dims` = OpenCL global size (gx, gy, gz).
+ * Sample position: point = corner + step * (float)gid, mul then add, not fused
+ * (grid_eval.cl:31, subdivision.cl:22, mass_properties.cl:25-27; SURVEY.md note 5).
+ * ---------------------------------------------------------------------------------- */
+static inline f4 sample_point(const float *corner, float step, uint32_t x, uint32_t y, uint32_t z)
+{
+    return mk4(corner[0] + step * (float)x, corner[1] + step * (float)y,
+               corner[2] + step * (float)z, 0.0f);
+}
+
+int oracle_evaluate_points(const float *tape, int n_tape, const float *pts, int n, float *out)
+{
+    for (int i = 0; i < n; ++i) {
+        f4 r;
+        int rc = evaluate(tape, tape + n_tape, mk4(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], 0), &r);
+        if (rc) return rc;
+        out[4 * i] = r.x; out[4 * i + 1] = r.y; out[4 * i + 2] = r.z; out[4 * i + 3] = r.w;
+    }
+    return 0;
+}
+
+/* grid_eval.cl:23-34; output index INDEX3 = z + sz*(y + sy*x) (cl_util/indexing.h:4).
+ * `threads` > 1 splits the x axis with OpenMP (CPU-baseline timing only). */
+int oracle_grid_eval(const float *tape, int n_tape, const float *corner, float step,
+                     const uint32_t *dims, float *out, int threads)
+{
+    int err = 0;
+    uint32_t sx = dims[0], sy = dims[1], sz = dims[2];
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(dynamic, 1)
+    for (uint32_t x = 0; x < sx; ++x)
+        for (uint32_t y = 0; y < sy; ++y)
+            for (uint32_t z = 0; z < sz; ++z) {
+                f4 r;
+                int rc = evaluate(tape, tape + n_tape, sample_point(corner, step, x, y, z), &r);
+                if (rc) { err = rc; continue; }
+                size_t idx = (size_t)z + (size_t)sz * ((size_t)y + (size_t)sy * x);
+                out[4 * idx] = r.x; out[4 * idx + 1] = r.y; out[4 * idx + 2] = r.z; out[4 * idx + 3] = r.w;
+            }
+    return err;
+}
+
+/* grid_eval.cl:2-21; index = z + (x + (sy-1-y)*sx)*sz */
+int oracle_grid_eval_pymcubes(const float *tape, int n_tape, const float *corner, float step,
+                              const uint32_t *dims, float *out, int threads)
+{
+    int err = 0;
+    uint32_t sx = dims[0], sy = dims[1], sz = dims[2];
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(dynamic, 1)
+    for (uint32_t x = 0; x < sx; ++x)
+        for (uint32_t y = 0; y < sy; ++y)
+            for (uint32_t z = 0; z < sz; ++z) {
+                f4 r;
+                int rc = evaluate(tape, tape + n_tape, sample_point(corner, step, x, y, z), &r);
+                if (rc) { err = rc; continue; }
+                size_t idx = (size_t)z + ((size_t)x + (size_t)(sy - y - 1) * sx) * sz;
+                out[idx] = r.w;
+            }
+    return err;
+}
+
+/* subdivision.cl:12-30.  The reference appends with a global atomic (order
+ * nondeterministic); the oracle appends in gid order x-major.  list = uchar4. */
+int oracle_subdivision_step(const float *tape, int n_tape, const float *corner, float step,
+                            float thr, const uint32_t *dims, uint32_t *counter, uint8_t *list)
+{
+    uint32_t n = 0;
+    for (uint32_t x = 0; x < dims[0]; ++x)
+        for (uint32_t y = 0; y < dims[1]; ++y)
+            for (uint32_t z = 0; z < dims[2]; ++z) {
+                f4 r;
+                int rc = evaluate(tape, tape + n_tape, sample_point(corner, step, x, y, z), &r);
+                if (rc) return rc;
+                if (r.w > -thr && r.w < thr) {
+                    list[4 * n] = (uint8_t)x; list[4 * n + 1] = (uint8_t)y;
+                    list[4 * n + 2] = (uint8_t)z; list[4 * n + 3] = 0;
+                    ++n;
+                }
+            }
+    *counter = n;
+    return 0;
+}
+
+/* mass_properties.cl:7-56.  sum[10] order xx,xy,xz,x,yy,yz,y,zz,z,n
+ * (mass_properties.py:125-127), uint32 wrap-around arithmetic like the device. */
+int oracle_mass_properties(const float *tape, int n_tape, const float *corner, float step,
+                           float thr, const uint32_t *dims, uint32_t *sum, uint32_t *counter,
+                           uint8_t *list)
+{
+    uint32_t n = 0;
+    for (int i = 0; i < 10; ++i) sum[i] = 0;
+    for (uint32_t x = 0; x < dims[0]; ++x)
+        for (uint32_t y = 0; y < dims[1]; ++y)
+            for (uint32_t z = 0; z < dims[2]; ++z) {
+                f4 r;
+                int rc = evaluate(tape, tape + n_tape, sample_point(corner, step, x, y, z), &r);
+                if (rc) return rc;
+                if (r.w <= -thr) {
+                    uint32_t c[4] = { x, y, z, 1 };
+                    int i = 0;
+                    for (int j = 0; j < 4; ++j)
+                        for (int k = j; k < 4; ++k)
+                            sum[i++] += c[j] * c[k];
+                } else if (r.w < thr) {
+                    list[4 * n] = (uint8_t)x; list[4 * n + 1] = (uint8_t)y;
+                    list[4 * n + 2] = (uint8_t)z; list[4 * n + 3] = 0;
+                    ++n;
+                }
+            }
+    *counter = n;
+    return 0;
+}
+
+/* det_math probes for tests/test_oracle_math.py: op selects the function. */
+int oracle_det_math(int op, const float *a, const float *b, int n, float *out, float *out2)
+{
+    for (int i = 0; i < n; ++i) {
+        switch (op) {
+        case 0: out[i] = dm_atan2(a[i], b[i]); break;
+        case 1: dm_sincos(a[i], &out[i], &out2[i]); break;
+        case 2: out[i] = dm_tan(a[i]); break;
+        case 3: out[i] = dm_acos(a[i]); break;
+        case 4: out[i] = dm_fmod(a[i], b[i]); break;
+        case 5: out[i] = dm_remainder_inv(a[i], b[i], 1.0f / b[i]); break;
+        case 6: out[i] = dm_hypot(a[i], b[i]); break;
+        default: return -1;
+        }
+    }
+    return 0;
+}
