@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""bench.py -- SDF Mvoxels/s (grid_eval + subdivision) on the 512^3 Menger sponge.
+
+One "step" is one pass of the hot path over one batch of synthetic input (no RNG: the only
+input is the CSG tree), per GPU:
+  A. dense grid_eval (float4) of sponge(4) on the 512^3 cell-centred grid          [k_grid_eval<0>]
+  B. adaptive subdivision of sponge(4) at resolution 1/512, grid 16, overlapping
+     leaf samples: levels [(240,3^3),(15,16^3),(1,16^3)], survivors compacted by the
+     wavefront ballot scan                                                      [k_classify<0,1>]
+  C. grid_eval of ALL surviving 16^3 leaf blocks in one launch (float, PyMCubes layout,
+     what the reference's mesh pipeline does block by block)                [k_grid_eval_blocks<1>]
+`value` counts SDF samples actually evaluated (A + B + C) per second over all ranks; nothing
+is cached between steps and the output buffers are rewritten every step.
+
+N > 1 (torchrun, one rank per GPU, RCCL): weak scaling -- the job is N sponges; the dense
+grid is x-slab sharded (rank r owns object r's 512^3 slab, no collective); the subdivision
+hierarchy of all N objects is ONE global parent list per level, cut into balanced slices,
+with a variable-length RCCL all-gather of the survivors between levels (codecad_amd/dist.py).
+
+The JSON line also carries `roofline` for the dominant kernel (k_grid_eval<0>, measured with
+HIP events on its own stream) and `cpu_baseline` (the CPU oracle on a bounded sample).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N = 512
+SPONGE_DEPTH = 4
+SUBDIV_GRID = 16
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_PEAK_TFLOPS = 157.3   # vector FP32, FMA-counted
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--n", type=int, default=N, help="grid edge (default 512)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import codecad_amd as cc
+    from codecad_amd import hip_util, dist
+    from codecad_amd.hip_util import check
+    import ctypes
+
+    rank, world = dist.init()
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    hip_util.manager.use_device(local)
+    m = hip_util.manager
+    lib = m.lib
+    dev = torch.device("cuda", local)
+    n = args.n
+
+    shape = cc.examples.sponge(SPONGE_DEPTH)
+    tape = cc.nodes.make_program_buffer(shape)
+    queue = m.queue
+    stream = queue.handle
+
+    # ---- A: dense grid ------------------------------------------------------------------
+    step_f = np.float32(1.0 / n)
+    corner = np.array([-0.5 + 0.5 / n] * 3 + [0.0], dtype=np.float32)
+    dims = (ctypes.c_uint32 * 3)(n, n, n)
+    dense_out = torch.empty((n, n, n, 4), dtype=torch.float32, device=dev)
+    dense_voxels = n ** 3
+
+    # ---- B: subdivision hierarchy ---------------------------------------------------------
+    resolution = 1.0 / n
+    box = shape.bounding_box().expanded_additive(resolution / 2)
+    levels = cc.subdivision.calculate_block_sizes(box, 3, resolution, SUBDIV_GRID, True)
+    origin = (ctypes.c_double * 3)(box.a.x, box.a.y, box.a.z)
+    counter = torch.zeros(1, dtype=torch.int32, device=dev)
+    stats = {"samples": 0, "leaves": 0, "level_counts": None}
+    capacity = [1 << 16] * len(levels)
+
+    def classify(level, parents):
+        int_step, ldims = levels[level]
+        k = int(parents.shape[0])
+        cells = int(ldims[0]) * int(ldims[1]) * int(ldims[2])
+        stats["samples"] += k * cells
+        if k == 0:
+            return parents[:0]
+        d = (ctypes.c_uint32 * 3)(int(ldims[0]), int(ldims[1]), int(ldims[2]))
+        box_step = int_step * resolution
+        thr = box_step * math.sqrt(3) / 2
+        parents = parents.contiguous()
+        while True:
+            children = torch.empty((capacity[level], 4), dtype=torch.int32, device=dev)
+            check(lib.hu_memset(counter.data_ptr(), 0, 4, stream), "memset")
+            check(lib.hu_subdivision_level(tape.device_ptr, parents.data_ptr(), k, int(int_step), d, 3,
+                                           resolution, origin, np.float32(box_step), np.float32(thr),
+                                           counter.data_ptr(), children.data_ptr(), capacity[level], stream),
+                  "hu_subdivision_level")
+            queue.synchronize()
+            count = int(counter.item())
+            if count <= capacity[level]:
+                return children[:count]
+            capacity[level] = int(count * 1.25)
+
+    top = torch.zeros((world, 4), dtype=torch.int32, device=dev)
+    top[:, 3] = torch.arange(world, dtype=torch.int32, device=dev)   # one hierarchy per object
+    leaf_int_step, leaf_dims = levels[-1]
+    leaf_cells = int(leaf_dims[0]) * int(leaf_dims[1]) * int(leaf_dims[2])
+    ld = (ctypes.c_uint32 * 3)(int(leaf_dims[0]), int(leaf_dims[1]), int(leaf_dims[2]))
+    leaf_out = [None]
+
+    ev0, ev1 = ctypes.c_void_p(), ctypes.c_void_p()
+    check(lib.hu_event_create(ctypes.byref(ev0)), "event")
+    check(lib.hu_event_create(ctypes.byref(ev1)), "event")
+    dense_ms = []
+
+    def one_step(timed):
+        # A
+        check(lib.hu_event_record(ev0, stream), "record")
+        check(lib.hu_grid_eval(tape.device_ptr, corner.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), step_f,
+                               dims, dense_out.data_ptr(), stream), "hu_grid_eval")
+        check(lib.hu_event_record(ev1, stream), "record")
+        # B
+        stats["samples"] = 0
+        leaves, counts = dist.run_levels(top, len(levels) - 1, classify)
+        stats["level_counts"] = counts
+        # C: this rank's balanced share of the global leaf list
+        b, e = dist.balanced_slice(int(leaves.shape[0]), rank, world)
+        mine = leaves[b:e].contiguous()
+        k = int(mine.shape[0])
+        stats["leaves"] = k
+        if leaf_out[0] is None or leaf_out[0].shape[0] < k:
+            leaf_out[0] = torch.empty((int(k * 1.1) + 1, leaf_cells), dtype=torch.float32, device=dev)
+        check(lib.hu_grid_eval_blocks(tape.device_ptr, mine.data_ptr(), k, resolution, origin,
+                                      np.float32(leaf_int_step * resolution), ld, 1, leaf_out[0].data_ptr(), stream),
+              "hu_grid_eval_blocks")
+        if timed:
+            check(lib.hu_event_synchronize(ev1), "sync")
+            ms = ctypes.c_float()
+            check(lib.hu_event_elapsed_ms(ev0, ev1, ctypes.byref(ms)), "elapsed")
+            dense_ms.append(ms.value)
+
+    def barrier():
+        queue.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    per_rank_samples = dense_voxels + stats["samples"] + stats["leaves"] * leaf_cells
+    tot = torch.tensor([per_rank_samples], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(tot, op=torch.distributed.ReduceOp.SUM)
+    job_samples = float(tot.item())
+    value = job_samples * args.steps / elapsed / 1e6
+
+    if rank == 0:
+        flop = tape_flop(tape.host_tape)
+        dense_avg_ms = sum(dense_ms) / len(dense_ms)
+        alg_bytes = dense_voxels * 16.0
+        achieved = alg_bytes / (dense_avg_ms * 1e-3) / 1e9
+        line = {
+            "metric": "SDF Mvoxels/s (grid_eval+subdivision), 512^3 menger_sponge",
+            "value": round(value, 1), "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "menger_sponge depth=4, %d^3: dense float4 grid_eval + adaptive subdivision "
+                                   "(grid %d, overlap) + grid_eval of all leaf blocks; one object per GPU" % (n, SUBDIV_GRID),
+                       "tape_floats": int(tape.host_tape.size), "tape_instructions": tape.n_instructions,
+                       "value_registers": tape.n_registers, "parallelism": "x-slab/object per rank, "
+                       "balanced parent slices + RCCL all-gather of survivors per level" if world > 1 else "single GPU"},
+            "samples_per_step_per_gpu": {"dense": dense_voxels, "subdivision": stats["samples"],
+                                         "leaf_blocks": stats["leaves"] * leaf_cells,
+                                         "survivors_per_level_global": stats["level_counts"]},
+            "roofline": {"bound": "hbm", "kernel": "k_grid_eval<0>", "achieved": round(achieved, 2),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": None, "kernel_ms": round(dense_avg_ms, 4),
+                         "voxels_per_s": round(dense_voxels / (dense_avg_ms * 1e-3), 0),
+                         "note": "this tape is FP32-VALU-bound, not HBM-bound: see valu_* fields",
+                         "valu_flop_per_voxel": flop,
+                         "valu_achieved_tflops": round(dense_voxels * flop / (dense_avg_ms * 1e-3) / 1e12, 2),
+                         "valu_peak_tflops": FP32_PEAK_TFLOPS,
+                         "valu_frac": round(dense_voxels * flop / (dense_avg_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(tape.host_tape, n)
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+# FLOPs per instruction of the canonical arithmetic (DESIGN.md "Algorithmic FLOPs"): 1 per
+# add/mul/compare-select/abs/copysign, 2 per fma, sqrt 1, divide 1, as executed on the common path.
+_FLOP = {0: 0, 1: 0, 2: 0, 3: 14, 4: 9, 5: 90, 6: 0, 7: 12, 8: 1, 9: 4, 10: 120, 11: 39, 12: 39, 13: 40,
+         14: 1, 15: 1, 16: 1, 17: 3, 18: 15, 19: 90, 20: 90, 21: 160, 22: 14, 23: 8, 24: 120, 25: 2,
+         26: 2, 27: 6, 28: 4}
+_PARAMS = {0: 0, 1: 0, 2: 0, 3: 2, 4: 1, 5: 2, 7: 1, 8: 0, 9: 0, 10: 2, 11: 7, 12: 7, 13: 4, 14: 0, 15: 0,
+           16: 1, 17: 1, 18: 3, 19: 1, 20: 1, 21: 2, 22: 1, 23: 0, 24: 3, 25: 0, 26: 1, 27: 1, 28: 1}
+
+
+def tape_flop(tape):
+    pc, total = 0, 0
+    while pc < len(tape):
+        op = int(tape[pc]) // 512
+        pc += 1
+        if op == 6:
+            cnt = int(tape[pc])
+            total += 25 * cnt
+            pc += 1 + 2 * cnt
+        else:
+            total += _FLOP[op]
+            pc += _PARAMS[op]
+        if op == 0:
+            break
+    return total
+
+
+def cpu_baseline(tape, n):
+    """The CPU oracle (a port: the reference's OpenCL code cannot be built here) on a bounded
+    sample of workload A: the first `planes` x-planes of the same n^3 grid, all host cores."""
+    import numpy as np
+    import oracle
+    cores = os.cpu_count() or 1
+    step = np.float32(1.0 / n)
+    corner = [-0.5 + 0.5 / n] * 3
+    oracle.grid_eval(tape, corner, step, (1, 64, 64), threads=1)  # load + warm
+    t0 = time.perf_counter()
+    oracle.grid_eval(tape, corner, step, (2, n, n), threads=1)
+    one = 2 * n * n / (time.perf_counter() - t0)
+    planes = max(cores, min(n, int(one * cores * 6.0 / (n * n))))   # aim for ~6 s wall
+    t0 = time.perf_counter()
+    oracle.grid_eval(tape, corner, step, (planes, n, n), threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": round(planes * n * n / dt / 1e6, 2), "unit": "Mvoxels/s", "cores": cores, "kind": "port",
+            "sample": "oracle grid_eval (C restatement, OpenMP over x) of the first %d of %d x-planes of the "
+                      "same %d^3 sponge(4) grid, %.1f s wall" % (planes, n, n, dt),
+            "single_thread_mvoxels_s": round(one / 1e6, 3)}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,687 @@
+// codecad_amd/csrc/hip_util.hip -- gfx950 kernels + the C ABI declared in include/hip_util.h.
+//
+// Kernels (reference counterparts, paths relative to /root/reference/codecad/):
+//   k_grid_eval            grid_eval.cl:2-34 (both layouts), dense slab of a logical grid
+//   k_grid_eval_blocks     the per-leaf-block launches of rendering/mesh.py:53-60, batched
+//   k_classify<MASS,BATCH> subdivision.cl:12-30 and mass_properties.cl:7-56, either one block
+//                          (reference-shaped) or every parent of a level in one launch
+//
+// Build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fno-fast-math
+//        -fhip-fp32-correctly-rounded-divide-sqrt -fPIC -shared (see codecad_amd/hip_util/builder.py)
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/hip_util.h"
+#include "interp.hpp"
+
+using sdf::Rec;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+#define HU_HIP(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(HU_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------
+
+// Sample position of reference grid_eval.cl:31 / subdivision.cl:22 / mass_properties.cl:25-27:
+// corner + step * (float)gid, multiply then add, not fused.
+__device__ __forceinline__ float sample(float corner, float step, uint32_t i) { return corner + step * (float)i; }
+
+// Workgroup-aggregated stream compaction: 64-lane ballot + popcount prefix inside each
+// wavefront, wave totals combined through LDS, ONE global atomic per workgroup.  Returns the
+// slot for this lane (meaningful where flag is set).  The reference does one global
+// atomic_inc per surviving work-item (subdivision.cl:28).
+__device__ __forceinline__ uint32_t wg_compact_slot(bool flag, uint32_t* __restrict__ counter, uint32_t* scratch)
+{
+    const uint64_t mask = __ballot(flag);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t prefix = __popcll(mask & ((1ull << lane) - 1ull));
+    if (lane == 0) scratch[wave] = __popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t nw = (blockDim.x + 63u) >> 6;
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < nw; ++w) {
+            uint32_t c = scratch[w];
+            scratch[w] = total;
+            total += c;
+        }
+        scratch[4] = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    return scratch[4] + scratch[wave] + prefix;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// dense grid evaluation
+// ------------------------------------------------------------------------------------------
+template <int LAYOUT>
+__global__ void __launch_bounds__(256)
+k_grid_eval(const Rec* __restrict__ prog, const float* __restrict__ extra, float cx, float cy,
+            float cz, float step, uint32_t sx, uint32_t sy, uint32_t sz, uint32_t x0,
+            uint32_t n_cells, void* __restrict__ out)
+{
+    extern __shared__ float4 lds[];
+    const uint32_t lin = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = lin < n_cells;
+    const uint32_t l = active ? lin : 0u;  // idle tail lanes follow the (uniform) tape harmlessly
+    const uint32_t z = l % sz, t = l / sz;
+    const uint32_t y = t % sy, x = x0 + t / sy;
+    const float4 r = sdf::run_tape(prog, extra, sample(cx, step, x), sample(cy, step, y),
+                                   sample(cz, step, z), lds + threadIdx.x, blockDim.x);
+    if (!active) return;
+    if (LAYOUT == 0) {
+        // INDEX3 = z + sz*(y + sy*x) (cl_util/indexing.h:4): inside a slab this is `lin`;
+        // 64 lanes store 1 KiB contiguous.
+        static_cast<float4*>(out)[lin] = r;
+    } else {
+        // grid_eval.cl:18: z + (x + (sy-1-y)*sx)*sz; z-fastest so a wave stores 256 B runs
+        const size_t idx = (size_t)z + ((size_t)x + (size_t)(sy - 1u - y) * sx) * sz;
+        static_cast<float*>(out)[idx] = r.w;
+    }
+}
+
+template <int LAYOUT>
+__global__ void __launch_bounds__(256)
+k_grid_eval_blocks(const Rec* __restrict__ prog, const float* __restrict__ extra,
+                   const int4* __restrict__ blocks, uint32_t chunks, double res, double ox,
+                   double oy, double oz, float step, uint32_t sx, uint32_t sy, uint32_t sz,
+                   void* __restrict__ out)
+{
+    extern __shared__ float4 lds[];
+    const uint32_t b = blockIdx.x / chunks, chunk = blockIdx.x - b * chunks;
+    const uint32_t cells = sx * sy * sz;
+    const int4 ic = blocks[b];
+    // subdivision.py:100: pos = int_pos * resolution + origin (fp64), cast once (geometry.py:98-99)
+    const float cx = (float)((double)ic.x * res + ox);
+    const float cy = (float)((double)ic.y * res + oy);
+    const float cz = (float)((double)ic.z * res + oz);
+    const uint32_t lin = chunk * blockDim.x + threadIdx.x;
+    const bool active = lin < cells;
+    const uint32_t l = active ? lin : 0u;
+    const uint32_t z = l % sz, t = l / sz;
+    const uint32_t y = t % sy, x = t / sy;
+    const float4 r = sdf::run_tape(prog, extra, sample(cx, step, x), sample(cy, step, y),
+                                   sample(cz, step, z), lds + threadIdx.x, blockDim.x);
+    if (!active) return;
+    const size_t base = (size_t)b * cells;
+    if (LAYOUT == 0)
+        static_cast<float4*>(out)[base + lin] = r;
+    else
+        static_cast<float*>(out)[base + (size_t)z + ((size_t)x + (size_t)(sy - 1u - y) * sx) * sz] = r.w;
+}
+
+// ------------------------------------------------------------------------------------------
+// classification kernels: subdivision_step / mass_properties, single block or whole level
+// ------------------------------------------------------------------------------------------
+struct ClassifyArgs {
+    const Rec* prog;
+    const float* extra;
+    const void* parents;   // BATCH: int4[] (subdivision) or double4[] (mass); else unused
+    uint32_t chunks;       // workgroups per parent
+    uint32_t sx, sy, sz;
+    float cx, cy, cz;      // !BATCH: sample corner as given by the caller
+    float step, thr;
+    int32_t int_step;      // BATCH subdivision: cell size of this level in resolution units
+    int32_t dimension;
+    double res, ox, oy, oz;  // BATCH subdivision: resolution + origin
+    double s;                // BATCH mass: cell size of this level
+    uint32_t* counter;
+    void* list;            // !BATCH: uchar4[]; BATCH: int4[] / double4[] children
+    uint32_t capacity;
+    uint32_t* sums;        // MASS: uint32[10] per parent
+    uint32_t regfile_f4;   // float4 slots taken by the register file (scratch follows)
+};
+
+template <bool MASS, bool BATCH>
+__global__ void __launch_bounds__(256) k_classify(const ClassifyArgs a)
+{
+    extern __shared__ float4 lds[];
+    uint32_t* scratch = reinterpret_cast<uint32_t*>(lds + a.regfile_f4);  // [0..4] compaction, [8..17] sums
+    const uint32_t b = BATCH ? blockIdx.x / a.chunks : 0u;
+    const uint32_t chunk = BATCH ? blockIdx.x - b * a.chunks : blockIdx.x;
+    const uint32_t cells = a.sx * a.sy * a.sz;
+
+    float cx = a.cx, cy = a.cy, cz = a.cz;
+    int4 ipar = make_int4(0, 0, 0, 0);
+    double pcx = 0.0, pcy = 0.0, pcz = 0.0, pcw = 0.0;
+    if (BATCH) {
+        if (MASS) {
+            // mass_properties.py:86: shifted_corner = box_corner + splat(box_step/2), fp64
+            const double4 pc = static_cast<const double4*>(a.parents)[b];
+            pcx = pc.x; pcy = pc.y; pcz = pc.z; pcw = pc.w;
+            const double h = a.s / 2;
+            cx = (float)(pcx + h); cy = (float)(pcy + h); cz = (float)(pcz + h);
+        } else {
+            // subdivision.py:56-65: (int_corner + int_step/2) * resolution + origin, fp64;
+            // 2D shapes shift x and y only
+            ipar = static_cast<const int4*>(a.parents)[b];
+            const double h = (double)a.int_step / 2;
+            cx = (float)(((double)ipar.x + h) * a.res + a.ox);
+            cy = (float)(((double)ipar.y + h) * a.res + a.oy);
+            cz = (float)(((double)ipar.z + (a.dimension == 3 ? h : 0.0)) * a.res + a.oz);
+        }
+    }
+    if (MASS) {
+        if (threadIdx.x < 10) scratch[8 + threadIdx.x] = 0u;
+    }
+
+    const uint32_t lin = chunk * blockDim.x + threadIdx.x;
+    const bool active = lin < cells;
+    const uint32_t l = active ? lin : 0u;
+    const uint32_t z = l % a.sz, t = l / a.sz;
+    const uint32_t y = t % a.sy, x = t / a.sy;
+    const float w = sdf::run_tape(a.prog, a.extra, sample(cx, a.step, x), sample(cy, a.step, y),
+                                  sample(cz, a.step, z), lds + threadIdx.x, blockDim.x).w;
+
+    bool ambiguous;
+    if (MASS) {
+        // mass_properties.cl:31-52: inside (w <= -thr) -> moments of the integer cell index;
+        // else w < thr -> ambiguous
+        const bool inside = active && (w <= -a.thr);
+        ambiguous = active && !inside && (w < a.thr);
+        const uint64_t imask = __ballot(inside);
+        __syncthreads();  // scratch[8..17] zeroed
+        if (imask != 0ull) {  // wave-uniform
+            const uint32_t m = inside ? 1u : 0u;
+            const uint32_t xm = x * m, ym = y * m, zm = z * m;
+            uint32_t v[10] = {xm * x, xm * y, xm * z, xm, ym * y, ym * z, ym, zm * z, zm, m};
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                const uint32_t sum = wave_sum(v[i]);
+                if ((threadIdx.x & 63u) == 0 && sum) atomicAdd(&scratch[8 + i], sum);
+            }
+        }
+    } else {
+        // subdivision.cl:25: -thr < w < thr
+        ambiguous = active && (w > -a.thr) && (w < a.thr);
+    }
+
+    const uint32_t slot = wg_compact_slot(ambiguous, a.counter, scratch);  // has __syncthreads
+    if (ambiguous && slot < a.capacity) {
+        if (!BATCH) {
+            static_cast<uchar4*>(a.list)[slot] = make_uchar4((unsigned char)x, (unsigned char)y, (unsigned char)z, 0);
+        } else if (MASS) {
+            // mass_properties.py:155: Vector(i,j,k)*s + box_corner, fp64
+            static_cast<double4*>(a.list)[slot] =
+                make_double4((double)x * a.s + pcx, (double)y * a.s + pcy, (double)z * a.s + pcz, pcw);
+        } else {
+            // subdivision.py:91-94: Vector(i,j,k)*int_box_step + int_box_corner
+            static_cast<int4*>(a.list)[slot] =
+                make_int4(ipar.x + (int)x * a.int_step, ipar.y + (int)y * a.int_step, ipar.z + (int)z * a.int_step, ipar.w);
+        }
+    }
+    if (MASS) {
+        // wg_compact_slot's barriers ordered the LDS atomics before this read
+        if (threadIdx.x < 10) {
+            const uint32_t v = scratch[8 + threadIdx.x];
+            if (v) atomicAdd(&a.sums[(size_t)b * 10 + threadIdx.x], v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+constexpr size_t kMaxLds = 160 * 1024;
+constexpr size_t kScratchBytes = 128;
+
+struct LaunchShape {
+    uint32_t block;
+    size_t lds;
+};
+
+}  // namespace
+
+struct hu_tape_s {
+    Rec* recs_dev = nullptr;
+    float* extra_dev = nullptr;
+    int n_instr = 0;
+    int n_regs = 0;
+    int flags = 0;
+};
+
+namespace {
+
+// Workgroup size from the register file: keep the LDS footprint per workgroup <= 40 KiB
+// (>= 4 workgroups per CU) while the tape allows it; never below one wavefront.
+int launch_shape(const hu_tape_s* t, LaunchShape& ls)
+{
+    uint32_t bs = 256;
+    while (bs > 64 && (size_t)t->n_regs * bs * 16 > 40 * 1024) bs >>= 1;
+    size_t lds = (size_t)t->n_regs * bs * 16 + kScratchBytes;
+    if (lds > kMaxLds)
+        return fail(HU_ERR_UNSUPPORTED, "tape uses " + std::to_string(t->n_regs) +
+                                            " value registers; at most 159 fit the 160 KiB LDS register file");
+    ls.block = bs;
+    ls.lds = lds;
+    return HU_OK;
+}
+
+template <typename K>
+int allow_big_lds(K kernel)
+{
+    HU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
+    return HU_OK;
+}
+
+int ensure_attrs()
+{
+    static thread_local int done_for_device = -1;
+    int dev = 0;
+    HU_HIP(hipGetDevice(&dev));
+    if (done_for_device == dev) return HU_OK;
+    int rc;
+    if ((rc = allow_big_lds(k_grid_eval<0>))) return rc;
+    if ((rc = allow_big_lds(k_grid_eval<1>))) return rc;
+    if ((rc = allow_big_lds(k_grid_eval_blocks<0>))) return rc;
+    if ((rc = allow_big_lds(k_grid_eval_blocks<1>))) return rc;
+    if ((rc = allow_big_lds(k_classify<false, false>))) return rc;
+    if ((rc = allow_big_lds(k_classify<false, true>))) return rc;
+    if ((rc = allow_big_lds(k_classify<true, false>))) return rc;
+    if ((rc = allow_big_lds(k_classify<true, true>))) return rc;
+    done_for_device = dev;
+    return HU_OK;
+}
+
+int check_dims(const uint32_t dims[3], uint64_t& cells)
+{
+    if (!dims) return fail(HU_ERR_BAD_ARG, "dims is NULL");
+    if (dims[0] == 0 || dims[1] == 0 || dims[2] == 0) return fail(HU_ERR_BAD_ARG, "dims must be >= 1 on every axis");
+    cells = (uint64_t)dims[0] * dims[1] * dims[2];
+    return HU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hu_abi_version(void) { return HU_ABI_VERSION; }
+const char* hu_last_error(void) { return g_last_error.c_str(); }
+
+int hu_device_count(int* count)
+{
+    if (!count) return fail(HU_ERR_BAD_ARG, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(HU_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    }
+    *count = n;
+    return HU_OK;
+}
+
+int hu_set_device(int ordinal)
+{
+    HU_HIP(hipSetDevice(ordinal));
+    return HU_OK;
+}
+
+int hu_device_name(int ordinal, char* buf, size_t buflen)
+{
+    if (!buf || !buflen) return fail(HU_ERR_BAD_ARG, "buf is NULL");
+    hipDeviceProp_t prop;
+    HU_HIP(hipGetDeviceProperties(&prop, ordinal));
+    std::snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return HU_OK;
+}
+
+int hu_synchronize(void)
+{
+    HU_HIP(hipDeviceSynchronize());
+    return HU_OK;
+}
+
+int hu_malloc(void** out_dev, size_t bytes)
+{
+    if (!out_dev) return fail(HU_ERR_BAD_ARG, "out_dev is NULL");
+    *out_dev = nullptr;
+    HU_HIP(hipMalloc(out_dev, bytes ? bytes : 1));
+    return HU_OK;
+}
+
+int hu_free(void* dev)
+{
+    if (dev) HU_HIP(hipFree(dev));
+    return HU_OK;
+}
+
+int hu_host_alloc(void** out_host, size_t bytes)
+{
+    if (!out_host) return fail(HU_ERR_BAD_ARG, "out_host is NULL");
+    HU_HIP(hipHostMalloc(out_host, bytes ? bytes : 1, hipHostMallocDefault));
+    return HU_OK;
+}
+
+int hu_host_free(void* host)
+{
+    if (host) HU_HIP(hipHostFree(host));
+    return HU_OK;
+}
+
+int hu_memcpy_h2d(void* dst, const void* src, size_t n, void* stream)
+{
+    HU_HIP(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return HU_OK;
+}
+
+int hu_memcpy_d2h(void* dst, const void* src, size_t n, void* stream)
+{
+    HU_HIP(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return HU_OK;
+}
+
+int hu_memcpy_d2d(void* dst, const void* src, size_t n, void* stream)
+{
+    HU_HIP(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return HU_OK;
+}
+
+int hu_memset(void* dst, int value, size_t n, void* stream)
+{
+    HU_HIP(hipMemsetAsync(dst, value, n, (hipStream_t)stream));
+    return HU_OK;
+}
+
+int hu_stream_create(void** out)
+{
+    if (!out) return fail(HU_ERR_BAD_ARG, "out is NULL");
+    hipStream_t s;
+    HU_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *out = s;
+    return HU_OK;
+}
+
+int hu_stream_destroy(void* s)
+{
+    if (s) HU_HIP(hipStreamDestroy((hipStream_t)s));
+    return HU_OK;
+}
+
+int hu_stream_synchronize(void* s)
+{
+    HU_HIP(hipStreamSynchronize((hipStream_t)s));
+    return HU_OK;
+}
+
+int hu_stream_wait_event(void* s, void* ev)
+{
+    HU_HIP(hipStreamWaitEvent((hipStream_t)s, (hipEvent_t)ev, 0));
+    return HU_OK;
+}
+
+int hu_event_create(void** out)
+{
+    if (!out) return fail(HU_ERR_BAD_ARG, "out is NULL");
+    hipEvent_t e;
+    HU_HIP(hipEventCreate(&e));
+    *out = e;
+    return HU_OK;
+}
+
+int hu_event_destroy(void* e)
+{
+    if (e) HU_HIP(hipEventDestroy((hipEvent_t)e));
+    return HU_OK;
+}
+
+int hu_event_record(void* e, void* s)
+{
+    HU_HIP(hipEventRecord((hipEvent_t)e, (hipStream_t)s));
+    return HU_OK;
+}
+
+int hu_event_synchronize(void* e)
+{
+    HU_HIP(hipEventSynchronize((hipEvent_t)e));
+    return HU_OK;
+}
+
+int hu_event_elapsed_ms(void* a, void* b, float* out_ms)
+{
+    if (!out_ms) return fail(HU_ERR_BAD_ARG, "out_ms is NULL");
+    HU_HIP(hipEventElapsedTime(out_ms, (hipEvent_t)a, (hipEvent_t)b));
+    return HU_OK;
+}
+
+int hu_tape_create(const float* tape, size_t n, hu_tape* out)
+{
+    if (!tape || !out) return fail(HU_ERR_BAD_ARG, "tape/out is NULL");
+    *out = nullptr;
+    sdf::DecodedTape d;
+    std::string err = sdf::decode_tape(tape, n, d);
+    if (!err.empty()) return fail(HU_ERR_BAD_TAPE, "malformed tape: " + err);
+    hu_tape_s* t = new hu_tape_s();
+    t->n_instr = (int)d.recs.size() - 2;
+    t->n_regs = d.n_regs;
+    t->flags = d.direction_feeds_distance ? 1 : 0;
+    hipError_t e = hipMalloc((void**)&t->recs_dev, d.recs.size() * sizeof(Rec));
+    if (e == hipSuccess) e = hipMalloc((void**)&t->extra_dev, d.extra.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(t->recs_dev, d.recs.data(), d.recs.size() * sizeof(Rec), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(t->extra_dev, d.extra.data(), d.extra.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(t->recs_dev);
+        (void)hipFree(t->extra_dev);
+        delete t;
+        return fail(HU_ERR_HIP, std::string("tape upload: ") + hipGetErrorString(e));
+    }
+    *out = t;
+    return HU_OK;
+}
+
+int hu_tape_destroy(hu_tape t)
+{
+    if (!t) return HU_OK;
+    (void)hipFree(t->recs_dev);
+    (void)hipFree(t->extra_dev);
+    delete t;
+    return HU_OK;
+}
+
+int hu_tape_info(hu_tape t, int* n_instructions, int* n_registers, int* flags)
+{
+    if (!t) return fail(HU_ERR_BAD_ARG, "tape is NULL");
+    if (n_instructions) *n_instructions = t->n_instr;
+    if (n_registers) *n_registers = t->n_regs;
+    if (flags) *flags = t->flags;
+    return HU_OK;
+}
+
+int hu_grid_eval_slab(hu_tape t, const float corner[4], float step, const uint32_t dims[3],
+                      uint32_t x0, uint32_t x_count, int layout, void* out_dev, void* stream)
+{
+    if (!t || !corner || !out_dev) return fail(HU_ERR_BAD_ARG, "NULL argument");
+    if (layout != 0 && layout != 1) return fail(HU_ERR_BAD_ARG, "layout must be 0 (float4) or 1 (pymcubes float)");
+    uint64_t cells;
+    int rc;
+    if ((rc = check_dims(dims, cells))) return rc;
+    if ((uint64_t)x0 + x_count > dims[0]) return fail(HU_ERR_BAD_ARG, "slab exceeds the grid's x extent");
+    const uint64_t plane = (uint64_t)dims[1] * dims[2];
+    if (plane >= (1ull << 30)) return fail(HU_ERR_BAD_ARG, "dims[1]*dims[2] must be below 2^30");
+    LaunchShape ls;
+    if ((rc = launch_shape(t, ls))) return rc;
+    if ((rc = ensure_attrs())) return rc;
+    // at most 2^30 cells per launch keeps every in-kernel index in 32 bits
+    const uint32_t max_x = (uint32_t)((1ull << 30) / plane);
+    for (uint32_t done = 0; done < x_count;) {
+        const uint32_t nx = (x_count - done < max_x) ? (x_count - done) : max_x;
+        const uint32_t n_cells = (uint32_t)(nx * plane);
+        const uint32_t blocks = (n_cells + ls.block - 1) / ls.block;
+        if (layout == 0) {
+            float4* o = static_cast<float4*>(out_dev) + (size_t)done * plane;
+            hipLaunchKernelGGL(k_grid_eval<0>, dim3(blocks), dim3(ls.block), ls.lds, (hipStream_t)stream,
+                               t->recs_dev, t->extra_dev, corner[0], corner[1], corner[2], step, dims[0],
+                               dims[1], dims[2], x0 + done, n_cells, (void*)o);
+        } else {
+            hipLaunchKernelGGL(k_grid_eval<1>, dim3(blocks), dim3(ls.block), ls.lds, (hipStream_t)stream,
+                               t->recs_dev, t->extra_dev, corner[0], corner[1], corner[2], step, dims[0],
+                               dims[1], dims[2], x0 + done, n_cells, out_dev);
+        }
+        HU_HIP(hipGetLastError());
+        done += nx;
+    }
+    return HU_OK;
+}
+
+int hu_grid_eval(hu_tape t, const float corner[4], float step, const uint32_t dims[3], void* out_dev, void* stream)
+{
+    if (!dims) return fail(HU_ERR_BAD_ARG, "dims is NULL");
+    return hu_grid_eval_slab(t, corner, step, dims, 0, dims[0], 0, out_dev, stream);
+}
+
+int hu_grid_eval_pymcubes(hu_tape t, const float corner[4], float step, const uint32_t dims[3], void* out_dev, void* stream)
+{
+    if (!dims) return fail(HU_ERR_BAD_ARG, "dims is NULL");
+    return hu_grid_eval_slab(t, corner, step, dims, 0, dims[0], 1, out_dev, stream);
+}
+
+int hu_grid_eval_blocks(hu_tape t, const int32_t* blocks_dev, uint32_t n_blocks, double resolution,
+                        const double origin[3], float step, const uint32_t dims[3], int layout,
+                        void* out_dev, void* stream)
+{
+    if (!t || !origin || !out_dev || (!blocks_dev && n_blocks)) return fail(HU_ERR_BAD_ARG, "NULL argument");
+    if (layout != 0 && layout != 1) return fail(HU_ERR_BAD_ARG, "layout must be 0 or 1");
+    uint64_t cells;
+    int rc;
+    if ((rc = check_dims(dims, cells))) return rc;
+    if (cells > (1ull << 24)) return fail(HU_ERR_BAD_ARG, "a block may have at most 2^24 cells (256^3)");
+    if (n_blocks == 0) return HU_OK;
+    LaunchShape ls;
+    if ((rc = launch_shape(t, ls))) return rc;
+    if ((rc = ensure_attrs())) return rc;
+    const uint32_t chunks = (uint32_t)((cells + ls.block - 1) / ls.block);
+    if ((uint64_t)chunks * n_blocks > 0x7fffffffull) return fail(HU_ERR_BAD_ARG, "too many workgroups in one launch");
+    const dim3 grid(chunks * n_blocks), block(ls.block);
+    if (layout == 0)
+        hipLaunchKernelGGL(k_grid_eval_blocks<0>, grid, block, ls.lds, (hipStream_t)stream, t->recs_dev,
+                           t->extra_dev, (const int4*)blocks_dev, chunks, resolution, origin[0], origin[1],
+                           origin[2], step, dims[0], dims[1], dims[2], out_dev);
+    else
+        hipLaunchKernelGGL(k_grid_eval_blocks<1>, grid, block, ls.lds, (hipStream_t)stream, t->recs_dev,
+                           t->extra_dev, (const int4*)blocks_dev, chunks, resolution, origin[0], origin[1],
+                           origin[2], step, dims[0], dims[1], dims[2], out_dev);
+    HU_HIP(hipGetLastError());
+    return HU_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+template <bool MASS, bool BATCH>
+int launch_classify(hu_tape t, ClassifyArgs& a, uint32_t n_parents, const uint32_t dims[3], void* stream)
+{
+    uint64_t cells;
+    int rc;
+    if ((rc = check_dims(dims, cells))) return rc;
+    if (cells > (1ull << 24)) return fail(HU_ERR_BAD_ARG, "at most 2^24 cells (256^3) per block: cell indices are uchar4");
+    if (dims[0] > 256 || dims[1] > 256 || dims[2] > 256)
+        return fail(HU_ERR_BAD_ARG, "grid size > 256 would overflow the uchar4 cell index (reference subdivision.py:206-208)");
+    if (n_parents == 0) return HU_OK;
+    LaunchShape ls;
+    if ((rc = launch_shape(t, ls))) return rc;
+    if ((rc = ensure_attrs())) return rc;
+    a.prog = t->recs_dev;
+    a.extra = t->extra_dev;
+    a.sx = dims[0];
+    a.sy = dims[1];
+    a.sz = dims[2];
+    a.chunks = (uint32_t)((cells + ls.block - 1) / ls.block);
+    a.regfile_f4 = (uint32_t)t->n_regs * ls.block;
+    if ((uint64_t)a.chunks * n_parents > 0x7fffffffull) return fail(HU_ERR_BAD_ARG, "too many workgroups in one launch");
+    hipLaunchKernelGGL((k_classify<MASS, BATCH>), dim3(a.chunks * n_parents), dim3(ls.block), ls.lds,
+                       (hipStream_t)stream, a);
+    HU_HIP(hipGetLastError());
+    return HU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hu_subdivision_step(hu_tape t, const float corner[4], float step, float threshold, const uint32_t dims[3],
+                        uint32_t* counter_dev, void* list_dev, void* stream)
+{
+    if (!t || !corner || !counter_dev || !list_dev) return fail(HU_ERR_BAD_ARG, "NULL argument");
+    ClassifyArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.cx = corner[0]; a.cy = corner[1]; a.cz = corner[2];
+    a.step = step; a.thr = threshold;
+    a.counter = counter_dev; a.list = list_dev; a.capacity = 0xffffffffu;
+    return launch_classify<false, false>(t, a, 1, dims, stream);
+}
+
+int hu_mass_properties(hu_tape t, const float corner[4], float step, float threshold, const uint32_t dims[3],
+                       uint32_t* sum_dev, uint32_t* counter_dev, void* list_dev, void* stream)
+{
+    if (!t || !corner || !sum_dev || !counter_dev || !list_dev) return fail(HU_ERR_BAD_ARG, "NULL argument");
+    ClassifyArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.cx = corner[0]; a.cy = corner[1]; a.cz = corner[2];
+    a.step = step; a.thr = threshold;
+    a.counter = counter_dev; a.list = list_dev; a.capacity = 0xffffffffu;
+    a.sums = sum_dev;
+    return launch_classify<true, false>(t, a, 1, dims, stream);
+}
+
+int hu_subdivision_level(hu_tape t, const int32_t* parents_dev, uint32_t n_parents, int32_t int_step,
+                         const uint32_t dims[3], int dimension, double resolution, const double origin[3],
+                         float step, float threshold, uint32_t* counter_dev, int32_t* children_dev,
+                         uint32_t capacity, void* stream)
+{
+    if (!t || !origin || !counter_dev || (!children_dev && capacity) || (!parents_dev && n_parents))
+        return fail(HU_ERR_BAD_ARG, "NULL argument");
+    if (dimension != 2 && dimension != 3) return fail(HU_ERR_BAD_ARG, "dimension must be 2 or 3");
+    ClassifyArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.parents = parents_dev;
+    a.int_step = int_step; a.dimension = dimension;
+    a.res = resolution; a.ox = origin[0]; a.oy = origin[1]; a.oz = origin[2];
+    a.step = step; a.thr = threshold;
+    a.counter = counter_dev; a.list = children_dev; a.capacity = capacity;
+    return launch_classify<false, true>(t, a, n_parents, dims, stream);
+}
+
+int hu_mass_properties_level(hu_tape t, const double* parents_dev, uint32_t n_parents, double s,
+                             const uint32_t dims[3], float step, float threshold, uint32_t* sums_dev,
+                             uint32_t* counter_dev, double* children_dev, uint32_t capacity, void* stream)
+{
+    if (!t || !sums_dev || !counter_dev || (!children_dev && capacity) || (!parents_dev && n_parents))
+        return fail(HU_ERR_BAD_ARG, "NULL argument");
+    ClassifyArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.parents = parents_dev;
+    a.s = s;
+    a.step = step; a.thr = threshold;
+    a.counter = counter_dev; a.list = children_dev; a.capacity = capacity;
+    a.sums = sums_dev;
+    return launch_classify<true, true>(t, a, n_parents, dims, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,178 @@
+// codecad_amd/csrc/tape.hpp
+//
+// The float32 instruction tape (reference nodes/program.py:55-76, opcode table
+// nodes/node.py:12-56) and its pre-decoded device form.
+//
+// Reference tape: a flat float32 array; each instruction is one float
+// `opcode*512 + secondaryRegister` followed by its parameters; the interpreter
+// (reference nodes/codegen.py:5-63) re-derives opcode/register with an integer divide and
+// modulo per instruction per work-item and reads parameters one float at a time.
+//
+// Device form: the tape is a straight line (no branches), identical for every voxel, so it
+// is decoded ONCE on the host at upload into fixed 48-byte records the wave fetches with
+// scalar loads (s_load_dwordx8 + x4, prefetched one record ahead), with every
+// tape-constant subexpression folded in (|q|^2, 1/|q|^2, w^2-|v|^2, 1/spacing, gear
+// constants ...) using the same IEEE operations the per-voxel code would use.
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sdf_math.hpp"
+
+namespace sdf {
+
+enum Op : uint32_t {
+    OP_RETURN = 0, OP_STORE = 1, OP_LOAD = 2, OP_RECTANGLE = 3, OP_CIRCLE = 4,
+    OP_REGULAR_POLYGON2D = 5, OP_POLYGON2D = 6, OP_SPHERE = 7, OP_HALF_SPACE = 8,
+    OP_REVOLUTION_TO = 9, OP_TWIST_REVOLUTION_TO = 10, OP_INITIAL_TRANSFORMATION_TO = 11,
+    OP_TRANSFORMATION_TO = 12, OP_TRANSFORMATION_FROM = 13, OP_MIRROR = 14,
+    OP_SYMMETRICAL_TO = 15, OP_OFFSET = 16, OP_SHELL = 17, OP_REPETITION = 18,
+    OP_CIRCULAR_REPETITION_TO = 19, OP_CIRCULAR_REPETITION_FROM = 20, OP_INVOLUTE_GEAR = 21,
+    OP_EXTRUSION = 22, OP_REVOLUTION_FROM = 23, OP_TWIST_REVOLUTION_FROM = 24,
+    OP_SYMMETRICAL_FROM = 25, OP_UNION = 26, OP_INTERSECTION = 27, OP_SUBTRACTION = 28,
+    OP_COUNT = 29
+};
+
+constexpr int kRefRegisterCount = 512;  // reference nodes/__init__.py:6
+constexpr int kVariableParams = -1;
+
+// (parameter count, arity) per opcode -- reference nodes/node.py:15-53
+struct OpInfo { const char* name; int params; int arity; };
+inline const OpInfo& op_info(uint32_t op)
+{
+    static const OpInfo table[OP_COUNT] = {
+        {"_return", 0, 1}, {"_store", 0, 1}, {"_load", 0, 1}, {"rectangle", 2, 1},
+        {"circle", 1, 1}, {"regular_polygon2d", 2, 1}, {"polygon2d", kVariableParams, 1},
+        {"sphere", 1, 1}, {"half_space", 0, 1}, {"revolution_to", 0, 1},
+        {"twist_revolution_to", 2, 1}, {"initial_transformation_to", 7, 0},
+        {"transformation_to", 7, 1}, {"transformation_from", 4, 1}, {"mirror", 0, 1},
+        {"symmetrical_to", 0, 1}, {"offset", 1, 1}, {"shell", 1, 1}, {"repetition", 3, 1},
+        {"circular_repetition_to", 1, 1}, {"circular_repetition_from", 1, 2},
+        {"involute_gear", 2, 1}, {"extrusion", 1, 2}, {"revolution_from", 0, 2},
+        {"twist_revolution_from", 3, 2}, {"symmetrical_from", 0, 2}, {"union", 1, 2},
+        {"intersection", 1, 2}, {"subtraction", 1, 2}};
+    return table[op];
+}
+
+// One decoded instruction: 12 dwords.  hdr = opcode | (secondaryRegister << 8).
+struct alignas(16) Rec {
+    uint32_t hdr;
+    float p[11];
+};
+static_assert(sizeof(Rec) == 48, "Rec must be 48 bytes");
+
+inline float bits_f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+
+struct DecodedTape {
+    std::vector<Rec> recs;
+    std::vector<float> extra;     // polygon2d vertex data
+    int n_regs = 0;               // highest register index + 1
+    bool direction_feeds_distance = false;  // any rounded union (r >= 0)
+    bool deterministic_only = true;
+};
+
+// quaternion helpers used for the folded constants; same op order as the kernels/oracle
+inline float q_k(const float* q) { return fma_(q[3], q[3], -fma_(q[2], q[2], fma_(q[1], q[1], q[0] * q[0]))); }
+inline float q_scale(const float* q) { return fma_(q[3], q[3], fma_(q[2], q[2], fma_(q[1], q[1], q[0] * q[0]))); }
+
+// Validate + decode.  Returns "" on success, otherwise the reason the tape is malformed.
+inline std::string decode_tape(const float* tape, size_t n, DecodedTape& out)
+{
+    size_t pc = 0;
+    bool returned = false;
+    out = DecodedTape();
+    while (pc < n) {
+        float word = tape[pc++];
+        if (!(word >= 0.0f) || word >= float(OP_COUNT * kRefRegisterCount) || word != float(uint32_t(word)))
+            return "instruction word " + std::to_string(word) + " at float " + std::to_string(pc - 1) + " is not a valid opcode*512+register";
+        uint32_t ins = uint32_t(word);
+        uint32_t op = ins / kRefRegisterCount, reg = ins % kRefRegisterCount;
+        const OpInfo& info = op_info(op);
+        Rec r;
+        std::memset(&r, 0, sizeof(r));
+        r.hdr = op | (reg << 8);
+        int np = info.params;
+        if (np == kVariableParams) {
+            if (pc >= n) return "truncated polygon2d";
+            float cnt = tape[pc];
+            if (!(cnt >= 3.0f) || cnt > 1.0e6f || cnt != float(uint32_t(cnt))) return "bad polygon2d point count";
+            uint32_t count = uint32_t(cnt);
+            if (pc + 1 + 2 * size_t(count) > n) return "truncated polygon2d points";
+            r.p[0] = bits_f(count);
+            r.p[1] = bits_f(uint32_t(out.extra.size()));
+            out.extra.insert(out.extra.end(), tape + pc + 1, tape + pc + 1 + 2 * size_t(count));
+            pc += 1 + 2 * size_t(count);
+        } else {
+            if (pc + size_t(np) > n) return std::string("truncated parameters of ") + info.name;
+            const float* p = tape + pc;
+            for (int i = 0; i < np; ++i) r.p[i] = p[i];
+            switch (op) {
+            case OP_REGULAR_POLYGON2D:
+                r.p[2] = 2.0f * p[0];
+                r.p[3] = p[1] * sin_(p[0]);
+                r.p[4] = -(p[1] * cos_(p[0]));
+                break;
+            case OP_INITIAL_TRANSFORMATION_TO:
+            case OP_TRANSFORMATION_TO:
+                r.p[7] = q_k(p);
+                break;
+            case OP_TRANSFORMATION_FROM: {
+                float scale = q_scale(p);
+                r.p[4] = q_k(p);
+                r.p[5] = scale;
+                r.p[6] = 1.0f / scale;
+                break;
+            }
+            case OP_REPETITION:
+                for (int i = 0; i < 3; ++i) r.p[3 + i] = 1.0f / p[i];
+                break;
+            case OP_CIRCULAR_REPETITION_TO:
+            case OP_CIRCULAR_REPETITION_FROM:
+                r.p[1] = 2.0f * p[0];
+                break;
+            case OP_INVOLUTE_GEAR: {
+                float base = cos_(p[1]);
+                float tooth = kPi / p[0];
+                r.p[2] = base;
+                r.p[3] = tooth;
+                r.p[4] = (tooth / 2.0f + tan_(p[1])) - p[1];
+                r.p[5] = 2.0f * tooth;
+                r.p[6] = -(base * base);
+                break;
+            }
+            case OP_TWIST_REVOLUTION_FROM: {
+                float lip = (((p[1] - p[0]) * 2.0f) *
+                             sin_(__builtin_fminf(kPi, (kPi2 * kPi2) / abs_(p[2])))) / p[0];
+                r.p[3] = 0.05f * p[1];
+                r.p[4] = p[1] - p[0];
+                r.p[5] = __builtin_fminf(1.0f, lip);
+                break;
+            }
+            case OP_UNION:
+            case OP_INTERSECTION:
+            case OP_SUBTRACTION:
+                if (p[0] >= 0.0f) out.direction_feeds_distance = true;
+                break;
+            default: break;
+            }
+            pc += size_t(np);
+        }
+        bool uses_reg = (op == OP_STORE || op == OP_LOAD || info.arity == 2);
+        if (uses_reg && int(reg) + 1 > out.n_regs) out.n_regs = int(reg) + 1;
+        out.recs.push_back(r);
+        if (op == OP_RETURN) { returned = true; break; }
+    }
+    if (!returned) return "tape does not end with _return";
+    if (out.extra.empty()) out.extra.push_back(0.0f);
+    // Two zero records of padding: the interpreter prefetches one record ahead.
+    Rec pad;
+    std::memset(&pad, 0, sizeof(pad));
+    out.recs.push_back(pad);
+    out.recs.push_back(pad);
+    return "";
+}
+
+}  // namespace sdf

@@ -1,0 +1,287 @@
+"""Device buffers, tape handles and the two-deep job interleavers.
+
+`Buffer` has the surface of the reference's `cl_util.Buffer` (reference
+cl_util/cl_buffer.py:9-131): numpy dtype + shape, a host shadow array, `read`,
+`enqueue_read`, `enqueue_write`, `map`, indexing on the shadow.  The shadow lives in pinned
+host memory so enqueue_* are genuinely asynchronous on the buffer's stream.
+"""
+import contextlib
+import ctypes
+
+import numpy
+
+from . import manager as _manager
+from .manager import check, Event
+
+
+class mem_flags:
+    """Accepted for source compatibility with pyopencl.mem_flags; HBM has no such modes."""
+    READ_WRITE = 1
+    WRITE_ONLY = 2
+    READ_ONLY = 4
+    ALLOC_HOST_PTR = 16
+    COPY_HOST_PTR = 32
+
+
+class map_flags:
+    READ = 1
+    WRITE = 2
+    WRITE_INVALIDATE_REGION = 4
+
+
+class Buffer:
+    @staticmethod
+    def dual_dtype(scalar):
+        return numpy.dtype([(n, scalar) for n in "xy"])
+
+    @staticmethod
+    def quad_dtype(scalar):
+        return numpy.dtype([(n, scalar) for n in "xyzw"])
+
+    def __init__(self, dtype, shape, mem_flags=None, queue=None):
+        m = _manager.instance
+        self.manager = m
+        self.queue = queue if queue is not None else m.queue
+        self.dtype = numpy.dtype(dtype)
+        try:
+            self.shape = tuple(int(s) for s in shape)
+        except TypeError:
+            self.shape = (int(shape),)
+        self.nitems = 1
+        for s in self.shape:
+            self.nitems *= s
+        self.size = self.nitems * self.dtype.itemsize  # bytes
+        self.array = None
+        self._pinned = None
+        p = ctypes.c_void_p()
+        check(m.lib.hu_malloc(ctypes.byref(p), self.size), "hu_malloc")
+        self.device_ptr = p.value
+
+    # -- host shadow ---------------------------------------------------------------------
+    def create_host_side_array(self):
+        """Allocate the pinned shadow array `self.array` (uninitialised)."""
+        p = ctypes.c_void_p()
+        check(self.manager.lib.hu_host_alloc(ctypes.byref(p), max(self.size, 1)), "hu_host_alloc")
+        self._pinned = p.value
+        raw = (ctypes.c_char * max(self.size, 1)).from_address(p.value)
+        self.array = numpy.frombuffer(raw, dtype=self.dtype, count=self.nitems).reshape(self.shape)
+
+    def _host(self, array):
+        if array is not None:
+            return array
+        if self.array is None:
+            self.create_host_side_array()
+        return self.array
+
+    def _wait_all(self, wait_for):
+        for ev in (wait_for or ()):
+            if getattr(ev, "stream", None) is not self.queue and hasattr(ev, "_stop"):
+                check(self.manager.lib.hu_stream_wait_event(self.queue.handle, ev._stop), "hu_stream_wait_event")
+
+    # -- transfers -----------------------------------------------------------------------
+    def enqueue_read(self, out=None, wait_for=None):
+        """Device -> host (self.array or `out`), asynchronous; returns an Event."""
+        host = self._host(out)
+        if host.nbytes < self.size:
+            raise RuntimeError("Not enough space to store contents of the buffer")
+        self._wait_all(wait_for)
+        ev = Event(self.manager, self.queue)
+        check(self.manager.lib.hu_memcpy_d2h(host.ctypes.data, self.device_ptr, self.size, self.queue.handle), "hu_memcpy_d2h")
+        return ev._done()
+
+    def read(self, out=None, wait_for=None):
+        """Blocking device -> host; returns the array."""
+        host = self._host(out)
+        self.enqueue_read(out=host, wait_for=wait_for).wait()
+        return host
+
+    def enqueue_write(self, a=None, wait_for=None):
+        """Host (self.array or `a`) -> device, asynchronous; returns an Event."""
+        host = self._host(a)
+        host = numpy.ascontiguousarray(host)
+        if host.nbytes > self.size:
+            raise RuntimeError("Not enough space to store contents in the buffer")
+        self._wait_all(wait_for)
+        ev = Event(self.manager, self.queue)
+        self._keepalive = host  # the copy is asynchronous: keep the source alive
+        check(self.manager.lib.hu_memcpy_h2d(self.device_ptr, host.ctypes.data, host.nbytes, self.queue.handle), "hu_memcpy_h2d")
+        if a is not None and self._pinned is None:
+            self.queue.synchronize()  # pageable source: do not return before it is consumed
+        return ev._done()
+
+    def enqueue_zero_fill_compatible(self, wait_for=None):
+        return self.enqueue_fill(0, wait_for=wait_for)
+
+    def enqueue_fill(self, byte_value=0, wait_for=None):
+        """hipMemsetAsync on the buffer's stream (the reference writes zeros from the host)."""
+        self._wait_all(wait_for)
+        ev = Event(self.manager, self.queue)
+        check(self.manager.lib.hu_memset(self.device_ptr, byte_value, self.size, self.queue.handle), "hu_memset")
+        return ev._done()
+
+    @contextlib.contextmanager
+    def map(self, flags, offset=None, shape=None, wait_for=None):
+        """Context manager giving a host view; written back on exit when mapped for writing."""
+        if offset not in (None, 0) or (shape is not None and tuple(numpy.atleast_1d(shape)) != self.shape):
+            raise NotImplementedError("partial maps are not supported")
+        host = self._host(None)
+        for ev in (wait_for or ()):
+            ev.wait()
+        if flags & map_flags.READ or flags & map_flags.WRITE:
+            self.read()
+        yield host
+        if flags & (map_flags.WRITE | map_flags.WRITE_INVALIDATE_REGION):
+            self.enqueue_write().wait()
+
+    # -- container protocol ----------------------------------------------------------------
+    def __getitem__(self, key):
+        return self.array[key]
+
+    def __setitem__(self, key, value):
+        self.array[key] = value
+
+    def __len__(self):
+        return self.nitems
+
+    def release(self):
+        """Free device and pinned memory now (idempotent)."""
+        lib = self.manager.lib
+        if self.device_ptr:
+            check(lib.hu_free(self.device_ptr), "hu_free")
+            self.device_ptr = None
+        if self._pinned:
+            self.array = None
+            check(lib.hu_host_free(self._pinned), "hu_host_free")
+            self._pinned = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+class BufferList:
+    """Release many buffers together (reference cl_buffer.py:134-158)."""
+
+    def __init__(self, buffers=()):
+        self.buffers = list(buffers)
+
+    def add(self, buff):
+        self.buffers.append(buff)
+
+    def release(self):
+        try:
+            for b in self.buffers:
+                b.release()
+        finally:
+            self.buffers = []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.release()
+
+
+class Tape:
+    """A decoded instruction tape resident in HBM (replaces the reference's program buffer,
+    nodes/program.py:79-84).  Accepted as the `scene` argument of every kernel."""
+
+    def __init__(self, tape):
+        m = _manager.instance
+        self.manager = m
+        t = numpy.ascontiguousarray(tape, dtype=numpy.float32)
+        self.host_tape = t
+        h = ctypes.c_void_p()
+        check(m.lib.hu_tape_create(t.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), t.size, ctypes.byref(h)), "hu_tape_create")
+        self.device_ptr = h.value
+        self.device = m.device
+        n, r, f = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        check(m.lib.hu_tape_info(h, ctypes.byref(n), ctypes.byref(r), ctypes.byref(f)), "hu_tape_info")
+        self.n_instructions, self.n_registers, self.flags = n.value, r.value, f.value
+
+    @property
+    def alive(self):
+        return self.device_ptr is not None
+
+    def release(self):
+        if self.device_ptr:
+            check(self.manager.lib.hu_tape_destroy(self.device_ptr), "hu_tape_destroy")
+            self.device_ptr = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------------------------------
+# Two-deep software pipelines over events.  Semantics pinned by the reference's
+# tests/test_clutil.py:188-248 (restated in tests/test_hip_util_host.py): children are only
+# started after their parent finished, at most two jobs are in flight, LIFO job stack.
+# The level-synchronous drivers in this package do not need them (one launch per level),
+# they exist for callers written against the reference's per-block style.
+# ---------------------------------------------------------------------------------------
+def interleave(initial_jobs, helper1, helper2):
+    """Alternate `enqueue(*job)` / `process_result(event)` between two helpers
+    (reference cl_buffer.py:161-198)."""
+    pending = list(initial_jobs)
+    if not pending:
+        raise AssertionError("There must be at least one job to start")
+
+    class _Slot:
+        def __init__(self, helper):
+            self.helper, self.event = helper, None
+
+        def start(self, job):
+            self.event = self.helper.enqueue(*job)
+
+        def finish(self):
+            return self.helper.process_result(self.event)
+
+    busy, idle = _Slot(helper1), _Slot(helper2)
+    busy.start(pending.pop())
+    while True:
+        had_more = bool(pending)
+        if had_more:
+            idle.start(pending.pop())
+        pending.extend(busy.finish())
+        if not had_more:
+            if not pending:
+                return
+            idle.start(pending.pop())
+        busy, idle = idle, busy
+
+
+def interleave2(job_func, initial_jobs):
+    """Run generator jobs two at a time, switching whenever one yields an event
+    (anything with .wait()); a job's return value is an iterable of follow-up job specs
+    (reference cl_util/__init__.py:8-67)."""
+
+    class _Ready:
+        @staticmethod
+        def wait():
+            pass
+
+    pending = list(initial_jobs)
+    current = other = None  # each: [generator, event]
+    while True:
+        if current is None:
+            if pending:
+                current = [job_func(pending.pop()), _Ready]
+            elif other is None:
+                return
+            else:
+                current, other = other, None
+                continue
+        current[1].wait()
+        try:
+            current[1] = current[0].send(None)
+        except StopIteration as stop:
+            if stop.value is not None:
+                pending.extend(stop.value)
+            current = None
+        else:
+            current, other = other, current

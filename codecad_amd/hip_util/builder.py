@@ -1,0 +1,62 @@
+"""Build libhip_util.so for gfx950 with hipcc (in-tree, next to this file).
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the resulting
+.so travels to the GPU box with the repository snapshot.
+"""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.normpath(os.path.join(HERE, "..", "csrc"))
+INCLUDE = os.path.normpath(os.path.join(HERE, "..", "..", "include"))
+LIB_PATH = os.path.join(HERE, "libhip_util.so")
+SOURCES = ["hip_util.hip"]
+HEADERS = ["interp.hpp", "tape.hpp", "sdf_math.hpp"]
+
+# Strict IEEE arithmetic is part of the contract (DESIGN.md "Canonical arithmetic"):
+# no contraction, no fast-math, correctly rounded sqrt/divide.
+HIPCC_FLAGS = [
+    "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
+    "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
+    "-Wall", "-Wno-unused-function",
+]
+
+
+def find_hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if cand and os.path.exists(cand):
+            return cand
+    return None
+
+
+def is_stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    built = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(INCLUDE, "hip_util.h"), __file__]
+    return any(os.path.getmtime(d) > built for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile if needed; returns the library path.  Raises RuntimeError on failure."""
+    if not force and not is_stale():
+        return LIB_PATH
+    hipcc = find_hipcc()
+    if hipcc is None:
+        raise RuntimeError("hipcc not found: cannot build libhip_util.so (set HIPCC or install ROCm)")
+    tmp = LIB_PATH + ".tmp.%d" % os.getpid()
+    cmd = [hipcc] + HIPCC_FLAGS + ["-I", INCLUDE, "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0:
+        if os.path.exists(tmp):
+            os.unlink(tmp)
+        raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + proc.stderr[-4000:])
+    os.replace(tmp, LIB_PATH)
+    if verbose:
+        print("built", LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    build(force=True, verbose=True)

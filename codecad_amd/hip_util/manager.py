@@ -1,0 +1,274 @@
+"""`hip_util.manager`: the process-wide device context and kernel launcher.
+
+Same shape as the reference's `cl_util.opencl_manager` singleton (reference
+cl_util/opencl_manager.py:87-144): `.queue`, `.k.<kernel>(global_size, local_size, *args,
+wait_for=None) -> Event`.  Differences that follow from the hardware mapping:
+  * nothing is JIT-compiled: the kernels are ahead-of-time gfx950 code in libhip_util.so,
+    so there are no compile units to register and the first launch costs nothing extra;
+  * the device is opened lazily on first use, not at import (one process per GPU: the
+    ordinal comes from LOCAL_RANK, see codecad_amd.dist);
+  * the queue is an in-order HIP stream; `wait_for=` events from other streams are honoured
+    with hipStreamWaitEvent.
+There is no CPU fallback: without the library or without a GPU every entry point raises.
+"""
+import ctypes
+import os
+
+import numpy
+
+from . import _lib
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = _lib.load().hu_last_error()
+        raise HipError("%s failed (%d): %s" % (what or "hip_util call", rc, msg.decode() if msg else "?"))
+
+
+def _ptr(obj):
+    """Device pointer of a Buffer / Tape / torch tensor / int."""
+    if obj is None:
+        return None
+    if hasattr(obj, "device_ptr"):
+        return obj.device_ptr
+    if hasattr(obj, "data_ptr"):
+        return obj.data_ptr()
+    return int(obj)
+
+
+def _float4(corner):
+    a = numpy.zeros(4, dtype=numpy.float32)
+    if isinstance(corner, numpy.ndarray) and corner.dtype.names:
+        vals = [corner[n] for n in corner.dtype.names]
+    else:
+        vals = list(numpy.asarray(corner).reshape(-1))
+    a[:min(4, len(vals))] = vals[:4]
+    return a
+
+
+def _dims3(global_size):
+    try:
+        dims = [int(v) for v in global_size]
+    except TypeError:
+        dims = [int(global_size)]
+    if not 1 <= len(dims) <= 3 or any(d < 1 for d in dims):
+        raise ValueError("global size must be 1-3 positive integers, got %r" % (global_size,))
+    return (ctypes.c_uint32 * 3)(*(dims + [1, 1])[:3])
+
+
+class Stream:
+    """An in-order HIP stream (the reference's command queue)."""
+
+    def __init__(self, manager, handle=None, owned=True):
+        self.manager = manager
+        if handle is None:
+            h = ctypes.c_void_p()
+            check(manager.lib.hu_stream_create(ctypes.byref(h)), "hu_stream_create")
+            handle = h.value
+        self.handle = handle
+        self._owned = owned
+
+    @property
+    def context(self):
+        return self.manager
+
+    def synchronize(self):
+        check(self.manager.lib.hu_stream_synchronize(self.handle), "hu_stream_synchronize")
+
+    finish = synchronize  # pyopencl spelling
+
+
+class _Profile:
+    def __init__(self, event):
+        self._event = event
+
+    @property
+    def start(self):
+        return self._event._ns(self._event._start)
+
+    @property
+    def end(self):
+        return self._event._ns(self._event._stop)
+
+
+class Event:
+    """Completion marker of one enqueued operation: `.wait()`, `.profile.start/.end` (ns)."""
+
+    def __init__(self, manager, stream):
+        self.manager = manager
+        self.stream = stream
+        self._start = manager._new_event()
+        self._stop = manager._new_event()
+        check(manager.lib.hu_event_record(self._start, stream.handle), "hu_event_record")
+        self.profile = _Profile(self)
+
+    def _done(self):
+        check(self.manager.lib.hu_event_record(self._stop, self.stream.handle), "hu_event_record")
+        return self
+
+    def wait(self):
+        check(self.manager.lib.hu_event_synchronize(self._stop), "hu_event_synchronize")
+
+    def elapsed_ms(self):
+        self.wait()
+        ms = ctypes.c_float()
+        check(self.manager.lib.hu_event_elapsed_ms(self._start, self._stop, ctypes.byref(ms)), "hu_event_elapsed_ms")
+        return ms.value
+
+    def _ns(self, ev):
+        self.wait()
+        ms = ctypes.c_float()
+        check(self.manager.lib.hu_event_elapsed_ms(self.manager._epoch, ev, ctypes.byref(ms)), "hu_event_elapsed_ms")
+        return int(ms.value * 1e6)
+
+    def __del__(self):
+        try:
+            self.manager._recycle_event(self._start)
+            self.manager._recycle_event(self._stop)
+        except Exception:
+            pass
+
+
+class _Kernels:
+    """`manager.k.<name>(global_size, local_size, *args, wait_for=None)`.
+
+    Positional arguments are those of the reference OpenCL kernels
+    (grid_eval.cl:2-4,23-25; subdivision.cl:12-16; mass_properties.cl:7-12).
+    `local_size` is accepted and ignored (the reference always passes None; the workgroup
+    shape is chosen from the tape's register count).
+    """
+
+    def __init__(self, manager):
+        self._m = manager
+
+    def _launch(self, wait_for, queue, fn):
+        m = self._m
+        stream = queue or m.queue
+        for ev in (wait_for or ()):
+            if getattr(ev, "stream", None) is not stream and hasattr(ev, "_stop"):
+                check(m.lib.hu_stream_wait_event(stream.handle, ev._stop), "hu_stream_wait_event")
+        ev = Event(m, stream)
+        fn(stream.handle)
+        return ev._done()
+
+    def grid_eval(self, global_size, local_size, scene, box_corner, box_step, output, wait_for=None, queue=None):
+        c, d = _float4(box_corner), _dims3(global_size)
+        return self._launch(wait_for, queue, lambda s: check(self._m.lib.hu_grid_eval(
+            _ptr(scene), c.ctypes.data_as(_lib._f4), float(box_step), d, _ptr(output), s), "hu_grid_eval"))
+
+    def grid_eval_pymcubes(self, global_size, local_size, scene, box_corner, box_step, output, wait_for=None, queue=None):
+        c, d = _float4(box_corner), _dims3(global_size)
+        return self._launch(wait_for, queue, lambda s: check(self._m.lib.hu_grid_eval_pymcubes(
+            _ptr(scene), c.ctypes.data_as(_lib._f4), float(box_step), d, _ptr(output), s), "hu_grid_eval_pymcubes"))
+
+    def subdivision_step(self, global_size, local_size, scene, box_corner, box_step, distance_threshold,
+                         intersecting_counter, list_buffer, wait_for=None, queue=None):
+        c, d = _float4(box_corner), _dims3(global_size)
+        return self._launch(wait_for, queue, lambda s: check(self._m.lib.hu_subdivision_step(
+            _ptr(scene), c.ctypes.data_as(_lib._f4), float(box_step), float(distance_threshold), d,
+            _ptr(intersecting_counter), _ptr(list_buffer), s), "hu_subdivision_step"))
+
+    def mass_properties(self, global_size, local_size, shape, box_corner, box_step, distance_threshold,
+                        sums, intersecting_counter, list_buffer, wait_for=None, queue=None):
+        c, d = _float4(box_corner), _dims3(global_size)
+        return self._launch(wait_for, queue, lambda s: check(self._m.lib.hu_mass_properties(
+            _ptr(shape), c.ctypes.data_as(_lib._f4), float(box_step), float(distance_threshold), d,
+            _ptr(sums), _ptr(intersecting_counter), _ptr(list_buffer), s), "hu_mass_properties"))
+
+
+class HipManager:
+    """Lazy singleton: `.lib`, `.device`, `.queue`, `.k`, `.device_name`."""
+
+    max_register_count = 512  # tape format limit (reference nodes/__init__.py:6)
+
+    def __init__(self):
+        self._lib = None
+        self._queue = None
+        self._epoch = None
+        self._free_events = []
+        self.device = None
+        self.k = _Kernels(self)
+
+    # -- lifecycle -----------------------------------------------------------------------
+    @property
+    def lib(self):
+        if self._lib is None:
+            self._open()
+        return self._lib
+
+    def _open(self, device=None):
+        lib = _lib.load()
+        n = ctypes.c_int()
+        rc = lib.hu_device_count(ctypes.byref(n))
+        if rc != 0 or n.value < 1:
+            msg = lib.hu_last_error()
+            raise HipError("no HIP device available (%s); codecad_amd has no CPU fallback"
+                           % (msg.decode() if msg else "device count 0"))
+        if device is None:
+            device = int(os.environ.get("CODECAD_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+            device %= n.value
+        check(lib.hu_set_device(device), "hu_set_device")
+        self._lib = lib
+        self.device = device
+        self.device_count = n.value
+        self._epoch = self._new_event()
+        check(lib.hu_event_record(self._epoch, None), "hu_event_record")
+
+    def use_device(self, device):
+        """Select the GPU ordinal for this process (before any allocation)."""
+        if self._lib is not None and device != self.device:
+            self._queue = None
+            self._free_events = []
+        self._open(device)
+
+    @property
+    def available(self):
+        try:
+            return self.lib is not None
+        except RuntimeError:
+            return False
+
+    @property
+    def context(self):
+        return self
+
+    @property
+    def queue(self):
+        if self._queue is None:
+            self._queue = Stream(self)
+        return self._queue
+
+    @property
+    def device_name(self):
+        buf = ctypes.create_string_buffer(256)
+        check(self.lib.hu_device_name(self.device, buf, 256), "hu_device_name")
+        return buf.value.decode()
+
+    def new_stream(self):
+        return Stream(self)
+
+    def wrap_stream(self, raw_handle):
+        """Adopt an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)."""
+        return Stream(self, handle=raw_handle, owned=False)
+
+    def synchronize(self):
+        check(self.lib.hu_synchronize(), "hu_synchronize")
+
+    # -- event pool ----------------------------------------------------------------------
+    def _new_event(self):
+        if self._free_events:
+            return self._free_events.pop()
+        h = ctypes.c_void_p()
+        check(self.lib.hu_event_create(ctypes.byref(h)), "hu_event_create")
+        return h.value
+
+    def _recycle_event(self, h):
+        if h is not None and len(self._free_events) < 256:
+            self._free_events.append(h)
+
+
+instance = HipManager()

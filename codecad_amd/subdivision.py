@@ -1,0 +1,173 @@
+"""Adaptive subdivision: skip provably empty / provably full space, return leaf blocks.
+
+Entry points keep the reference's names and return shapes (reference subdivision.py:116-253):
+`calculate_block_sizes(...)` and `subdivision(shape, resolution, overlap_edge_samples,
+grid_size) -> (tape_buffer, max_grid_dims, [(dims, corner, step, int_corner, int_step)])`.
+
+What changed underneath (MI355X-first): the reference walks the hierarchy one block at a
+time -- per block a 4-byte H2D, a launch of <= 128^3 work-items, a blocking 4-byte read and
+a blocking read of the WHOLE 8 MiB index list, then a Python object per survivor
+(subdivision.py:48-113).  Here every LEVEL is one launch over all surviving parents
+(`hu_subdivision_level`), survivors are compacted on the device with a wavefront
+ballot/prefix scan, stay in HBM as the next level's parent list, and the host reads one
+4-byte counter per level.  `subdivision_device()` exposes that form; `subdivision()`
+converts the final list to the reference's tuples.
+"""
+import ctypes
+import math
+
+import numpy
+
+from . import util
+from . import nodes
+from . import hip_util
+from .hip_util import manager as hip_manager, check
+
+
+def calculate_block_sizes(box, dimension, resolution, grid_size, overlap, level_size_multiplier=1):
+    """Hierarchy layout `[(cell_size_in_resolution_units, Vector grid_dims)]`, coarsest first.
+
+    Every level but the top is a full grid_size^dimension grid; a level's cell is covered
+    exactly by the next level's grid; with `overlap` the LEAF grids share their last sample
+    plane with the neighbour (so a leaf cell spans grid_size-1 steps); the top level is
+    cropped to the box (rounded up to `level_size_multiplier`).  Same results as reference
+    subdivision.py:116-166 (tests/test_subdivision_host.py compares against golden tables).
+    """
+    if grid_size % level_size_multiplier != 0:
+        raise ValueError("Grid size must be divisible by level_size_multiplier")
+    if dimension == 2:
+        full = util.Vector(grid_size, grid_size, 1)
+        box = box.flattened()
+    elif dimension == 3:
+        full = util.Vector.splat(grid_size)
+    else:
+        raise AssertionError("dimension must be 2 or 3")
+
+    extent = (box.size() / resolution).applyfunc(math.ceil)  # box size in resolution units
+    longest = extent.max()
+
+    cells = [1]  # cell size per level, finest first
+    while True:
+        shared = 1 if (overlap and len(cells) == 1) else 0
+        coarser = cells[-1] * (grid_size - shared)
+        if coarser >= longest:
+            break
+        cells.append(coarser)
+    shared = 1 if (overlap and len(cells) == 1) else 0  # single level: the top IS the leaf
+
+    top = cells[-1]
+    top_dims = util.Vector(*(
+        util.clamp(util.round_up_to(math.ceil(e / top) + shared, level_size_multiplier), 1, limit)
+        for e, limit in zip(extent, full)))
+    levels = [(c, full) for c in cells[:-1]] + [(top, top_dims)]
+    levels.reverse()
+    return levels
+
+
+class LeafBlocks:
+    """Device-resident result of `subdivision_device`: int32[n,4] leaf corners + metadata."""
+
+    def __init__(self, tape, blocks, count, dims, step, int_step, resolution, origin, level_counts, samples):
+        self.tape = tape
+        self.blocks = blocks            # hip_util.Buffer int32 (capacity, 4); first `count` valid
+        self.count = count
+        self.dims = dims                # Vector: samples per leaf block
+        self.step = step                # sample spacing inside a leaf block (float)
+        self.int_step = int_step
+        self.resolution = resolution
+        self.origin = origin            # Vector: position of integer coordinate (0,0,0)
+        self.level_counts = level_counts  # survivors after each evaluated level
+        self.samples = samples          # SDF evaluations spent
+
+    def int_corners(self):
+        """(count, 3) int32 numpy array, sorted lexicographically (deterministic order)."""
+        if self.count == 0:
+            return numpy.zeros((0, 3), dtype=numpy.int32)
+        host = numpy.empty((self.blocks.shape[0], 4), dtype=numpy.int32)
+        self.blocks.read(out=host)
+        a = host[:self.count, :3]
+        order = numpy.lexsort((a[:, 2], a[:, 1], a[:, 0]))
+        return numpy.ascontiguousarray(a[order])
+
+
+def _level_launch(tape, parents, n_parents, int_step, dims, dimension, resolution, origin, counter, queue,
+                  capacity_hint=None):
+    """Run one level, growing the child list until everything fits.  Returns (children, count)."""
+    lib = hip_manager.lib
+    cells = int(dims[0]) * int(dims[1]) * int(dims[2])
+    box_step = int_step * resolution
+    thr = box_step * math.sqrt(dimension) / 2  # reference subdivision.py:67
+    d = (ctypes.c_uint32 * 3)(int(dims[0]), int(dims[1]), int(dims[2]))
+    o = (ctypes.c_double * 3)(origin.x, origin.y, origin.z)
+    upper = n_parents * cells
+    if capacity_hint is None:
+        # the surface crosses O(cells^(2/3)) cells of a block; x4 headroom, retried if short
+        capacity_hint = max(1 << 14, 4 * n_parents * int(round(cells ** (2.0 / 3.0))))
+    capacity = min(upper, capacity_hint)
+    while True:
+        children = hip_util.Buffer(numpy.int32, (max(capacity, 1), 4), queue=queue)
+        counter.enqueue_fill(0)
+        check(lib.hu_subdivision_level(tape.device_ptr, parents.device_ptr, n_parents, int(int_step), d,
+                                       dimension, float(resolution), o, numpy.float32(box_step),
+                                       numpy.float32(thr), counter.device_ptr, children.device_ptr,
+                                       capacity, queue.handle), "hu_subdivision_level")
+        count = int(counter.read()[0])
+        if count <= capacity:
+            return children, count
+        children.release()
+        capacity = count
+
+
+def subdivision_device(shape, resolution, overlap_edge_samples=True, grid_size=None, queue=None):
+    """Level-synchronous subdivision that leaves the leaf list on the GPU -> LeafBlocks."""
+    if grid_size is None:
+        grid_size = 128
+    assert resolution > 0, "Non-positive resolution makes no sense"
+    assert grid_size > 1, "Grid needs to be at least 2x2x2"
+    assert grid_size <= 256, "Grid size > 256 would cause overflows in returned index list."
+    queue = queue or hip_manager.queue
+    tape = nodes.make_program_buffer(shape)
+    dimension = shape.dimension()
+    box = shape.bounding_box().expanded_additive(resolution / 2)
+    if dimension == 2:
+        box = box.flattened()
+    levels = calculate_block_sizes(box, dimension, resolution, grid_size, overlap_edge_samples)
+
+    parents = hip_util.Buffer(numpy.int32, (1, 4), queue=queue)
+    parents.enqueue_write(numpy.zeros((1, 4), dtype=numpy.int32))
+    count, level_counts, samples = 1, [], 0
+    counter = hip_util.Buffer(numpy.uint32, 1, queue=queue)
+    for int_step, dims in levels[:-1]:  # the leaf level is left to the consumer (reference :96-111)
+        samples += count * int(dims[0]) * int(dims[1]) * int(dims[2])
+        children, count = _level_launch(tape, parents, count, int_step, dims, dimension, resolution, box.a,
+                                        counter, queue)
+        parents.release()
+        parents = children
+        level_counts.append(count)
+        if count == 0:
+            break
+    counter.release()
+    leaf_int_step, leaf_dims = levels[-1]
+    return LeafBlocks(tape, parents, count, leaf_dims, leaf_int_step * resolution, leaf_int_step, resolution,
+                      box.a, level_counts, samples)
+
+
+def subdivision(shape, resolution, overlap_edge_samples=True, grid_size=None):
+    """Reference-shaped result: `(tape_buffer, max_grid_dims, final_blocks)`.
+
+    `final_blocks` is a list of `(grid_dims, corner, spacing, int_corner, int_spacing)`;
+    `corner = int_corner * resolution + origin` with origin the (expanded) bounding box
+    corner, exactly as reference subdivision.py:96-111.  Blocks come sorted by integer
+    corner (the reference's order depends on atomics and traversal and is unspecified).
+    """
+    leaves = subdivision_device(shape, resolution, overlap_edge_samples, grid_size)
+    if leaves.int_step == 1 and not leaves.level_counts:
+        # the whole shape fits one block (reference subdivision.py:222-227)
+        return (leaves.tape, leaves.dims,
+                [(leaves.dims, leaves.origin, resolution, util.Vector(0, 0, 0), 1)])
+    blocks = []
+    for ix, iy, iz in leaves.int_corners().tolist():
+        ip = util.Vector(ix, iy, iz)
+        blocks.append((leaves.dims, ip * resolution + leaves.origin, leaves.step, ip, leaves.int_step))
+    leaves.blocks.release()
+    return leaves.tape, leaves.dims, blocks

@@ -1,0 +1,136 @@
+/* include/hip_util.h -- C ABI of libhip_util.so, the MI355X (gfx950) replacement for the
+ * device half of bluecube/codecad's hot path.
+ *
+ * What it replaces (paths relative to /root/reference/codecad/):
+ *   - cl_util/opencl_manager.py:73-85   `opencl_manager.k.<kernel>(global, local, *args)`
+ *   - cl_util/cl_buffer.py:9-131        `Buffer` (device allocation + host transfers)
+ *   - nodes/program.py:79-84            `make_program_buffer` (tape upload)
+ *   - grid_eval.cl, subdivision.cl, mass_properties.cl and the generated evaluate()
+ *
+ * Conventions: every function returns 0 on success or a negative hu_status code; the
+ * message for the last failure on the calling thread is hu_last_error().  All pointers
+ * named *_dev are device pointers (from hu_malloc or any hipMalloc-compatible allocator,
+ * e.g. a torch tensor's data_ptr()).  `stream` is a hipStream_t passed as void*
+ * (NULL = the legacy default stream).  Launch functions are asynchronous and perform no
+ * allocation or synchronisation, so they can be captured into a hipGraph.
+ * The caller owns every handle; there are no hidden global allocations.
+ */
+#ifndef HIP_UTIL_H
+#define HIP_UTIL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HU_ABI_VERSION 1
+
+enum hu_status {
+    HU_OK = 0,
+    HU_ERR_HIP = -1,        /* a HIP runtime call failed (message has hipGetErrorString) */
+    HU_ERR_BAD_TAPE = -2,   /* malformed instruction tape */
+    HU_ERR_BAD_ARG = -3,    /* NULL pointer, zero/oversized dims, ... */
+    HU_ERR_NO_DEVICE = -4,  /* no gfx950 device / no HIP runtime */
+    HU_ERR_UNSUPPORTED = -5 /* e.g. tape needs more value registers than fit in LDS */
+};
+
+typedef struct hu_tape_s* hu_tape; /* opaque: decoded program resident in HBM */
+
+/* ---- runtime (replaces OpenCLManager.__init__, opencl_manager.py:88-98) ---------------- */
+int hu_abi_version(void);
+const char* hu_last_error(void);
+int hu_device_count(int* count);
+int hu_set_device(int ordinal);
+int hu_device_name(int ordinal, char* buf, size_t buflen);
+int hu_synchronize(void);
+
+/* ---- memory (replaces cl_util.Buffer / pyopencl.enqueue_copy, cl_buffer.py:31-94) ------ */
+int hu_malloc(void** out_dev, size_t bytes);
+int hu_free(void* dev); /* NULL is a no-op */
+int hu_host_alloc(void** out_host, size_t bytes); /* pinned host memory */
+int hu_host_free(void* host);
+int hu_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream);
+int hu_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream);
+int hu_memcpy_d2d(void* dst_dev, const void* src_dev, size_t bytes, void* stream);
+int hu_memset(void* dst_dev, int value, size_t bytes, void* stream);
+
+/* ---- streams and events (replaces the OOO queue + pyopencl.Event, wait_for=) ----------- */
+int hu_stream_create(void** out_stream);
+int hu_stream_destroy(void* stream);
+int hu_stream_synchronize(void* stream);
+int hu_stream_wait_event(void* stream, void* event);
+int hu_event_create(void** out_event);
+int hu_event_destroy(void* event);
+int hu_event_record(void* event, void* stream);
+int hu_event_synchronize(void* event);
+int hu_event_elapsed_ms(void* start, void* stop, float* out_ms);
+
+/* ---- tape (replaces nodes.make_program_buffer, nodes/program.py:79-84) ------------------ */
+/* `tape`: the reference float32 instruction tape (opcode*512+register words + params,
+ * nodes/program.py:55-71).  Validated, pre-decoded and uploaded; synchronous. */
+int hu_tape_create(const float* tape, size_t n_floats, hu_tape* out);
+int hu_tape_destroy(hu_tape t);
+/* n_instructions, value registers used, flags bit0 = a rounded union/intersection is present */
+int hu_tape_info(hu_tape t, int* n_instructions, int* n_registers, int* flags);
+
+/* ---- reference-shaped kernels: same arguments as the OpenCL kernels --------------------- */
+/* grid_eval.cl:23-25  out_dev: float4[dims[0]*dims[1]*dims[2]], index z + sz*(y + sy*x) */
+int hu_grid_eval(hu_tape t, const float corner[4], float step, const uint32_t dims[3],
+                 void* out_dev, void* stream);
+/* grid_eval.cl:2-4    out_dev: float[...], index z + (x + (sy-1-y)*sx)*sz */
+int hu_grid_eval_pymcubes(hu_tape t, const float corner[4], float step, const uint32_t dims[3],
+                          void* out_dev, void* stream);
+/* subdivision.cl:12-16  counter_dev: uint32 (caller zeroes it); list_dev: uchar4[cells] */
+int hu_subdivision_step(hu_tape t, const float corner[4], float step, float threshold,
+                        const uint32_t dims[3], uint32_t* counter_dev, void* list_dev,
+                        void* stream);
+/* mass_properties.cl:7-12  sum_dev: uint32[10] xx,xy,xz,x,yy,yz,y,zz,z,n (caller zeroes) */
+int hu_mass_properties(hu_tape t, const float corner[4], float step, float threshold,
+                       const uint32_t dims[3], uint32_t* sum_dev, uint32_t* counter_dev,
+                       void* list_dev, void* stream);
+
+/* ---- level-batched kernels (one launch per subdivision LEVEL instead of one per block) -- */
+/* Dense grid sharded along x: evaluates x in [x0, x0+x_count) of the logical grid `dims`
+ * and writes them at out_dev (which points at the FIRST voxel of the slab).  layout 0 =
+ * float4 grid_eval, 1 = float grid_eval_pymcubes (then out_dev is the whole-grid base). */
+int hu_grid_eval_slab(hu_tape t, const float corner[4], float step, const uint32_t dims[3],
+                      uint32_t x0, uint32_t x_count, int layout, void* out_dev, void* stream);
+
+/* Leaf blocks of subdivision() (subdivision.py:96-111): blocks_dev = int32[4]*n_blocks
+ * integer corners; float corner = int*resolution + origin in fp64, cast once
+ * (util/geometry.py:98-99).  out_dev: n_blocks consecutive grids of `dims`. */
+int hu_grid_eval_blocks(hu_tape t, const int32_t* blocks_dev, uint32_t n_blocks,
+                        double resolution, const double origin[3], float step,
+                        const uint32_t dims[3], int layout, void* out_dev, void* stream);
+
+/* One level of subdivision() for ALL parents at once (subdivision.py:48-113).
+ * parents_dev: int32[4]*n_parents integer box corners; per parent the sample corner is
+ * (int_corner + int_step/2)*resolution + origin in fp64 (z unshifted when dimension==2),
+ * threshold = step*sqrt(dimension)/2 is computed by the caller.  Ambiguous cells are
+ * appended (wavefront ballot scan, one atomic per workgroup) to children_dev as
+ * int32[4] = parent + (x,y,z)*int_step, ready to be the next level's parents; the 4th
+ * component is a caller tag (e.g. an object id) copied from parent to child untouched.
+ * counter_dev (uint32, caller zeroes) ends up as the number of ambiguous cells even when it
+ * exceeds `capacity` (extra cells are dropped: the caller re-runs with a larger list). */
+int hu_subdivision_level(hu_tape t, const int32_t* parents_dev, uint32_t n_parents,
+                         int32_t int_step, const uint32_t dims[3], int dimension,
+                         double resolution, const double origin[3], float step, float threshold,
+                         uint32_t* counter_dev, int32_t* children_dev, uint32_t capacity,
+                         void* stream);
+
+/* One level of mass_properties() for ALL parents (mass_properties.py:69-157).
+ * parents_dev: double[4]*n_parents box corners; sample corner = corner + s/2 (fp64), cast
+ * once.  sums_dev: uint32[10]*n_parents (caller zeroes), same order as hu_mass_properties.
+ * children_dev: double[4] = (i,j,k)*s + corner (fp64), 4th component = the parent's tag,
+ * appended like above. */
+int hu_mass_properties_level(hu_tape t, const double* parents_dev, uint32_t n_parents, double s,
+                             const uint32_t dims[3], float step, float threshold,
+                             uint32_t* sums_dev, uint32_t* counter_dev, double* children_dev,
+                             uint32_t capacity, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIP_UTIL_H */

@@ -1,0 +1,47 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden_tapes():
+    with open(os.path.join(ROOT, "tests", "golden", "ref_tapes.json")) as f:
+        data = json.load(f)
+    out = {}
+    for s in data["shapes"]:
+        s = dict(s)
+        s["tape"] = np.array(s["tape_u32"], dtype=np.uint32).view(np.float32)
+        s["bbox_a"] = [float(v) for v in s["bbox_a"]]
+        s["bbox_b"] = [float(v) for v in s["bbox_b"]]
+        out[s["name"]] = s
+    return out
+
+
+@pytest.fixture(scope="session")
+def golden_tapes():
+    return load_golden_tapes()
+
+
+@pytest.fixture(scope="session")
+def golden_block_sizes():
+    with open(os.path.join(ROOT, "tests", "golden", "ref_block_sizes.json")) as f:
+        return json.load(f)["rows"]
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """The opened HIP manager.  On a GPU box a missing library or device is a FAILURE."""
+    from codecad_amd import hip_util
+    hip_util.manager.lib  # raises loudly if the extension or the device is missing
+    return hip_util.manager
