@@ -10,7 +10,7 @@ import ctypes
 
 import numpy
 
-from . import manager as _manager
+from .manager import instance as _instance
 from .manager import check, Event
 
 
@@ -39,7 +39,7 @@ class Buffer:
         return numpy.dtype([(n, scalar) for n in "xyzw"])
 
     def __init__(self, dtype, shape, mem_flags=None, queue=None):
-        m = _manager.instance
+        m = _instance
         self.manager = m
         self.queue = queue if queue is not None else m.queue
         self.dtype = numpy.dtype(dtype)
@@ -189,7 +189,7 @@ class Tape:
     nodes/program.py:79-84).  Accepted as the `scene` argument of every kernel."""
 
     def __init__(self, tape):
-        m = _manager.instance
+        m = _instance
         self.manager = m
         t = numpy.ascontiguousarray(tape, dtype=numpy.float32)
         self.host_tape = t
