@@ -478,7 +478,7 @@ int hu_tape_create(const float* tape, size_t n, hu_tape* out)
     std::string err = sdf::decode_tape(tape, n, d);
     if (!err.empty()) return fail(HU_ERR_BAD_TAPE, "malformed tape: " + err);
     hu_tape_s* t = new hu_tape_s();
-    t->n_instr = (int)d.recs.size() - 2;
+    t->n_instr = (int)d.recs.size() - sdf::kTapePadding;
     t->n_regs = d.n_regs;
     t->flags = d.direction_feeds_distance ? 1 : 0;
     hipError_t e = hipMalloc((void**)&t->recs_dev, d.recs.size() * sizeof(Rec));

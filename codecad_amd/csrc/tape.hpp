@@ -38,6 +38,7 @@ enum Op : uint32_t {
 
 constexpr int kRefRegisterCount = 512;  // reference nodes/__init__.py:6
 constexpr int kVariableParams = -1;
+constexpr int kTapePadding = 8;         // >= interp.hpp kFetchGroup
 
 // (parameter count, arity) per opcode -- reference nodes/node.py:15-53
 struct OpInfo { const char* name; int params; int arity; };
@@ -167,11 +168,10 @@ inline std::string decode_tape(const float* tape, size_t n, DecodedTape& out)
     }
     if (!returned) return "tape does not end with _return";
     if (out.extra.empty()) out.extra.push_back(0.0f);
-    // Two zero records of padding: the interpreter prefetches one record ahead.
+    // Zero (= _return) records of padding: the interpreter fetches records in groups.
     Rec pad;
     std::memset(&pad, 0, sizeof(pad));
-    out.recs.push_back(pad);
-    out.recs.push_back(pad);
+    for (int i = 0; i < kTapePadding; ++i) out.recs.push_back(pad);
     return "";
 }
 

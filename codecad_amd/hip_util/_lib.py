@@ -72,7 +72,7 @@ def load():
     if _lib is not None:
         return _lib
     try:
-        path = _build.build()
+        path = os.environ.get("CODECAD_AMD_LIB") or _build.build()
     except RuntimeError:
         if os.path.exists(_build.LIB_PATH):
             path = _build.LIB_PATH  # no hipcc here, but a prebuilt library travelled with us

@@ -20,6 +20,17 @@ HIPCC_FLAGS = [
     "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
     "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
     "-Wall", "-Wno-unused-function",
+    # The tape dispatch loop is wave-uniform control flow (scalar branches).  By default the
+    # AMDGPU backend still runs StructurizeCFG over it and turns the opcode switch into a
+    # chain of flag-guarded blocks (~37 SALU + phi copies per tape instruction, measured
+    # with rocprofv3: profiles/r01_*).  Skipping uniform regions keeps it a compare tree +
+    # one branch back.  Every op inlined into the loop is written branch-free (selects) and
+    # ops with divergent branches are __noinline__, so the loop region IS uniform.
+    "-mllvm", "-structurizecfg-skip-uniform-regions",
+    # Keep the grouped scalar loads of the tape records at the top of the dispatch loop (the
+    # interpreter issues a whole fetch group, then waits once); MachineSink would push each
+    # load down to its first use and re-expose the scalar-cache latency per instruction.
+    "-mllvm", "-disable-machine-sink",
 ]
 
 
@@ -38,15 +49,23 @@ def is_stale():
     return any(os.path.getmtime(d) > built for d in deps)
 
 
-def build(force=False, verbose=False):
-    """Compile if needed; returns the library path.  Raises RuntimeError on failure."""
+def build(force=False, verbose=False, extra_flags=(), out_path=None):
+    """Compile if needed; returns the library path.  Raises RuntimeError on failure.
+    `extra_flags`/`out_path` build an experimental variant next to the default library
+    (selected at run time with CODECAD_AMD_LIB=<path>)."""
+    if out_path is not None:
+        return _compile(out_path, list(extra_flags), verbose)
     if not force and not is_stale():
         return LIB_PATH
+    return _compile(LIB_PATH, [], verbose)
+
+
+def _compile(LIB_PATH, extra_flags, verbose):
     hipcc = find_hipcc()
     if hipcc is None:
         raise RuntimeError("hipcc not found: cannot build libhip_util.so (set HIPCC or install ROCm)")
     tmp = LIB_PATH + ".tmp.%d" % os.getpid()
-    cmd = [hipcc] + HIPCC_FLAGS + ["-I", INCLUDE, "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+    cmd = [hipcc] + HIPCC_FLAGS + extra_flags + ["-I", INCLUDE, "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
     proc = subprocess.run(cmd, capture_output=True, text=True)
     if proc.returncode != 0:
         if os.path.exists(tmp):
