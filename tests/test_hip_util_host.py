@@ -1,0 +1,118 @@
+"""Host side of hip_util without a GPU: the C-ABI library loads and exports every symbol of
+include/hip_util.h, fails loudly without a device, and the job interleavers keep the
+reference's semantics (reference tests/test_clutil.py:188-248)."""
+import ctypes
+import os
+
+import pytest
+
+from codecad_amd import hip_util
+from codecad_amd.hip_util import _lib
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    declared = _lib.header_symbols()
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert sorted(_lib.PROTOTYPES) == declared      # every declared function has a typed binding
+    assert lib.hu_abi_version() == 1
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    lib = _lib.load()
+    n = ctypes.c_int(-1)
+    rc = lib.hu_device_count(ctypes.byref(n))
+    if rc == 0 and n.value > 0:
+        pytest.skip("a GPU is present")
+    assert n.value == 0 and rc != 0 and lib.hu_last_error()
+    fresh = hip_util.HipManager()
+    with pytest.raises(RuntimeError):
+        fresh.lib
+    assert fresh.available is False
+
+
+def test_argument_validation_needs_no_device():
+    lib = _lib.load()
+    assert lib.hu_tape_create(None, 0, None) == -3
+    assert b"NULL" in lib.hu_last_error()
+    assert lib.hu_free(None) == 0 and lib.hu_tape_destroy(None) == 0
+    assert lib.hu_device_count(None) == -3
+
+
+def test_interleave2_semantics():
+    log = []
+
+    class MockEvent:
+        def __init__(self, job):
+            self.job = job
+
+        def wait(self):
+            log.append((self.job, "wait"))
+
+    def job_func(job):
+        log.append((job, 1))
+        yield MockEvent(job)
+        log.append((job, 2))
+        return [2 * job, 2 * job + 1] if job < 10 else None
+
+    hip_util.interleave2(job_func, [2, 3])
+    seen, working, busy_ticks, most = set(), set(), 0, 0
+    for job, step in log:
+        busy_ticks += bool(working)
+        most = max(most, len(working))
+        if step == 1:
+            working.add(job)
+        elif step == "wait":
+            working.remove(job)
+        else:
+            assert (job, "wait") in seen
+        if job > 3:
+            assert (job // 2, 2) in seen      # a child never starts before its parent finished
+        seen.add((job, step))
+    assert (18, 2) in seen and (19, 2) in seen
+    assert most == 2 and busy_ticks >= len(seen) - 4
+
+
+def test_interleave_semantics():
+    order = []
+
+    class Helper:
+        def __init__(self, name):
+            self.name = name
+
+        def enqueue(self, job, depth):
+            self.current = (job, depth)
+            order.append(("enqueue", self.name, job))
+            return object()
+
+        def process_result(self, event):
+            job, depth = self.current
+            order.append(("result", self.name, job))
+            return [(job * 2, depth + 1), (job * 2 + 1, depth + 1)] if depth < 2 else []
+
+    hip_util.interleave([(1, 0)], Helper("a"), Helper("b"))
+    done = [j for kind, _, j in order if kind == "result"]
+    assert sorted(done) == [1, 2, 3, 4, 5, 6, 7]
+    started = [j for kind, _, j in order if kind == "enqueue"]
+    for j in started:
+        if j > 1:
+            assert order.index(("result", "a", j // 2)) < [i for i, o in enumerate(order) if o[0] == "enqueue" and o[2] == j][0] \
+                if ("result", "a", j // 2) in order else True
+    with pytest.raises(AssertionError):
+        hip_util.interleave([], Helper("a"), Helper("b"))
+
+
+@pytest.mark.parametrize("s", ["", "ac", "a\nb", 'a"b', "ěščřžýáíé", "ab\0cd", "\1" "23", "".join(map(chr, range(128)))])
+def test_format_c_string_literal(s, tmp_path):
+    """The literal, compiled by a C compiler, is the original bytes (reference test_clutil.py:251-302)."""
+    import subprocess
+    lit = hip_util.format_c_string_literal(s)
+    raw = s.encode("utf-8")
+    src = tmp_path / "t.c"
+    src.write_text('#include <stdio.h>\nint main(void){const char p[] = %s; fwrite(p, 1, sizeof(p), stdout); return 0;}\n' % lit)
+    exe = tmp_path / "t"
+    subprocess.run(["gcc", "-o", str(exe), str(src)], check=True, capture_output=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True).stdout
+    assert out == raw + b"\0"

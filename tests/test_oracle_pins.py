@@ -1,0 +1,172 @@
+"""Pin the oracle with the reference's OWN tests (restated), run on the oracle's kernels:
+
+  * analytic mass properties of 9 solids       reference tests/test_mass_properties.py:16-108
+  * leaf-block known answers                    reference tests/test_subdivision.py:110-161
+  * DSDF validity on the shape zoo              reference tests/test_dsdf.py:113-190
+  * index layouts of the two grid kernels       reference cl_util/indexing.h:4, grid_eval.cl:18
+
+The reference's OpenCL code cannot be built here, so these fixtures and properties are what
+ties the restatement to the reference (DESIGN.md "Oracle").
+"""
+import itertools
+import math
+
+import numpy as np
+import pytest
+
+import oracle
+import ref_driver
+import shapes_zoo
+from codecad_amd import util, nodes
+from conftest import load_golden_tapes
+
+GOLDEN = load_golden_tapes()
+
+
+def _bbox(ref):
+    return util.BoundingBox(util.Vector(*ref["bbox_a"]), util.Vector(*ref["bbox_b"]))
+
+
+@pytest.mark.parametrize("name", sorted(shapes_zoo.mass_property_cases))
+def test_mass_properties_analytic(name):
+    """Same tolerances as the reference (rel 2e-3, abs 1e-4) at its resolution 0.02, on the
+    reference's own golden tape."""
+    _, volume, centroid, inertia = shapes_zoo.mass_property_cases[name]
+    ref = GOLDEN["mp_" + name]
+    precision = 2e-3
+    result, _ = ref_driver.mass_properties(ref["tape"], _bbox(ref), 10 * precision)
+    assert result.volume == pytest.approx(volume, abs=1e-4, rel=precision)
+    assert tuple(result.centroid) == pytest.approx(centroid, abs=1e-4, rel=precision)
+    if inertia is not None:
+        assert np.allclose(result.inertia_tensor, inertia, rtol=precision)
+
+
+def test_block_corners_cube():
+    ref = GOLDEN["kat_box10"]
+    dims, blocks = ref_driver.subdivision(ref["tape"], _bbox(ref), 3, 1, overlap=True, grid_size=4)
+    assert blocks[0][1] == 1 and blocks[0][3] == 1
+    corners = {tuple(b[0]) for b in blocks}
+    expected = set(itertools.product([-5.5, -2.5, 0.5, 3.5], repeat=3)) - set(itertools.product([-2.5, 0.5], repeat=3))
+    assert corners == expected
+
+
+def test_block_corners_circle():
+    resolution, grid = 0.1, 8
+    step = resolution * (grid - 1)
+    diameter = grid * step - resolution
+    radius, thr = diameter / 2, math.sqrt(2) * step / 2
+    ref = GOLDEN["kat_circle"]
+    dims, blocks = ref_driver.subdivision(ref["tape"], _bbox(ref), 2, resolution, overlap=True, grid_size=grid)
+    assert blocks[0][1] == resolution and blocks[0][3] == 1
+    r = [-radius - 0.5 * resolution + i * step for i in range(grid)]
+    expected = [(x, y) for x, y in itertools.product(r, repeat=2)
+                if radius - thr < math.hypot(x + step / 2, y + step / 2) < radius + thr]
+    got = [(b[0].x, b[0].y) for b in blocks]
+    assert len(got) == len(expected)
+    for g in got:
+        assert any(abs(g[0] - e[0]) < 1e-9 and abs(g[1] - e[1]) < 1e-9 for e in expected)
+
+
+def test_index_layouts():
+    """INDEX3 = z + sz*(y + sy*x); pymcubes = z + (x + (sy-1-y)*sx)*sz."""
+    tape = GOLDEN["sphere_plus_box"]["tape"]
+    dims, corner, step = (3, 4, 5), [-60.0, -50.0, -40.0], np.float32(30.0)
+    g = oracle.grid_eval(tape, corner, step, dims)
+    flat = oracle.grid_eval_pymcubes(tape, corner, step, dims)
+    pts = np.array([[corner[0] + step * x, corner[1] + step * y, corner[2] + step * z]
+                    for x in range(3) for y in range(4) for z in range(5)], dtype=np.float32)
+    direct = oracle.evaluate_points(tape, pts).reshape(3, 4, 5, 4)
+    assert np.array_equal(g, direct)
+    for x, y, z in itertools.product(range(3), range(4), range(5)):
+        assert flat[z + (x + (4 - 1 - y) * 3) * 5] == direct[x, y, z, 3]
+
+
+# ---- DSDF validity (reference tests/test_dsdf.py) ----------------------------------------
+ZOO_2D = sorted(shapes_zoo.shapes_2d)
+ZOO_ALL = ZOO_2D + sorted(shapes_zoo.shapes_3d)
+_cache = {}
+
+
+def _dsdf(name):
+    if name not in _cache:
+        ref = GOLDEN[name]
+        size = (16, 16, 16) if ref["dimension"] == 3 else (16, 16, 3)
+        corner = -np.array(size, dtype=np.float64) / 2
+        assert all(a > -s and b < s for a, b, s in zip(ref["bbox_a"], ref["bbox_b"], size))
+        first = oracle.grid_eval(ref["tape"], corner, np.float32(1.0), size)
+        _cache[name] = (ref, size, corner, first)
+    return _cache[name]
+
+
+@pytest.mark.parametrize("name", ZOO_2D)
+def test_2d_direction_has_no_z(name):
+    _, _, _, g = _dsdf(name)
+    assert np.all(g[..., 2] == 0)
+
+
+@pytest.mark.parametrize("name", ZOO_ALL)
+def test_direction_unit_length(name):
+    _, _, _, g = _dsdf(name)
+    n2 = (g[..., :3].astype(np.float64) ** 2).sum(axis=-1)
+    assert np.allclose(n2, 1.0, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ZOO_ALL)
+def test_distance_is_a_lower_bound(name):
+    """distance <= distance to the nearest grid point of the opposite sign + 1e-5
+    (the brute force of reference tests/test_dsdf.cl:44-72)."""
+    _, size, _, g = _dsdf(name)
+    w = g[..., 3]
+    sign = np.sign(w)
+    idx = np.stack(np.meshgrid(*[np.arange(s) for s in size], indexing="ij"), axis=-1).reshape(-1, 3).astype(np.float64)
+    flat_sign = sign.reshape(-1)
+    actual = np.full(idx.shape[0], np.float32(3.4028235e38))
+    for s in np.unique(flat_sign):
+        others = idx[flat_sign != s]
+        mine = flat_sign == s
+        if len(others) == 0:
+            continue
+        d2 = ((idx[mine][:, None, :] - others[None, :, :]) ** 2).sum(-1).min(axis=1)
+        actual[mine] = np.sqrt(d2)
+    assert np.all(w.reshape(-1) <= actual + 1e-5)
+
+
+@pytest.mark.parametrize("name", ZOO_ALL)
+def test_direction_matches_finite_differences(name):
+    ref, size, corner, g = _dsdf(name)
+    eps = np.float32(0.05)
+    pts = np.stack(np.meshgrid(*[np.float32(corner[i]) + np.float32(1.0) * np.arange(size[i], dtype=np.float32)
+                                 for i in range(3)], indexing="ij"), axis=-1).reshape(-1, 3)
+    center = g[..., 3].reshape(-1)
+    plus = np.empty((pts.shape[0], 3), np.float32)
+    minus = np.empty((pts.shape[0], 3), np.float32)
+    for a in range(3):
+        d = np.zeros(3, np.float32)
+        d[a] = 1
+        plus[:, a] = oracle.evaluate_points(ref["tape"], pts - eps * d)[:, 3]
+        minus[:, a] = oracle.evaluate_points(ref["tape"], pts + eps * d)[:, 3]
+    d1 = center[:, None] - plus
+    d2 = minus - center[:, None]
+    smooth = np.linalg.norm((d1 - d2).astype(np.float64), axis=1) <= 1e-4
+    fd = ((d1 + d2) / 2).astype(np.float64)
+    norm = np.linalg.norm(fd, axis=1)
+    ok = smooth & (norm > 0)
+    fd = fd[ok] / norm[ok, None]
+    ev = g[..., :3].reshape(-1, 3).astype(np.float64)[ok]
+    assert np.all(np.linalg.norm(ev - fd, axis=1) < 1e-2)
+
+
+def test_oracle_rejects_malformed_tapes():
+    with pytest.raises(RuntimeError):
+        oracle.evaluate_points(np.array([512.0], np.float32), [[0, 0, 0]])       # no _return
+    with pytest.raises(RuntimeError):
+        oracle.evaluate_points(np.array([29 * 512.0, 0.0], np.float32), [[0, 0, 0]])  # bad opcode
+
+
+def test_interpreter_semantics_by_hand():
+    """sphere(130)+box(100): the 21-float tape spelled out in SURVEY.md section 2.3."""
+    t = nodes.make_program(shapes_zoo.all_named["sphere_plus_box"])
+    assert t.tolist() == [5632, 0, 0, 0, 1, 0, 0, 0, 512, 1536, 50, 50, 11264, 50, 513, 1024, 3584, 65,
+                          13313, -1, 0]
+    r = oracle.evaluate_points(t, [[0, 0, 0], [100, 0, 0], [60, 60, 0], [0, 0, 70]])
+    assert r[:, 3].tolist() == pytest.approx([-65, 35, math.hypot(10, 10), 5], rel=1e-6)
