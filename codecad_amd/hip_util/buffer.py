@@ -29,6 +29,30 @@ class map_flags:
     WRITE_INVALIDATE_REGION = 4
 
 
+class _PinnedBlock:
+    """Owns one hipHostMalloc allocation; freed when the last numpy view of it dies, so an
+    array returned by Buffer.read() stays valid after the Buffer itself is gone."""
+
+    def __init__(self, manager, nbytes):
+        self.manager = manager
+        p = ctypes.c_void_p()
+        check(manager.lib.hu_host_alloc(ctypes.byref(p), max(nbytes, 1)), "hu_host_alloc")
+        self.ptr = p.value
+
+    def view(self, dtype, nitems, shape, nbytes):
+        raw = (ctypes.c_char * max(nbytes, 1)).from_address(self.ptr)
+        raw._owner = self  # numpy keeps `raw` as the array's base, `raw` keeps us
+        return numpy.frombuffer(raw, dtype=dtype, count=nitems).reshape(shape)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self.manager.lib.hu_host_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
 class Buffer:
     @staticmethod
     def dual_dtype(scalar):
@@ -60,11 +84,8 @@ class Buffer:
     # -- host shadow ---------------------------------------------------------------------
     def create_host_side_array(self):
         """Allocate the pinned shadow array `self.array` (uninitialised)."""
-        p = ctypes.c_void_p()
-        check(self.manager.lib.hu_host_alloc(ctypes.byref(p), max(self.size, 1)), "hu_host_alloc")
-        self._pinned = p.value
-        raw = (ctypes.c_char * max(self.size, 1)).from_address(p.value)
-        self.array = numpy.frombuffer(raw, dtype=self.dtype, count=self.nitems).reshape(self.shape)
+        self._pinned = _PinnedBlock(self.manager, self.size)
+        self.array = self._pinned.view(self.dtype, self.nitems, self.shape, self.size)
 
     def _host(self, array):
         if array is not None:
@@ -144,15 +165,13 @@ class Buffer:
         return self.nitems
 
     def release(self):
-        """Free device and pinned memory now (idempotent)."""
+        """Free the device memory now (idempotent).  The pinned shadow is freed when the last
+        array that views it is gone."""
         lib = self.manager.lib
         if self.device_ptr:
             check(lib.hu_free(self.device_ptr), "hu_free")
             self.device_ptr = None
-        if self._pinned:
-            self.array = None
-            check(lib.hu_host_free(self._pinned), "hu_host_free")
-            self._pinned = None
+        self._pinned = None
 
     def __del__(self):
         try:

@@ -1,0 +1,271 @@
+"""GPU drivers (level-batched kernels, torch interop, full-size properties) against the oracle."""
+import ctypes
+import math
+
+import numpy as np
+import pytest
+
+import oracle
+import ref_driver
+import shapes_zoo
+from codecad_amd import util
+from conftest import load_golden_tapes
+
+pytestmark = pytest.mark.gpu
+GOLDEN = load_golden_tapes()
+
+
+def _bbox(ref):
+    return util.BoundingBox(util.Vector(*ref["bbox_a"]), util.Vector(*ref["bbox_b"]))
+
+
+def _tape_shape(name):
+    from codecad_amd.shapes import TapeShape
+    ref = GOLDEN[name]
+    return TapeShape(ref["tape"], _bbox(ref), float(ref["feature_size"]), ref["dimension"])
+
+
+SUBDIV_CASES = [("sponge2", 1 / 54, 4, True), ("sponge2", 1 / 27, 8, False), ("csg_example", 2.0, 8, True),
+                ("kat_box10", 1, 4, True), ("kat_circle", 0.1, 8, True), ("gear", 0.05, 8, True),
+                ("torus", 0.1, 16, True), ("sponge4", 1 / 512, 16, True), ("planetary", 1.0, 8, True)]
+
+
+@pytest.mark.parametrize("name, resolution, grid, overlap", SUBDIV_CASES)
+def test_level_batched_subdivision_equals_per_block_reference_traversal(hip, name, resolution, grid, overlap):
+    """One launch per LEVEL (GPU) == the reference's block-by-block traversal run on the oracle:
+    identical leaf-block sets (integer corners), identical leaf dims."""
+    import codecad_amd as cc
+    ref = GOLDEN[name]
+    want_dims, want = ref_driver.subdivision(ref["tape"], _bbox(ref), ref["dimension"], resolution, overlap, grid)
+    leaves = cc.subdivision.subdivision_device(_tape_shape(name), resolution, overlap, grid)
+    got = leaves.int_corners()
+    assert tuple(int(d) for d in leaves.dims) == tuple(int(d) for d in want_dims)
+    assert leaves.count == len(want)
+    assert sorted(map(tuple, got.tolist())) == sorted(b[2] for b in want)
+    # and through the reference-shaped return value
+    _, dims, blocks = cc.subdivision.subdivision(_tape_shape(name), resolution, overlap, grid)
+    assert len(blocks) == len(want)
+    by_int = {b[2]: b for b in want}
+    for bdims, corner, step, icorner, istep in blocks[:200]:
+        w = by_int[tuple(icorner)]
+        assert tuple(corner) == tuple(w[0]) and step == w[1] and istep == w[3]
+
+
+MASS_CASES = [("sponge2", 1 / 27, 3), ("sponge2", 1 / 54, 8), ("csg_example", 2.0, 8), ("mp_drunk_box", 0.05, 16),
+              ("planetary", 2.0, 8), ("mirror_3d", 0.1, 16)]
+
+
+@pytest.mark.parametrize("name, resolution, grid", MASS_CASES)
+def test_level_batched_mass_properties_equals_reference_traversal(hip, name, resolution, grid):
+    """Same integer moment sums per block => volume / centroid / inertia agree to summation
+    order (1e-12 relative; the north star asks for 1e-5)."""
+    import codecad_amd as cc
+    ref = GOLDEN[name]
+    want, evaluations = ref_driver.mass_properties(ref["tape"], _bbox(ref), resolution, grid)
+    got = cc.mass_properties(_tape_shape(name), resolution, grid)
+    assert cc.mass_properties.last_stats["function_evaluations"] == evaluations
+    assert got.volume == pytest.approx(want.volume, rel=1e-12)
+    assert tuple(got.centroid) == pytest.approx(tuple(want.centroid), rel=1e-10, abs=1e-12)
+    assert np.allclose(got.inertia_tensor, want.inertia_tensor, rtol=1e-10, atol=1e-9 * abs(want.volume))
+
+
+def test_sponge_volume_is_exact_at_aligned_resolution(hip):
+    """At resolution 3^-k the cell centres never touch the surface: volume == (20/27)^n."""
+    import codecad_amd as cc
+    for n, res in ((1, 1 / 9), (2, 1 / 27), (3, 1 / 81)):
+        mp = cc.mass_properties(cc.examples.sponge(n), res, grid_size=9)
+        assert mp.volume == pytest.approx((20 / 27) ** n, rel=1e-12)
+        assert tuple(mp.centroid) == pytest.approx((0, 0, 0), abs=1e-12)
+
+
+def test_leaf_block_grid_eval_matches_oracle(hip):
+    import codecad_amd as cc
+    shape = cc.examples.sponge(3)
+    tape = cc.nodes.make_program(shape)
+    leaves = cc.subdivision.subdivision_device(shape, 1 / 128, True, 8)
+    corners = leaves.int_corners()
+    assert leaves.count == len(corners) > 50
+    # int_corners() sorts; re-upload in that order so block i is corners[i]
+    from codecad_amd import hip_util
+    blocks = np.zeros((len(corners), 4), np.int32)
+    blocks[:, :3] = corners
+    leaves.blocks.release()
+    leaves.blocks = hip_util.Buffer(np.int32, blocks.shape)
+    leaves.blocks.enqueue_write(blocks)
+    dims = tuple(int(d) for d in leaves.dims)
+    g4 = cc.grid_eval.grid_eval_blocks(leaves).read().view(np.float32).reshape((len(corners),) + dims + (4,))
+    g1 = cc.grid_eval.grid_eval_blocks(leaves, pymcubes=True).read().reshape(len(corners), -1)
+    for i in list(range(0, len(corners), max(1, len(corners) // 25))):
+        corner = util.Vector(*corners[i].tolist()) * leaves.resolution + leaves.origin
+        c32 = np.array(tuple(corner), np.float64).astype(np.float32)
+        assert np.array_equal(g4[i], oracle.grid_eval(tape, c32, np.float32(leaves.step), dims))
+        assert np.array_equal(g1[i], oracle.grid_eval_pymcubes(tape, c32, np.float32(leaves.step), dims))
+
+
+def _dense_torch(hip, tape_obj, n, x0=0, x_count=None, layout=0):
+    import torch
+    x_count = n if x_count is None else x_count
+    step = np.float32(1.0 / n)
+    corner = np.array([-0.5 + 0.5 / n] * 3 + [0.0], np.float32)
+    dims = (ctypes.c_uint32 * 3)(n, n, n)
+    out = torch.empty((x_count, n, n, 4) if layout == 0 else (n, n, n), dtype=torch.float32, device="cuda")
+    from codecad_amd.hip_util import check
+    check(hip.lib.hu_grid_eval_slab(tape_obj.device_ptr, corner.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                    step, dims, x0, x_count, layout, out.data_ptr(), None), "hu_grid_eval_slab")
+    torch.cuda.synchronize()
+    return out, corner, step
+
+
+def test_full_size_512_dense_properties(hip):
+    """BASELINE size (512^3 sponge(4), 2 GiB of float4): slabs tile the grid exactly, a random
+    sample of 200k voxels equals the oracle bit for bit, the inside fraction is the sponge's
+    volume, and the field is mirror-symmetric."""
+    import torch
+    import codecad_amd as cc
+    n = 512
+    shape = cc.examples.sponge(4)
+    tape = cc.nodes.make_program_buffer(shape)
+    whole, corner, step = _dense_torch(hip, tape, n)
+    # (a) x-slab sharding (what each rank of an 8-GPU job computes) reproduces the whole grid
+    for x0, cnt in ((0, 64), (448, 64), (200, 37)):
+        slab, _, _ = _dense_torch(hip, tape, n, x0, cnt)
+        assert torch.equal(slab, whole[x0:x0 + cnt])
+    # (b) sampled bit-parity with the oracle
+    rng = np.random.default_rng(3)
+    idx = rng.integers(0, n, size=(200000, 3))
+    pts = corner[:3][None, :] + step * idx.astype(np.float32)
+    want = oracle.evaluate_points(tape.host_tape, pts)
+    ti = torch.from_numpy(idx).cuda()
+    got = whole[ti[:, 0], ti[:, 1], ti[:, 2]].cpu().numpy()
+    assert np.array_equal(got, want)
+    # (c) volume fraction: cell centres of a 512 grid are never on a sponge(4) face
+    inside = float((whole[..., 3] <= 0).double().mean().item())
+    assert inside == pytest.approx((20 / 27) ** 4, rel=2e-3)
+    # (d) the distance field is symmetric under x -> -x, y -> -y, z -> -z and axis swaps
+    w = whole[..., 3]
+    assert torch.allclose(w, w.flip(0), atol=1e-6) and torch.allclose(w, w.flip(2), atol=1e-6)
+    assert torch.allclose(w, w.permute(2, 1, 0), atol=1e-6)
+    # pymcubes layout of the same grid: out[z + (x + (n-1-y)*n)*n]
+    flat, _, _ = _dense_torch(hip, tape, n, layout=1)
+    assert torch.equal(flat.reshape(n, n, n), w.permute(1, 0, 2).flip(0).contiguous())
+
+
+def test_more_than_2_pow_30_cells_in_one_call(hip):
+    """The C ABI splits launches at 2^30 cells; indices stay exact across the seam."""
+    import torch
+    from codecad_amd import hip_util
+    from codecad_amd.hip_util import check
+    ref = GOLDEN["sphere_plus_box"]
+    tape = hip_util.Tape(ref["tape"])
+    dims_t = (1030, 1024, 1024)                      # 1.08e9 cells > 2^30
+    dims = (ctypes.c_uint32 * 3)(*dims_t)
+    step = np.float32(0.13)
+    corner = np.array([-66.0, -66.0, -66.0, 0.0], np.float32)
+    out = torch.empty(dims_t[0] * dims_t[1] * dims_t[2], dtype=torch.float32, device="cuda")
+    check(hip.lib.hu_grid_eval_pymcubes(tape.device_ptr, corner.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), step,
+                                        dims, out.data_ptr(), None), "hu_grid_eval_pymcubes")
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(5)
+    idx = np.concatenate([rng.integers(0, 1024, size=(50000, 3)),
+                          np.array([[1023, 0, 0], [1024, 1023, 1023], [1029, 5, 7], [1024, 0, 0]])])
+    idx[:50000, 0] = rng.integers(0, 1030, size=50000)
+    pts = corner[:3][None, :] + step * idx.astype(np.float32)
+    want = oracle.evaluate_points(ref["tape"], pts)[:, 3]
+    lin = idx[:, 2] + (idx[:, 0] + (dims_t[1] - 1 - idx[:, 1]) * dims_t[0]) * dims_t[2]
+    got = out[torch.from_numpy(lin).cuda()].cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+def test_object_tags_and_torch_interop(hip):
+    """N objects in one parent list (the multi-GPU layout of bench.py) == N single runs;
+    parents/children live in torch tensors passed by data_ptr()."""
+    import torch
+    import codecad_amd as cc
+    from codecad_amd import dist
+    from codecad_amd.hip_util import check
+    shape = cc.examples.sponge(2)
+    tape = cc.nodes.make_program_buffer(shape)
+    res = 1 / 54
+    box = shape.bounding_box().expanded_additive(res / 2)
+    levels = cc.subdivision.calculate_block_sizes(box, 3, res, 8, True)
+    origin = (ctypes.c_double * 3)(box.a.x, box.a.y, box.a.z)
+    counter = torch.zeros(1, dtype=torch.int32, device="cuda")
+
+    def classify(level, parents):
+        int_step, d = levels[level]
+        dd = (ctypes.c_uint32 * 3)(int(d[0]), int(d[1]), int(d[2]))
+        cap = int(parents.shape[0]) * int(d[0]) * int(d[1]) * int(d[2])
+        children = torch.empty((cap, 4), dtype=torch.int32, device="cuda")
+        counter.zero_()
+        torch.cuda.synchronize()
+        check(hip.lib.hu_subdivision_level(tape.device_ptr, parents.contiguous().data_ptr(), int(parents.shape[0]),
+                                           int(int_step), dd, 3, res, origin, np.float32(int_step * res),
+                                           np.float32(int_step * res * math.sqrt(3) / 2), counter.data_ptr(),
+                                           children.data_ptr(), cap, None), "hu_subdivision_level")
+        torch.cuda.synchronize()
+        return children[:int(counter.item())]
+
+    top = torch.zeros((3, 4), dtype=torch.int32, device="cuda")
+    top[:, 3] = torch.arange(3, dtype=torch.int32)
+    leaves, counts = dist.run_levels(top, len(levels) - 1, classify)
+    rows = leaves.cpu().numpy()
+    single = cc.subdivision.subdivision_device(shape, res, True, 8).int_corners()
+    for obj in range(3):
+        mine = rows[rows[:, 3] == obj][:, :3]
+        assert sorted(map(tuple, mine.tolist())) == sorted(map(tuple, single.tolist()))
+    assert counts[-1] == 3 * len(single)
+
+
+def test_overflowing_child_list_is_detected_and_retried(hip):
+    """capacity < survivors: the counter still reports the true count, nothing is written past
+    the end, and the driver's retry path gives the full set."""
+    import codecad_amd as cc
+    from codecad_amd import hip_util, subdivision
+    shape = cc.examples.sponge(2)
+    tape = cc.nodes.make_program_buffer(shape)
+    res = 1 / 54
+    box = shape.bounding_box().expanded_additive(res / 2)
+    levels = subdivision.calculate_block_sizes(box, 3, res, 8, True)
+    parents = hip_util.Buffer(np.int32, (1, 4))
+    parents.enqueue_write(np.zeros((1, 4), np.int32))
+    counter = hip_util.Buffer(np.uint32, 1)
+    full, n_full = subdivision._level_launch(tape, parents, 1, levels[0][0], levels[0][1], 3, res, box.a, counter,
+                                             hip.queue)
+    small, n_small = subdivision._level_launch(tape, parents, 1, levels[0][0], levels[0][1], 3, res, box.a, counter,
+                                               hip.queue, capacity_hint=3)
+    assert n_small == n_full > 3
+    a = np.empty((full.shape[0], 4), np.int32)
+    b = np.empty((small.shape[0], 4), np.int32)
+    full.read(out=a)
+    small.read(out=b)
+    assert sorted(map(tuple, a[:n_full].tolist())) == sorted(map(tuple, b[:n_small].tolist()))
+
+
+def test_buffer_surface(hip):
+    """Buffer semantics of reference tests/test_clutil.py:18-111 that apply without OpenCL."""
+    from codecad_amd import hip_util
+    for shape, nitems in ((4, 4), ((4,), 4), ((4, 4), 16), ((4, 4, 4), 64)):
+        for dtype, size in ((hip_util.Buffer.quad_dtype(np.uint32), 16), (np.uint8, 1), (np.float64, 8)):
+            b = hip_util.Buffer(dtype, shape)
+            b.create_host_side_array()
+            assert b.nitems == nitems == len(b) and b.size == nitems * size and b.array.nbytes == b.size
+    b = hip_util.Buffer(np.uint64, 1)
+    b.create_host_side_array()
+    b[0] = 42
+    ev = b.enqueue_write()
+    ev.wait()          # asynchronous copy from the pinned shadow: do not touch it before this
+    b[0] = 0
+    assert b.read(wait_for=[ev])[0] == 42
+    with b.map(hip_util.map_flags.WRITE_INVALIDATE_REGION) as m:
+        m[0] = 31
+    with b.map(hip_util.map_flags.READ) as m:
+        assert m[0] == 31
+    with pytest.raises(RuntimeError):
+        b.read(out=np.zeros(1, np.uint8))
+    with pytest.raises(RuntimeError):
+        b.enqueue_write(np.zeros(4, np.uint64))
+    ev = b.enqueue_fill(0)
+    assert ev.profile.end >= ev.profile.start
+    assert b.read()[0] == 0
+    b.release()
+    b.release()
