@@ -193,7 +193,7 @@ def main():
                                          "survivors_per_level_global": stats["level_counts"]},
             "roofline": {"bound": "hbm", "kernel": "k_grid_eval<0>", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": None, "kernel_ms": round(dense_avg_ms, 4),
+                         "traffic": measured_traffic(n), "kernel_ms": round(dense_avg_ms, 4),
                          "voxels_per_s": round(dense_voxels / (dense_avg_ms * 1e-3), 0),
                          "note": "this tape is FP32-VALU-bound, not HBM-bound: see valu_* fields",
                          "valu_flop_per_voxel": flop,
@@ -218,6 +218,22 @@ _PARAMS = {0: 0, 1: 0, 2: 0, 3: 2, 4: 1, 5: 2, 7: 1, 8: 0, 9: 0, 10: 2, 11: 7, 1
            16: 1, 17: 1, 18: 3, 19: 1, 20: 1, 21: 2, 22: 1, 23: 0, 24: 3, 25: 0, 26: 1, 27: 1, 28: 1}
 
 
+def measured_traffic(n):
+    """HBM bytes per launch of the dense kernel from the committed rocprofv3 PMC passes
+    (profiles/*_summary.json, produced by tools/collect_profiles.sh for this same kernel and
+    grid); None when no profile of this grid size is present."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*summary.json"))):
+        try:
+            d = json.load(open(f))
+        except ValueError:
+            continue
+        if d.get("grid_edge", 512) == n and "hbm_traffic_bytes_per_launch" in d:
+            best = d["hbm_traffic_bytes_per_launch"]
+    return best
+
+
 def tape_flop(tape):
     pc, total = 0, 0
     while pc < len(tape):
@@ -235,12 +251,27 @@ def tape_flop(tape):
     return total
 
 
+def effective_cores():
+    """Host cores this process may actually use: affinity mask, capped by the cgroup CPU quota."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
 def cpu_baseline(tape, n):
     """The CPU oracle (a port: the reference's OpenCL code cannot be built here) on a bounded
     sample of workload A: the first `planes` x-planes of the same n^3 grid, all host cores."""
     import numpy as np
     import oracle
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     step = np.float32(1.0 / n)
     corner = [-0.5 + 0.5 / n] * 3
     oracle.grid_eval(tape, corner, step, (1, 64, 64), threads=1)  # load + warm
