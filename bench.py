@@ -54,7 +54,7 @@ def main():
     import ctypes
 
     rank, world = dist.init()
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = dist.local_device()
     torch.cuda.set_device(local)
     hip_util.manager.use_device(local)
     m = hip_util.manager
@@ -148,8 +148,7 @@ def main():
     def barrier():
         queue.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
-            torch.distributed.barrier()
+        dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -161,15 +160,10 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = float(dist.allreduce_max(torch.tensor([elapsed], dtype=torch.float64, device=dev)).item())
 
     per_rank_samples = dense_voxels + stats["samples"] + stats["leaves"] * leaf_cells
-    tot = torch.tensor([per_rank_samples], dtype=torch.float64, device=dev)
-    if world > 1:
-        torch.distributed.all_reduce(tot, op=torch.distributed.ReduceOp.SUM)
-    job_samples = float(tot.item())
+    job_samples = float(dist.allreduce_sum(torch.tensor([per_rank_samples], dtype=torch.float64, device=dev)).item())
     value = job_samples * args.steps / elapsed / 1e6
 
     if rank == 0:
@@ -205,7 +199,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(tape.host_tape, n)
         print(json.dumps(line))
     if world > 1:
-        torch.distributed.barrier()
+        dist.barrier()
         torch.distributed.destroy_process_group()
 
 

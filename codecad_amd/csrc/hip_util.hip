@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -80,7 +81,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 // ------------------------------------------------------------------------------------------
 // dense grid evaluation
 // ------------------------------------------------------------------------------------------
-template <int LAYOUT>
+template <int LAYOUT, bool DO>
 __global__ void __launch_bounds__(256)
 k_grid_eval(const Rec* __restrict__ prog, const float* __restrict__ extra, float cx, float cy,
             float cz, float step, uint32_t sx, uint32_t sy, uint32_t sz, uint32_t x0,
@@ -92,8 +93,8 @@ k_grid_eval(const Rec* __restrict__ prog, const float* __restrict__ extra, float
     const uint32_t l = active ? lin : 0u;  // idle tail lanes follow the (uniform) tape harmlessly
     const uint32_t z = l % sz, t = l / sz;
     const uint32_t y = t % sy, x = x0 + t / sy;
-    const float4 r = sdf::run_tape(prog, extra, sample(cx, step, x), sample(cy, step, y),
-                                   sample(cz, step, z), lds + threadIdx.x, blockDim.x);
+    const float4 r = sdf::run_tape<DO>(prog, extra, sample(cx, step, x), sample(cy, step, y),
+                                       sample(cz, step, z), lds + threadIdx.x, blockDim.x);
     if (!active) return;
     if (LAYOUT == 0) {
         // INDEX3 = z + sz*(y + sy*x) (cl_util/indexing.h:4): inside a slab this is `lin`;
@@ -106,7 +107,7 @@ k_grid_eval(const Rec* __restrict__ prog, const float* __restrict__ extra, float
     }
 }
 
-template <int LAYOUT>
+template <int LAYOUT, bool DO>
 __global__ void __launch_bounds__(256)
 k_grid_eval_blocks(const Rec* __restrict__ prog, const float* __restrict__ extra,
                    const int4* __restrict__ blocks, uint32_t chunks, double res, double ox,
@@ -126,8 +127,8 @@ k_grid_eval_blocks(const Rec* __restrict__ prog, const float* __restrict__ extra
     const uint32_t l = active ? lin : 0u;
     const uint32_t z = l % sz, t = l / sz;
     const uint32_t y = t % sy, x = t / sy;
-    const float4 r = sdf::run_tape(prog, extra, sample(cx, step, x), sample(cy, step, y),
-                                   sample(cz, step, z), lds + threadIdx.x, blockDim.x);
+    const float4 r = sdf::run_tape<DO>(prog, extra, sample(cx, step, x), sample(cy, step, y),
+                                       sample(cz, step, z), lds + threadIdx.x, blockDim.x);
     if (!active) return;
     const size_t base = (size_t)b * cells;
     if (LAYOUT == 0)
@@ -158,7 +159,7 @@ struct ClassifyArgs {
     uint32_t regfile_f4;   // float4 slots taken by the register file (scratch follows)
 };
 
-template <bool MASS, bool BATCH>
+template <bool MASS, bool BATCH, bool DO>
 __global__ void __launch_bounds__(256) k_classify(const ClassifyArgs a)
 {
     extern __shared__ float4 lds[];
@@ -196,8 +197,8 @@ __global__ void __launch_bounds__(256) k_classify(const ClassifyArgs a)
     const uint32_t l = active ? lin : 0u;
     const uint32_t z = l % a.sz, t = l / a.sz;
     const uint32_t y = t % a.sy, x = t / a.sy;
-    const float w = sdf::run_tape(a.prog, a.extra, sample(cx, a.step, x), sample(cy, a.step, y),
-                                  sample(cz, a.step, z), lds + threadIdx.x, blockDim.x).w;
+    const float w = sdf::run_tape<DO>(a.prog, a.extra, sample(cx, a.step, x), sample(cy, a.step, y),
+                                      sample(cz, a.step, z), lds + threadIdx.x, blockDim.x).w;
 
     bool ambiguous;
     if (MASS) {
@@ -268,6 +269,15 @@ struct hu_tape_s {
 
 namespace {
 
+// Kernels that only consume the distance run the distance-only interpreter unless the tape has a
+// rounded blend (the one op through which a direction feeds a distance) or the caller forces
+// the full interpreter (HU_FULL_INTERPRETER=1, used by the parity tests to cover both).
+bool distance_only(const hu_tape_s* t)
+{
+    static const bool forced_full = [] { const char* e = getenv("HU_FULL_INTERPRETER"); return e && e[0] == '1'; }();
+    return !forced_full && (t->flags & 1) == 0;
+}
+
 // Workgroup size from the register file: keep the LDS footprint per workgroup <= 40 KiB
 // (>= 4 workgroups per CU) while the tape allows it; never below one wavefront.
 int launch_shape(const hu_tape_s* t, LaunchShape& ls)
@@ -297,14 +307,20 @@ int ensure_attrs()
     HU_HIP(hipGetDevice(&dev));
     if (done_for_device == dev) return HU_OK;
     int rc;
-    if ((rc = allow_big_lds(k_grid_eval<0>))) return rc;
-    if ((rc = allow_big_lds(k_grid_eval<1>))) return rc;
-    if ((rc = allow_big_lds(k_grid_eval_blocks<0>))) return rc;
-    if ((rc = allow_big_lds(k_grid_eval_blocks<1>))) return rc;
-    if ((rc = allow_big_lds(k_classify<false, false>))) return rc;
-    if ((rc = allow_big_lds(k_classify<false, true>))) return rc;
-    if ((rc = allow_big_lds(k_classify<true, false>))) return rc;
-    if ((rc = allow_big_lds(k_classify<true, true>))) return rc;
+    if ((rc = allow_big_lds(k_grid_eval<0, false>))) return rc;
+    if ((rc = allow_big_lds(k_grid_eval<1, false>))) return rc;
+    if ((rc = allow_big_lds(k_grid_eval<1, true>))) return rc;
+    if ((rc = allow_big_lds(k_grid_eval_blocks<0, false>))) return rc;
+    if ((rc = allow_big_lds(k_grid_eval_blocks<1, false>))) return rc;
+    if ((rc = allow_big_lds(k_grid_eval_blocks<1, true>))) return rc;
+    if ((rc = allow_big_lds(k_classify<false, false, false>))) return rc;
+    if ((rc = allow_big_lds(k_classify<false, true, false>))) return rc;
+    if ((rc = allow_big_lds(k_classify<true, false, false>))) return rc;
+    if ((rc = allow_big_lds(k_classify<true, true, false>))) return rc;
+    if ((rc = allow_big_lds(k_classify<false, false, true>))) return rc;
+    if ((rc = allow_big_lds(k_classify<false, true, true>))) return rc;
+    if ((rc = allow_big_lds(k_classify<true, false, true>))) return rc;
+    if ((rc = allow_big_lds(k_classify<true, true, true>))) return rc;
     done_for_device = dev;
     return HU_OK;
 }
@@ -535,11 +551,15 @@ int hu_grid_eval_slab(hu_tape t, const float corner[4], float step, const uint32
         const uint32_t blocks = (n_cells + ls.block - 1) / ls.block;
         if (layout == 0) {
             float4* o = static_cast<float4*>(out_dev) + (size_t)done * plane;
-            hipLaunchKernelGGL(k_grid_eval<0>, dim3(blocks), dim3(ls.block), ls.lds, (hipStream_t)stream,
+            hipLaunchKernelGGL((k_grid_eval<0, false>), dim3(blocks), dim3(ls.block), ls.lds, (hipStream_t)stream,
                                t->recs_dev, t->extra_dev, corner[0], corner[1], corner[2], step, dims[0],
                                dims[1], dims[2], x0 + done, n_cells, (void*)o);
+        } else if (distance_only(t)) {
+            hipLaunchKernelGGL((k_grid_eval<1, true>), dim3(blocks), dim3(ls.block), ls.lds, (hipStream_t)stream,
+                               t->recs_dev, t->extra_dev, corner[0], corner[1], corner[2], step, dims[0],
+                               dims[1], dims[2], x0 + done, n_cells, out_dev);
         } else {
-            hipLaunchKernelGGL(k_grid_eval<1>, dim3(blocks), dim3(ls.block), ls.lds, (hipStream_t)stream,
+            hipLaunchKernelGGL((k_grid_eval<1, false>), dim3(blocks), dim3(ls.block), ls.lds, (hipStream_t)stream,
                                t->recs_dev, t->extra_dev, corner[0], corner[1], corner[2], step, dims[0],
                                dims[1], dims[2], x0 + done, n_cells, out_dev);
         }
@@ -579,11 +599,15 @@ int hu_grid_eval_blocks(hu_tape t, const int32_t* blocks_dev, uint32_t n_blocks,
     if ((uint64_t)chunks * n_blocks > 0x7fffffffull) return fail(HU_ERR_BAD_ARG, "too many workgroups in one launch");
     const dim3 grid(chunks * n_blocks), block(ls.block);
     if (layout == 0)
-        hipLaunchKernelGGL(k_grid_eval_blocks<0>, grid, block, ls.lds, (hipStream_t)stream, t->recs_dev,
+        hipLaunchKernelGGL((k_grid_eval_blocks<0, false>), grid, block, ls.lds, (hipStream_t)stream, t->recs_dev,
+                           t->extra_dev, (const int4*)blocks_dev, chunks, resolution, origin[0], origin[1],
+                           origin[2], step, dims[0], dims[1], dims[2], out_dev);
+    else if (distance_only(t))
+        hipLaunchKernelGGL((k_grid_eval_blocks<1, true>), grid, block, ls.lds, (hipStream_t)stream, t->recs_dev,
                            t->extra_dev, (const int4*)blocks_dev, chunks, resolution, origin[0], origin[1],
                            origin[2], step, dims[0], dims[1], dims[2], out_dev);
     else
-        hipLaunchKernelGGL(k_grid_eval_blocks<1>, grid, block, ls.lds, (hipStream_t)stream, t->recs_dev,
+        hipLaunchKernelGGL((k_grid_eval_blocks<1, false>), grid, block, ls.lds, (hipStream_t)stream, t->recs_dev,
                            t->extra_dev, (const int4*)blocks_dev, chunks, resolution, origin[0], origin[1],
                            origin[2], step, dims[0], dims[1], dims[2], out_dev);
     HU_HIP(hipGetLastError());
@@ -615,8 +639,12 @@ int launch_classify(hu_tape t, ClassifyArgs& a, uint32_t n_parents, const uint32
     a.chunks = (uint32_t)((cells + ls.block - 1) / ls.block);
     a.regfile_f4 = (uint32_t)t->n_regs * ls.block;
     if ((uint64_t)a.chunks * n_parents > 0x7fffffffull) return fail(HU_ERR_BAD_ARG, "too many workgroups in one launch");
-    hipLaunchKernelGGL((k_classify<MASS, BATCH>), dim3(a.chunks * n_parents), dim3(ls.block), ls.lds,
-                       (hipStream_t)stream, a);
+    if (distance_only(t))
+        hipLaunchKernelGGL((k_classify<MASS, BATCH, true>), dim3(a.chunks * n_parents), dim3(ls.block), ls.lds,
+                           (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((k_classify<MASS, BATCH, false>), dim3(a.chunks * n_parents), dim3(ls.block), ls.lds,
+                           (hipStream_t)stream, a);
     HU_HIP(hipGetLastError());
     return HU_OK;
 }

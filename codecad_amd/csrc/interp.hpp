@@ -74,6 +74,16 @@ __device__ __forceinline__ float4 rectangle_op(float hw, float hh, float4 c)
               corner ? dist : (xs ? wx : wy));
 }
 
+// Distance-only forms (DISTANCE_ONLY interpreter): the same operations that produce .w above,
+// nothing else.  Valid for tapes without rounded blends, where no direction ever feeds a
+// distance (tape.hpp: direction_feeds_distance).
+__device__ __forceinline__ float perp_w(float a, float b)
+{
+    float dist = length2(a, b);
+    bool corner = (a > 0.0f) & (b > 0.0f);
+    return corner ? dist : ((a > b) ? a : b);
+}
+
 // reference shapes/simple3d.cl:18-21 = perp_intersection(slab_z(h, coords), in)
 __device__ __forceinline__ float4 extrusion_op(float hh, float4 in, float4 coords)
 {
@@ -336,6 +346,7 @@ __device__ __noinline__ float4 involute_gear_op(float base_radius, float tooth_a
 #endif
 constexpr int kFetchGroup = SDF_FETCH_GROUP;  // tape.hpp pads the program with kFetchGroup _return records
 
+template <bool DISTANCE_ONLY>
 __device__ __forceinline__ bool exec_one(const Rec& cur, float4& last, const float* __restrict__ extra,
                                          float px, float py, float pz, float4* regs, uint32_t stride)
 {
@@ -346,14 +357,26 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, float4& last, const flo
     case OP_RETURN: return true;
     case OP_STORE: regs[reg * stride] = last; break;
     case OP_LOAD: last = regs[reg * stride]; break;
-    case OP_RECTANGLE: last = rectangle_op(p[0], p[1], last); break;
-    case OP_CIRCLE: last = circle_op(p[0], last); break;
+    case OP_RECTANGLE:
+        if (DISTANCE_ONLY) last.w = perp_w(abs_(last.x) - p[0], abs_(last.y) - p[1]);
+        else last = rectangle_op(p[0], p[1], last);
+        break;
+    case OP_CIRCLE:
+        if (DISTANCE_ONLY) last.w = length2(last.x, last.y) - p[0];
+        else last = circle_op(p[0], last);
+        break;
     case OP_REGULAR_POLYGON2D: last = regular_polygon2d_op(p[0], p[1], p[2], p[3], p[4], last); break;
     case OP_POLYGON2D:
         last = polygon2d_op(extra + __float_as_uint(p[1]), __float_as_uint(p[0]), last);
         break;
-    case OP_SPHERE: last = sphere_op(p[0], last); break;
-    case OP_HALF_SPACE: last = f4(0.0f, -1.0f, 0.0f, -last.y); break;
+    case OP_SPHERE:
+        if (DISTANCE_ONLY) last.w = length3(last.x, last.y, last.z) - p[0];
+        else last = sphere_op(p[0], last);
+        break;
+    case OP_HALF_SPACE:
+        if (DISTANCE_ONLY) last.w = -last.y;
+        else last = f4(0.0f, -1.0f, 0.0f, -last.y);
+        break;
     case OP_REVOLUTION_TO: last = f4(length2(last.x, last.z), last.y, 0.0f, 0.0f); break;
     case OP_TWIST_REVOLUTION_TO: last = twist_revolution_to_op(p[0], p[1], last); break;
     case OP_INITIAL_TRANSFORMATION_TO: {
@@ -369,6 +392,10 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, float4& last, const flo
         break;
     }
     case OP_TRANSFORMATION_FROM: {
+        if (DISTANCE_ONLY) {
+            last.w = last.w * p[5];
+            break;
+        }
         float ox, oy, oz;
         quat_xform(p[0], p[1], p[2], p[3], p[4], last.x, last.y, last.z, ox, oy, oz);
         last = f4(ox * p[6], oy * p[6], oz * p[6], last.w * p[5]);
@@ -378,6 +405,10 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, float4& last, const flo
     case OP_SYMMETRICAL_TO: last.x = abs_(last.x); break;
     case OP_OFFSET: last.w = last.w - p[0]; break;
     case OP_SHELL: {
+        if (DISTANCE_ONLY) {
+            last.w = ((last.w >= 0.0f) ? last.w : -last.w) - p[0];
+            break;
+        }
         float4 s = select4(last.w >= 0.0f, last, neg(last));
         last = f4(s.x, s.y, s.z, s.w - p[0]);
         break;
@@ -388,27 +419,43 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, float4& last, const flo
         break;
     case OP_CIRCULAR_REPETITION_TO: last = circular_repetition_to_op(p[0], p[1], last); break;
     case OP_CIRCULAR_REPETITION_FROM:
-        last = circular_repetition_from_op(p[0], p[1], last, regs[reg * stride]);
+        if (!DISTANCE_ONLY) last = circular_repetition_from_op(p[0], p[1], last, regs[reg * stride]);
         break;
     case OP_INVOLUTE_GEAR: last = involute_gear_op(p[2], p[3], p[4], p[5], p[6], last); break;
-    case OP_EXTRUSION: last = extrusion_op(p[0], last, regs[reg * stride]); break;
-    case OP_REVOLUTION_FROM: last = revolution_from_op(last, regs[reg * stride]); break;
+    case OP_EXTRUSION:
+        if (DISTANCE_ONLY) last.w = perp_w(abs_(regs[reg * stride].z) - p[0], last.w);
+        else last = extrusion_op(p[0], last, regs[reg * stride]);
+        break;
+    case OP_REVOLUTION_FROM:
+        if (!DISTANCE_ONLY) last = revolution_from_op(last, regs[reg * stride]);
+        break;
     case OP_TWIST_REVOLUTION_FROM:
         last = twist_revolution_from_op(p[0], p[1], p[2], p[3], p[4], p[5], last, regs[reg * stride]);
         break;
     case OP_SYMMETRICAL_FROM: {
+        if (DISTANCE_ONLY) break;
         float4 pt = regs[reg * stride];
         last.x = (pt.x < 0.0f) ? -last.x : last.x;
         break;
     }
-    case OP_UNION: last = rounded_union(p[0], last, regs[reg * stride]); break;
-    case OP_INTERSECTION: last = neg(rounded_union(p[0], neg(last), neg(regs[reg * stride]))); break;
-    case OP_SUBTRACTION: last = neg(rounded_union(p[0], neg(last), regs[reg * stride])); break;
+    case OP_UNION:
+        if (DISTANCE_ONLY) { float b = regs[reg * stride].w; last.w = (last.w < b) ? last.w : b; }
+        else last = rounded_union(p[0], last, regs[reg * stride]);
+        break;
+    case OP_INTERSECTION:
+        if (DISTANCE_ONLY) { float a = -last.w, b = -regs[reg * stride].w; last.w = -((a < b) ? a : b); }
+        else last = neg(rounded_union(p[0], neg(last), neg(regs[reg * stride])));
+        break;
+    case OP_SUBTRACTION:
+        if (DISTANCE_ONLY) { float a = -last.w, b = regs[reg * stride].w; last.w = -((a < b) ? a : b); }
+        else last = neg(rounded_union(p[0], neg(last), regs[reg * stride]));
+        break;
     default: return true;  // unreachable: tapes are validated at upload
     }
     return false;
 }
 
+template <bool DISTANCE_ONLY = false>
 __device__ __forceinline__ float4 run_tape(const Rec* __restrict__ prog,
                                            const float* __restrict__ extra, float px, float py,
                                            float pz, float4* regs, uint32_t stride)
@@ -422,7 +469,7 @@ __device__ __forceinline__ float4 run_tape(const Rec* __restrict__ prog,
         pc += kFetchGroup;
 #pragma unroll
         for (int k = 0; k < kFetchGroup; ++k)
-            if (exec_one(group[k], last, extra, px, py, pz, regs, stride)) return last;
+            if (exec_one<DISTANCE_ONLY>(group[k], last, extra, px, py, pz, regs, stride)) return last;
     }
 }
 

@@ -30,11 +30,23 @@ def init(backend=None):
         return 0, 1
     if not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("CODECAD_AMD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
-            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+            torch.cuda.set_device(local_device())
         dist.init_process_group(backend=backend)
     return dist.get_rank(), dist.get_world_size()
+
+
+def local_device():
+    """GPU ordinal of this rank: LOCAL_RANK, wrapped onto the visible devices (so that a
+    multi-rank rehearsal can share one GPU with the gloo backend)."""
+    n = max(1, torch.cuda.device_count())
+    return int(os.environ.get("LOCAL_RANK", "0")) % n
+
+
+def _host_staged():
+    """gloo cannot gather device tensors: stage through the host (rehearsal path only)."""
+    return dist.get_backend() == "gloo"
 
 
 def rank_world():
@@ -61,6 +73,9 @@ def allgather_rows(rows, group=None):
     rank, world = rank_world()
     if world == 1:
         return rows
+    device = rows.device
+    if device.type != "cpu" and _host_staged():
+        return allgather_rows(rows.cpu(), group).to(device)
     n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device)
     counts = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(counts, n, group=group)
@@ -78,8 +93,31 @@ def allgather_rows(rows, group=None):
 def allreduce_sum(t, group=None):
     _, world = rank_world()
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        if t.device.type != "cpu" and _host_staged():
+            c = t.cpu()
+            dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
+            t.copy_(c)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
+
+
+def allreduce_max(t, group=None):
+    _, world = rank_world()
+    if world > 1:
+        if t.device.type != "cpu" and _host_staged():
+            c = t.cpu()
+            dist.all_reduce(c, op=dist.ReduceOp.MAX, group=group)
+            t.copy_(c)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return t
+
+
+def barrier():
+    _, world = rank_world()
+    if world > 1:
+        dist.barrier()
 
 
 def run_levels(top_parents, n_levels, classify_level):
