@@ -46,16 +46,62 @@ int fail(int code, const std::string& msg)
 // corner + step * (float)gid, multiply then add, not fused.
 __device__ __forceinline__ float sample(float corner, float step, uint32_t i) { return corner + step * (float)i; }
 
-// Workgroup-aggregated stream compaction: 64-lane ballot + popcount prefix inside each
-// wavefront, wave totals combined through LDS, ONE global atomic per workgroup.  Returns the
-// slot for this lane (meaningful where flag is set).  The reference does one global
+// N = voxels per lane (1: T = float, 2: T = packed float2, see interp.hpp)
+template <int N> struct Pack { using T = float; };
+template <> struct Pack<2> { using T = sdf::f2; };
+__device__ __forceinline__ float pack(const float (&v)[1]) { return v[0]; }
+__device__ __forceinline__ sdf::f2 pack(const float (&v)[2]) { return sdf::make_f2(v[0], v[1]); }
+
+// The N consecutive cells (z fastest) a lane owns, starting at linear index lin0 of a grid
+// with `n_cells` cells: coordinates by one divide for the first cell and carries for the rest.
+template <int N> struct Cells {
+    uint32_t x[N], y[N], z[N];
+    bool active[N];
+    __device__ __forceinline__ Cells(uint32_t lin0, uint32_t n_cells, uint32_t sy, uint32_t sz)
+    {
+        active[0] = lin0 < n_cells;
+        const uint32_t l = active[0] ? lin0 : 0u;  // idle tail lanes follow the (uniform) tape harmlessly
+        z[0] = l % sz;
+        const uint32_t t = l / sz;
+        y[0] = t % sy;
+        x[0] = t / sy;
+#pragma unroll
+        for (int i = 1; i < N; ++i) {
+            active[i] = active[0] && (lin0 + i < n_cells);
+            const bool wrap_z = z[i - 1] + 1u == sz;
+            const bool wrap_y = wrap_z && (y[i - 1] + 1u == sy);
+            z[i] = wrap_z ? 0u : z[i - 1] + 1u;
+            y[i] = wrap_y ? 0u : (wrap_z ? y[i - 1] + 1u : y[i - 1]);
+            x[i] = wrap_y ? x[i - 1] + 1u : x[i - 1];
+        }
+    }
+    __device__ __forceinline__ typename Pack<N>::T position(float corner, float step, const uint32_t (&c)[N], uint32_t c0 = 0) const
+    {
+        float v[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = sample(corner, step, c0 + c[i]);
+        return pack(v);
+    }
+};
+
+// Workgroup-aggregated stream compaction of N flags per lane: 64-lane ballots + popcount
+// prefixes inside each wavefront, wave totals combined through LDS, ONE global atomic per
+// workgroup.  slot[i] is meaningful where flag[i] is set.  The reference does one global
 // atomic_inc per surviving work-item (subdivision.cl:28).
-__device__ __forceinline__ uint32_t wg_compact_slot(bool flag, uint32_t* __restrict__ counter, uint32_t* scratch)
+template <int N>
+__device__ __forceinline__ void wg_compact_slots(const bool (&flag)[N], uint32_t* __restrict__ counter, uint32_t* scratch,
+                                                 uint32_t (&slot)[N])
 {
-    const uint64_t mask = __ballot(flag);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t prefix = __popcll(mask & ((1ull << lane) - 1ull));
-    if (lane == 0) scratch[wave] = __popcll(mask);
+    const uint64_t below = (1ull << lane) - 1ull;
+    uint32_t prefix = 0, total_w = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const uint64_t mask = __ballot(flag[i]);
+        prefix += __popcll(mask & below);
+        total_w += __popcll(mask);
+    }
+    if (lane == 0) scratch[wave] = total_w;
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t nw = (blockDim.x + 63u) >> 6;
@@ -68,7 +114,9 @@ __device__ __forceinline__ uint32_t wg_compact_slot(bool flag, uint32_t* __restr
         scratch[4] = total ? atomicAdd(counter, total) : 0u;
     }
     __syncthreads();
-    return scratch[4] + scratch[wave] + prefix;
+    slot[0] = scratch[4] + scratch[wave] + prefix;
+#pragma unroll
+    for (int i = 1; i < N; ++i) slot[i] = slot[i - 1] + (flag[i - 1] ? 1u : 0u);
 }
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
@@ -81,39 +129,42 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 // ------------------------------------------------------------------------------------------
 // dense grid evaluation
 // ------------------------------------------------------------------------------------------
-template <int LAYOUT, bool DO>
+template <int LAYOUT, bool DO, int N>
 __global__ void __launch_bounds__(256)
 k_grid_eval(const Rec* __restrict__ prog, const float* __restrict__ extra, float cx, float cy,
             float cz, float step, uint32_t sx, uint32_t sy, uint32_t sz, uint32_t x0,
             uint32_t n_cells, void* __restrict__ out)
 {
+    using T = typename Pack<N>::T;
     extern __shared__ float4 lds[];
-    const uint32_t lin = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = lin < n_cells;
-    const uint32_t l = active ? lin : 0u;  // idle tail lanes follow the (uniform) tape harmlessly
-    const uint32_t z = l % sz, t = l / sz;
-    const uint32_t y = t % sy, x = x0 + t / sy;
-    const float4 r = sdf::run_tape<DO>(prog, extra, sample(cx, step, x), sample(cy, step, y),
-                                       sample(cz, step, z), lds + threadIdx.x, blockDim.x);
-    if (!active) return;
-    if (LAYOUT == 0) {
-        // INDEX3 = z + sz*(y + sy*x) (cl_util/indexing.h:4): inside a slab this is `lin`;
-        // 64 lanes store 1 KiB contiguous.
-        static_cast<float4*>(out)[lin] = r;
-    } else {
-        // grid_eval.cl:18: z + (x + (sy-1-y)*sx)*sz; z-fastest so a wave stores 256 B runs
-        const size_t idx = (size_t)z + ((size_t)x + (size_t)(sy - 1u - y) * sx) * sz;
-        static_cast<float*>(out)[idx] = r.w;
+    const uint32_t lin0 = (blockIdx.x * blockDim.x + threadIdx.x) * N;
+    const Cells<N> c(lin0, n_cells, sy, sz);
+    const sdf::Regs<T> regs(lds, threadIdx.x, blockDim.x);
+    const sdf::V4<T> r = sdf::run_tape<T, DO>(prog, extra, c.position(cx, step, c.x, x0), c.position(cy, step, c.y),
+                                              c.position(cz, step, c.z), regs);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        if (!c.active[i]) continue;
+        if (LAYOUT == 0) {
+            // INDEX3 = z + sz*(y + sy*x) (cl_util/indexing.h:4): inside a slab this is the linear
+            // cell index; 64 lanes store 1 KiB (N = 2: 2 KiB) contiguous.
+            static_cast<float4*>(out)[lin0 + i] = sdf::voxel(r, i);
+        } else {
+            // grid_eval.cl:18: z + (x + (sy-1-y)*sx)*sz; z-fastest so a wave stores contiguous runs
+            const size_t idx = (size_t)c.z[i] + ((size_t)(x0 + c.x[i]) + (size_t)(sy - 1u - c.y[i]) * sx) * sz;
+            static_cast<float*>(out)[idx] = sdf::get(r.w, i);
+        }
     }
 }
 
-template <int LAYOUT, bool DO>
+template <int LAYOUT, bool DO, int N>
 __global__ void __launch_bounds__(256)
 k_grid_eval_blocks(const Rec* __restrict__ prog, const float* __restrict__ extra,
                    const int4* __restrict__ blocks, uint32_t chunks, double res, double ox,
                    double oy, double oz, float step, uint32_t sx, uint32_t sy, uint32_t sz,
                    void* __restrict__ out)
 {
+    using T = typename Pack<N>::T;
     extern __shared__ float4 lds[];
     const uint32_t b = blockIdx.x / chunks, chunk = blockIdx.x - b * chunks;
     const uint32_t cells = sx * sy * sz;
@@ -122,19 +173,21 @@ k_grid_eval_blocks(const Rec* __restrict__ prog, const float* __restrict__ extra
     const float cx = (float)((double)ic.x * res + ox);
     const float cy = (float)((double)ic.y * res + oy);
     const float cz = (float)((double)ic.z * res + oz);
-    const uint32_t lin = chunk * blockDim.x + threadIdx.x;
-    const bool active = lin < cells;
-    const uint32_t l = active ? lin : 0u;
-    const uint32_t z = l % sz, t = l / sz;
-    const uint32_t y = t % sy, x = t / sy;
-    const float4 r = sdf::run_tape<DO>(prog, extra, sample(cx, step, x), sample(cy, step, y),
-                                       sample(cz, step, z), lds + threadIdx.x, blockDim.x);
-    if (!active) return;
+    const uint32_t lin0 = (chunk * blockDim.x + threadIdx.x) * N;
+    const Cells<N> c(lin0, cells, sy, sz);
+    const sdf::Regs<T> regs(lds, threadIdx.x, blockDim.x);
+    const sdf::V4<T> r = sdf::run_tape<T, DO>(prog, extra, c.position(cx, step, c.x), c.position(cy, step, c.y),
+                                              c.position(cz, step, c.z), regs);
     const size_t base = (size_t)b * cells;
-    if (LAYOUT == 0)
-        static_cast<float4*>(out)[base + lin] = r;
-    else
-        static_cast<float*>(out)[base + (size_t)z + ((size_t)x + (size_t)(sy - 1u - y) * sx) * sz] = r.w;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        if (!c.active[i]) continue;
+        if (LAYOUT == 0)
+            static_cast<float4*>(out)[base + lin0 + i] = sdf::voxel(r, i);
+        else
+            static_cast<float*>(out)[base + (size_t)c.z[i] + ((size_t)c.x[i] + (size_t)(sy - 1u - c.y[i]) * sx) * sz] =
+                sdf::get(r.w, i);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -156,14 +209,15 @@ struct ClassifyArgs {
     void* list;            // !BATCH: uchar4[]; BATCH: int4[] / double4[] children
     uint32_t capacity;
     uint32_t* sums;        // MASS: uint32[10] per parent
-    uint32_t regfile_f4;   // float4 slots taken by the register file (scratch follows)
+    uint32_t scratch_offset;  // bytes of LDS taken by the register file (scratch follows)
 };
 
-template <bool MASS, bool BATCH, bool DO>
+template <bool MASS, bool BATCH, bool DO, int N>
 __global__ void __launch_bounds__(256) k_classify(const ClassifyArgs a)
 {
+    using T = typename Pack<N>::T;
     extern __shared__ float4 lds[];
-    uint32_t* scratch = reinterpret_cast<uint32_t*>(lds + a.regfile_f4);  // [0..4] compaction, [8..17] sums
+    uint32_t* scratch = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(lds) + a.scratch_offset);  // [0..4] compaction, [8..17] sums
     const uint32_t b = BATCH ? blockIdx.x / a.chunks : 0u;
     const uint32_t chunk = BATCH ? blockIdx.x - b * a.chunks : blockIdx.x;
     const uint32_t cells = a.sx * a.sy * a.sz;
@@ -192,26 +246,38 @@ __global__ void __launch_bounds__(256) k_classify(const ClassifyArgs a)
         if (threadIdx.x < 10) scratch[8 + threadIdx.x] = 0u;
     }
 
-    const uint32_t lin = chunk * blockDim.x + threadIdx.x;
-    const bool active = lin < cells;
-    const uint32_t l = active ? lin : 0u;
-    const uint32_t z = l % a.sz, t = l / a.sz;
-    const uint32_t y = t % a.sy, x = t / a.sy;
-    const float w = sdf::run_tape<DO>(a.prog, a.extra, sample(cx, a.step, x), sample(cy, a.step, y),
-                                      sample(cz, a.step, z), lds + threadIdx.x, blockDim.x).w;
+    const uint32_t lin0 = (chunk * blockDim.x + threadIdx.x) * N;
+    const Cells<N> c(lin0, cells, a.sy, a.sz);
+    const sdf::Regs<T> regs(lds, threadIdx.x, blockDim.x);
+    const T w = sdf::run_tape<T, DO>(a.prog, a.extra, c.position(cx, a.step, c.x), c.position(cy, a.step, c.y),
+                                     c.position(cz, a.step, c.z), regs).w;
 
-    bool ambiguous;
+    bool ambiguous[N];
     if (MASS) {
         // mass_properties.cl:31-52: inside (w <= -thr) -> moments of the integer cell index;
         // else w < thr -> ambiguous
-        const bool inside = active && (w <= -a.thr);
-        ambiguous = active && !inside && (w < a.thr);
-        const uint64_t imask = __ballot(inside);
+        bool inside[N];
+        bool any_inside = false;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const float wi = sdf::get(w, i);
+            inside[i] = c.active[i] && (wi <= -a.thr);
+            ambiguous[i] = c.active[i] && !inside[i] && (wi < a.thr);
+            any_inside |= inside[i];
+        }
+        const uint64_t imask = __ballot(any_inside);
         __syncthreads();  // scratch[8..17] zeroed
         if (imask != 0ull) {  // wave-uniform
-            const uint32_t m = inside ? 1u : 0u;
-            const uint32_t xm = x * m, ym = y * m, zm = z * m;
-            uint32_t v[10] = {xm * x, xm * y, xm * z, xm, ym * y, ym * z, ym, zm * z, zm, m};
+            uint32_t v[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const uint32_t m = inside[i] ? 1u : 0u;
+                const uint32_t x = c.x[i], y = c.y[i], z = c.z[i];
+                const uint32_t xm = x * m, ym = y * m, zm = z * m;
+                v[0] += xm * x; v[1] += xm * y; v[2] += xm * z; v[3] += xm;
+                v[4] += ym * y; v[5] += ym * z; v[6] += ym;
+                v[7] += zm * z; v[8] += zm; v[9] += m;
+            }
 #pragma unroll
             for (int i = 0; i < 10; ++i) {
                 const uint32_t sum = wave_sum(v[i]);
@@ -220,25 +286,33 @@ __global__ void __launch_bounds__(256) k_classify(const ClassifyArgs a)
         }
     } else {
         // subdivision.cl:25: -thr < w < thr
-        ambiguous = active && (w > -a.thr) && (w < a.thr);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const float wi = sdf::get(w, i);
+            ambiguous[i] = c.active[i] && (wi > -a.thr) && (wi < a.thr);
+        }
     }
 
-    const uint32_t slot = wg_compact_slot(ambiguous, a.counter, scratch);  // has __syncthreads
-    if (ambiguous && slot < a.capacity) {
+    uint32_t slot[N];
+    wg_compact_slots<N>(ambiguous, a.counter, scratch, slot);  // has __syncthreads
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        if (!(ambiguous[i] && slot[i] < a.capacity)) continue;
+        const uint32_t x = c.x[i], y = c.y[i], z = c.z[i];
         if (!BATCH) {
-            static_cast<uchar4*>(a.list)[slot] = make_uchar4((unsigned char)x, (unsigned char)y, (unsigned char)z, 0);
+            static_cast<uchar4*>(a.list)[slot[i]] = make_uchar4((unsigned char)x, (unsigned char)y, (unsigned char)z, 0);
         } else if (MASS) {
             // mass_properties.py:155: Vector(i,j,k)*s + box_corner, fp64
-            static_cast<double4*>(a.list)[slot] =
+            static_cast<double4*>(a.list)[slot[i]] =
                 make_double4((double)x * a.s + pcx, (double)y * a.s + pcy, (double)z * a.s + pcz, pcw);
         } else {
             // subdivision.py:91-94: Vector(i,j,k)*int_box_step + int_box_corner
-            static_cast<int4*>(a.list)[slot] =
+            static_cast<int4*>(a.list)[slot[i]] =
                 make_int4(ipar.x + (int)x * a.int_step, ipar.y + (int)y * a.int_step, ipar.z + (int)z * a.int_step, ipar.w);
         }
     }
     if (MASS) {
-        // wg_compact_slot's barriers ordered the LDS atomics before this read
+        // wg_compact_slots' barriers ordered the LDS atomics before this read
         if (threadIdx.x < 10) {
             const uint32_t v = scratch[8 + threadIdx.x];
             if (v) atomicAdd(&a.sums[(size_t)b * 10 + threadIdx.x], v);
@@ -255,6 +329,8 @@ constexpr size_t kScratchBytes = 128;
 struct LaunchShape {
     uint32_t block;
     size_t lds;
+    size_t regfile_bytes;
+    int voxels_per_lane;
 };
 
 }  // namespace
@@ -278,25 +354,59 @@ bool distance_only(const hu_tape_s* t)
     return !forced_full && (t->flags & 1) == 0;
 }
 
-// Workgroup size from the register file: keep the LDS footprint per workgroup <= 40 KiB
-// (>= 4 workgroups per CU) while the tape allows it; never below one wavefront.
-int launch_shape(const hu_tape_s* t, LaunchShape& ls)
+// Voxels per lane and workgroup size from the register file.
+// Measured on MI355X (tools/prof_shape.py): the distance-only interpreter
+// is limited by scalar issue and latency, so two voxels per lane (packed float2) win there
+// (sponge(4) 512^3: 4.66 vs 5.42 ms); the full interpreter is VALU-bound at one voxel per lane
+// and loses occupancy with two (5.27 vs 5.63 ms).  HU_VOXELS_PER_LANE=1|2 forces a choice
+// (the parity tests run both).  The LDS footprint per workgroup is kept <= 48 KiB while the
+// tape allows it; never below one wavefront.
+int launch_shape(const hu_tape_s* t, LaunchShape& ls, bool distance_only_kernel)
 {
-    uint32_t bs = 256;
-    while (bs > 64 && (size_t)t->n_regs * bs * 16 > 40 * 1024) bs >>= 1;
-    size_t lds = (size_t)t->n_regs * bs * 16 + kScratchBytes;
-    if (lds > kMaxLds)
-        return fail(HU_ERR_UNSUPPORTED, "tape uses " + std::to_string(t->n_regs) +
-                                            " value registers; at most 159 fit the 160 KiB LDS register file");
-    ls.block = bs;
-    ls.lds = lds;
-    return HU_OK;
+    static const int forced = [] { const char* e = getenv("HU_VOXELS_PER_LANE"); return e ? atoi(e) : 0; }();
+    const int wanted = (forced == 1 || forced == 2) ? forced : (distance_only_kernel ? 2 : 1);
+    for (int n = wanted; n >= 1; --n) {
+        const size_t per_lane = (size_t)t->n_regs * 16 * n;
+        uint32_t bs = 256;
+        while (bs > 64 && per_lane * bs > 48 * 1024) bs >>= 1;
+        const size_t regfile = per_lane * bs;
+        if (regfile + kScratchBytes <= kMaxLds) {
+            ls.block = bs;
+            ls.regfile_bytes = regfile;
+            ls.lds = regfile + kScratchBytes;
+            ls.voxels_per_lane = n;
+            return HU_OK;
+        }
+    }
+    return fail(HU_ERR_UNSUPPORTED, "tape uses " + std::to_string(t->n_regs) +
+                                        " value registers; at most 159 fit the 160 KiB LDS register file");
 }
 
 template <typename K>
 int allow_big_lds(K kernel)
 {
     HU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
+    return HU_OK;
+}
+
+template <int N>
+int ensure_attrs_n()
+{
+    int rc;
+    if ((rc = allow_big_lds(k_grid_eval<0, false, N>))) return rc;
+    if ((rc = allow_big_lds(k_grid_eval<1, false, N>))) return rc;
+    if ((rc = allow_big_lds(k_grid_eval<1, true, N>))) return rc;
+    if ((rc = allow_big_lds(k_grid_eval_blocks<0, false, N>))) return rc;
+    if ((rc = allow_big_lds(k_grid_eval_blocks<1, false, N>))) return rc;
+    if ((rc = allow_big_lds(k_grid_eval_blocks<1, true, N>))) return rc;
+    if ((rc = allow_big_lds(k_classify<false, false, false, N>))) return rc;
+    if ((rc = allow_big_lds(k_classify<false, true, false, N>))) return rc;
+    if ((rc = allow_big_lds(k_classify<true, false, false, N>))) return rc;
+    if ((rc = allow_big_lds(k_classify<true, true, false, N>))) return rc;
+    if ((rc = allow_big_lds(k_classify<false, false, true, N>))) return rc;
+    if ((rc = allow_big_lds(k_classify<false, true, true, N>))) return rc;
+    if ((rc = allow_big_lds(k_classify<true, false, true, N>))) return rc;
+    if ((rc = allow_big_lds(k_classify<true, true, true, N>))) return rc;
     return HU_OK;
 }
 
@@ -307,20 +417,8 @@ int ensure_attrs()
     HU_HIP(hipGetDevice(&dev));
     if (done_for_device == dev) return HU_OK;
     int rc;
-    if ((rc = allow_big_lds(k_grid_eval<0, false>))) return rc;
-    if ((rc = allow_big_lds(k_grid_eval<1, false>))) return rc;
-    if ((rc = allow_big_lds(k_grid_eval<1, true>))) return rc;
-    if ((rc = allow_big_lds(k_grid_eval_blocks<0, false>))) return rc;
-    if ((rc = allow_big_lds(k_grid_eval_blocks<1, false>))) return rc;
-    if ((rc = allow_big_lds(k_grid_eval_blocks<1, true>))) return rc;
-    if ((rc = allow_big_lds(k_classify<false, false, false>))) return rc;
-    if ((rc = allow_big_lds(k_classify<false, true, false>))) return rc;
-    if ((rc = allow_big_lds(k_classify<true, false, false>))) return rc;
-    if ((rc = allow_big_lds(k_classify<true, true, false>))) return rc;
-    if ((rc = allow_big_lds(k_classify<false, false, true>))) return rc;
-    if ((rc = allow_big_lds(k_classify<false, true, true>))) return rc;
-    if ((rc = allow_big_lds(k_classify<true, false, true>))) return rc;
-    if ((rc = allow_big_lds(k_classify<true, true, true>))) return rc;
+    if ((rc = ensure_attrs_n<1>())) return rc;
+    if ((rc = ensure_attrs_n<2>())) return rc;
     done_for_device = dev;
     return HU_OK;
 }
@@ -541,28 +639,31 @@ int hu_grid_eval_slab(hu_tape t, const float corner[4], float step, const uint32
     const uint64_t plane = (uint64_t)dims[1] * dims[2];
     if (plane >= (1ull << 30)) return fail(HU_ERR_BAD_ARG, "dims[1]*dims[2] must be below 2^30");
     LaunchShape ls;
-    if ((rc = launch_shape(t, ls))) return rc;
+    if ((rc = launch_shape(t, ls, layout == 1 && distance_only(t)))) return rc;
     if ((rc = ensure_attrs())) return rc;
     // at most 2^30 cells per launch keeps every in-kernel index in 32 bits
     const uint32_t max_x = (uint32_t)((1ull << 30) / plane);
     for (uint32_t done = 0; done < x_count;) {
         const uint32_t nx = (x_count - done < max_x) ? (x_count - done) : max_x;
         const uint32_t n_cells = (uint32_t)(nx * plane);
-        const uint32_t blocks = (n_cells + ls.block - 1) / ls.block;
-        if (layout == 0) {
-            float4* o = static_cast<float4*>(out_dev) + (size_t)done * plane;
-            hipLaunchKernelGGL((k_grid_eval<0, false>), dim3(blocks), dim3(ls.block), ls.lds, (hipStream_t)stream,
-                               t->recs_dev, t->extra_dev, corner[0], corner[1], corner[2], step, dims[0],
-                               dims[1], dims[2], x0 + done, n_cells, (void*)o);
-        } else if (distance_only(t)) {
-            hipLaunchKernelGGL((k_grid_eval<1, true>), dim3(blocks), dim3(ls.block), ls.lds, (hipStream_t)stream,
-                               t->recs_dev, t->extra_dev, corner[0], corner[1], corner[2], step, dims[0],
-                               dims[1], dims[2], x0 + done, n_cells, out_dev);
+        const uint32_t per_block = ls.block * ls.voxels_per_lane;
+        const uint32_t blocks = (n_cells + per_block - 1) / per_block;
+        void* o = (layout == 0) ? (void*)(static_cast<float4*>(out_dev) + (size_t)done * plane) : out_dev;
+#define HU_LAUNCH_DENSE(L, D, NV)                                                                                  \
+    hipLaunchKernelGGL((k_grid_eval<L, D, NV>), dim3(blocks), dim3(ls.block), ls.lds, (hipStream_t)stream, t->recs_dev, \
+                       t->extra_dev, corner[0], corner[1], corner[2], step, dims[0], dims[1], dims[2], x0 + done,  \
+                       n_cells, o)
+        const bool d_only = layout == 1 && distance_only(t);
+        if (ls.voxels_per_lane == 2) {
+            if (layout == 0) HU_LAUNCH_DENSE(0, false, 2);
+            else if (d_only) HU_LAUNCH_DENSE(1, true, 2);
+            else HU_LAUNCH_DENSE(1, false, 2);
         } else {
-            hipLaunchKernelGGL((k_grid_eval<1, false>), dim3(blocks), dim3(ls.block), ls.lds, (hipStream_t)stream,
-                               t->recs_dev, t->extra_dev, corner[0], corner[1], corner[2], step, dims[0],
-                               dims[1], dims[2], x0 + done, n_cells, out_dev);
+            if (layout == 0) HU_LAUNCH_DENSE(0, false, 1);
+            else if (d_only) HU_LAUNCH_DENSE(1, true, 1);
+            else HU_LAUNCH_DENSE(1, false, 1);
         }
+#undef HU_LAUNCH_DENSE
         HU_HIP(hipGetLastError());
         done += nx;
     }
@@ -593,23 +694,27 @@ int hu_grid_eval_blocks(hu_tape t, const int32_t* blocks_dev, uint32_t n_blocks,
     if (cells > (1ull << 24)) return fail(HU_ERR_BAD_ARG, "a block may have at most 2^24 cells (256^3)");
     if (n_blocks == 0) return HU_OK;
     LaunchShape ls;
-    if ((rc = launch_shape(t, ls))) return rc;
+    if ((rc = launch_shape(t, ls, layout == 1 && distance_only(t)))) return rc;
     if ((rc = ensure_attrs())) return rc;
-    const uint32_t chunks = (uint32_t)((cells + ls.block - 1) / ls.block);
+    const uint32_t per_block = ls.block * ls.voxels_per_lane;
+    const uint32_t chunks = (uint32_t)((cells + per_block - 1) / per_block);
     if ((uint64_t)chunks * n_blocks > 0x7fffffffull) return fail(HU_ERR_BAD_ARG, "too many workgroups in one launch");
     const dim3 grid(chunks * n_blocks), block(ls.block);
-    if (layout == 0)
-        hipLaunchKernelGGL((k_grid_eval_blocks<0, false>), grid, block, ls.lds, (hipStream_t)stream, t->recs_dev,
-                           t->extra_dev, (const int4*)blocks_dev, chunks, resolution, origin[0], origin[1],
-                           origin[2], step, dims[0], dims[1], dims[2], out_dev);
-    else if (distance_only(t))
-        hipLaunchKernelGGL((k_grid_eval_blocks<1, true>), grid, block, ls.lds, (hipStream_t)stream, t->recs_dev,
-                           t->extra_dev, (const int4*)blocks_dev, chunks, resolution, origin[0], origin[1],
-                           origin[2], step, dims[0], dims[1], dims[2], out_dev);
-    else
-        hipLaunchKernelGGL((k_grid_eval_blocks<1, false>), grid, block, ls.lds, (hipStream_t)stream, t->recs_dev,
-                           t->extra_dev, (const int4*)blocks_dev, chunks, resolution, origin[0], origin[1],
-                           origin[2], step, dims[0], dims[1], dims[2], out_dev);
+#define HU_LAUNCH_BLOCKS(L, D, NV)                                                                                 \
+    hipLaunchKernelGGL((k_grid_eval_blocks<L, D, NV>), grid, block, ls.lds, (hipStream_t)stream, t->recs_dev,      \
+                       t->extra_dev, (const int4*)blocks_dev, chunks, resolution, origin[0], origin[1], origin[2], \
+                       step, dims[0], dims[1], dims[2], out_dev)
+    const bool d_only = layout == 1 && distance_only(t);
+    if (ls.voxels_per_lane == 2) {
+        if (layout == 0) HU_LAUNCH_BLOCKS(0, false, 2);
+        else if (d_only) HU_LAUNCH_BLOCKS(1, true, 2);
+        else HU_LAUNCH_BLOCKS(1, false, 2);
+    } else {
+        if (layout == 0) HU_LAUNCH_BLOCKS(0, false, 1);
+        else if (d_only) HU_LAUNCH_BLOCKS(1, true, 1);
+        else HU_LAUNCH_BLOCKS(1, false, 1);
+    }
+#undef HU_LAUNCH_BLOCKS
     HU_HIP(hipGetLastError());
     return HU_OK;
 }
@@ -629,22 +734,26 @@ int launch_classify(hu_tape t, ClassifyArgs& a, uint32_t n_parents, const uint32
         return fail(HU_ERR_BAD_ARG, "grid size > 256 would overflow the uchar4 cell index (reference subdivision.py:206-208)");
     if (n_parents == 0) return HU_OK;
     LaunchShape ls;
-    if ((rc = launch_shape(t, ls))) return rc;
+    if ((rc = launch_shape(t, ls, distance_only(t)))) return rc;
     if ((rc = ensure_attrs())) return rc;
     a.prog = t->recs_dev;
     a.extra = t->extra_dev;
     a.sx = dims[0];
     a.sy = dims[1];
     a.sz = dims[2];
-    a.chunks = (uint32_t)((cells + ls.block - 1) / ls.block);
-    a.regfile_f4 = (uint32_t)t->n_regs * ls.block;
+    const uint32_t per_block = ls.block * ls.voxels_per_lane;
+    a.chunks = (uint32_t)((cells + per_block - 1) / per_block);
+    a.scratch_offset = (uint32_t)ls.regfile_bytes;
     if ((uint64_t)a.chunks * n_parents > 0x7fffffffull) return fail(HU_ERR_BAD_ARG, "too many workgroups in one launch");
-    if (distance_only(t))
-        hipLaunchKernelGGL((k_classify<MASS, BATCH, true>), dim3(a.chunks * n_parents), dim3(ls.block), ls.lds,
-                           (hipStream_t)stream, a);
-    else
-        hipLaunchKernelGGL((k_classify<MASS, BATCH, false>), dim3(a.chunks * n_parents), dim3(ls.block), ls.lds,
-                           (hipStream_t)stream, a);
+    const dim3 grid(a.chunks * n_parents), block(ls.block);
+    const bool d_only = distance_only(t);
+    if (ls.voxels_per_lane == 2) {
+        if (d_only) hipLaunchKernelGGL((k_classify<MASS, BATCH, true, 2>), grid, block, ls.lds, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((k_classify<MASS, BATCH, false, 2>), grid, block, ls.lds, (hipStream_t)stream, a);
+    } else {
+        if (d_only) hipLaunchKernelGGL((k_classify<MASS, BATCH, true, 1>), grid, block, ls.lds, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((k_classify<MASS, BATCH, false, 1>), grid, block, ls.lds, (hipStream_t)stream, a);
+    }
     HU_HIP(hipGetLastError());
     return HU_OK;
 }

@@ -12,17 +12,79 @@
 //    scalar compare tree + branch, parameters are SGPR operands of the VALU ops -- no VGPRs,
 //    no LDS bandwidth and no VALU cycles are spent on instruction fetch/decode;
 //  * the value registers (`registers[secondaryRegister]`, dynamically indexed, so they
-//    cannot live in VGPRs) are per-lane float4 slots in LDS laid out [reg][lane]:
-//    one ds_write_b128 / ds_read_b128 per access, consecutive lanes 16 B apart
-//    (conflict-free); the reference keeps a fixed 8 KiB private array per work-item.
+//    cannot live in VGPRs) are per-lane slots in LDS; the reference keeps a fixed 8 KiB
+//    private array per work-item;
+//  * a lane evaluates ONE voxel (T = float) or TWO adjacent voxels (T = f2, a 2-vector):
+//    with two, every scalar instruction of the dispatch (fetch, decode, compare tree, branch --
+//    measured to be the co-limiter next to VALU issue) is amortised over twice the work, and
+//    the arithmetic maps to packed v_pk_fma/mul/add_f32, the only way to reach the FP32 peak.
+//    Each component of a packed op is an IEEE binary32 op, so results are unchanged.
 #pragma once
+
+#include <type_traits>
 
 #include "tape.hpp"
 
 namespace sdf {
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef int i2 __attribute__((ext_vector_type(2)));
+
+// ---- the small overload set the generic ops are written against --------------------------
+template <class T> struct lanes_of { static constexpr int value = 1; };
+template <> struct lanes_of<f2> { static constexpr int value = 2; };
+
+template <class T> __device__ __forceinline__ T bc(float s) { return (T)(s); }  // broadcast a tape constant
+
+__device__ __forceinline__ f2 fma_(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 sqrt_(f2 x) { return __builtin_elementwise_sqrt(x); }
+__device__ __forceinline__ f2 abs_(f2 x) { return __builtin_elementwise_abs(x); }
+__device__ __forceinline__ f2 copysign_(f2 m, f2 s) { return __builtin_elementwise_copysign(m, s); }
+__device__ __forceinline__ float rint_(float x) { return __builtin_rintf(x); }
+__device__ __forceinline__ f2 rint_(f2 x) { return __builtin_elementwise_rint(x); }
+__device__ __forceinline__ float sel(bool m, float a, float b) { return m ? a : b; }
+__device__ __forceinline__ f2 sel(i2 m, f2 a, f2 b) { return m ? a : b; }
+__device__ __forceinline__ float get(float v, int) { return v; }
+__device__ __forceinline__ float get(f2 v, int i) { return i ? v.y : v.x; }
+__device__ __forceinline__ f2 make_f2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }  // NOT (f2)(a, b): in C++ that casts a comma expression
+
+template <class T> struct V4 { T x, y, z, w; };
+template <class T> __device__ __forceinline__ V4<T> v4(T x, T y, T z, T w) { V4<T> r = {x, y, z, w}; return r; }
+template <class T> __device__ __forceinline__ V4<T> neg(V4<T> a) { return v4<T>(-a.x, -a.y, -a.z, -a.w); }
+template <class T, class M> __device__ __forceinline__ V4<T> sel4(M m, V4<T> a, V4<T> b)
+{
+    return v4<T>(sel(m, a.x, b.x), sel(m, a.y, b.y), sel(m, a.z, b.z), sel(m, a.w, b.w));
+}
 __device__ __forceinline__ float4 f4(float x, float y, float z, float w) { return make_float4(x, y, z, w); }
-__device__ __forceinline__ float4 neg(float4 a) { return f4(-a.x, -a.y, -a.z, -a.w); }
+__device__ __forceinline__ float4 voxel(const V4<float>& v, int) { return f4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ float4 voxel(const V4<f2>& v, int i) { return f4(get(v.x, i), get(v.y, i), get(v.z, i), get(v.w, i)); }
+__device__ __forceinline__ void join(V4<float>& o, float4 a, float4) { o = v4<float>(a.x, a.y, a.z, a.w); }
+__device__ __forceinline__ void join(V4<f2>& o, float4 a, float4 b)
+{
+    o.x = make_f2(a.x, b.x); o.y = make_f2(a.y, b.y); o.z = make_f2(a.z, b.z); o.w = make_f2(a.w, b.w);
+}
+
+// Run a scalar (one-voxel) op on each voxel of the lane: used for the rare, branchy ops that
+// are __noinline__ functions on float4.
+template <class T, class F> __device__ __forceinline__ V4<T> per_voxel(const V4<T>& a, const V4<T>& b, F f)
+{
+    V4<T> o;
+    if constexpr (lanes_of<T>::value == 1) {
+        join(o, f(voxel(a, 0), voxel(b, 0)), f4(0, 0, 0, 0));
+    } else {
+        float4 r0 = f(voxel(a, 0), voxel(b, 0));
+        float4 r1 = f(voxel(a, 1), voxel(b, 1));
+        join(o, r0, r1);
+    }
+    return o;
+}
+
+template <class T> __device__ __forceinline__ T dot3(T ax, T ay, T az, T bx, T by, T bz)
+{
+    return fma_(az, bz, fma_(ay, by, ax * bx));
+}
+template <class T> __device__ __forceinline__ T len2(T x, T y) { return sqrt_(fma_(y, y, x * x)); }
+template <class T> __device__ __forceinline__ T len3(T x, T y, T z) { return sqrt_(fma_(z, z, fma_(y, y, x * x))); }
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz)
 {
     return fma_(az, bz, fma_(ay, by, ax * bx));
@@ -30,80 +92,66 @@ __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, fl
 __device__ __forceinline__ float dot2(float ax, float ay, float bx, float by) { return fma_(ay, by, ax * bx); }
 
 // reference shapes/common.cl:1-6; k = w*w - dot(v,v) is folded at decode time
-__device__ __forceinline__ void quat_xform(float qx, float qy, float qz, float qw, float k,
-                                           float px, float py, float pz,
-                                           float& ox, float& oy, float& oz)
+template <class T>
+__device__ __forceinline__ void quat_xform(float qx, float qy, float qz, float qw, float k, T px, T py, T pz,
+                                           T& ox, T& oy, T& oz)
 {
-    float d = dot3(qx, qy, qz, px, py, pz);
-    float cx = fma_(qy, pz, -(qz * py));
-    float cy = fma_(qz, px, -(qx * pz));
-    float cz = fma_(qx, py, -(qy * px));
-    float tx = fma_(cx, qw, qx * d);
-    float ty = fma_(cy, qw, qy * d);
-    float tz = fma_(cz, qw, qz * d);
-    ox = fma_(px, k, tx + tx);
-    oy = fma_(py, k, ty + ty);
-    oz = fma_(pz, k, tz + tz);
-}
-
-// reference shapes/common.cl:15-31
-__device__ __forceinline__ float4 perp_intersection(float4 a, float4 b)
-{
-    if (a.w > 0.0f && b.w > 0.0f) {
-        float dist = length2(a.w, b.w);
-        float inv = 1.0f / dist;
-        float m1 = a.w * inv, m2 = b.w * inv;
-        return f4(fma_(b.x, m2, a.x * m1), fma_(b.y, m2, a.y * m1), fma_(b.z, m2, a.z * m1), dist);
-    }
-    return (a.w > b.w) ? a : b;
+    const T QX = bc<T>(qx), QY = bc<T>(qy), QZ = bc<T>(qz), QW = bc<T>(qw), K = bc<T>(k);
+    T d = fma_(QZ, pz, fma_(QY, py, QX * px));
+    T cx = fma_(QY, pz, -(QZ * py));
+    T cy = fma_(QZ, px, -(QX * pz));
+    T cz = fma_(QX, py, -(QY * px));
+    T tx = fma_(cx, QW, QX * d);
+    T ty = fma_(cy, QW, QY * d);
+    T tz = fma_(cz, QW, QZ * d);
+    ox = fma_(px, K, tx + tx);
+    oy = fma_(py, K, ty + ty);
+    oz = fma_(pz, K, tz + tz);
 }
 
 // reference shapes/simple2d.cl:1-4 (slab_x/slab_y of common.cl:33-39 inlined).  Equal to
-// perp_intersection(slab_x, slab_y) under ==: the zero components only drop exact zeros.
-// Written with selects, not branches: a divergent branch inside the dispatch loop makes the
-// compiler structurize the WHOLE loop (flag registers, phi copies, ~4x instruction bloat).
-__device__ __forceinline__ float4 rectangle_op(float hw, float hh, float4 c)
+// perpendicular_intersection(slab_x, slab_y) (common.cl:15-31) under ==: the zero components
+// only drop exact zeros.  Written with selects, not branches: a divergent branch inside the
+// dispatch loop makes the compiler structurize the WHOLE loop (~4x instruction bloat).
+template <class T> __device__ __forceinline__ V4<T> rectangle_op(float hw, float hh, V4<T> c)
 {
-    float sx = copysign_(1.0f, c.x), sy = copysign_(1.0f, c.y);
-    float wx = abs_(c.x) - hw, wy = abs_(c.y) - hh;
-    float dist = length2(wx, wy);
-    float inv = 1.0f / dist;
-    bool corner = (wx > 0.0f) & (wy > 0.0f);
-    bool xs = wx > wy;
-    return f4(corner ? sx * (wx * inv) : (xs ? sx : 0.0f), corner ? sy * (wy * inv) : (xs ? 0.0f : sy), 0.0f,
-              corner ? dist : (xs ? wx : wy));
+    const T one = bc<T>(1.0f), zero = bc<T>(0.0f);
+    T sx = copysign_(one, c.x), sy = copysign_(one, c.y);
+    T wx = abs_(c.x) - hw, wy = abs_(c.y) - hh;
+    T dist = len2(wx, wy);
+    T inv = 1.0f / dist;
+    auto corner = (wx > 0.0f) & (wy > 0.0f);
+    auto xs = wx > wy;
+    return v4<T>(sel(corner, sx * (wx * inv), sel(xs, sx, zero)), sel(corner, sy * (wy * inv), sel(xs, zero, sy)), zero,
+                 sel(corner, dist, sel(xs, wx, wy)));
 }
 
 // Distance-only forms (DISTANCE_ONLY interpreter): the same operations that produce .w above,
 // nothing else.  Valid for tapes without rounded blends, where no direction ever feeds a
 // distance (tape.hpp: direction_feeds_distance).
-__device__ __forceinline__ float perp_w(float a, float b)
+template <class T> __device__ __forceinline__ T perp_w(T a, T b)
 {
-    float dist = length2(a, b);
-    bool corner = (a > 0.0f) & (b > 0.0f);
-    return corner ? dist : ((a > b) ? a : b);
+    T dist = len2(a, b);
+    auto corner = (a > 0.0f) & (b > 0.0f);
+    return sel(corner, dist, sel(a > b, a, b));
 }
 
-// reference shapes/simple3d.cl:18-21 = perp_intersection(slab_z(h, coords), in)
-__device__ __forceinline__ float4 extrusion_op(float hh, float4 in, float4 coords)
+// reference shapes/simple3d.cl:18-21 = perpendicular_intersection(slab_z(h, coords), in)
+template <class T> __device__ __forceinline__ V4<T> extrusion_op(float hh, V4<T> in, V4<T> coords)
 {
-    float sz = copysign_(1.0f, coords.z);
-    float wz = abs_(coords.z) - hh;
-    float dist = length2(wz, in.w);
-    float inv = 1.0f / dist;
-    float m1 = wz * inv, m2 = in.w * inv;
-    bool corner = (wz > 0.0f) & (in.w > 0.0f);
-    bool cap = wz > in.w;
-    return f4(corner ? in.x * m2 : (cap ? 0.0f : in.x), corner ? in.y * m2 : (cap ? 0.0f : in.y),
-              corner ? fma_(in.z, m2, sz * m1) : (cap ? sz : in.z), corner ? dist : (cap ? wz : in.w));
+    const T one = bc<T>(1.0f), zero = bc<T>(0.0f);
+    T sz = copysign_(one, coords.z);
+    T wz = abs_(coords.z) - hh;
+    T dist = len2(wz, in.w);
+    T inv = 1.0f / dist;
+    T m1 = wz * inv, m2 = in.w * inv;
+    auto corner = (wz > 0.0f) & (in.w > 0.0f);
+    auto cap = wz > in.w;
+    return v4<T>(sel(corner, in.x * m2, sel(cap, zero, in.x)), sel(corner, in.y * m2, sel(cap, zero, in.y)),
+                 sel(corner, fma_(in.z, m2, sz * m1), sel(cap, sz, in.z)), sel(corner, dist, sel(cap, wz, in.w)));
 }
 
 // reference shapes/common.cl:45-64
-__device__ __forceinline__ float4 select4(bool c, float4 a, float4 b)
-{
-    return f4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w);
-}
-
 __device__ __noinline__ float4 rounded_blend(float r, float4 a, float4 b)
 {
     float cos_alpha = dot3(a.x, a.y, a.z, b.x, b.y, b.z);
@@ -116,30 +164,42 @@ __device__ __noinline__ float4 rounded_blend(float r, float4 a, float4 b)
     return (a.w < b.w) ? a : b;
 }
 
-__device__ __forceinline__ float4 rounded_union(float r, float4 a, float4 b)
+
+template <class T> __device__ __forceinline__ V4<T> rounded_union(float r, V4<T> a, V4<T> b)
 {
-    if (r >= 0.0f) return rounded_blend(r, a, b);  // wave-uniform: r is a tape constant
-    return select4(a.w < b.w, a, b);
+    if (r >= 0.0f)  // wave-uniform: r is a tape constant
+        return per_voxel(a, b, [r](float4 x, float4 y) { return rounded_blend(r, x, y); });
+    return sel4(a.w < b.w, a, b);
 }
 
 // reference shapes/simple2d.cl:6-14
-__device__ __forceinline__ float4 circle_op(float r, float4 c)
+template <class T> __device__ __forceinline__ V4<T> circle_op(float r, V4<T> c)
 {
-    float a = length2(c.x, c.y);
-    float inv = 1.0f / a;
-    bool zero = (a == 0.0f);
-    return f4(zero ? 1.0f : c.x * inv, zero ? 0.0f : c.y * inv, 0.0f, a - r);
+    T a = len2(c.x, c.y);
+    T inv = 1.0f / a;
+    auto zero = (a == 0.0f);
+    return v4<T>(sel(zero, bc<T>(1.0f), c.x * inv), sel(zero, bc<T>(0.0f), c.y * inv), bc<T>(0.0f), a - r);
 }
 
 // reference shapes/simple3d.cl:1-12
-__device__ __forceinline__ float4 sphere_op(float r, float4 c)
+template <class T> __device__ __forceinline__ V4<T> sphere_op(float r, V4<T> c)
 {
-    float a = length3(c.x, c.y, c.z);
-    float inv = 1.0f / a;
-    bool zero = (a == 0.0f);
-    return f4(zero ? 1.0f : c.x * inv, zero ? 0.0f : c.y * inv, zero ? 0.0f : c.z * inv, a - r);
+    T a = len3(c.x, c.y, c.z);
+    T inv = 1.0f / a;
+    auto zero = (a == 0.0f);
+    return v4<T>(sel(zero, bc<T>(1.0f), c.x * inv), sel(zero, bc<T>(0.0f), c.y * inv), sel(zero, bc<T>(0.0f), c.z * inv),
+                 a - r);
 }
 
+// remainder with a pre-rounded reciprocal; inv_y == 0 (y = +inf) returns x (sdf_math.hpp)
+template <class T> __device__ __forceinline__ T remainder_t(T x, float y, float inv_y)
+{
+    T n = rint_(x * inv_y);
+    T r = fma_(-n, bc<T>(y), x);
+    return (inv_y == 0.0f) ? x : r;
+}
+
+// ---- rare ops: scalar, branchy, outlined ---------------------------------------------------
 __device__ __forceinline__ float sign_f(float s) { return (s > 0.0f) ? 1.0f : ((s < 0.0f) ? -1.0f : 0.0f); }
 
 __device__ __forceinline__ float sector_alpha(float y, float x, float pi_over_n)
@@ -331,9 +391,43 @@ __device__ __noinline__ float4 involute_gear_op(float base_radius, float tooth_a
     return f4(nx, ny, 0.0f, distance);
 }
 
+
 // ---------------------------------------------------------------------------------------
-// The interpreter.  `regs` points at this lane's slot of register 0 in LDS; register r is
-// regs[r * stride] (stride = lanes per workgroup).  `prog` and `extra` are wave-uniform.
+// Value registers in LDS.
+//   T = float: [reg][lane] float4 slots, ds_read/write_b128, lanes 16 B apart (conflict-free).
+//   T = f2:    [reg][component][lane] 8-byte slots, ds_read/write_b64, lanes 8 B apart
+//              (conflict-free; the packed register pairs go out as they are, no repacking).
+// ---------------------------------------------------------------------------------------
+template <class T> struct Regs;
+template <> struct Regs<float> {
+    float4* base;  // this lane's slot of register 0
+    uint32_t stride;
+    static constexpr uint32_t kBytesPerLanePerReg = 16;
+    __device__ __forceinline__ Regs(void* lds, uint32_t lane, uint32_t lanes) : base((float4*)lds + lane), stride(lanes) {}
+    __device__ __forceinline__ V4<float> load(uint32_t r) const { float4 v = base[r * stride]; return v4<float>(v.x, v.y, v.z, v.w); }
+    __device__ __forceinline__ void store(uint32_t r, const V4<float>& v) const { base[r * stride] = f4(v.x, v.y, v.z, v.w); }
+    __device__ __forceinline__ float load_x(uint32_t r) const { return base[r * stride].x; }
+    __device__ __forceinline__ float load_z(uint32_t r) const { return base[r * stride].z; }
+    __device__ __forceinline__ float load_w(uint32_t r) const { return base[r * stride].w; }
+};
+template <> struct Regs<f2> {
+    f2* base;
+    uint32_t stride;
+    static constexpr uint32_t kBytesPerLanePerReg = 32;
+    __device__ __forceinline__ Regs(void* lds, uint32_t lane, uint32_t lanes) : base((f2*)lds + lane), stride(lanes) {}
+    __device__ __forceinline__ f2* slot(uint32_t r, uint32_t c) const { return base + (r * 4u + c) * stride; }
+    __device__ __forceinline__ V4<f2> load(uint32_t r) const { return v4<f2>(*slot(r, 0), *slot(r, 1), *slot(r, 2), *slot(r, 3)); }
+    __device__ __forceinline__ void store(uint32_t r, const V4<f2>& v) const
+    {
+        *slot(r, 0) = v.x; *slot(r, 1) = v.y; *slot(r, 2) = v.z; *slot(r, 3) = v.w;
+    }
+    __device__ __forceinline__ f2 load_x(uint32_t r) const { return *slot(r, 0); }
+    __device__ __forceinline__ f2 load_z(uint32_t r) const { return *slot(r, 2); }
+    __device__ __forceinline__ f2 load_w(uint32_t r) const { return *slot(r, 3); }
+};
+
+// ---------------------------------------------------------------------------------------
+// The interpreter.  `prog` and `extra` are wave-uniform.
 //
 // exec_one runs ONE decoded record; it returns true on _return.  run_tape fetches records
 // in groups of kFetchGroup: all scalar loads of a group are issued together at the top of
@@ -344,51 +438,63 @@ __device__ __noinline__ float4 involute_gear_op(float base_radius, float tooth_a
 #ifndef SDF_FETCH_GROUP
 #define SDF_FETCH_GROUP 4
 #endif
-constexpr int kFetchGroup = SDF_FETCH_GROUP;  // tape.hpp pads the program with kFetchGroup _return records
+constexpr int kFetchGroup = SDF_FETCH_GROUP;  // tape.hpp pads the program with kTapePadding _return records
 
-template <bool DISTANCE_ONLY>
-__device__ __forceinline__ bool exec_one(const Rec& cur, float4& last, const float* __restrict__ extra,
-                                         float px, float py, float pz, float4* regs, uint32_t stride)
+template <class T, bool DISTANCE_ONLY>
+__device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const float* __restrict__ extra, T px, T py,
+                                         T pz, const Regs<T>& regs)
 {
     const uint32_t op = cur.hdr & 0xffu;
     const uint32_t reg = cur.hdr >> 8;
     const float* p = cur.p;
+    const V4<T> none = v4<T>(bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f));
     switch (op) {
     case OP_RETURN: return true;
-    case OP_STORE: regs[reg * stride] = last; break;
-    case OP_LOAD: last = regs[reg * stride]; break;
+    case OP_STORE: regs.store(reg, last); break;
+    case OP_LOAD: last = regs.load(reg); break;
     case OP_RECTANGLE:
-        if (DISTANCE_ONLY) last.w = perp_w(abs_(last.x) - p[0], abs_(last.y) - p[1]);
+        if (DISTANCE_ONLY) last.w = perp_w<T>(abs_(last.x) - p[0], abs_(last.y) - p[1]);
         else last = rectangle_op(p[0], p[1], last);
         break;
     case OP_CIRCLE:
-        if (DISTANCE_ONLY) last.w = length2(last.x, last.y) - p[0];
+        if (DISTANCE_ONLY) last.w = len2(last.x, last.y) - p[0];
         else last = circle_op(p[0], last);
         break;
-    case OP_REGULAR_POLYGON2D: last = regular_polygon2d_op(p[0], p[1], p[2], p[3], p[4], last); break;
-    case OP_POLYGON2D:
-        last = polygon2d_op(extra + __float_as_uint(p[1]), __float_as_uint(p[0]), last);
+    case OP_REGULAR_POLYGON2D: {
+        const float a = p[0], b = p[1], c = p[2], d = p[3], e = p[4];
+        last = per_voxel(last, none, [=](float4 l, float4) { return regular_polygon2d_op(a, b, c, d, e, l); });
         break;
+    }
+    case OP_POLYGON2D: {
+        const float* pts = extra + __float_as_uint(p[1]);
+        const uint32_t n = __float_as_uint(p[0]);
+        last = per_voxel(last, none, [=](float4 l, float4) { return polygon2d_op(pts, n, l); });
+        break;
+    }
     case OP_SPHERE:
-        if (DISTANCE_ONLY) last.w = length3(last.x, last.y, last.z) - p[0];
+        if (DISTANCE_ONLY) last.w = len3(last.x, last.y, last.z) - p[0];
         else last = sphere_op(p[0], last);
         break;
     case OP_HALF_SPACE:
         if (DISTANCE_ONLY) last.w = -last.y;
-        else last = f4(0.0f, -1.0f, 0.0f, -last.y);
+        else last = v4<T>(bc<T>(0.0f), bc<T>(-1.0f), bc<T>(0.0f), -last.y);
         break;
-    case OP_REVOLUTION_TO: last = f4(length2(last.x, last.z), last.y, 0.0f, 0.0f); break;
-    case OP_TWIST_REVOLUTION_TO: last = twist_revolution_to_op(p[0], p[1], last); break;
+    case OP_REVOLUTION_TO: last = v4<T>(len2(last.x, last.z), last.y, bc<T>(0.0f), bc<T>(0.0f)); break;
+    case OP_TWIST_REVOLUTION_TO: {
+        const float a = p[0], b = p[1];
+        last = per_voxel(last, none, [=](float4 l, float4) { return twist_revolution_to_op(a, b, l); });
+        break;
+    }
     case OP_INITIAL_TRANSFORMATION_TO: {
-        float ox, oy, oz;
-        quat_xform(p[0], p[1], p[2], p[3], p[7], px, py, pz, ox, oy, oz);
-        last = f4(ox + p[4], oy + p[5], oz + p[6], 0.0f);
+        T ox, oy, oz;
+        quat_xform<T>(p[0], p[1], p[2], p[3], p[7], px, py, pz, ox, oy, oz);
+        last = v4<T>(ox + p[4], oy + p[5], oz + p[6], bc<T>(0.0f));
         break;
     }
     case OP_TRANSFORMATION_TO: {
-        float ox, oy, oz;
-        quat_xform(p[0], p[1], p[2], p[3], p[7], last.x, last.y, last.z, ox, oy, oz);
-        last = f4(ox + p[4], oy + p[5], oz + p[6], 0.0f);
+        T ox, oy, oz;
+        quat_xform<T>(p[0], p[1], p[2], p[3], p[7], last.x, last.y, last.z, ox, oy, oz);
+        last = v4<T>(ox + p[4], oy + p[5], oz + p[6], bc<T>(0.0f));
         break;
     }
     case OP_TRANSFORMATION_FROM: {
@@ -396,9 +502,9 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, float4& last, const flo
             last.w = last.w * p[5];
             break;
         }
-        float ox, oy, oz;
-        quat_xform(p[0], p[1], p[2], p[3], p[4], last.x, last.y, last.z, ox, oy, oz);
-        last = f4(ox * p[6], oy * p[6], oz * p[6], last.w * p[5]);
+        T ox, oy, oz;
+        quat_xform<T>(p[0], p[1], p[2], p[3], p[4], last.x, last.y, last.z, ox, oy, oz);
+        last = v4<T>(ox * p[6], oy * p[6], oz * p[6], last.w * p[5]);
         break;
     }
     case OP_MIRROR: last.x = -last.x; break;
@@ -406,61 +512,74 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, float4& last, const flo
     case OP_OFFSET: last.w = last.w - p[0]; break;
     case OP_SHELL: {
         if (DISTANCE_ONLY) {
-            last.w = ((last.w >= 0.0f) ? last.w : -last.w) - p[0];
+            last.w = sel(last.w >= 0.0f, last.w, -last.w) - p[0];
             break;
         }
-        float4 s = select4(last.w >= 0.0f, last, neg(last));
-        last = f4(s.x, s.y, s.z, s.w - p[0]);
+        V4<T> s = sel4(last.w >= 0.0f, last, neg(last));
+        last = v4<T>(s.x, s.y, s.z, s.w - p[0]);
         break;
     }
     case OP_REPETITION:
-        last = f4(remainder_inv(last.x, p[0], p[3]), remainder_inv(last.y, p[1], p[4]),
-                  remainder_inv(last.z, p[2], p[5]), 0.0f);
+        last = v4<T>(remainder_t(last.x, p[0], p[3]), remainder_t(last.y, p[1], p[4]), remainder_t(last.z, p[2], p[5]),
+                     bc<T>(0.0f));
         break;
-    case OP_CIRCULAR_REPETITION_TO: last = circular_repetition_to_op(p[0], p[1], last); break;
+    case OP_CIRCULAR_REPETITION_TO: {
+        const float a = p[0], b = p[1];
+        last = per_voxel(last, none, [=](float4 l, float4) { return circular_repetition_to_op(a, b, l); });
+        break;
+    }
     case OP_CIRCULAR_REPETITION_FROM:
-        if (!DISTANCE_ONLY) last = circular_repetition_from_op(p[0], p[1], last, regs[reg * stride]);
+        if (!DISTANCE_ONLY) {
+            const float a = p[0], b = p[1];
+            last = per_voxel(last, regs.load(reg), [=](float4 l, float4 r) { return circular_repetition_from_op(a, b, l, r); });
+        }
         break;
-    case OP_INVOLUTE_GEAR: last = involute_gear_op(p[2], p[3], p[4], p[5], p[6], last); break;
+    case OP_INVOLUTE_GEAR: {
+        const float a = p[2], b = p[3], c = p[4], d = p[5], e = p[6];
+        last = per_voxel(last, none, [=](float4 l, float4) { return involute_gear_op(a, b, c, d, e, l); });
+        break;
+    }
     case OP_EXTRUSION:
-        if (DISTANCE_ONLY) last.w = perp_w(abs_(regs[reg * stride].z) - p[0], last.w);
-        else last = extrusion_op(p[0], last, regs[reg * stride]);
+        if (DISTANCE_ONLY) last.w = perp_w<T>(abs_(regs.load_z(reg)) - p[0], last.w);
+        else last = extrusion_op(p[0], last, regs.load(reg));
         break;
     case OP_REVOLUTION_FROM:
-        if (!DISTANCE_ONLY) last = revolution_from_op(last, regs[reg * stride]);
+        if (!DISTANCE_ONLY) last = per_voxel(last, regs.load(reg), [](float4 l, float4 r) { return revolution_from_op(l, r); });
         break;
-    case OP_TWIST_REVOLUTION_FROM:
-        last = twist_revolution_from_op(p[0], p[1], p[2], p[3], p[4], p[5], last, regs[reg * stride]);
+    case OP_TWIST_REVOLUTION_FROM: {
+        const float a = p[0], b = p[1], c = p[2], d = p[3], e = p[4], f = p[5];
+        last = per_voxel(last, regs.load(reg),
+                         [=](float4 l, float4 r) { return twist_revolution_from_op(a, b, c, d, e, f, l, r); });
         break;
+    }
     case OP_SYMMETRICAL_FROM: {
         if (DISTANCE_ONLY) break;
-        float4 pt = regs[reg * stride];
-        last.x = (pt.x < 0.0f) ? -last.x : last.x;
+        T ptx = regs.load_x(reg);
+        last.x = sel(ptx < 0.0f, -last.x, last.x);
         break;
     }
     case OP_UNION:
-        if (DISTANCE_ONLY) { float b = regs[reg * stride].w; last.w = (last.w < b) ? last.w : b; }
-        else last = rounded_union(p[0], last, regs[reg * stride]);
+        if (DISTANCE_ONLY) { T b = regs.load_w(reg); last.w = sel(last.w < b, last.w, b); }
+        else last = rounded_union(p[0], last, regs.load(reg));
         break;
     case OP_INTERSECTION:
-        if (DISTANCE_ONLY) { float a = -last.w, b = -regs[reg * stride].w; last.w = -((a < b) ? a : b); }
-        else last = neg(rounded_union(p[0], neg(last), neg(regs[reg * stride])));
+        if (DISTANCE_ONLY) { T a = -last.w, b = -regs.load_w(reg); last.w = -sel(a < b, a, b); }
+        else last = neg(rounded_union(p[0], neg(last), neg(regs.load(reg))));
         break;
     case OP_SUBTRACTION:
-        if (DISTANCE_ONLY) { float a = -last.w, b = regs[reg * stride].w; last.w = -((a < b) ? a : b); }
-        else last = neg(rounded_union(p[0], neg(last), regs[reg * stride]));
+        if (DISTANCE_ONLY) { T a = -last.w, b = regs.load_w(reg); last.w = -sel(a < b, a, b); }
+        else last = neg(rounded_union(p[0], neg(last), regs.load(reg)));
         break;
     default: return true;  // unreachable: tapes are validated at upload
     }
     return false;
 }
 
-template <bool DISTANCE_ONLY = false>
-__device__ __forceinline__ float4 run_tape(const Rec* __restrict__ prog,
-                                           const float* __restrict__ extra, float px, float py,
-                                           float pz, float4* regs, uint32_t stride)
+template <class T, bool DISTANCE_ONLY>
+__device__ __forceinline__ V4<T> run_tape(const Rec* __restrict__ prog, const float* __restrict__ extra, T px, T py,
+                                          T pz, const Regs<T>& regs)
 {
-    float4 last = f4(0.0f, 0.0f, 0.0f, 0.0f);
+    V4<T> last = v4<T>(bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f));
     const Rec* pc = prog;
     for (;;) {
         Rec group[kFetchGroup];
@@ -469,7 +588,7 @@ __device__ __forceinline__ float4 run_tape(const Rec* __restrict__ prog,
         pc += kFetchGroup;
 #pragma unroll
         for (int k = 0; k < kFetchGroup; ++k)
-            if (exec_one<DISTANCE_ONLY>(group[k], last, extra, px, py, pz, regs, stride)) return last;
+            if (exec_one<T, DISTANCE_ONLY>(group[k], last, extra, px, py, pz, regs)) return last;
     }
 }
 
