@@ -131,7 +131,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 // ------------------------------------------------------------------------------------------
 template <int LAYOUT, bool DO, int N>
 __global__ void __launch_bounds__(256)
-k_grid_eval(const Rec* __restrict__ prog, const float* __restrict__ extra, float cx, float cy,
+k_grid_eval(const Rec* __restrict__ prog, const float* __restrict__ extra, uint32_t n4, float cx, float cy,
             float cz, float step, uint32_t sx, uint32_t sy, uint32_t sz, uint32_t x0,
             uint32_t n_cells, void* __restrict__ out)
 {
@@ -139,7 +139,7 @@ k_grid_eval(const Rec* __restrict__ prog, const float* __restrict__ extra, float
     extern __shared__ float4 lds[];
     const uint32_t lin0 = (blockIdx.x * blockDim.x + threadIdx.x) * N;
     const Cells<N> c(lin0, n_cells, sy, sz);
-    const sdf::Regs<T> regs(lds, threadIdx.x, blockDim.x);
+    const sdf::Regs<T> regs(lds, threadIdx.x, blockDim.x, n4);
     const sdf::V4<T> r = sdf::run_tape<T, DO>(prog, extra, c.position(cx, step, c.x, x0), c.position(cy, step, c.y),
                                               c.position(cz, step, c.z), regs);
 #pragma unroll
@@ -159,7 +159,7 @@ k_grid_eval(const Rec* __restrict__ prog, const float* __restrict__ extra, float
 
 template <int LAYOUT, bool DO, int N>
 __global__ void __launch_bounds__(256)
-k_grid_eval_blocks(const Rec* __restrict__ prog, const float* __restrict__ extra,
+k_grid_eval_blocks(const Rec* __restrict__ prog, const float* __restrict__ extra, uint32_t n4,
                    const int4* __restrict__ blocks, uint32_t chunks, double res, double ox,
                    double oy, double oz, float step, uint32_t sx, uint32_t sy, uint32_t sz,
                    void* __restrict__ out)
@@ -175,7 +175,7 @@ k_grid_eval_blocks(const Rec* __restrict__ prog, const float* __restrict__ extra
     const float cz = (float)((double)ic.z * res + oz);
     const uint32_t lin0 = (chunk * blockDim.x + threadIdx.x) * N;
     const Cells<N> c(lin0, cells, sy, sz);
-    const sdf::Regs<T> regs(lds, threadIdx.x, blockDim.x);
+    const sdf::Regs<T> regs(lds, threadIdx.x, blockDim.x, n4);
     const sdf::V4<T> r = sdf::run_tape<T, DO>(prog, extra, c.position(cx, step, c.x), c.position(cy, step, c.y),
                                               c.position(cz, step, c.z), regs);
     const size_t base = (size_t)b * cells;
@@ -210,6 +210,7 @@ struct ClassifyArgs {
     uint32_t capacity;
     uint32_t* sums;        // MASS: uint32[10] per parent
     uint32_t scratch_offset;  // bytes of LDS taken by the register file (scratch follows)
+    uint32_t n4;              // float4 slots of the register file (scalar slots follow them)
 };
 
 template <bool MASS, bool BATCH, bool DO, int N>
@@ -248,7 +249,7 @@ __global__ void __launch_bounds__(256) k_classify(const ClassifyArgs a)
 
     const uint32_t lin0 = (chunk * blockDim.x + threadIdx.x) * N;
     const Cells<N> c(lin0, cells, a.sy, a.sz);
-    const sdf::Regs<T> regs(lds, threadIdx.x, blockDim.x);
+    const sdf::Regs<T> regs(lds, threadIdx.x, blockDim.x, a.n4);
     const T w = sdf::run_tape<T, DO>(a.prog, a.extra, c.position(cx, a.step, c.x), c.position(cy, a.step, c.y),
                                      c.position(cz, a.step, c.z), regs).w;
 
@@ -327,6 +328,8 @@ constexpr size_t kMaxLds = 160 * 1024;
 constexpr size_t kScratchBytes = 128;
 
 struct LaunchShape {
+    const Rec* prog;   // the program variant this launch runs
+    uint32_t n4;       // its float4 slot count
     uint32_t block;
     size_t lds;
     size_t regfile_bytes;
@@ -336,10 +339,13 @@ struct LaunchShape {
 }  // namespace
 
 struct hu_tape_s {
-    Rec* recs_dev = nullptr;
+    Rec* recs_dev = nullptr;     // full program
+    Rec* recs_do_dev = nullptr;  // distance-only program (NULL when the tape has a rounded blend)
     float* extra_dev = nullptr;
     int n_instr = 0;
-    int n_regs = 0;
+    int n_regs = 0;              // registers named by the tape
+    int n_slots = 0;             // float4 slots of the full program after renaming
+    int n_point_slots = 0, n_result_slots = 0;  // distance-only program
     int flags = 0;
 };
 
@@ -351,7 +357,7 @@ namespace {
 bool distance_only(const hu_tape_s* t)
 {
     static const bool forced_full = [] { const char* e = getenv("HU_FULL_INTERPRETER"); return e && e[0] == '1'; }();
-    return !forced_full && (t->flags & 1) == 0;
+    return !forced_full && t->recs_do_dev != nullptr;
 }
 
 // Voxels per lane and workgroup size from the register file.
@@ -365,8 +371,12 @@ int launch_shape(const hu_tape_s* t, LaunchShape& ls, bool distance_only_kernel)
 {
     static const int forced = [] { const char* e = getenv("HU_VOXELS_PER_LANE"); return e ? atoi(e) : 0; }();
     const int wanted = (forced == 1 || forced == 2) ? forced : (distance_only_kernel ? 2 : 1);
+    const Rec* prog = distance_only_kernel ? t->recs_do_dev : t->recs_dev;
+    ls.prog = prog;
+    ls.n4 = (uint32_t)(distance_only_kernel ? t->n_point_slots : t->n_slots);
     for (int n = wanted; n >= 1; --n) {
-        const size_t per_lane = (size_t)t->n_regs * 16 * n;
+        const size_t per_lane = (distance_only_kernel ? (size_t)t->n_point_slots * 16 + (size_t)t->n_result_slots * 4
+                                                      : (size_t)t->n_slots * 16) * n;
         uint32_t bs = 256;
         while (bs > 64 && per_lane * bs > 48 * 1024) bs >>= 1;
         const size_t regfile = per_lane * bs;
@@ -378,8 +388,8 @@ int launch_shape(const hu_tape_s* t, LaunchShape& ls, bool distance_only_kernel)
             return HU_OK;
         }
     }
-    return fail(HU_ERR_UNSUPPORTED, "tape uses " + std::to_string(t->n_regs) +
-                                        " value registers; at most 159 fit the 160 KiB LDS register file");
+    return fail(HU_ERR_UNSUPPORTED, "tape keeps " + std::to_string(t->n_slots) +
+                                        " values live at once; at most 159 fit the 160 KiB LDS register file");
 }
 
 template <typename K>
@@ -594,13 +604,21 @@ int hu_tape_create(const float* tape, size_t n, hu_tape* out)
     hu_tape_s* t = new hu_tape_s();
     t->n_instr = (int)d.recs.size() - sdf::kTapePadding;
     t->n_regs = d.n_regs;
+    t->n_slots = d.n_slots;
+    t->n_point_slots = d.n_point_slots;
+    t->n_result_slots = d.n_result_slots;
     t->flags = d.direction_feeds_distance ? 1 : 0;
     hipError_t e = hipMalloc((void**)&t->recs_dev, d.recs.size() * sizeof(Rec));
+    if (e == hipSuccess && !d.recs_do.empty()) {
+        e = hipMalloc((void**)&t->recs_do_dev, d.recs_do.size() * sizeof(Rec));
+        if (e == hipSuccess) e = hipMemcpy(t->recs_do_dev, d.recs_do.data(), d.recs_do.size() * sizeof(Rec), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess) e = hipMalloc((void**)&t->extra_dev, d.extra.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(t->recs_dev, d.recs.data(), d.recs.size() * sizeof(Rec), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(t->extra_dev, d.extra.data(), d.extra.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         (void)hipFree(t->recs_dev);
+        (void)hipFree(t->recs_do_dev);
         (void)hipFree(t->extra_dev);
         delete t;
         return fail(HU_ERR_HIP, std::string("tape upload: ") + hipGetErrorString(e));
@@ -613,6 +631,7 @@ int hu_tape_destroy(hu_tape t)
 {
     if (!t) return HU_OK;
     (void)hipFree(t->recs_dev);
+    (void)hipFree(t->recs_do_dev);
     (void)hipFree(t->extra_dev);
     delete t;
     return HU_OK;
@@ -622,7 +641,7 @@ int hu_tape_info(hu_tape t, int* n_instructions, int* n_registers, int* flags)
 {
     if (!t) return fail(HU_ERR_BAD_ARG, "tape is NULL");
     if (n_instructions) *n_instructions = t->n_instr;
-    if (n_registers) *n_registers = t->n_regs;
+    if (n_registers) *n_registers = t->n_slots;
     if (flags) *flags = t->flags;
     return HU_OK;
 }
@@ -650,8 +669,8 @@ int hu_grid_eval_slab(hu_tape t, const float corner[4], float step, const uint32
         const uint32_t blocks = (n_cells + per_block - 1) / per_block;
         void* o = (layout == 0) ? (void*)(static_cast<float4*>(out_dev) + (size_t)done * plane) : out_dev;
 #define HU_LAUNCH_DENSE(L, D, NV)                                                                                  \
-    hipLaunchKernelGGL((k_grid_eval<L, D, NV>), dim3(blocks), dim3(ls.block), ls.lds, (hipStream_t)stream, t->recs_dev, \
-                       t->extra_dev, corner[0], corner[1], corner[2], step, dims[0], dims[1], dims[2], x0 + done,  \
+    hipLaunchKernelGGL((k_grid_eval<L, D, NV>), dim3(blocks), dim3(ls.block), ls.lds, (hipStream_t)stream, ls.prog,    \
+                       t->extra_dev, ls.n4, corner[0], corner[1], corner[2], step, dims[0], dims[1], dims[2], x0 + done,  \
                        n_cells, o)
         const bool d_only = layout == 1 && distance_only(t);
         if (ls.voxels_per_lane == 2) {
@@ -701,8 +720,8 @@ int hu_grid_eval_blocks(hu_tape t, const int32_t* blocks_dev, uint32_t n_blocks,
     if ((uint64_t)chunks * n_blocks > 0x7fffffffull) return fail(HU_ERR_BAD_ARG, "too many workgroups in one launch");
     const dim3 grid(chunks * n_blocks), block(ls.block);
 #define HU_LAUNCH_BLOCKS(L, D, NV)                                                                                 \
-    hipLaunchKernelGGL((k_grid_eval_blocks<L, D, NV>), grid, block, ls.lds, (hipStream_t)stream, t->recs_dev,      \
-                       t->extra_dev, (const int4*)blocks_dev, chunks, resolution, origin[0], origin[1], origin[2], \
+    hipLaunchKernelGGL((k_grid_eval_blocks<L, D, NV>), grid, block, ls.lds, (hipStream_t)stream, ls.prog,          \
+                       t->extra_dev, ls.n4, (const int4*)blocks_dev, chunks, resolution, origin[0], origin[1], origin[2], \
                        step, dims[0], dims[1], dims[2], out_dev)
     const bool d_only = layout == 1 && distance_only(t);
     if (ls.voxels_per_lane == 2) {
@@ -736,7 +755,8 @@ int launch_classify(hu_tape t, ClassifyArgs& a, uint32_t n_parents, const uint32
     LaunchShape ls;
     if ((rc = launch_shape(t, ls, distance_only(t)))) return rc;
     if ((rc = ensure_attrs())) return rc;
-    a.prog = t->recs_dev;
+    a.prog = ls.prog;
+    a.n4 = ls.n4;
     a.extra = t->extra_dev;
     a.sx = dims[0];
     a.sy = dims[1];

@@ -393,28 +393,37 @@ __device__ __noinline__ float4 involute_gear_op(float base_radius, float tooth_a
 
 
 // ---------------------------------------------------------------------------------------
-// Value registers in LDS.
-//   T = float: [reg][lane] float4 slots, ds_read/write_b128, lanes 16 B apart (conflict-free).
-//   T = f2:    [reg][component][lane] 8-byte slots, ds_read/write_b64, lanes 8 B apart
-//              (conflict-free; the packed register pairs go out as they are, no repacking).
+// Value registers in LDS.  Slots are assigned by tape.hpp allocate_slots (liveness-packed).
+// Two areas: `n4` float4 slots (points; in the full program also results), then scalar slots
+// (distance-only program: a result is just its distance).
+//   T = float: float4 area [slot][lane] (ds_*_b128, lanes 16 B apart), scalar area [slot][lane]
+//              (ds_*_b32, lanes 4 B apart) -- both conflict-free.
+//   T = f2:    float4 area [slot][component][lane] of 8-byte pairs (ds_*_b64), scalar area
+//              [slot][lane] of 8-byte pairs -- conflict-free, and the packed register pairs go
+//              out as they are, no repacking.
 // ---------------------------------------------------------------------------------------
 template <class T> struct Regs;
 template <> struct Regs<float> {
-    float4* base;  // this lane's slot of register 0
+    float4* base;  // this lane's slot of float4 register 0
+    float* res;    // this lane's slot of scalar register 0
     uint32_t stride;
-    static constexpr uint32_t kBytesPerLanePerReg = 16;
-    __device__ __forceinline__ Regs(void* lds, uint32_t lane, uint32_t lanes) : base((float4*)lds + lane), stride(lanes) {}
+    static constexpr uint32_t kLaneBytes = 4;
+    __device__ __forceinline__ Regs(void* lds, uint32_t lane, uint32_t lanes, uint32_t n4)
+        : base((float4*)lds + lane), res((float*)((float4*)lds + n4 * lanes) + lane), stride(lanes) {}
     __device__ __forceinline__ V4<float> load(uint32_t r) const { float4 v = base[r * stride]; return v4<float>(v.x, v.y, v.z, v.w); }
     __device__ __forceinline__ void store(uint32_t r, const V4<float>& v) const { base[r * stride] = f4(v.x, v.y, v.z, v.w); }
     __device__ __forceinline__ float load_x(uint32_t r) const { return base[r * stride].x; }
     __device__ __forceinline__ float load_z(uint32_t r) const { return base[r * stride].z; }
-    __device__ __forceinline__ float load_w(uint32_t r) const { return base[r * stride].w; }
+    __device__ __forceinline__ float load_res(uint32_t r) const { return res[r * stride]; }
+    __device__ __forceinline__ void store_res(uint32_t r, float w) const { res[r * stride] = w; }
 };
 template <> struct Regs<f2> {
     f2* base;
+    f2* res;
     uint32_t stride;
-    static constexpr uint32_t kBytesPerLanePerReg = 32;
-    __device__ __forceinline__ Regs(void* lds, uint32_t lane, uint32_t lanes) : base((f2*)lds + lane), stride(lanes) {}
+    static constexpr uint32_t kLaneBytes = 8;
+    __device__ __forceinline__ Regs(void* lds, uint32_t lane, uint32_t lanes, uint32_t n4)
+        : base((f2*)lds + lane), res((f2*)lds + n4 * 4u * lanes + lane), stride(lanes) {}
     __device__ __forceinline__ f2* slot(uint32_t r, uint32_t c) const { return base + (r * 4u + c) * stride; }
     __device__ __forceinline__ V4<f2> load(uint32_t r) const { return v4<f2>(*slot(r, 0), *slot(r, 1), *slot(r, 2), *slot(r, 3)); }
     __device__ __forceinline__ void store(uint32_t r, const V4<f2>& v) const
@@ -423,7 +432,8 @@ template <> struct Regs<f2> {
     }
     __device__ __forceinline__ f2 load_x(uint32_t r) const { return *slot(r, 0); }
     __device__ __forceinline__ f2 load_z(uint32_t r) const { return *slot(r, 2); }
-    __device__ __forceinline__ f2 load_w(uint32_t r) const { return *slot(r, 3); }
+    __device__ __forceinline__ f2 load_res(uint32_t r) const { return res[r * stride]; }
+    __device__ __forceinline__ void store_res(uint32_t r, f2 w) const { res[r * stride] = w; }
 };
 
 // ---------------------------------------------------------------------------------------
@@ -445,13 +455,20 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const floa
                                          T pz, const Regs<T>& regs)
 {
     const uint32_t op = cur.hdr & 0xffu;
-    const uint32_t reg = cur.hdr >> 8;
+    const uint32_t reg = (cur.hdr >> 8) & 0xffffu;
+    const bool scalar_slot = DISTANCE_ONLY && (cur.hdr & kResultKind);  // wave-uniform
     const float* p = cur.p;
     const V4<T> none = v4<T>(bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f));
     switch (op) {
     case OP_RETURN: return true;
-    case OP_STORE: regs.store(reg, last); break;
-    case OP_LOAD: last = regs.load(reg); break;
+    case OP_STORE:
+        if (scalar_slot) regs.store_res(reg, last.w);
+        else regs.store(reg, last);
+        break;
+    case OP_LOAD:
+        if (scalar_slot) last.w = regs.load_res(reg);
+        else last = regs.load(reg);
+        break;
     case OP_RECTANGLE:
         if (DISTANCE_ONLY) last.w = perp_w<T>(abs_(last.x) - p[0], abs_(last.y) - p[1]);
         else last = rectangle_op(p[0], p[1], last);
@@ -559,15 +576,15 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const floa
         break;
     }
     case OP_UNION:
-        if (DISTANCE_ONLY) { T b = regs.load_w(reg); last.w = sel(last.w < b, last.w, b); }
+        if (DISTANCE_ONLY) { T b = regs.load_res(reg); last.w = sel(last.w < b, last.w, b); }
         else last = rounded_union(p[0], last, regs.load(reg));
         break;
     case OP_INTERSECTION:
-        if (DISTANCE_ONLY) { T a = -last.w, b = -regs.load_w(reg); last.w = -sel(a < b, a, b); }
+        if (DISTANCE_ONLY) { T a = -last.w, b = -regs.load_res(reg); last.w = -sel(a < b, a, b); }
         else last = neg(rounded_union(p[0], neg(last), neg(regs.load(reg))));
         break;
     case OP_SUBTRACTION:
-        if (DISTANCE_ONLY) { T a = -last.w, b = regs.load_w(reg); last.w = -sel(a < b, a, b); }
+        if (DISTANCE_ONLY) { T a = -last.w, b = regs.load_res(reg); last.w = -sel(a < b, a, b); }
         else last = neg(rounded_union(p[0], neg(last), regs.load(reg)));
         break;
     default: return true;  // unreachable: tapes are validated at upload

@@ -58,7 +58,10 @@ inline const OpInfo& op_info(uint32_t op)
     return table[op];
 }
 
-// One decoded instruction: 12 dwords.  hdr = opcode | (secondaryRegister << 8).
+// One decoded instruction: 12 dwords.  hdr = opcode | (slot << 8) | kResultKind?.
+// `slot` is NOT the tape's register number: registers are renamed at decode time
+// (allocate_slots below) to the smallest set of LDS slots that liveness allows.
+constexpr uint32_t kResultKind = 0x80000000u;  // distance-only program: the slot holds a bare distance
 struct alignas(16) Rec {
     uint32_t hdr;
     float p[11];
@@ -68,12 +71,105 @@ static_assert(sizeof(Rec) == 48, "Rec must be 48 bytes");
 inline float bits_f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 
 struct DecodedTape {
-    std::vector<Rec> recs;
+    std::vector<Rec> recs;        // full program: every slot is a float4 (direction + distance / point)
+    std::vector<Rec> recs_do;     // distance-only program: point slots (float4) and result slots (float)
     std::vector<float> extra;     // polygon2d vertex data
-    int n_regs = 0;               // highest register index + 1
-    bool direction_feeds_distance = false;  // any rounded union (r >= 0)
-    bool deterministic_only = true;
+    int n_regs = 0;               // highest register index of the TAPE + 1 (what the reference allocates)
+    int n_slots = 0;              // float4 slots the full program needs
+    int n_point_slots = 0;        // distance-only program: float4 slots
+    int n_result_slots = 0;       // distance-only program: float slots
+    bool direction_feeds_distance = false;  // any rounded union (r >= 0): no distance-only program
 };
+
+// Does the op leave a POINT (xyz meaningful) or a RESULT (direction + distance) in lastValue?
+inline bool produces_point(uint32_t op)
+{
+    switch (op) {
+    case OP_INITIAL_TRANSFORMATION_TO: case OP_TRANSFORMATION_TO: case OP_SYMMETRICAL_TO: case OP_REPETITION:
+    case OP_CIRCULAR_REPETITION_TO: case OP_REVOLUTION_TO: case OP_TWIST_REVOLUTION_TO:
+        return true;
+    default: return false;
+    }
+}
+// Binary ops whose register operand is a point (the sample coordinates), not a result.
+inline bool reads_point_operand(uint32_t op)
+{
+    return op == OP_EXTRUSION || op == OP_REVOLUTION_FROM || op == OP_TWIST_REVOLUTION_FROM ||
+           op == OP_SYMMETRICAL_FROM || op == OP_CIRCULAR_REPETITION_FROM;
+}
+
+// Register renaming.  The tape's register numbers come from the reference's scheduler, which
+// leaks registers (the planetary assembly uses 40 while at most 10 values are ever live), and
+// the interpreter keeps registers in LDS, where their number sets the occupancy.  Each _store
+// starts a live range that ends at the last read before the next _store to the same register;
+// ranges are packed greedily into slots.  For the distance-only program ranges are typed:
+// a range holding a RESULT only needs its distance (4 bytes instead of 16).
+// Returns false when the tape reads a register before writing it or mixes kinds in a way the
+// distance-only program cannot represent (then only the full program is used).
+inline bool allocate_slots(DecodedTape& d, std::string& err)
+{
+    struct Range { int first, last; bool result; int slot_full, slot_do; };
+    const int n = (int)d.recs.size();
+    std::vector<Range> ranges;
+    std::vector<int> open_range(kRefRegisterCount, -1);  // register -> index into ranges
+    std::vector<int> range_of(n, -1);                    // instruction -> range it writes/reads
+    bool last_is_result = false;
+    bool do_ok = !d.direction_feeds_distance;
+    for (int i = 0; i < n; ++i) {
+        const uint32_t op = d.recs[i].hdr & 0xffu, reg = d.recs[i].hdr >> 8;
+        const int arity = op_info(op).arity;
+        if (op == OP_STORE) {
+            ranges.push_back({i, i, last_is_result, -1, -1});
+            open_range[reg] = (int)ranges.size() - 1;
+            range_of[i] = open_range[reg];
+        } else if (op == OP_LOAD || arity == 2) {
+            const int r = open_range[reg];
+            if (r < 0) { err = std::string(op_info(op).name) + " reads register " + std::to_string(reg) + " before any _store"; return false; }
+            ranges[r].last = i;
+            range_of[i] = r;
+            if (op == OP_LOAD) last_is_result = ranges[r].result;
+            else {
+                if (ranges[r].result == reads_point_operand(op)) do_ok = false;  // kind mismatch
+                last_is_result = true;
+            }
+        } else if (op == OP_MIRROR || op == OP_RETURN) {
+            // keeps the kind
+        } else {
+            last_is_result = !produces_point(op);
+        }
+        if (op == OP_RETURN) break;
+    }
+    // greedy interval packing in order of start (ranges are already sorted by `first`)
+    auto pack = [&](bool typed, bool want_result, int Range::*slot) {
+        std::vector<int> busy_until;  // per slot
+        int used = 0;
+        for (auto& r : ranges) {
+            if (typed && r.result != want_result) continue;
+            int s = 0;
+            while (s < (int)busy_until.size() && busy_until[s] >= r.first) ++s;
+            if (s == (int)busy_until.size()) busy_until.push_back(-1);
+            busy_until[s] = r.last;
+            r.*slot = s;
+            used = (int)busy_until.size();
+        }
+        return used;
+    };
+    d.n_slots = pack(false, false, &Range::slot_full);
+    d.recs_do.clear();
+    if (do_ok) {
+        d.n_point_slots = pack(true, false, &Range::slot_do);
+        d.n_result_slots = pack(true, true, &Range::slot_do);
+        d.recs_do = d.recs;
+    }
+    for (int i = 0; i < n; ++i) {
+        if (range_of[i] < 0) continue;
+        const Range& r = ranges[range_of[i]];
+        const uint32_t op = d.recs[i].hdr & 0xffu;
+        d.recs[i].hdr = op | ((uint32_t)r.slot_full << 8);
+        if (do_ok) d.recs_do[i].hdr = op | ((uint32_t)r.slot_do << 8) | (r.result ? kResultKind : 0u);
+    }
+    return true;
+}
 
 // quaternion helpers used for the folded constants; same op order as the kernels/oracle
 inline float q_k(const float* q) { return fma_(q[3], q[3], -fma_(q[2], q[2], fma_(q[1], q[1], q[0] * q[0]))); }
@@ -168,10 +264,17 @@ inline std::string decode_tape(const float* tape, size_t n, DecodedTape& out)
     }
     if (!returned) return "tape does not end with _return";
     if (out.extra.empty()) out.extra.push_back(0.0f);
+    {
+        std::string err;
+        if (!allocate_slots(out, err)) return err;
+    }
     // Zero (= _return) records of padding: the interpreter fetches records in groups.
     Rec pad;
     std::memset(&pad, 0, sizeof(pad));
-    for (int i = 0; i < kTapePadding; ++i) out.recs.push_back(pad);
+    for (int i = 0; i < kTapePadding; ++i) {
+        out.recs.push_back(pad);
+        if (!out.recs_do.empty()) out.recs_do.push_back(pad);
+    }
     return "";
 }
 

@@ -54,7 +54,9 @@ def _integrals(sums, corners, s):
         "xz": s3 * (n * bx * bz + bx * tz + bz * tx + txz),
         "yz": s3 * (n * by * bz + by * tz + bz * ty + tyz),
     }
-    return {k: math.fsum(v.tolist()) for k, v in parts.items()}
+    # extended-precision accumulation: at least as accurate as the reference's Kahan sums and
+    # independent of the order in which parents were listed
+    return {k: float(numpy.sum(v, dtype=numpy.longdouble)) for k, v in parts.items()}
 
 
 def finish(total):
