@@ -185,7 +185,7 @@ def main():
             "samples_per_step_per_gpu": {"dense": dense_voxels, "subdivision": stats["samples"],
                                          "leaf_blocks": stats["leaves"] * leaf_cells,
                                          "survivors_per_level_global": stats["level_counts"]},
-            "roofline": {"bound": "hbm", "kernel": "k_grid_eval<0>", "achieved": round(achieved, 2),
+            "roofline": {"bound": "hbm", "kernel": "k_grid_eval<0,false,1>", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": measured_traffic(n), "kernel_ms": round(dense_avg_ms, 4),
                          "voxels_per_s": round(dense_voxels / (dense_avg_ms * 1e-3), 0),

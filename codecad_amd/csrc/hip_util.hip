@@ -322,6 +322,61 @@ __global__ void __launch_bounds__(256) k_classify(const ClassifyArgs a)
 }
 
 // ------------------------------------------------------------------------------------------
+// mass_properties: per-parent index sums -> the ten integrals of this level, on the device.
+// The reference does this on the host, block by block, in Python doubles with Kahan sums
+// (mass_properties.py:119-148).  Same per-block formulas in fp64 (no contraction), summed
+// deterministically: thread t Kahan-accumulates parents t, t+1024, ... and the 1024 partial
+// sums are combined by a fixed tree, so the result does not depend on launch timing.
+// One workgroup: a level has at most a few 100k parents, i.e. microseconds of work.
+// out[10] order: 1, x, y, z, xx, yy, zz, xy, xz, yz.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+k_mass_integrals(const double4* __restrict__ parents, const uint32_t* __restrict__ sums, uint32_t n, double s,
+                 double* __restrict__ out)
+{
+    __shared__ double part[10][1024];
+    double acc[10], comp[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) acc[k] = comp[k] = 0.0;
+    const double s2 = s * s, s3 = s * s2, h = s / 2, twelfth = s2 / 12;
+    for (uint32_t p = threadIdx.x; p < n; p += 1024) {
+        const double4 c = parents[p];
+        const uint32_t* u = sums + (size_t)p * 10;
+        const double sxx = u[0], sxy = u[1], sxz = u[2], sx = u[3], syy = u[4], syz = u[5], sy = u[6], szz = u[7],
+                     sz = u[8], cnt = u[9];
+        const double bx = c.x + h, by = c.y + h, bz = c.z + h;
+        const double tx = s * sx, ty = s * sy, tz = s * sz;
+        const double v[10] = {
+            s3 * cnt,
+            s3 * (cnt * bx + tx), s3 * (cnt * by + ty), s3 * (cnt * bz + tz),
+            s3 * (cnt * (bx * bx + twelfth) + 2 * bx * tx + s2 * sxx),
+            s3 * (cnt * (by * by + twelfth) + 2 * by * ty + s2 * syy),
+            s3 * (cnt * (bz * bz + twelfth) + 2 * bz * tz + s2 * szz),
+            s3 * (cnt * bx * by + bx * ty + by * tx + s2 * sxy),
+            s3 * (cnt * bx * bz + bx * tz + bz * tx + s2 * sxz),
+            s3 * (cnt * by * bz + by * tz + bz * ty + s2 * syz)};
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {  // Kahan, like the reference's util.KahanSummation
+            const double y = v[k] - comp[k];
+            const double t = acc[k] + y;
+            comp[k] = (t - acc[k]) - y;
+            acc[k] = t;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 10; ++k) part[k][threadIdx.x] = acc[k];
+    __syncthreads();
+    for (uint32_t stride = 512; stride > 0; stride >>= 1) {
+        if (threadIdx.x < stride) {
+#pragma unroll
+            for (int k = 0; k < 10; ++k) part[k][threadIdx.x] += part[k][threadIdx.x + stride];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 10) out[threadIdx.x] = part[threadIdx.x][0];
+}
+
+// ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 constexpr size_t kMaxLds = 160 * 1024;
@@ -839,6 +894,16 @@ int hu_mass_properties_level(hu_tape t, const double* parents_dev, uint32_t n_pa
     a.counter = counter_dev; a.list = children_dev; a.capacity = capacity;
     a.sums = sums_dev;
     return launch_classify<true, true>(t, a, n_parents, dims, stream);
+}
+
+int hu_mass_integrals(const double* parents_dev, const uint32_t* sums_dev, uint32_t n_parents, double s,
+                      double* out10_dev, void* stream)
+{
+    if (!out10_dev || ((!parents_dev || !sums_dev) && n_parents)) return fail(HU_ERR_BAD_ARG, "NULL argument");
+    hipLaunchKernelGGL(k_mass_integrals, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const double4*)parents_dev,
+                       sums_dev, n_parents, s, out10_dev);
+    HU_HIP(hipGetLastError());
+    return HU_OK;
 }
 
 }  // extern "C"

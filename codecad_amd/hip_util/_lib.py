@@ -48,6 +48,7 @@ PROTOTYPES = {
     "hu_grid_eval_blocks": [_vp, _vp, _u32, _d, _d3, _f, _u3, _i, _vp, _vp],
     "hu_subdivision_level": [_vp, _vp, _u32, _c.c_int32, _u3, _i, _d, _d3, _f, _f, _vp, _vp, _u32, _vp],
     "hu_mass_properties_level": [_vp, _vp, _u32, _d, _u3, _f, _f, _vp, _vp, _vp, _u32, _vp],
+    "hu_mass_integrals": [_vp, _vp, _u32, _d, _vp, _vp],
 }
 
 HEADER = os.path.normpath(os.path.join(os.path.dirname(__file__), "..", "..", "include", "hip_util.h"))

@@ -29,8 +29,14 @@ class MassProperties(collections.namedtuple("MassProperties", "volume centroid i
     __slots__ = ()
 
 
-def _integrals(sums, corners, s):
-    """Per-parent index sums -> the ten integrals over the inside cells, exact-summed.
+_KEYS = ("1", "x", "y", "z", "xx", "yy", "zz", "xy", "xz", "yz")
+
+
+def integrals_host(sums, corners, s):
+    """Host (numpy) evaluation of the same formulas, used by the tests to cross-check the
+    device reduction `hu_mass_integrals`; the driver does not call it.
+
+    Per-parent index sums -> the ten integrals over the inside cells.
 
     sums: (n,10) uint32 in kernel order xx,xy,xz,x,yy,yz,y,zz,z,n; corners: (n,3) float64 box
     corners; s: cell size.  Formulas of reference mass_properties.py:119-148 (a cell
@@ -100,12 +106,14 @@ def level_integrals(tape, parents, n_parents, s, dims, leaf, queue, counter):
             break
         children.release()
         capacity = count
-    host_parents = numpy.empty((parents.shape[0], 4), dtype=numpy.float64)
-    parents.read(out=host_parents)
-    host_sums = numpy.empty((n_parents, 10), dtype=numpy.uint32)
-    sums.read(out=host_sums)
+    # the ten integrals of this level, reduced on the device: 80 bytes come back
+    out = hip_util.Buffer(numpy.float64, 10, queue=queue)
+    check(lib.hu_mass_integrals(parents.device_ptr, sums.device_ptr, n_parents, float(s), out.device_ptr,
+                                queue.handle), "hu_mass_integrals")
+    values = out.read().tolist()
     sums.release()
-    return _integrals(host_sums, host_parents[:n_parents, :3], s), children, (0 if leaf else count)
+    out.release()
+    return dict(zip(_KEYS, values)), children, (0 if leaf else count)
 
 
 def mass_properties(shape, resolution, grid_size=None):
@@ -125,7 +133,7 @@ def mass_properties(shape, resolution, grid_size=None):
     parents = hip_util.Buffer(numpy.float64, (1, 4), queue=queue)
     parents.enqueue_write(numpy.array([[box.a.x, box.a.y, box.a.z, 0.0]], dtype=numpy.float64))
     counter = hip_util.Buffer(numpy.uint32, 1, queue=queue)
-    total = dict.fromkeys(("1", "x", "y", "z", "xx", "yy", "zz", "xy", "xz", "yz"), 0.0)
+    total = {k: util.KahanSummation() for k in _KEYS}
     count = 1
     stats = {"kernel_invocations": 0, "function_evaluations": 0}
     for i, (s, dims) in enumerate(levels):
@@ -134,13 +142,13 @@ def mass_properties(shape, resolution, grid_size=None):
         stats["function_evaluations"] += count * int(dims[0]) * int(dims[1]) * int(dims[2])
         part, children, n_children = level_integrals(tape, parents, count, s, dims, leaf, queue, counter)
         for k in total:
-            total[k] = total[k] + part[k]
+            total[k] += part[k]
         parents.release()
         parents, count = children, n_children
         if count == 0:
             break
     parents.release()
     counter.release()
-    result = finish(total)
+    result = finish({k: v.result for k, v in total.items()})
     mass_properties.last_stats = stats
     return result

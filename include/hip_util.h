@@ -130,6 +130,12 @@ int hu_mass_properties_level(hu_tape t, const double* parents_dev, uint32_t n_pa
                              uint32_t* sums_dev, uint32_t* counter_dev, double* children_dev,
                              uint32_t capacity, void* stream);
 
+/* The ten integrals (1, x, y, z, xx, yy, zz, xy, xz, yz over the inside cells) of one level from
+ * the per-parent index sums, with the per-block formulas of mass_properties.py:119-148 in fp64,
+ * summed deterministically on the device.  out10_dev: double[10]. */
+int hu_mass_integrals(const double* parents_dev, const uint32_t* sums_dev, uint32_t n_parents, double s,
+                      double* out10_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

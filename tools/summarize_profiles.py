@@ -20,7 +20,7 @@ for f in glob.glob(os.path.join(root, "bench_stats", "*", "*_kernel_stats.csv"))
 for f in glob.glob(os.path.join(root, "pmc_*", "*", "*_counter_collection.csv")):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "k_grid_eval<0>" in r["Kernel_Name"]:
+        if "k_grid_eval<0," in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in acc.items():
         out["dense_kernel_counters_per_launch"][k] = sum(v) / len(v)
