@@ -64,7 +64,10 @@ def main():
 
     shape = cc.examples.sponge(SPONGE_DEPTH)
     tape = cc.nodes.make_program_buffer(shape)
-    queue = m.queue
+    # Everything is enqueued on torch's current stream: the survivor lists travel through
+    # torch.distributed (RCCL orders its collectives against that stream), so one stream gives
+    # the kernel -> all-gather -> kernel dependencies without extra synchronisation.
+    queue = m.wrap_stream(torch.cuda.current_stream().cuda_stream)
     stream = queue.handle
 
     # ---- A: dense grid ------------------------------------------------------------------
