@@ -416,16 +416,19 @@ bool distance_only(const hu_tape_s* t)
 }
 
 // Voxels per lane and workgroup size from the register file.
-// Measured on MI355X (tools/prof_shape.py): the distance-only interpreter
-// is limited by scalar issue and latency, so two voxels per lane (packed float2) win there
-// (sponge(4) 512^3: 4.66 vs 5.42 ms); the full interpreter is VALU-bound at one voxel per lane
-// and loses occupancy with two (5.27 vs 5.63 ms).  HU_VOXELS_PER_LANE=1|2 forces a choice
-// (the parity tests run both).  The LDS footprint per workgroup is kept <= 48 KiB while the
-// tape allows it; never below one wavefront.
+// Two voxels per lane (packed float2) halve the scalar work per voxel (fetch, decode, compare
+// tree, branch), which is what limits the interpreter once the VALU work is trimmed, but they
+// double the LDS register file.  Measured on MI355X (tools/prof_shape.py):
+// two win whenever a 256-lane workgroup's file still fits 48 KiB (>= 3 workgroups per CU):
+// always for the distance-only program (48-52 B per voxel), for the full program up to 6 live
+// float4 values (sponge(4): 5.3 vs 5.8 ms; sponge(5), 7 values: 8.0 vs 7.7 ms -> one voxel).
+// HU_VOXELS_PER_LANE=1|2 forces a choice (the parity tests run both).
 int launch_shape(const hu_tape_s* t, LaunchShape& ls, bool distance_only_kernel)
 {
     static const int forced = [] { const char* e = getenv("HU_VOXELS_PER_LANE"); return e ? atoi(e) : 0; }();
-    const int wanted = (forced == 1 || forced == 2) ? forced : (distance_only_kernel ? 2 : 1);
+    const size_t lane_bytes = distance_only_kernel ? (size_t)t->n_point_slots * 16 + (size_t)t->n_result_slots * 4
+                                                   : (size_t)t->n_slots * 16;
+    const int wanted = (forced == 1 || forced == 2) ? forced : ((lane_bytes * 2 * 256 <= 48 * 1024) ? 2 : 1);
     const Rec* prog = distance_only_kernel ? t->recs_do_dev : t->recs_dev;
     ls.prog = prog;
     ls.n4 = (uint32_t)(distance_only_kernel ? t->n_point_slots : t->n_slots);

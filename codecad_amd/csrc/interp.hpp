@@ -48,6 +48,20 @@ __device__ __forceinline__ float get(float v, int) { return v; }
 __device__ __forceinline__ float get(f2 v, int i) { return i ? v.y : v.x; }
 __device__ __forceinline__ f2 make_f2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }  // NOT (f2)(a, b): in C++ that casts a comma expression
 
+// Does any lane of the wavefront (any voxel of any lane) have the flag set?  Wave-uniform, so a
+// branch on it is a scalar branch: used to skip the sqrt / reciprocal blocks of the
+// perpendicular-intersection ops when no lane is in the corner region that needs them.
+#ifndef SDF_SKIP_CORNER
+#define SDF_SKIP_CORNER 1
+#endif
+#if SDF_SKIP_CORNER
+__device__ __forceinline__ bool any_lane(bool m) { return __ballot(m) != 0ull; }
+__device__ __forceinline__ bool any_lane(i2 m) { return __ballot((m.x | m.y) != 0) != 0ull; }
+#else
+__device__ __forceinline__ bool any_lane(bool) { return true; }
+__device__ __forceinline__ bool any_lane(i2) { return true; }
+#endif
+
 template <class T> struct V4 { T x, y, z, w; };
 template <class T> __device__ __forceinline__ V4<T> v4(T x, T y, T z, T w) { V4<T> r = {x, y, z, w}; return r; }
 template <class T> __device__ __forceinline__ V4<T> neg(V4<T> a) { return v4<T>(-a.x, -a.y, -a.z, -a.w); }
@@ -118,10 +132,13 @@ template <class T> __device__ __forceinline__ V4<T> rectangle_op(float hw, float
     const T one = bc<T>(1.0f), zero = bc<T>(0.0f);
     T sx = copysign_(one, c.x), sy = copysign_(one, c.y);
     T wx = abs_(c.x) - hw, wy = abs_(c.y) - hh;
-    T dist = len2(wx, wy);
-    T inv = 1.0f / dist;
     auto corner = (wx > 0.0f) & (wy > 0.0f);
     auto xs = wx > wy;
+    T dist = wx, inv = wx;  // only read where `corner` holds
+    if (any_lane(corner)) {
+        dist = len2(wx, wy);
+        inv = 1.0f / dist;
+    }
     return v4<T>(sel(corner, sx * (wx * inv), sel(xs, sx, zero)), sel(corner, sy * (wy * inv), sel(xs, zero, sy)), zero,
                  sel(corner, dist, sel(xs, wx, wy)));
 }
@@ -131,8 +148,9 @@ template <class T> __device__ __forceinline__ V4<T> rectangle_op(float hw, float
 // distance (tape.hpp: direction_feeds_distance).
 template <class T> __device__ __forceinline__ T perp_w(T a, T b)
 {
-    T dist = len2(a, b);
     auto corner = (a > 0.0f) & (b > 0.0f);
+    T dist = a;
+    if (any_lane(corner)) dist = len2(a, b);
     return sel(corner, dist, sel(a > b, a, b));
 }
 
@@ -142,11 +160,14 @@ template <class T> __device__ __forceinline__ V4<T> extrusion_op(float hh, V4<T>
     const T one = bc<T>(1.0f), zero = bc<T>(0.0f);
     T sz = copysign_(one, coords.z);
     T wz = abs_(coords.z) - hh;
-    T dist = len2(wz, in.w);
-    T inv = 1.0f / dist;
-    T m1 = wz * inv, m2 = in.w * inv;
     auto corner = (wz > 0.0f) & (in.w > 0.0f);
     auto cap = wz > in.w;
+    T dist = wz, inv = wz;  // only read where `corner` holds
+    if (any_lane(corner)) {
+        dist = len2(wz, in.w);
+        inv = 1.0f / dist;
+    }
+    T m1 = wz * inv, m2 = in.w * inv;
     return v4<T>(sel(corner, in.x * m2, sel(cap, zero, in.x)), sel(corner, in.y * m2, sel(cap, zero, in.y)),
                  sel(corner, fma_(in.z, m2, sz * m1), sel(cap, sz, in.z)), sel(corner, dist, sel(cap, wz, in.w)));
 }
@@ -522,6 +543,42 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const floa
         T ox, oy, oz;
         quat_xform<T>(p[0], p[1], p[2], p[3], p[4], last.x, last.y, last.z, ox, oy, oz);
         last = v4<T>(ox * p[6], oy * p[6], oz * p[6], last.w * p[5]);
+        break;
+    }
+    // transformation_from with an axis-aligned quaternion (decoder special cases, tape.hpp).
+    // Obtained from quat_xform by deleting every product with an exactly-zero quaternion
+    // component: a deleted term is +-0, adding it changes no non-zero value, and an fma with a
+    // +-0 addend rounds like the bare product.  Equal to the general op under == (a zero
+    // component may differ in sign; directions never reach copysign/atan2/division).
+    case OPX_FROM_SCALE:
+        if (DISTANCE_ONLY) { last.w = last.w * p[5]; break; }
+        last = v4<T>((last.x * p[4]) * p[6], (last.y * p[4]) * p[6], (last.z * p[4]) * p[6], last.w * p[5]);
+        break;
+    case OPX_FROM_AXIS_X: {
+        if (DISTANCE_ONLY) { last.w = last.w * p[5]; break; }
+        const float q = p[0], qw = p[3];
+        T d = last.x * q, cy = -(last.z * q), cz = last.y * q;
+        T tx = d * q, ty = cy * qw, tz = cz * qw;
+        last = v4<T>(fma_(last.x, bc<T>(p[4]), tx + tx) * p[6], fma_(last.y, bc<T>(p[4]), ty + ty) * p[6],
+                     fma_(last.z, bc<T>(p[4]), tz + tz) * p[6], last.w * p[5]);
+        break;
+    }
+    case OPX_FROM_AXIS_Y: {
+        if (DISTANCE_ONLY) { last.w = last.w * p[5]; break; }
+        const float q = p[1], qw = p[3];
+        T d = last.y * q, cx = last.z * q, cz = -(last.x * q);
+        T tx = cx * qw, ty = d * q, tz = cz * qw;
+        last = v4<T>(fma_(last.x, bc<T>(p[4]), tx + tx) * p[6], fma_(last.y, bc<T>(p[4]), ty + ty) * p[6],
+                     fma_(last.z, bc<T>(p[4]), tz + tz) * p[6], last.w * p[5]);
+        break;
+    }
+    case OPX_FROM_AXIS_Z: {
+        if (DISTANCE_ONLY) { last.w = last.w * p[5]; break; }
+        const float q = p[2], qw = p[3];
+        T d = last.z * q, cx = -(last.y * q), cy = last.x * q;
+        T tx = cx * qw, ty = cy * qw, tz = d * q;
+        last = v4<T>(fma_(last.x, bc<T>(p[4]), tx + tx) * p[6], fma_(last.y, bc<T>(p[4]), ty + ty) * p[6],
+                     fma_(last.z, bc<T>(p[4]), tz + tz) * p[6], last.w * p[5]);
         break;
     }
     case OP_MIRROR: last.x = -last.x; break;

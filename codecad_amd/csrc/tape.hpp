@@ -33,8 +33,16 @@ enum Op : uint32_t {
     OP_CIRCULAR_REPETITION_TO = 19, OP_CIRCULAR_REPETITION_FROM = 20, OP_INVOLUTE_GEAR = 21,
     OP_EXTRUSION = 22, OP_REVOLUTION_FROM = 23, OP_TWIST_REVOLUTION_FROM = 24,
     OP_SYMMETRICAL_FROM = 25, OP_UNION = 26, OP_INTERSECTION = 27, OP_SUBTRACTION = 28,
-    OP_COUNT = 29
+    OP_COUNT = 29,
+    // Internal opcodes: never in a tape, produced by the decoder for special cases that are
+    // provably equal (under ==) to the general op.  transformation_from rotates a DIRECTION by
+    // the quaternion; when its vector part is zero (pure scale) or has a single non-zero
+    // component (rotation about a coordinate axis) most products are exact zeros.
+    OPX_FROM_SCALE = 29, OPX_FROM_AXIS_X = 30, OPX_FROM_AXIS_Y = 31, OPX_FROM_AXIS_Z = 32
 };
+
+// arity of a decoded record (internal opcodes included)
+inline int rec_arity(uint32_t op);
 
 constexpr int kRefRegisterCount = 512;  // reference nodes/__init__.py:6
 constexpr int kVariableParams = -1;
@@ -62,11 +70,16 @@ inline const OpInfo& op_info(uint32_t op)
 // `slot` is NOT the tape's register number: registers are renamed at decode time
 // (allocate_slots below) to the smallest set of LDS slots that liveness allows.
 constexpr uint32_t kResultKind = 0x80000000u;  // distance-only program: the slot holds a bare distance
-struct alignas(16) Rec {
+#ifndef SDF_REC_DWORDS
+#define SDF_REC_DWORDS 12
+#endif
+struct alignas(SDF_REC_DWORDS == 16 ? 64 : 16) Rec {
     uint32_t hdr;
-    float p[11];
+    float p[SDF_REC_DWORDS - 1];
 };
-static_assert(sizeof(Rec) == 48, "Rec must be 48 bytes");
+static_assert(sizeof(Rec) == 4 * SDF_REC_DWORDS, "unexpected Rec size");
+
+inline int rec_arity(uint32_t op) { return op < OP_COUNT ? op_info(op).arity : 1; }
 
 inline float bits_f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 
@@ -117,14 +130,14 @@ inline bool allocate_slots(DecodedTape& d, std::string& err)
     bool do_ok = !d.direction_feeds_distance;
     for (int i = 0; i < n; ++i) {
         const uint32_t op = d.recs[i].hdr & 0xffu, reg = d.recs[i].hdr >> 8;
-        const int arity = op_info(op).arity;
+        const int arity = rec_arity(op);
         if (op == OP_STORE) {
             ranges.push_back({i, i, last_is_result, -1, -1});
             open_range[reg] = (int)ranges.size() - 1;
             range_of[i] = open_range[reg];
         } else if (op == OP_LOAD || arity == 2) {
             const int r = open_range[reg];
-            if (r < 0) { err = std::string(op_info(op).name) + " reads register " + std::to_string(reg) + " before any _store"; return false; }
+            if (r < 0) { err = std::string(op < OP_COUNT ? op_info(op).name : "op") + " reads register " + std::to_string(reg) + " before any _store"; return false; }
             ranges[r].last = i;
             range_of[i] = r;
             if (op == OP_LOAD) last_is_result = ranges[r].result;
@@ -221,6 +234,17 @@ inline std::string decode_tape(const float* tape, size_t n, DecodedTape& out)
                 r.p[4] = q_k(p);
                 r.p[5] = scale;
                 r.p[6] = 1.0f / scale;
+                const bool zx = p[0] == 0.0f, zy = p[1] == 0.0f, zz = p[2] == 0.0f;
+                uint32_t special = op;
+#ifndef SDF_FROM_SPECIAL
+#define SDF_FROM_SPECIAL 1
+#endif
+                if (!SDF_FROM_SPECIAL) special = op;
+                else if (zx && zy && zz) special = OPX_FROM_SCALE;
+                else if (zy && zz) special = OPX_FROM_AXIS_X;
+                else if (zx && zz) special = OPX_FROM_AXIS_Y;
+                else if (zx && zy) special = OPX_FROM_AXIS_Z;
+                r.hdr = special | (reg << 8);
                 break;
             }
             case OP_REPETITION:
