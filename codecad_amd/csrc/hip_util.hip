@@ -17,9 +17,11 @@
 #include <vector>
 
 #include "../../include/hip_util.h"
-#include "interp.hpp"
+#include "kernels.hpp"
+#include "tape.hpp"
 
 using sdf::Rec;
+using namespace sdfk;
 
 namespace {
 
@@ -37,289 +39,6 @@ int fail(int code, const std::string& msg)
         if (e_ != hipSuccess)                                                                \
             return fail(HU_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
     } while (0)
-
-// ------------------------------------------------------------------------------------------
-// device helpers
-// ------------------------------------------------------------------------------------------
-
-// Sample position of reference grid_eval.cl:31 / subdivision.cl:22 / mass_properties.cl:25-27:
-// corner + step * (float)gid, multiply then add, not fused.
-__device__ __forceinline__ float sample(float corner, float step, uint32_t i) { return corner + step * (float)i; }
-
-// N = voxels per lane (1: T = float, 2: T = packed float2, see interp.hpp)
-template <int N> struct Pack { using T = float; };
-template <> struct Pack<2> { using T = sdf::f2; };
-__device__ __forceinline__ float pack(const float (&v)[1]) { return v[0]; }
-__device__ __forceinline__ sdf::f2 pack(const float (&v)[2]) { return sdf::make_f2(v[0], v[1]); }
-
-// The N consecutive cells (z fastest) a lane owns, starting at linear index lin0 of a grid
-// with `n_cells` cells: coordinates by one divide for the first cell and carries for the rest.
-template <int N> struct Cells {
-    uint32_t x[N], y[N], z[N];
-    bool active[N];
-    __device__ __forceinline__ Cells(uint32_t lin0, uint32_t n_cells, uint32_t sy, uint32_t sz)
-    {
-        active[0] = lin0 < n_cells;
-        const uint32_t l = active[0] ? lin0 : 0u;  // idle tail lanes follow the (uniform) tape harmlessly
-        z[0] = l % sz;
-        const uint32_t t = l / sz;
-        y[0] = t % sy;
-        x[0] = t / sy;
-#pragma unroll
-        for (int i = 1; i < N; ++i) {
-            active[i] = active[0] && (lin0 + i < n_cells);
-            const bool wrap_z = z[i - 1] + 1u == sz;
-            const bool wrap_y = wrap_z && (y[i - 1] + 1u == sy);
-            z[i] = wrap_z ? 0u : z[i - 1] + 1u;
-            y[i] = wrap_y ? 0u : (wrap_z ? y[i - 1] + 1u : y[i - 1]);
-            x[i] = wrap_y ? x[i - 1] + 1u : x[i - 1];
-        }
-    }
-    __device__ __forceinline__ typename Pack<N>::T position(float corner, float step, const uint32_t (&c)[N], uint32_t c0 = 0) const
-    {
-        float v[N];
-#pragma unroll
-        for (int i = 0; i < N; ++i) v[i] = sample(corner, step, c0 + c[i]);
-        return pack(v);
-    }
-};
-
-// Workgroup-aggregated stream compaction of N flags per lane: 64-lane ballots + popcount
-// prefixes inside each wavefront, wave totals combined through LDS, ONE global atomic per
-// workgroup.  slot[i] is meaningful where flag[i] is set.  The reference does one global
-// atomic_inc per surviving work-item (subdivision.cl:28).
-template <int N>
-__device__ __forceinline__ void wg_compact_slots(const bool (&flag)[N], uint32_t* __restrict__ counter, uint32_t* scratch,
-                                                 uint32_t (&slot)[N])
-{
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint64_t below = (1ull << lane) - 1ull;
-    uint32_t prefix = 0, total_w = 0;
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        const uint64_t mask = __ballot(flag[i]);
-        prefix += __popcll(mask & below);
-        total_w += __popcll(mask);
-    }
-    if (lane == 0) scratch[wave] = total_w;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t nw = (blockDim.x + 63u) >> 6;
-        uint32_t total = 0;
-        for (uint32_t w = 0; w < nw; ++w) {
-            uint32_t c = scratch[w];
-            scratch[w] = total;
-            total += c;
-        }
-        scratch[4] = total ? atomicAdd(counter, total) : 0u;
-    }
-    __syncthreads();
-    slot[0] = scratch[4] + scratch[wave] + prefix;
-#pragma unroll
-    for (int i = 1; i < N; ++i) slot[i] = slot[i - 1] + (flag[i - 1] ? 1u : 0u);
-}
-
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
-// ------------------------------------------------------------------------------------------
-// dense grid evaluation
-// ------------------------------------------------------------------------------------------
-template <int LAYOUT, bool DO, int N>
-__global__ void __launch_bounds__(256)
-k_grid_eval(const Rec* __restrict__ prog, const float* __restrict__ extra, uint32_t n4, float cx, float cy,
-            float cz, float step, uint32_t sx, uint32_t sy, uint32_t sz, uint32_t x0,
-            uint32_t n_cells, void* __restrict__ out)
-{
-    using T = typename Pack<N>::T;
-    extern __shared__ float4 lds[];
-    const uint32_t lin0 = (blockIdx.x * blockDim.x + threadIdx.x) * N;
-    const Cells<N> c(lin0, n_cells, sy, sz);
-    const sdf::Regs<T> regs(lds, threadIdx.x, blockDim.x, n4);
-    const sdf::V4<T> r = sdf::run_tape<T, DO>(prog, extra, c.position(cx, step, c.x, x0), c.position(cy, step, c.y),
-                                              c.position(cz, step, c.z), regs);
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        if (!c.active[i]) continue;
-        if (LAYOUT == 0) {
-            // INDEX3 = z + sz*(y + sy*x) (cl_util/indexing.h:4): inside a slab this is the linear
-            // cell index; 64 lanes store 1 KiB (N = 2: 2 KiB) contiguous.
-            static_cast<float4*>(out)[lin0 + i] = sdf::voxel(r, i);
-        } else {
-            // grid_eval.cl:18: z + (x + (sy-1-y)*sx)*sz; z-fastest so a wave stores contiguous runs
-            const size_t idx = (size_t)c.z[i] + ((size_t)(x0 + c.x[i]) + (size_t)(sy - 1u - c.y[i]) * sx) * sz;
-            static_cast<float*>(out)[idx] = sdf::get(r.w, i);
-        }
-    }
-}
-
-template <int LAYOUT, bool DO, int N>
-__global__ void __launch_bounds__(256)
-k_grid_eval_blocks(const Rec* __restrict__ prog, const float* __restrict__ extra, uint32_t n4,
-                   const int4* __restrict__ blocks, uint32_t chunks, double res, double ox,
-                   double oy, double oz, float step, uint32_t sx, uint32_t sy, uint32_t sz,
-                   void* __restrict__ out)
-{
-    using T = typename Pack<N>::T;
-    extern __shared__ float4 lds[];
-    const uint32_t b = blockIdx.x / chunks, chunk = blockIdx.x - b * chunks;
-    const uint32_t cells = sx * sy * sz;
-    const int4 ic = blocks[b];
-    // subdivision.py:100: pos = int_pos * resolution + origin (fp64), cast once (geometry.py:98-99)
-    const float cx = (float)((double)ic.x * res + ox);
-    const float cy = (float)((double)ic.y * res + oy);
-    const float cz = (float)((double)ic.z * res + oz);
-    const uint32_t lin0 = (chunk * blockDim.x + threadIdx.x) * N;
-    const Cells<N> c(lin0, cells, sy, sz);
-    const sdf::Regs<T> regs(lds, threadIdx.x, blockDim.x, n4);
-    const sdf::V4<T> r = sdf::run_tape<T, DO>(prog, extra, c.position(cx, step, c.x), c.position(cy, step, c.y),
-                                              c.position(cz, step, c.z), regs);
-    const size_t base = (size_t)b * cells;
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        if (!c.active[i]) continue;
-        if (LAYOUT == 0)
-            static_cast<float4*>(out)[base + lin0 + i] = sdf::voxel(r, i);
-        else
-            static_cast<float*>(out)[base + (size_t)c.z[i] + ((size_t)c.x[i] + (size_t)(sy - 1u - c.y[i]) * sx) * sz] =
-                sdf::get(r.w, i);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// classification kernels: subdivision_step / mass_properties, single block or whole level
-// ------------------------------------------------------------------------------------------
-struct ClassifyArgs {
-    const Rec* prog;
-    const float* extra;
-    const void* parents;   // BATCH: int4[] (subdivision) or double4[] (mass); else unused
-    uint32_t chunks;       // workgroups per parent
-    uint32_t sx, sy, sz;
-    float cx, cy, cz;      // !BATCH: sample corner as given by the caller
-    float step, thr;
-    int32_t int_step;      // BATCH subdivision: cell size of this level in resolution units
-    int32_t dimension;
-    double res, ox, oy, oz;  // BATCH subdivision: resolution + origin
-    double s;                // BATCH mass: cell size of this level
-    uint32_t* counter;
-    void* list;            // !BATCH: uchar4[]; BATCH: int4[] / double4[] children
-    uint32_t capacity;
-    uint32_t* sums;        // MASS: uint32[10] per parent
-    uint32_t scratch_offset;  // bytes of LDS taken by the register file (scratch follows)
-    uint32_t n4;              // float4 slots of the register file (scalar slots follow them)
-};
-
-template <bool MASS, bool BATCH, bool DO, int N>
-__global__ void __launch_bounds__(256) k_classify(const ClassifyArgs a)
-{
-    using T = typename Pack<N>::T;
-    extern __shared__ float4 lds[];
-    uint32_t* scratch = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(lds) + a.scratch_offset);  // [0..4] compaction, [8..17] sums
-    const uint32_t b = BATCH ? blockIdx.x / a.chunks : 0u;
-    const uint32_t chunk = BATCH ? blockIdx.x - b * a.chunks : blockIdx.x;
-    const uint32_t cells = a.sx * a.sy * a.sz;
-
-    float cx = a.cx, cy = a.cy, cz = a.cz;
-    int4 ipar = make_int4(0, 0, 0, 0);
-    double pcx = 0.0, pcy = 0.0, pcz = 0.0, pcw = 0.0;
-    if (BATCH) {
-        if (MASS) {
-            // mass_properties.py:86: shifted_corner = box_corner + splat(box_step/2), fp64
-            const double4 pc = static_cast<const double4*>(a.parents)[b];
-            pcx = pc.x; pcy = pc.y; pcz = pc.z; pcw = pc.w;
-            const double h = a.s / 2;
-            cx = (float)(pcx + h); cy = (float)(pcy + h); cz = (float)(pcz + h);
-        } else {
-            // subdivision.py:56-65: (int_corner + int_step/2) * resolution + origin, fp64;
-            // 2D shapes shift x and y only
-            ipar = static_cast<const int4*>(a.parents)[b];
-            const double h = (double)a.int_step / 2;
-            cx = (float)(((double)ipar.x + h) * a.res + a.ox);
-            cy = (float)(((double)ipar.y + h) * a.res + a.oy);
-            cz = (float)(((double)ipar.z + (a.dimension == 3 ? h : 0.0)) * a.res + a.oz);
-        }
-    }
-    if (MASS) {
-        if (threadIdx.x < 10) scratch[8 + threadIdx.x] = 0u;
-    }
-
-    const uint32_t lin0 = (chunk * blockDim.x + threadIdx.x) * N;
-    const Cells<N> c(lin0, cells, a.sy, a.sz);
-    const sdf::Regs<T> regs(lds, threadIdx.x, blockDim.x, a.n4);
-    const T w = sdf::run_tape<T, DO>(a.prog, a.extra, c.position(cx, a.step, c.x), c.position(cy, a.step, c.y),
-                                     c.position(cz, a.step, c.z), regs).w;
-
-    bool ambiguous[N];
-    if (MASS) {
-        // mass_properties.cl:31-52: inside (w <= -thr) -> moments of the integer cell index;
-        // else w < thr -> ambiguous
-        bool inside[N];
-        bool any_inside = false;
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            const float wi = sdf::get(w, i);
-            inside[i] = c.active[i] && (wi <= -a.thr);
-            ambiguous[i] = c.active[i] && !inside[i] && (wi < a.thr);
-            any_inside |= inside[i];
-        }
-        const uint64_t imask = __ballot(any_inside);
-        __syncthreads();  // scratch[8..17] zeroed
-        if (imask != 0ull) {  // wave-uniform
-            uint32_t v[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-                const uint32_t m = inside[i] ? 1u : 0u;
-                const uint32_t x = c.x[i], y = c.y[i], z = c.z[i];
-                const uint32_t xm = x * m, ym = y * m, zm = z * m;
-                v[0] += xm * x; v[1] += xm * y; v[2] += xm * z; v[3] += xm;
-                v[4] += ym * y; v[5] += ym * z; v[6] += ym;
-                v[7] += zm * z; v[8] += zm; v[9] += m;
-            }
-#pragma unroll
-            for (int i = 0; i < 10; ++i) {
-                const uint32_t sum = wave_sum(v[i]);
-                if ((threadIdx.x & 63u) == 0 && sum) atomicAdd(&scratch[8 + i], sum);
-            }
-        }
-    } else {
-        // subdivision.cl:25: -thr < w < thr
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            const float wi = sdf::get(w, i);
-            ambiguous[i] = c.active[i] && (wi > -a.thr) && (wi < a.thr);
-        }
-    }
-
-    uint32_t slot[N];
-    wg_compact_slots<N>(ambiguous, a.counter, scratch, slot);  // has __syncthreads
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        if (!(ambiguous[i] && slot[i] < a.capacity)) continue;
-        const uint32_t x = c.x[i], y = c.y[i], z = c.z[i];
-        if (!BATCH) {
-            static_cast<uchar4*>(a.list)[slot[i]] = make_uchar4((unsigned char)x, (unsigned char)y, (unsigned char)z, 0);
-        } else if (MASS) {
-            // mass_properties.py:155: Vector(i,j,k)*s + box_corner, fp64
-            static_cast<double4*>(a.list)[slot[i]] =
-                make_double4((double)x * a.s + pcx, (double)y * a.s + pcy, (double)z * a.s + pcz, pcw);
-        } else {
-            // subdivision.py:91-94: Vector(i,j,k)*int_box_step + int_box_corner
-            static_cast<int4*>(a.list)[slot[i]] =
-                make_int4(ipar.x + (int)x * a.int_step, ipar.y + (int)y * a.int_step, ipar.z + (int)z * a.int_step, ipar.w);
-        }
-    }
-    if (MASS) {
-        // wg_compact_slots' barriers ordered the LDS atomics before this read
-        if (threadIdx.x < 10) {
-            const uint32_t v = scratch[8 + threadIdx.x];
-            if (v) atomicAdd(&a.sums[(size_t)b * 10 + threadIdx.x], v);
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------
 // mass_properties: per-parent index sums -> the ten integrals of this level, on the device.
@@ -461,20 +180,20 @@ template <int N>
 int ensure_attrs_n()
 {
     int rc;
-    if ((rc = allow_big_lds(k_grid_eval<0, false, N>))) return rc;
-    if ((rc = allow_big_lds(k_grid_eval<1, false, N>))) return rc;
-    if ((rc = allow_big_lds(k_grid_eval<1, true, N>))) return rc;
-    if ((rc = allow_big_lds(k_grid_eval_blocks<0, false, N>))) return rc;
-    if ((rc = allow_big_lds(k_grid_eval_blocks<1, false, N>))) return rc;
-    if ((rc = allow_big_lds(k_grid_eval_blocks<1, true, N>))) return rc;
-    if ((rc = allow_big_lds(k_classify<false, false, false, N>))) return rc;
-    if ((rc = allow_big_lds(k_classify<false, true, false, N>))) return rc;
-    if ((rc = allow_big_lds(k_classify<true, false, false, N>))) return rc;
-    if ((rc = allow_big_lds(k_classify<true, true, false, N>))) return rc;
-    if ((rc = allow_big_lds(k_classify<false, false, true, N>))) return rc;
-    if ((rc = allow_big_lds(k_classify<false, true, true, N>))) return rc;
-    if ((rc = allow_big_lds(k_classify<true, false, true, N>))) return rc;
-    if ((rc = allow_big_lds(k_classify<true, true, true, N>))) return rc;
+    if ((rc = allow_big_lds(k_grid_eval<InterpEval<false>, 0, N>))) return rc;
+    if ((rc = allow_big_lds(k_grid_eval<InterpEval<false>, 1, N>))) return rc;
+    if ((rc = allow_big_lds(k_grid_eval<InterpEval<true>, 1, N>))) return rc;
+    if ((rc = allow_big_lds(k_grid_eval_blocks<InterpEval<false>, 0, N>))) return rc;
+    if ((rc = allow_big_lds(k_grid_eval_blocks<InterpEval<false>, 1, N>))) return rc;
+    if ((rc = allow_big_lds(k_grid_eval_blocks<InterpEval<true>, 1, N>))) return rc;
+    if ((rc = allow_big_lds(k_classify<InterpEval<false>, false, false, N>))) return rc;
+    if ((rc = allow_big_lds(k_classify<InterpEval<false>, false, true, N>))) return rc;
+    if ((rc = allow_big_lds(k_classify<InterpEval<false>, true, false, N>))) return rc;
+    if ((rc = allow_big_lds(k_classify<InterpEval<false>, true, true, N>))) return rc;
+    if ((rc = allow_big_lds(k_classify<InterpEval<true>, false, false, N>))) return rc;
+    if ((rc = allow_big_lds(k_classify<InterpEval<true>, false, true, N>))) return rc;
+    if ((rc = allow_big_lds(k_classify<InterpEval<true>, true, false, N>))) return rc;
+    if ((rc = allow_big_lds(k_classify<InterpEval<true>, true, true, N>))) return rc;
     return HU_OK;
 }
 
@@ -727,9 +446,9 @@ int hu_grid_eval_slab(hu_tape t, const float corner[4], float step, const uint32
         const uint32_t blocks = (n_cells + per_block - 1) / per_block;
         void* o = (layout == 0) ? (void*)(static_cast<float4*>(out_dev) + (size_t)done * plane) : out_dev;
 #define HU_LAUNCH_DENSE(L, D, NV)                                                                                  \
-    hipLaunchKernelGGL((k_grid_eval<L, D, NV>), dim3(blocks), dim3(ls.block), ls.lds, (hipStream_t)stream, ls.prog,    \
-                       t->extra_dev, ls.n4, corner[0], corner[1], corner[2], step, dims[0], dims[1], dims[2], x0 + done,  \
-                       n_cells, o)
+    hipLaunchKernelGGL((k_grid_eval<InterpEval<D>, L, NV>), dim3(blocks), dim3(ls.block), ls.lds, (hipStream_t)stream, \
+                       (InterpEval<D>{ls.prog, t->extra_dev, ls.n4}), corner[0], corner[1], corner[2], step, dims[0],  \
+                       dims[1], dims[2], x0 + done, n_cells, o)
         const bool d_only = layout == 1 && distance_only(t);
         if (ls.voxels_per_lane == 2) {
             if (layout == 0) HU_LAUNCH_DENSE(0, false, 2);
@@ -778,9 +497,9 @@ int hu_grid_eval_blocks(hu_tape t, const int32_t* blocks_dev, uint32_t n_blocks,
     if ((uint64_t)chunks * n_blocks > 0x7fffffffull) return fail(HU_ERR_BAD_ARG, "too many workgroups in one launch");
     const dim3 grid(chunks * n_blocks), block(ls.block);
 #define HU_LAUNCH_BLOCKS(L, D, NV)                                                                                 \
-    hipLaunchKernelGGL((k_grid_eval_blocks<L, D, NV>), grid, block, ls.lds, (hipStream_t)stream, ls.prog,          \
-                       t->extra_dev, ls.n4, (const int4*)blocks_dev, chunks, resolution, origin[0], origin[1], origin[2], \
-                       step, dims[0], dims[1], dims[2], out_dev)
+    hipLaunchKernelGGL((k_grid_eval_blocks<InterpEval<D>, L, NV>), grid, block, ls.lds, (hipStream_t)stream,           \
+                       (InterpEval<D>{ls.prog, t->extra_dev, ls.n4}), (const int4*)blocks_dev, chunks, resolution,        \
+                       origin[0], origin[1], origin[2], step, dims[0], dims[1], dims[2], out_dev)
     const bool d_only = layout == 1 && distance_only(t);
     if (ls.voxels_per_lane == 2) {
         if (layout == 0) HU_LAUNCH_BLOCKS(0, false, 2);
@@ -813,9 +532,6 @@ int launch_classify(hu_tape t, ClassifyArgs& a, uint32_t n_parents, const uint32
     LaunchShape ls;
     if ((rc = launch_shape(t, ls, distance_only(t)))) return rc;
     if ((rc = ensure_attrs())) return rc;
-    a.prog = ls.prog;
-    a.n4 = ls.n4;
-    a.extra = t->extra_dev;
     a.sx = dims[0];
     a.sy = dims[1];
     a.sz = dims[2];
@@ -825,13 +541,17 @@ int launch_classify(hu_tape t, ClassifyArgs& a, uint32_t n_parents, const uint32
     if ((uint64_t)a.chunks * n_parents > 0x7fffffffull) return fail(HU_ERR_BAD_ARG, "too many workgroups in one launch");
     const dim3 grid(a.chunks * n_parents), block(ls.block);
     const bool d_only = distance_only(t);
+#define HU_LAUNCH_CLASSIFY(D, NV)                                                                                \
+    hipLaunchKernelGGL((k_classify<InterpEval<D>, MASS, BATCH, NV>), grid, block, ls.lds, (hipStream_t)stream,     \
+                       (InterpEval<D>{ls.prog, t->extra_dev, ls.n4}), a)
     if (ls.voxels_per_lane == 2) {
-        if (d_only) hipLaunchKernelGGL((k_classify<MASS, BATCH, true, 2>), grid, block, ls.lds, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL((k_classify<MASS, BATCH, false, 2>), grid, block, ls.lds, (hipStream_t)stream, a);
+        if (d_only) HU_LAUNCH_CLASSIFY(true, 2);
+        else HU_LAUNCH_CLASSIFY(false, 2);
     } else {
-        if (d_only) hipLaunchKernelGGL((k_classify<MASS, BATCH, true, 1>), grid, block, ls.lds, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL((k_classify<MASS, BATCH, false, 1>), grid, block, ls.lds, (hipStream_t)stream, a);
+        if (d_only) HU_LAUNCH_CLASSIFY(true, 1);
+        else HU_LAUNCH_CLASSIFY(false, 1);
     }
+#undef HU_LAUNCH_CLASSIFY
     HU_HIP(hipGetLastError());
     return HU_OK;
 }

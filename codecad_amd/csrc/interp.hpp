@@ -21,9 +21,7 @@
 //    Each component of a packed op is an IEEE binary32 op, so results are unchanged.
 #pragma once
 
-#include <type_traits>
-
-#include "tape.hpp"
+#include "tape_format.hpp"
 
 namespace sdf {
 
@@ -457,6 +455,18 @@ template <> struct Regs<f2> {
     __device__ __forceinline__ void store_res(uint32_t r, f2 w) const { res[r * stride] = w; }
 };
 
+// Register file of SPECIALISED code (jit.hpp): every slot index is a compile-time constant
+// once exec_one is inlined with a literal record, so the array dissolves into VGPRs.
+template <class T, int SLOTS> struct RegsV {
+    V4<T> v[SLOTS > 0 ? SLOTS : 1];
+    __device__ __forceinline__ V4<T> load(uint32_t r) const { return v[r]; }
+    __device__ __forceinline__ void store(uint32_t r, const V4<T>& x) { v[r] = x; }
+    __device__ __forceinline__ T load_x(uint32_t r) const { return v[r].x; }
+    __device__ __forceinline__ T load_z(uint32_t r) const { return v[r].z; }
+    __device__ __forceinline__ T load_res(uint32_t r) const { return v[r].w; }
+    __device__ __forceinline__ void store_res(uint32_t r, T w) { v[r].w = w; }
+};
+
 // ---------------------------------------------------------------------------------------
 // The interpreter.  `prog` and `extra` are wave-uniform.
 //
@@ -471,9 +481,9 @@ template <> struct Regs<f2> {
 #endif
 constexpr int kFetchGroup = SDF_FETCH_GROUP;  // tape.hpp pads the program with kTapePadding _return records
 
-template <class T, bool DISTANCE_ONLY>
+template <class T, bool DISTANCE_ONLY, class R>
 __device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const float* __restrict__ extra, T px, T py,
-                                         T pz, const Regs<T>& regs)
+                                         T pz, R& regs)
 {
     const uint32_t op = cur.hdr & 0xffu;
     const uint32_t reg = (cur.hdr >> 8) & 0xffffu;
@@ -649,9 +659,9 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const floa
     return false;
 }
 
-template <class T, bool DISTANCE_ONLY>
+template <class T, bool DISTANCE_ONLY, class R>
 __device__ __forceinline__ V4<T> run_tape(const Rec* __restrict__ prog, const float* __restrict__ extra, T px, T py,
-                                          T pz, const Regs<T>& regs)
+                                          T pz, R& regs)
 {
     V4<T> last = v4<T>(bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f));
     const Rec* pc = prog;
@@ -662,7 +672,7 @@ __device__ __forceinline__ V4<T> run_tape(const Rec* __restrict__ prog, const fl
         pc += kFetchGroup;
 #pragma unroll
         for (int k = 0; k < kFetchGroup; ++k)
-            if (exec_one<T, DISTANCE_ONLY>(group[k], last, extra, px, py, pz, regs)) return last;
+            if (exec_one<T, DISTANCE_ONLY, R>(group[k], last, extra, px, py, pz, regs)) return last;
     }
 }
 

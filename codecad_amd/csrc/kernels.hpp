@@ -1,0 +1,303 @@
+// codecad_amd/csrc/kernels.hpp
+//
+// The gfx950 kernels of the hot path, generic over HOW a voxel is evaluated:
+//   * InterpEval<DO>: the tape interpreter (interp.hpp run_tape), registers in LDS;
+//   * a specialised evaluator generated per tape and compiled with hipRTC (jit in hip_util.hip).
+// Reference counterparts (paths relative to /root/reference/codecad/):
+//   k_grid_eval            grid_eval.cl:2-34 (both layouts), dense slab of a logical grid
+//   k_grid_eval_blocks     the per-leaf-block launches of rendering/mesh.py:53-60, batched
+//   k_classify<MASS,BATCH> subdivision.cl:12-30 and mass_properties.cl:7-56, either one block
+//                          (reference-shaped) or every parent of a level in one launch
+#pragma once
+
+#include "interp.hpp"
+
+namespace sdfk {
+
+using sdf::Rec;
+
+// Evaluate through the interpreter.  `prog` is the full or the distance-only program (DO).
+template <bool DO> struct InterpEval {
+    const Rec* prog;
+    const float* extra;
+    uint32_t n4;  // float4 slots of the LDS register file (scalar slots follow them)
+    template <class T> __device__ __forceinline__ sdf::V4<T> operator()(T px, T py, T pz, void* lds) const
+    {
+        sdf::Regs<T> regs(lds, threadIdx.x, blockDim.x, n4);
+        return sdf::run_tape<T, DO>(prog, extra, px, py, pz, regs);
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------
+
+// Sample position of reference grid_eval.cl:31 / subdivision.cl:22 / mass_properties.cl:25-27:
+// corner + step * (float)gid, multiply then add, not fused.
+__device__ __forceinline__ float sample(float corner, float step, uint32_t i) { return corner + step * (float)i; }
+
+// N = voxels per lane (1: T = float, 2: T = packed float2, see interp.hpp)
+template <int N> struct Pack { using T = float; };
+template <> struct Pack<2> { using T = sdf::f2; };
+__device__ __forceinline__ float pack(const float (&v)[1]) { return v[0]; }
+__device__ __forceinline__ sdf::f2 pack(const float (&v)[2]) { return sdf::make_f2(v[0], v[1]); }
+
+// The N consecutive cells (z fastest) a lane owns, starting at linear index lin0 of a grid
+// with `n_cells` cells: coordinates by one divide for the first cell and carries for the rest.
+template <int N> struct Cells {
+    uint32_t x[N], y[N], z[N];
+    bool active[N];
+    __device__ __forceinline__ Cells(uint32_t lin0, uint32_t n_cells, uint32_t sy, uint32_t sz)
+    {
+        active[0] = lin0 < n_cells;
+        const uint32_t l = active[0] ? lin0 : 0u;  // idle tail lanes follow the (uniform) tape harmlessly
+        z[0] = l % sz;
+        const uint32_t t = l / sz;
+        y[0] = t % sy;
+        x[0] = t / sy;
+#pragma unroll
+        for (int i = 1; i < N; ++i) {
+            active[i] = active[0] && (lin0 + i < n_cells);
+            const bool wrap_z = z[i - 1] + 1u == sz;
+            const bool wrap_y = wrap_z && (y[i - 1] + 1u == sy);
+            z[i] = wrap_z ? 0u : z[i - 1] + 1u;
+            y[i] = wrap_y ? 0u : (wrap_z ? y[i - 1] + 1u : y[i - 1]);
+            x[i] = wrap_y ? x[i - 1] + 1u : x[i - 1];
+        }
+    }
+    __device__ __forceinline__ typename Pack<N>::T position(float corner, float step, const uint32_t (&c)[N], uint32_t c0 = 0) const
+    {
+        float v[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = sample(corner, step, c0 + c[i]);
+        return pack(v);
+    }
+};
+
+// Workgroup-aggregated stream compaction of N flags per lane: 64-lane ballots + popcount
+// prefixes inside each wavefront, wave totals combined through LDS, ONE global atomic per
+// workgroup.  slot[i] is meaningful where flag[i] is set.  The reference does one global
+// atomic_inc per surviving work-item (subdivision.cl:28).
+template <int N>
+__device__ __forceinline__ void wg_compact_slots(const bool (&flag)[N], uint32_t* __restrict__ counter, uint32_t* scratch,
+                                                 uint32_t (&slot)[N])
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t below = (1ull << lane) - 1ull;
+    uint32_t prefix = 0, total_w = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const uint64_t mask = __ballot(flag[i]);
+        prefix += __popcll(mask & below);
+        total_w += __popcll(mask);
+    }
+    if (lane == 0) scratch[wave] = total_w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t nw = (blockDim.x + 63u) >> 6;
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < nw; ++w) {
+            uint32_t c = scratch[w];
+            scratch[w] = total;
+            total += c;
+        }
+        scratch[4] = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    slot[0] = scratch[4] + scratch[wave] + prefix;
+#pragma unroll
+    for (int i = 1; i < N; ++i) slot[i] = slot[i - 1] + (flag[i - 1] ? 1u : 0u);
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// dense grid evaluation
+// ------------------------------------------------------------------------------------------
+template <class E, int LAYOUT, int N>
+__global__ void __launch_bounds__(256)
+k_grid_eval(const E ev, float cx, float cy, float cz, float step, uint32_t sx, uint32_t sy, uint32_t sz, uint32_t x0,
+            uint32_t n_cells, void* __restrict__ out)
+{
+    using T = typename Pack<N>::T;
+    extern __shared__ float4 lds[];
+    const uint32_t lin0 = (blockIdx.x * blockDim.x + threadIdx.x) * N;
+    const Cells<N> c(lin0, n_cells, sy, sz);
+    const sdf::V4<T> r = ev(c.position(cx, step, c.x, x0), c.position(cy, step, c.y), c.position(cz, step, c.z), lds);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        if (!c.active[i]) continue;
+        if (LAYOUT == 0) {
+            // INDEX3 = z + sz*(y + sy*x) (cl_util/indexing.h:4): inside a slab this is the linear
+            // cell index; 64 lanes store 1 KiB (N = 2: 2 KiB) contiguous.
+            static_cast<float4*>(out)[lin0 + i] = sdf::voxel(r, i);
+        } else {
+            // grid_eval.cl:18: z + (x + (sy-1-y)*sx)*sz; z-fastest so a wave stores contiguous runs
+            const size_t idx = (size_t)c.z[i] + ((size_t)(x0 + c.x[i]) + (size_t)(sy - 1u - c.y[i]) * sx) * sz;
+            static_cast<float*>(out)[idx] = sdf::get(r.w, i);
+        }
+    }
+}
+
+template <class E, int LAYOUT, int N>
+__global__ void __launch_bounds__(256)
+k_grid_eval_blocks(const E ev, const int4* __restrict__ blocks, uint32_t chunks, double res, double ox,
+                   double oy, double oz, float step, uint32_t sx, uint32_t sy, uint32_t sz,
+                   void* __restrict__ out)
+{
+    using T = typename Pack<N>::T;
+    extern __shared__ float4 lds[];
+    const uint32_t b = blockIdx.x / chunks, chunk = blockIdx.x - b * chunks;
+    const uint32_t cells = sx * sy * sz;
+    const int4 ic = blocks[b];
+    // subdivision.py:100: pos = int_pos * resolution + origin (fp64), cast once (geometry.py:98-99)
+    const float cx = (float)((double)ic.x * res + ox);
+    const float cy = (float)((double)ic.y * res + oy);
+    const float cz = (float)((double)ic.z * res + oz);
+    const uint32_t lin0 = (chunk * blockDim.x + threadIdx.x) * N;
+    const Cells<N> c(lin0, cells, sy, sz);
+    const sdf::V4<T> r = ev(c.position(cx, step, c.x), c.position(cy, step, c.y), c.position(cz, step, c.z), lds);
+    const size_t base = (size_t)b * cells;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        if (!c.active[i]) continue;
+        if (LAYOUT == 0)
+            static_cast<float4*>(out)[base + lin0 + i] = sdf::voxel(r, i);
+        else
+            static_cast<float*>(out)[base + (size_t)c.z[i] + ((size_t)c.x[i] + (size_t)(sy - 1u - c.y[i]) * sx) * sz] =
+                sdf::get(r.w, i);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// classification kernels: subdivision_step / mass_properties, single block or whole level
+// ------------------------------------------------------------------------------------------
+struct ClassifyArgs {
+    const void* parents;   // BATCH: int4[] (subdivision) or double4[] (mass); else unused
+    uint32_t chunks;       // workgroups per parent
+    uint32_t sx, sy, sz;
+    float cx, cy, cz;      // !BATCH: sample corner as given by the caller
+    float step, thr;
+    int32_t int_step;      // BATCH subdivision: cell size of this level in resolution units
+    int32_t dimension;
+    double res, ox, oy, oz;  // BATCH subdivision: resolution + origin
+    double s;                // BATCH mass: cell size of this level
+    uint32_t* counter;
+    void* list;            // !BATCH: uchar4[]; BATCH: int4[] / double4[] children
+    uint32_t capacity;
+    uint32_t* sums;        // MASS: uint32[10] per parent
+    uint32_t scratch_offset;  // bytes of LDS taken by the register file (scratch follows)
+};
+
+template <class E, bool MASS, bool BATCH, int N>
+__global__ void __launch_bounds__(256) k_classify(const E ev, const ClassifyArgs a)
+{
+    using T = typename Pack<N>::T;
+    extern __shared__ float4 lds[];
+    uint32_t* scratch = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(lds) + a.scratch_offset);  // [0..4] compaction, [8..17] sums
+    const uint32_t b = BATCH ? blockIdx.x / a.chunks : 0u;
+    const uint32_t chunk = BATCH ? blockIdx.x - b * a.chunks : blockIdx.x;
+    const uint32_t cells = a.sx * a.sy * a.sz;
+
+    float cx = a.cx, cy = a.cy, cz = a.cz;
+    int4 ipar = make_int4(0, 0, 0, 0);
+    double pcx = 0.0, pcy = 0.0, pcz = 0.0, pcw = 0.0;
+    if (BATCH) {
+        if (MASS) {
+            // mass_properties.py:86: shifted_corner = box_corner + splat(box_step/2), fp64
+            const double4 pc = static_cast<const double4*>(a.parents)[b];
+            pcx = pc.x; pcy = pc.y; pcz = pc.z; pcw = pc.w;
+            const double h = a.s / 2;
+            cx = (float)(pcx + h); cy = (float)(pcy + h); cz = (float)(pcz + h);
+        } else {
+            // subdivision.py:56-65: (int_corner + int_step/2) * resolution + origin, fp64;
+            // 2D shapes shift x and y only
+            ipar = static_cast<const int4*>(a.parents)[b];
+            const double h = (double)a.int_step / 2;
+            cx = (float)(((double)ipar.x + h) * a.res + a.ox);
+            cy = (float)(((double)ipar.y + h) * a.res + a.oy);
+            cz = (float)(((double)ipar.z + (a.dimension == 3 ? h : 0.0)) * a.res + a.oz);
+        }
+    }
+    if (MASS) {
+        if (threadIdx.x < 10) scratch[8 + threadIdx.x] = 0u;
+    }
+
+    const uint32_t lin0 = (chunk * blockDim.x + threadIdx.x) * N;
+    const Cells<N> c(lin0, cells, a.sy, a.sz);
+    const T w = ev(c.position(cx, a.step, c.x), c.position(cy, a.step, c.y), c.position(cz, a.step, c.z), lds).w;
+
+    bool ambiguous[N];
+    if (MASS) {
+        // mass_properties.cl:31-52: inside (w <= -thr) -> moments of the integer cell index;
+        // else w < thr -> ambiguous
+        bool inside[N];
+        bool any_inside = false;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const float wi = sdf::get(w, i);
+            inside[i] = c.active[i] && (wi <= -a.thr);
+            ambiguous[i] = c.active[i] && !inside[i] && (wi < a.thr);
+            any_inside |= inside[i];
+        }
+        const uint64_t imask = __ballot(any_inside);
+        __syncthreads();  // scratch[8..17] zeroed
+        if (imask != 0ull) {  // wave-uniform
+            uint32_t v[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const uint32_t m = inside[i] ? 1u : 0u;
+                const uint32_t x = c.x[i], y = c.y[i], z = c.z[i];
+                const uint32_t xm = x * m, ym = y * m, zm = z * m;
+                v[0] += xm * x; v[1] += xm * y; v[2] += xm * z; v[3] += xm;
+                v[4] += ym * y; v[5] += ym * z; v[6] += ym;
+                v[7] += zm * z; v[8] += zm; v[9] += m;
+            }
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                const uint32_t sum = wave_sum(v[i]);
+                if ((threadIdx.x & 63u) == 0 && sum) atomicAdd(&scratch[8 + i], sum);
+            }
+        }
+    } else {
+        // subdivision.cl:25: -thr < w < thr
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const float wi = sdf::get(w, i);
+            ambiguous[i] = c.active[i] && (wi > -a.thr) && (wi < a.thr);
+        }
+    }
+
+    uint32_t slot[N];
+    wg_compact_slots<N>(ambiguous, a.counter, scratch, slot);  // has __syncthreads
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        if (!(ambiguous[i] && slot[i] < a.capacity)) continue;
+        const uint32_t x = c.x[i], y = c.y[i], z = c.z[i];
+        if (!BATCH) {
+            static_cast<uchar4*>(a.list)[slot[i]] = make_uchar4((unsigned char)x, (unsigned char)y, (unsigned char)z, 0);
+        } else if (MASS) {
+            // mass_properties.py:155: Vector(i,j,k)*s + box_corner, fp64
+            static_cast<double4*>(a.list)[slot[i]] =
+                make_double4((double)x * a.s + pcx, (double)y * a.s + pcy, (double)z * a.s + pcz, pcw);
+        } else {
+            // subdivision.py:91-94: Vector(i,j,k)*int_box_step + int_box_corner
+            static_cast<int4*>(a.list)[slot[i]] =
+                make_int4(ipar.x + (int)x * a.int_step, ipar.y + (int)y * a.int_step, ipar.z + (int)z * a.int_step, ipar.w);
+        }
+    }
+    if (MASS) {
+        // wg_compact_slots' barriers ordered the LDS atomics before this read
+        if (threadIdx.x < 10) {
+            const uint32_t v = scratch[8 + threadIdx.x];
+            if (v) atomicAdd(&a.sums[(size_t)b * 10 + threadIdx.x], v);
+        }
+    }
+}
+
+}  // namespace sdfk

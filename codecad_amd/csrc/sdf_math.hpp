@@ -14,8 +14,9 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
-#include <cmath>
+#ifndef __HIPCC_RTC__
 #include <cstdint>
+#endif
 
 #define SDF_HD __host__ __device__ __forceinline__
 
