@@ -9,10 +9,12 @@
 // Build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fno-fast-math
 //        -fhip-fp32-correctly-rounded-divide-sqrt -fPIC -shared (see codecad_amd/hip_util/builder.py)
 #include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
 
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -121,6 +123,8 @@ struct hu_tape_s {
     int n_slots = 0;             // float4 slots of the full program after renaming
     int n_point_slots = 0, n_result_slots = 0;  // distance-only program
     int flags = 0;
+    std::vector<Rec> recs_host;  // full program, kept for hu_tape_specialize
+    struct SpecKernels* spec = nullptr;
 };
 
 namespace {
@@ -217,6 +221,59 @@ int check_dims(const uint32_t dims[3], uint64_t& cells)
     cells = (uint64_t)dims[0] * dims[1] * dims[2];
     return HU_OK;
 }
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// Per-tape specialisation (the analogue of the reference's generate_fixed_eval_source_code,
+// nodes/codegen.py:137-204): the decoded program is unrolled into straight-line HIP source --
+// one exec_one call per record with the record as a literal -- and compiled with hipRTC against
+// the SAME op library (interp.hpp).  With a literal record the opcode switch folds to one case
+// and every slot index is a constant, so the register file dissolves into VGPRs: no dispatch,
+// no scalar fetch, no LDS.  Kernels that only read the distance get the direction arithmetic
+// removed by dead-code elimination.  The arithmetic is the interpreter's, operation for
+// operation, so results are identical (tests run the parity suite on specialised tapes).
+// ------------------------------------------------------------------------------------------
+struct SpecKernels {
+    hipModule_t module = nullptr;
+    hipFunction_t dense[2] = {nullptr, nullptr};
+    hipFunction_t blocks[2] = {nullptr, nullptr};
+    hipFunction_t classify[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [MASS][BATCH]
+};
+
+namespace {
+
+constexpr int kSpecVoxelsPerLane = 2;
+constexpr uint32_t kSpecBlock = 256;
+
+std::string generate_source(const hu_tape_s* t)
+{
+    std::ostringstream o;
+    o << "#include \"kernels.hpp\"\nnamespace sdfk {\n"
+      << "template <class T> __device__ __forceinline__ sdf::V4<T> tape_eval(T px, T py, T pz, const float* __restrict__ extra)\n{\n"
+      << "    using namespace sdf;\n    RegsV<T, " << t->n_slots << "> regs;\n"
+      << "    V4<T> last = v4<T>(bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f));\n";
+    char buf[32];
+    for (const Rec& r : t->recs_host) {
+        if ((r.hdr & 0xffu) == sdf::OP_RETURN) break;
+        std::snprintf(buf, sizeof buf, "0x%08xu", r.hdr);
+        o << "    { const Rec r = {" << buf << ", {";
+        for (int i = 0; i < SDF_REC_DWORDS - 1; ++i) {
+            uint32_t bits;
+            std::memcpy(&bits, &r.p[i], 4);
+            std::snprintf(buf, sizeof buf, "0x%08xu", bits);
+            o << (i ? ", " : "") << "__builtin_bit_cast(float, " << buf << ")";
+        }
+        o << "}}; exec_one<T, false>(r, last, extra, px, py, pz, regs); }\n";
+    }
+    o << "    return last;\n}\n"
+      << "struct JitEval {\n    const float* extra;\n"
+      << "    template <class T> __device__ __forceinline__ sdf::V4<T> operator()(T px, T py, T pz, void*) const\n"
+      << "    { return tape_eval<T>(px, py, pz, extra); }\n};\n}  // namespace sdfk\n";
+    return o.str();
+}
+
+struct SpecEval { const float* extra; };  // same layout as the generated sdfk::JitEval
 
 }  // namespace
 
@@ -385,6 +442,7 @@ int hu_tape_create(const float* tape, size_t n, hu_tape* out)
     t->n_point_slots = d.n_point_slots;
     t->n_result_slots = d.n_result_slots;
     t->flags = d.direction_feeds_distance ? 1 : 0;
+    t->recs_host = d.recs;
     hipError_t e = hipMalloc((void**)&t->recs_dev, d.recs.size() * sizeof(Rec));
     if (e == hipSuccess && !d.recs_do.empty()) {
         e = hipMalloc((void**)&t->recs_do_dev, d.recs_do.size() * sizeof(Rec));
@@ -407,6 +465,10 @@ int hu_tape_create(const float* tape, size_t n, hu_tape* out)
 int hu_tape_destroy(hu_tape t)
 {
     if (!t) return HU_OK;
+    if (t->spec) {
+        if (t->spec->module) (void)hipModuleUnload(t->spec->module);
+        delete t->spec;
+    }
     (void)hipFree(t->recs_dev);
     (void)hipFree(t->recs_do_dev);
     (void)hipFree(t->extra_dev);
@@ -434,6 +496,23 @@ int hu_grid_eval_slab(hu_tape t, const float corner[4], float step, const uint32
     if ((uint64_t)x0 + x_count > dims[0]) return fail(HU_ERR_BAD_ARG, "slab exceeds the grid's x extent");
     const uint64_t plane = (uint64_t)dims[1] * dims[2];
     if (plane >= (1ull << 30)) return fail(HU_ERR_BAD_ARG, "dims[1]*dims[2] must be below 2^30");
+    if (t->spec) {
+        const uint32_t max_x = (uint32_t)((1ull << 30) / plane);
+        SpecEval ev{t->extra_dev};
+        float cx = corner[0], cy = corner[1], cz = corner[2];
+        uint32_t sx = dims[0], sy = dims[1], sz = dims[2];
+        for (uint32_t done = 0; done < x_count;) {
+            const uint32_t nx = (x_count - done < max_x) ? (x_count - done) : max_x;
+            uint32_t n_cells = (uint32_t)(nx * plane), xs = x0 + done;
+            void* o = (layout == 0) ? (void*)(static_cast<float4*>(out_dev) + (size_t)done * plane) : out_dev;
+            void* args[] = {&ev, &cx, &cy, &cz, &step, &sx, &sy, &sz, &xs, &n_cells, &o};
+            const uint32_t per_block = kSpecBlock * kSpecVoxelsPerLane;
+            HU_HIP(hipModuleLaunchKernel(t->spec->dense[layout], (n_cells + per_block - 1) / per_block, 1, 1, kSpecBlock, 1, 1,
+                                         0, (hipStream_t)stream, args, nullptr));
+            done += nx;
+        }
+        return HU_OK;
+    }
     LaunchShape ls;
     if ((rc = launch_shape(t, ls, layout == 1 && distance_only(t)))) return rc;
     if ((rc = ensure_attrs())) return rc;
@@ -489,6 +568,19 @@ int hu_grid_eval_blocks(hu_tape t, const int32_t* blocks_dev, uint32_t n_blocks,
     if ((rc = check_dims(dims, cells))) return rc;
     if (cells > (1ull << 24)) return fail(HU_ERR_BAD_ARG, "a block may have at most 2^24 cells (256^3)");
     if (n_blocks == 0) return HU_OK;
+    if (t->spec) {
+        const uint32_t per_block = kSpecBlock * kSpecVoxelsPerLane;
+        uint32_t chunks = (uint32_t)((cells + per_block - 1) / per_block);
+        if ((uint64_t)chunks * n_blocks > 0x7fffffffull) return fail(HU_ERR_BAD_ARG, "too many workgroups in one launch");
+        SpecEval ev{t->extra_dev};
+        const int4* b = (const int4*)blocks_dev;
+        double res = resolution, ox = origin[0], oy = origin[1], oz = origin[2];
+        uint32_t sx = dims[0], sy = dims[1], sz = dims[2];
+        void* args[] = {&ev, &b, &chunks, &res, &ox, &oy, &oz, &step, &sx, &sy, &sz, &out_dev};
+        HU_HIP(hipModuleLaunchKernel(t->spec->blocks[layout], chunks * n_blocks, 1, 1, kSpecBlock, 1, 1, 0, (hipStream_t)stream,
+                                     args, nullptr));
+        return HU_OK;
+    }
     LaunchShape ls;
     if ((rc = launch_shape(t, ls, layout == 1 && distance_only(t)))) return rc;
     if ((rc = ensure_attrs())) return rc;
@@ -529,6 +621,18 @@ int launch_classify(hu_tape t, ClassifyArgs& a, uint32_t n_parents, const uint32
     if (dims[0] > 256 || dims[1] > 256 || dims[2] > 256)
         return fail(HU_ERR_BAD_ARG, "grid size > 256 would overflow the uchar4 cell index (reference subdivision.py:206-208)");
     if (n_parents == 0) return HU_OK;
+    if (t->spec) {
+        const uint32_t per_block = kSpecBlock * kSpecVoxelsPerLane;
+        a.sx = dims[0]; a.sy = dims[1]; a.sz = dims[2];
+        a.chunks = (uint32_t)((cells + per_block - 1) / per_block);
+        a.scratch_offset = 0;
+        if ((uint64_t)a.chunks * n_parents > 0x7fffffffull) return fail(HU_ERR_BAD_ARG, "too many workgroups in one launch");
+        SpecEval ev{t->extra_dev};
+        void* args[] = {&ev, &a};
+        HU_HIP(hipModuleLaunchKernel(t->spec->classify[MASS ? 1 : 0][BATCH ? 1 : 0], a.chunks * n_parents, 1, 1, kSpecBlock, 1, 1,
+                                     (unsigned)kScratchBytes, (hipStream_t)stream, args, nullptr));
+        return HU_OK;
+    }
     LaunchShape ls;
     if ((rc = launch_shape(t, ls, distance_only(t)))) return rc;
     if ((rc = ensure_attrs())) return rc;
@@ -626,6 +730,67 @@ int hu_mass_integrals(const double* parents_dev, const uint32_t* sums_dev, uint3
     hipLaunchKernelGGL(k_mass_integrals, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const double4*)parents_dev,
                        sums_dev, n_parents, s, out10_dev);
     HU_HIP(hipGetLastError());
+    return HU_OK;
+}
+
+int hu_tape_specialize(hu_tape t, const char* include_dir)
+{
+    if (!t || !include_dir) return fail(HU_ERR_BAD_ARG, "NULL argument");
+    if (t->spec) return HU_OK;
+    const std::string src = generate_source(t);
+    hiprtcProgram prog;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "tape_specialised.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+        return fail(HU_ERR_UNSUPPORTED, "hiprtcCreateProgram failed");
+    static const char* const names[8] = {
+        "sdfk::k_grid_eval<sdfk::JitEval, 0, 2>",          "sdfk::k_grid_eval<sdfk::JitEval, 1, 2>",
+        "sdfk::k_grid_eval_blocks<sdfk::JitEval, 0, 2>",   "sdfk::k_grid_eval_blocks<sdfk::JitEval, 1, 2>",
+        "sdfk::k_classify<sdfk::JitEval, false, false, 2>", "sdfk::k_classify<sdfk::JitEval, false, true, 2>",
+        "sdfk::k_classify<sdfk::JitEval, true, false, 2>",  "sdfk::k_classify<sdfk::JitEval, true, true, 2>"};
+    for (const char* n : names) (void)hiprtcAddNameExpression(prog, n);
+    const std::string inc = std::string("-I") + include_dir;
+    // same numerical contract as the ahead-of-time build: no contraction, IEEE sqrt/divide (HIP default)
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", inc.c_str()};
+    const hiprtcResult rc = hiprtcCompileProgram(prog, 5, opts);
+    if (rc != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        std::string log;
+        if (hiprtcGetProgramLogSize(prog, &n) == HIPRTC_SUCCESS && n > 1) {
+            log.resize(n);
+            (void)hiprtcGetProgramLog(prog, &log[0]);
+        }
+        (void)hiprtcDestroyProgram(&prog);
+        return fail(HU_ERR_UNSUPPORTED, std::string("hipRTC compile failed: ") + hiprtcGetErrorString(rc) + "\n" + log.substr(0, 4000));
+    }
+    size_t size = 0;
+    (void)hiprtcGetCodeSize(prog, &size);
+    std::vector<char> code(size);
+    (void)hiprtcGetCode(prog, code.data());
+    SpecKernels* k = new SpecKernels();
+    hipError_t e = hipModuleLoadData(&k->module, code.data());
+    hipFunction_t* slots[8] = {&k->dense[0], &k->dense[1], &k->blocks[0], &k->blocks[1],
+                               &k->classify[0][0], &k->classify[0][1], &k->classify[1][0], &k->classify[1][1]};
+    for (int i = 0; i < 8 && e == hipSuccess; ++i) {
+        const char* lowered = nullptr;
+        if (hiprtcGetLoweredName(prog, names[i], &lowered) != HIPRTC_SUCCESS || !lowered) {
+            e = hipErrorNotFound;
+            break;
+        }
+        e = hipModuleGetFunction(slots[i], k->module, lowered);
+    }
+    (void)hiprtcDestroyProgram(&prog);
+    if (e != hipSuccess) {
+        if (k->module) (void)hipModuleUnload(k->module);
+        delete k;
+        return fail(HU_ERR_HIP, std::string("loading the specialised module: ") + hipGetErrorString(e));
+    }
+    t->spec = k;
+    return HU_OK;
+}
+
+int hu_tape_specialized(hu_tape t, int* out)
+{
+    if (!t || !out) return fail(HU_ERR_BAD_ARG, "NULL argument");
+    *out = t->spec ? 1 : 0;
     return HU_OK;
 }
 

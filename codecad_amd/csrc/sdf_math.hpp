@@ -13,9 +13,14 @@
 // See DESIGN.md "Canonical arithmetic".
 #pragma once
 
+#ifndef __HIPCC_RTC__  // hipRTC (specialised tapes) has the runtime built in and no host headers
 #include <hip/hip_runtime.h>
-#ifndef __HIPCC_RTC__
 #include <cstdint>
+#else
+using __hip_internal::int32_t;
+using __hip_internal::uint32_t;
+using __hip_internal::uint64_t;
+typedef unsigned long size_t;
 #endif
 
 #define SDF_HD __host__ __device__ __forceinline__

@@ -7,6 +7,7 @@ host memory so enqueue_* are genuinely asynchronous on the buffer's stream.
 """
 import contextlib
 import ctypes
+import os
 
 import numpy
 
@@ -219,6 +220,19 @@ class Tape:
         n, r, f = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         check(m.lib.hu_tape_info(h, ctypes.byref(n), ctypes.byref(r), ctypes.byref(f)), "hu_tape_info")
         self.n_instructions, self.n_registers, self.flags = n.value, r.value, f.value
+        self.specialized = False
+        if os.environ.get("CODECAD_AMD_SPECIALIZE", "0") == "1":
+            self.specialize()
+
+    def specialize(self):
+        """Compile straight-line kernels for this tape with hipRTC (seconds, once); afterwards
+        every launch with this tape uses them.  Same results as the interpreter.  Raises
+        RuntimeError (with the compiler log) if hipRTC cannot build it."""
+        if not self.specialized:
+            from . import builder
+            check(self.manager.lib.hu_tape_specialize(self.device_ptr, builder.CSRC.encode()), "hu_tape_specialize")
+            self.specialized = True
+        return self
 
     @property
     def alive(self):

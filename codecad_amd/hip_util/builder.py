@@ -65,7 +65,8 @@ def _compile(LIB_PATH, extra_flags, verbose):
     if hipcc is None:
         raise RuntimeError("hipcc not found: cannot build libhip_util.so (set HIPCC or install ROCm)")
     tmp = LIB_PATH + ".tmp.%d" % os.getpid()
-    cmd = [hipcc] + HIPCC_FLAGS + extra_flags + ["-I", INCLUDE, "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+    cmd = ([hipcc] + HIPCC_FLAGS + extra_flags + ["-I", INCLUDE, "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+           + ["-lhiprtc"])
     proc = subprocess.run(cmd, capture_output=True, text=True)
     if proc.returncode != 0:
         if os.path.exists(tmp):

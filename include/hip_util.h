@@ -136,6 +136,14 @@ int hu_mass_properties_level(hu_tape t, const double* parents_dev, uint32_t n_pa
 int hu_mass_integrals(const double* parents_dev, const uint32_t* sums_dev, uint32_t n_parents, double s,
                       double* out10_dev, void* stream);
 
+/* Per-tape specialisation (the reference's generate_fixed_eval_source_code, nodes/codegen.py:137-204):
+ * unroll the decoded program into straight-line gfx950 code with hipRTC, using the op library
+ * headers found in `include_dir` (codecad_amd/csrc).  Afterwards every launch with this tape runs
+ * the specialised kernels; results are identical to the interpreter's.  Costs one compilation
+ * (seconds); returns HU_ERR_UNSUPPORTED with the compiler log if hipRTC cannot build it. */
+int hu_tape_specialize(hu_tape t, const char* include_dir);
+int hu_tape_specialized(hu_tape t, int* out_flag);
+
 #ifdef __cplusplus
 }
 #endif
