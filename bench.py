@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--n", type=int, default=N, help="grid edge (default 512)")
+    ap.add_argument("--evaluator", choices=["auto", "specialised", "interpreter"], default="auto",
+                    help="auto = per-tape hipRTC specialisation when it builds, else the tape interpreter")
     args = ap.parse_args()
 
     import numpy as np
@@ -64,6 +66,16 @@ def main():
 
     shape = cc.examples.sponge(SPONGE_DEPTH)
     tape = cc.nodes.make_program_buffer(shape)
+    interp_tape = tape            # the same program, always interpreted (reported beside the headline)
+    evaluator = "interpreter"
+    if args.evaluator != "interpreter":
+        try:
+            tape = hip_util.Tape(tape.host_tape).specialize()   # ~1 s of hipRTC, outside the timed region
+            evaluator = "specialised"
+        except RuntimeError as e:
+            if args.evaluator == "specialised":
+                raise
+            print("bench: hipRTC specialisation unavailable, using the interpreter: %s" % str(e)[:300], file=sys.stderr)
     # Everything is enqueued on torch's current stream: the survivor lists travel through
     # torch.distributed (RCCL orders its collectives against that stream), so one stream gives
     # the kernel -> all-gather -> kernel dependencies without extra synchronisation.
@@ -156,6 +168,18 @@ def main():
 
     for _ in range(args.warmup):
         one_step(False)
+    # the interpreter on the same dense grid, timed the same way (reported, not part of `value`)
+    interp_ms = []
+    for i in range(3):
+        check(lib.hu_event_record(ev0, stream), "record")
+        check(lib.hu_grid_eval(interp_tape.device_ptr, corner.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), step_f,
+                               dims, dense_out.data_ptr(), stream), "hu_grid_eval")
+        check(lib.hu_event_record(ev1, stream), "record")
+        check(lib.hu_event_synchronize(ev1), "sync")
+        ms = ctypes.c_float()
+        check(lib.hu_event_elapsed_ms(ev0, ev1, ctypes.byref(ms)), "elapsed")
+        if i:
+            interp_ms.append(ms.value)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -182,15 +206,19 @@ def main():
             "data": "synthetic",
             "config": {"workload": "menger_sponge depth=4, %d^3: dense float4 grid_eval + adaptive subdivision "
                                    "(grid %d, overlap) + grid_eval of all leaf blocks; one object per GPU" % (n, SUBDIV_GRID),
+                       "evaluator": evaluator + (" (per-tape straight-line kernels compiled with hipRTC from the same "
+                                                  "op library; bit-identical to the interpreter)" if evaluator == "specialised" else ""),
                        "tape_floats": int(tape.host_tape.size), "tape_instructions": tape.n_instructions,
                        "value_registers": tape.n_registers, "parallelism": "x-slab/object per rank, "
                        "balanced parent slices + RCCL all-gather of survivors per level" if world > 1 else "single GPU"},
             "samples_per_step_per_gpu": {"dense": dense_voxels, "subdivision": stats["samples"],
                                          "leaf_blocks": stats["leaves"] * leaf_cells,
                                          "survivors_per_level_global": stats["level_counts"]},
-            "roofline": {"bound": "hbm", "kernel": "k_grid_eval<0,false,1>", "achieved": round(achieved, 2),
+            "interpreter_dense_kernel_ms": round(sum(interp_ms) / len(interp_ms), 4),
+            "roofline": {"bound": "hbm", "kernel": "k_grid_eval<%s, 0, 2>" % ("JitEval" if evaluator == "specialised" else "InterpEval<false>"),
+                         "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": measured_traffic(n), "kernel_ms": round(dense_avg_ms, 4),
+                         "traffic": measured_traffic(n, evaluator), "kernel_ms": round(dense_avg_ms, 4),
                          "voxels_per_s": round(dense_voxels / (dense_avg_ms * 1e-3), 0),
                          "note": "this tape is FP32-VALU-bound, not HBM-bound: see valu_* fields",
                          "valu_flop_per_voxel": flop,
@@ -215,7 +243,7 @@ _PARAMS = {0: 0, 1: 0, 2: 0, 3: 2, 4: 1, 5: 2, 7: 1, 8: 0, 9: 0, 10: 2, 11: 7, 1
            16: 1, 17: 1, 18: 3, 19: 1, 20: 1, 21: 2, 22: 1, 23: 0, 24: 3, 25: 0, 26: 1, 27: 1, 28: 1}
 
 
-def measured_traffic(n):
+def measured_traffic(n, evaluator="specialised"):
     """HBM bytes per launch of the dense kernel from the committed rocprofv3 PMC passes
     (profiles/*_summary.json, produced by tools/collect_profiles.sh for this same kernel and
     grid); None when no profile of this grid size is present."""
@@ -226,7 +254,8 @@ def measured_traffic(n):
             d = json.load(open(f))
         except ValueError:
             continue
-        if d.get("grid_edge", 512) == n and "hbm_traffic_bytes_per_launch" in d:
+        if d.get("grid_edge", 512) == n and d.get("evaluator", "interpreter") == evaluator and \
+                "hbm_traffic_bytes_per_launch" in d:
             best = d["hbm_traffic_bytes_per_launch"]
     return best
 

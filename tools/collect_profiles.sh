@@ -4,10 +4,13 @@
 # Counters are collected in their own passes, only with --kernel-trace (never with sys/hip traces).
 set -u
 TAG=${1:-r01}
+# evaluator for the PMC passes: CODECAD_AMD_SPECIALIZE=1 (default, what bench.py measures) or 0
+export CODECAD_AMD_SPECIALIZE=${CODECAD_AMD_SPECIALIZE:-1}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 rm -rf "$OUT" && mkdir -p "$OUT"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_stats" -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/bench_under_rocprof.log" 2>&1
+EVAL=auto; [ "$CODECAD_AMD_SPECIALIZE" = "0" ] && EVAL=interpreter
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_stats" -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --evaluator $EVAL > "$OUT/bench_under_rocprof.log" 2>&1
 echo "bench_stats rc=$?"
 pass() { # name counters...
   local name=$1; shift

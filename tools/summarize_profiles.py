@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 CSV output (tools/collect_profiles.sh) into one JSON summary."""
 import collections
+import re
 import csv
 import glob
 import json
@@ -13,14 +14,14 @@ for f in glob.glob(os.path.join(root, "bench_stats", "*", "*_kernel_stats.csv"))
     for r in csv.DictReader(open(f)):
         name = r["Name"]
         if "k_" in name or "rocclr" in name:
-            out["kernel_stats"].append({"name": name.split("(")[0].replace("void (anonymous namespace)::", ""),
+            out["kernel_stats"].append({"name": name.split("(")[0].replace("void ", "").replace("sdfk::", ""),
                                         "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
                                         "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"]),
                                         "percent": float(r["Percentage"])})
 for f in glob.glob(os.path.join(root, "pmc_*", "*", "*_counter_collection.csv")):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "k_grid_eval<0," in r["Kernel_Name"]:
+        if re.search(r"k_grid_eval<.*, 0, \d>", r["Kernel_Name"]):
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in acc.items():
         out["dense_kernel_counters_per_launch"][k] = sum(v) / len(v)
