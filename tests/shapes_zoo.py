@@ -126,3 +126,15 @@ all_named.update(shapes_3d)
 all_named.update(("mp_" + k, v[0]) for k, v in mass_property_cases.items())
 all_named["kat_box10"] = box(10)
 all_named["kat_circle"] = circle(kat_circle_diameter)
+
+# Rounded blends (union / intersection with r >= 0, reference shapes/common.cl:45-64): the one op
+# through which a direction feeds a distance.  Not in the reference's test zoo; compiled by our
+# compiler only (no golden tape), checked HIP-vs-oracle and for the blend's own properties.
+rounded_shapes = {
+    "rounded_union_3d": union([box(2), sphere(2.5).translated(1, 0, 0)], r=0.4),
+    "rounded_intersection_3d": __import__("codecad_amd").shapes.intersection(
+        [box(3).rotated((1, 1, 0), 30), sphere(3.6)], r=0.3),
+    "rounded_union_2d": union([circle(2).translated_x(0.8), rectangle(2, 1)], r=0.25),
+    "rounded_nested": union([union([box(1).translated_x(-1), box(1).translated_x(1)], r=0.2), sphere(1.2)], r=0.3)
+    - cylinder(h=4, d=0.6),
+}

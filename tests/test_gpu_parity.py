@@ -200,3 +200,44 @@ def test_mass_properties_driver_analytic(hip, name):
     assert tuple(result.centroid) == pytest.approx(centroid, abs=1e-4, rel=precision)
     if inertia is not None:
         assert np.allclose(result.inertia_tensor, inertia, rtol=precision)
+
+
+@pytest.mark.parametrize("name", sorted(shapes_zoo.rounded_shapes))
+def test_rounded_blends_match_oracle(hip, name):
+    """Tapes with rounded blends run the FULL interpreter in every kernel (a direction feeds a
+    distance): grid_eval, pymcubes, subdivision_step and mass_properties against the oracle."""
+    from codecad_amd import hip_util, nodes
+    shape = shapes_zoo.rounded_shapes[name]
+    tape_f = nodes.make_program(shape)
+    bb = shape.bounding_box()
+    ref = {"bbox_a": list(bb.a), "bbox_b": list(bb.b), "dimension": shape.dimension()}
+    corner, step, dims = _grid_for(ref, 28)
+    tape = hip_util.Tape(tape_f)
+    assert tape.flags & 1
+    c4 = np.zeros(4, np.float32)
+    c4[:3] = corner
+    out = hip_util.Buffer(hip_util.Buffer.quad_dtype(np.float32), dims)
+    hip.k.grid_eval(dims, None, tape, c4, step, out).wait()
+    want = oracle.grid_eval(tape_f, corner, step, dims)
+    got = out.read().view(np.float32).reshape(dims + (4,))
+    assert _same(got, want), "max |diff| = %g" % np.nanmax(np.abs(got - want))
+    assert np.any((want[..., :3] == 0).all(axis=-1)), "the grid must cross a blend region"
+    flat = hip_util.Buffer(np.float32, dims)
+    hip.k.grid_eval_pymcubes(dims, None, tape, c4, step, flat).wait()
+    assert _same(flat.read().reshape(-1), oracle.grid_eval_pymcubes(tape_f, corner, step, dims))
+    thr = np.float32(float(step) * math.sqrt(shape.dimension()) / 2)
+    counter = hip_util.Buffer(np.uint32, 1)
+    lst = hip_util.Buffer(hip_util.Buffer.quad_dtype(np.uint8), dims[0] * dims[1] * dims[2])
+    counter.enqueue_fill(0)
+    hip.k.subdivision_step(dims, None, tape, c4, step, thr, counter, lst).wait()
+    want_n, want_l = oracle.subdivision_step(tape_f, corner, step, thr, dims)
+    n = int(counter.read()[0])
+    assert n == want_n
+    assert sorted(map(tuple, lst.read().view(np.uint8).reshape(-1, 4)[:n].tolist())) == sorted(map(tuple, want_l.tolist()))
+    if shape.dimension() == 3:
+        sums = hip_util.Buffer(np.uint32, 10)
+        sums.enqueue_fill(0)
+        counter.enqueue_fill(0)
+        hip.k.mass_properties(dims, None, tape, c4, step, thr, sums, counter, lst).wait()
+        ws, wn, _ = oracle.mass_properties(tape_f, corner, step, thr, dims)
+        assert sums.read().tolist() == ws.tolist() and int(counter.read()[0]) == wn

@@ -25,3 +25,70 @@ def test_forced_variant_matches_oracle(hip, voxels_per_lane, full_interpreter):
     proc = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-2000:]
     assert " passed" in proc.stdout
+
+
+SPEC_SHAPES = ["sphere_plus_box", "csg_example", "sponge4", "gear", "mirror_3d", "kat_circle", "nonconvex_shell2",
+               "torus", "extreme_twisted_revolve", "revolved_pentagon", "rotated_pattern_2d", "planetary"]
+
+
+@pytest.mark.parametrize("name", SPEC_SHAPES + sorted(__import__("shapes_zoo").rounded_shapes))
+def test_specialised_tape_is_bit_identical_to_the_interpreter(hip, name):
+    """hu_tape_specialize (hipRTC straight-line kernels) vs the interpreter, byte for byte, through
+    all four reference-shaped kernels and one level-batched launch."""
+    import math
+    import ctypes
+    import numpy as np
+    import shapes_zoo
+    from conftest import load_golden_tapes
+    from codecad_amd import hip_util, nodes
+    from codecad_amd.hip_util import check
+    if name in shapes_zoo.rounded_shapes:
+        shape = shapes_zoo.rounded_shapes[name]
+        tape_f, dim = nodes.make_program(shape), shape.dimension()
+        bb = shape.bounding_box()
+        a, b = np.array(bb.a, float), np.array(bb.b, float)
+    else:
+        ref = load_golden_tapes()[name]
+        tape_f, dim = ref["tape"], ref["dimension"]
+        a, b = np.array(ref["bbox_a"]), np.array(ref["bbox_b"])
+    a, b = np.where(np.isfinite(a), a, -2.0), np.where(np.isfinite(b), b, 2.0)
+    n = 21
+    size = float(np.max(b - a)) * 1.2 + 1e-3
+    step = np.float32(size / n)
+    c4 = np.zeros(4, np.float32)
+    c4[:3] = (a + b) / 2 - size / 2 + size / n / 2
+    dims = (n, n, n) if dim == 3 else (n, n, 1)
+    if dim == 2:
+        c4[2] = 0
+    thr = np.float32(float(step) * math.sqrt(dim) / 2)
+    cells = dims[0] * dims[1] * dims[2]
+    results = []
+    for specialise in (False, True):
+        tape = hip_util.Tape(tape_f)
+        if specialise:
+            tape.specialize()
+            flag = ctypes.c_int()
+            check(hip.lib.hu_tape_specialized(tape.device_ptr, ctypes.byref(flag)), "hu_tape_specialized")
+            assert flag.value == 1
+        got = []
+        g4 = hip_util.Buffer(hip_util.Buffer.quad_dtype(np.float32), dims)
+        hip.k.grid_eval(dims, None, tape, c4, step, g4).wait()
+        got.append(g4.read().view(np.uint32).copy())
+        g1 = hip_util.Buffer(np.float32, dims)
+        hip.k.grid_eval_pymcubes(dims, None, tape, c4, step, g1).wait()
+        got.append(g1.read().view(np.uint32).copy())
+        counter = hip_util.Buffer(np.uint32, 1)
+        lst = hip_util.Buffer(hip_util.Buffer.quad_dtype(np.uint8), cells)
+        counter.enqueue_fill(0)
+        hip.k.subdivision_step(dims, None, tape, c4, step, thr, counter, lst).wait()
+        k = int(counter.read()[0])
+        got.append(np.array(sorted(map(tuple, lst.read().view(np.uint8).reshape(-1, 4)[:k].tolist())), dtype=np.uint8))
+        sums = hip_util.Buffer(np.uint32, 10)
+        sums.enqueue_fill(0)
+        counter.enqueue_fill(0)
+        hip.k.mass_properties(dims, None, tape, c4, step, thr, sums, counter, lst).wait()
+        got.append(sums.read().copy())
+        got.append(counter.read().copy())
+        results.append(got)
+    for x, y in zip(*results):
+        assert np.array_equal(x, y)
