@@ -199,8 +199,11 @@ def test_rounded_blend_properties(name):
     if shape.dimension() == 2:
         line[:, 2] = 0
     w = oracle.evaluate_points(nodes.make_program(shape), line)[:, 3].astype(np.float64)
-    # (where the two normals are exactly opposite the reference formula divides by 1 - cos^2 = 0;
-    # that artefact is restated faithfully, so isolated non-finite samples are ignored here)
-    d = np.abs(np.diff(w))
-    d = d[np.isfinite(d)]
-    assert np.percentile(d, 99.5) < 3 * np.linalg.norm(hi - lo) / 4000
+    ws = oracle.evaluate_points(nodes.make_program(sharp), line)[:, 3]
+    # Outside the solid the blended field is continuous.  (Deep inside, where the two normals
+    # are opposite, the reference formula divides by 1 - cos^2 -> 0 and returns huge negative
+    # values; that artefact is restated faithfully and harmless: the sign stays negative.)
+    outside = (ws[:-1] > 0) & (ws[1:] > 0)
+    assert outside.sum() > 100
+    assert np.max(np.abs(np.diff(w))[outside]) < 3 * np.linalg.norm(hi - lo) / 4000
+    assert np.all(w[ws < 0] < 0)
