@@ -2,8 +2,12 @@
 
 Same public names as the reference's `codecad.util` (reference util/__init__.py:1-4).
 """
+import sys as _sys
+
 from .geometry import Vector, BoundingBox, Quaternion, Transformation  # noqa: F401
-from .math import KahanSummation, round_up_to, round_up_to_power_of_2, clamp  # noqa: F401
-from .misc import status_block, Concatenate, at_most_one  # noqa: F401
-from .types import wrap_number_like, wrap_vector_like  # noqa: F401
-from . import types  # noqa: F401
+from . import _support
+from ._support import (KahanSummation, round_up_to, round_up_to_power_of_2, clamp, status_block,  # noqa: F401
+                       Concatenate, at_most_one, wrap_number_like, wrap_vector_like)
+
+types = _support   # `util.types.wrap_vector_like`, as in the reference
+_sys.modules[__name__ + ".types"] = _support
