@@ -16,26 +16,34 @@ from .base import TapeShape  # noqa: F401
 
 
 def rectangle(x=1, y=None):
+    """Axis-aligned rectangle centred on the origin; one argument gives a square.
+    Tape op `rectangle(half_w, half_h)`: exact distance, outward unit direction."""
     return _s2.Rectangle(x, x if y is None else y)
 
 
 def circle(d=1, r=None):
+    """Circle centred on the origin by diameter `d` or radius `r` (tape op `circle(r)`)."""
     return _s2.Circle(d, r)
 
 
 def half_plane():
+    """The half plane y > 0 (tape op `half_space`, shared with the 3D half space)."""
     return _s2.HalfPlane()
 
 
 def regular_polygon2d(n, d=1, r=None, side_length=None, across_flats=None):
+    """Regular n-gon with a vertex on +x, sized by exactly one of circumscribed diameter `d`,
+    circumscribed radius `r`, `side_length` or `across_flats`."""
     return _s2.RegularPolygon2D(n, d, r, side_length, across_flats)
 
 
 def polygon2d(points):
+    """Simple polygon from (x, y) points, either winding; rejects self-intersections."""
     return _polygons2d.Polygon2D(points)
 
 
 def polygon2d_builder(origin_x, origin_y):
+    """Turtle-style builder: `.dx(..).dy(..).angle(..).close()` -> polygon."""
     return _polygons2d.Polygon2D.build(origin_x, origin_y)
 
 
@@ -47,6 +55,8 @@ def capsule(x1, y1, x2, y2, width):
 
 
 def box(x=1, y=None, z=None):
+    """Cuboid centred on the origin (a rectangle extruded symmetrically); one argument gives a cube.
+    `float("inf")` along z gives an infinite prism (the extrusion node is then omitted)."""
     if (y is None) != (z is None):
         raise ValueError("y and z must either both be None, or both be number")
     if y is None:
@@ -55,14 +65,18 @@ def box(x=1, y=None, z=None):
 
 
 def sphere(d=1, r=None):
+    """Sphere centred on the origin by diameter or radius (tape op `sphere(r)`)."""
     return _s3.Sphere(2 * r if r is not None else d)
 
 
 def cylinder(h=1, d=1, r=None, symmetrical=True):
+    """Cylinder along z: a circle extruded by `h`, centred on z = 0 unless symmetrical=False
+    (then it stands on the z = 0 plane)."""
     return circle(d=d, r=r).extruded(h, symmetrical)
 
 
 def half_space():
+    """The half space y > 0."""
     return _s3.HalfSpace()
 
 
@@ -84,4 +98,5 @@ def union(shapes, r=-1):
 
 
 def intersection(shapes, r=-1):
+    """Intersection; r >= 0 rounds the seams with that radius."""
     return _group(shapes, "Intersection", _s2.Intersection2D, _s3.Intersection, r)

@@ -8,6 +8,7 @@ norm is the scale factor (reference geometry.py:186-196).
 """
 import itertools
 import math
+import operator
 from typing import NamedTuple
 
 import numpy
@@ -23,44 +24,54 @@ class _VectorBase(NamedTuple):
     z: float
 
 
+def _each(op, *vectors):
+    """Apply `op` component by component: the one place Vector arithmetic is spelled out."""
+    return Vector(*map(op, *vectors))
+
+
 class Vector(_VectorBase):
-    """3-vector; 2D code simply leaves z = 0 (reference geometry.py:8-12)."""
+    """3-vector of Python numbers; 2D code simply leaves z = 0 (reference geometry.py:8-12).
+
+    Immutable (a named tuple), so it hashes and compares by value: the drivers put corners
+    into sets and the tests compare leaf-block corners exactly.
+    """
 
     __slots__ = ()
 
     def __new__(cls, x, y, z=0):
         return super().__new__(cls, x, y, z)
 
+    # constructors -------------------------------------------------------------------------
     @classmethod
     def splat(cls, value):
         return cls(value, value, value)
 
     @classmethod
     def zero(cls):
-        return cls(0, 0, 0)
+        return cls.splat(0)
 
     @classmethod
     def polar(cls, r, phi, rho=0):
         """Spherical coordinates in degrees: phi = longitude, rho = latitude."""
-        phi, rho = math.radians(phi), math.radians(rho)
-        c = math.cos(rho)
-        return cls(c * math.cos(phi), c * math.sin(phi), math.sin(rho)) * r
+        lon, lat = math.radians(phi), math.radians(rho)
+        ring = math.cos(lat)
+        return cls(ring * math.cos(lon), ring * math.sin(lon), math.sin(lat)) * r
 
-    # arithmetic ---------------------------------------------------------------------
-    def __add__(self, o):
-        return Vector(self.x + o.x, self.y + o.y, self.z + o.z)
+    # arithmetic: vector (+,-) vector, vector (*,/) scalar -------------------------------------
+    def __add__(self, other):
+        return _each(operator.add, self, other)
 
-    def __sub__(self, o):
-        return Vector(self.x - o.x, self.y - o.y, self.z - o.z)
+    def __sub__(self, other):
+        return _each(operator.sub, self, other)
 
     def __mul__(self, k):
-        return Vector(self.x * k, self.y * k, self.z * k)
+        return _each(lambda c: c * k, self)
 
     def __truediv__(self, k):
-        return Vector(self.x / k, self.y / k, self.z / k)
+        return _each(lambda c: c / k, self)
 
     def __neg__(self):
-        return Vector(-self.x, -self.y, -self.z)
+        return _each(operator.neg, self)
 
     def __pos__(self):
         return self
@@ -68,42 +79,39 @@ class Vector(_VectorBase):
     def __abs__(self):
         return math.sqrt(self.abs_squared())
 
+    def dot(self, other):
+        # left-to-right sum of the three products, like the reference, so fp64 results agree
+        px, py, pz = map(operator.mul, self, other)
+        return px + py + pz
+
     def abs_squared(self):
         return self.dot(self)
 
-    def dot(self, o):
-        return self.x * o.x + self.y * o.y + self.z * o.z
-
     def cross(self, o):
-        return Vector(self.y * o.z - self.z * o.y,
-                      self.z * o.x - self.x * o.z,
-                      self.x * o.y - self.y * o.x)
+        (ax, ay, az), (bx, by, bz) = self, o
+        return Vector(ay * bz - az * by, az * bx - ax * bz, ax * by - ay * bx)
 
     def normalized(self):
         return self / abs(self)
 
     def elementwise_abs(self):
-        return Vector(abs(self.x), abs(self.y), abs(self.z))
+        return _each(abs, self)
 
-    def elementwise_mul(self, o):
-        return Vector(self.x * o.x, self.y * o.y, self.z * o.z)
+    def elementwise_mul(self, other):
+        return _each(operator.mul, self, other)
 
-    def elementwise_div(self, o):
-        return Vector(self.x / o.x, self.y / o.y, self.z / o.z)
-
-    def _fold(self, other, op):
-        if other is None:
-            return op(self.x, self.y, self.z)
-        return Vector(op(self.x, other.x), op(self.y, other.y), op(self.z, other.z))
+    def elementwise_div(self, other):
+        return _each(operator.truediv, self, other)
 
     def max(self, other=None):
-        return self._fold(other, max)
+        """Largest component, or the component-wise maximum with another vector."""
+        return max(self) if other is None else _each(max, self, other)
 
     def min(self, other=None):
-        return self._fold(other, min)
+        return min(self) if other is None else _each(min, self, other)
 
     def applyfunc(self, f):
-        return Vector(f(self.x), f(self.y), f(self.z))
+        return _each(f, self)
 
     def flattened(self):
         return Vector(self.x, self.y, 0)
@@ -111,7 +119,7 @@ class Vector(_VectorBase):
     def perpendicular2d(self):
         return Vector(self.y, -self.x, self.z)
 
-    # conversions --------------------------------------------------------------------
+    # conversions ----------------------------------------------------------------------------
     def as_float4(self, w=0):
         """16-byte float4 kernel argument; the single fp64 -> fp32 rounding of a corner."""
         return numpy.array((self.x, self.y, self.z, w), dtype=FLOAT4)
@@ -120,13 +128,14 @@ class Vector(_VectorBase):
         return numpy.array((self.x, self.y), dtype=FLOAT2)
 
     def as_tuple2(self):
-        return (self.x, self.y)
+        return self[:2]
 
     def as_matrix(self):
-        return numpy.array([[self.x], [self.y], [self.z], [1]])
+        """Homogeneous column vector (4x1)."""
+        return numpy.array([[c] for c in self] + [[1]])
 
     def __str__(self):
-        return "({}, {}, {})".format(self.x, self.y, self.z)
+        return "({}, {}, {})".format(*self)
 
 
 class _BoxBase(NamedTuple):
