@@ -87,7 +87,12 @@ def allgather_rows(rows, group=None):
     padded[:rows.shape[0]] = rows
     gathered = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(gathered, padded, group=group)
-    return torch.cat([g[:c] for g, c in zip(gathered, counts)], dim=0)
+    out = torch.cat([g[:c] for g, c in zip(gathered, counts)], dim=0)
+    if out.is_cuda:
+        # the list is handed to kernels launched through the C ABI by data_ptr(): make sure the
+        # collective and the concatenation have finished, whatever stream they ran on
+        torch.cuda.current_stream(out.device).synchronize()
+    return out
 
 
 def allreduce_sum(t, group=None):

@@ -74,6 +74,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch wheels bundle their own copy of the HIP runtime.  A process must not initialise the
+    # system runtime first and torch's afterwards (torch then reports "No HIP GPUs are available"),
+    # and device pointers / streams are only interchangeable when both sides resolved the same
+    # runtime.  Importing torch first -- when it is installed -- gives one fixed, tested order.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     try:
         path = os.environ.get("CODECAD_AMD_LIB") or _build.build()
     except RuntimeError:

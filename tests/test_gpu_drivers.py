@@ -297,3 +297,86 @@ def test_device_integrals_match_host_formulas(hip):
         scale = max(abs(want[k]) for k in _KEYS) + 1e-300
         for k, v in zip(_KEYS, results[0]):
             assert v == pytest.approx(want[k], rel=1e-12, abs=1e-13 * scale * n)
+
+
+def _wide_tape(k):
+    """A hand-written tape that keeps k results live at once: k translated spheres are evaluated and
+    stored in registers 0..k-1, then folded with unions.  (Exercises big LDS register files: the
+    reference would just index its 512-entry private array.)"""
+    t = []
+    for i in range(k):
+        t += [11 * 512, 0, 0, 0, 1, -0.37 * i, 0.11 * i, -0.05 * i]   # initial_transformation_to(translate)
+        t += [7 * 512, 0.3 + 0.01 * i]                                  # sphere(r)
+        t += [1 * 512 + i]                                              # _store i
+    t += [2 * 512 + 0]                                                  # _load 0
+    for i in range(1, k):
+        t += [26 * 512 + i, -1.0]                                       # union(r=-1; reg i)
+    t += [0]
+    return np.array(t, dtype=np.float32)
+
+
+@pytest.mark.parametrize("k", [3, 12, 40, 100, 159])
+def test_wide_register_files(hip, k):
+    """3..159 simultaneously live values: every workgroup-size / voxels-per-lane choice of
+    launch_shape, the full and the distance-only program, against the oracle."""
+    from codecad_amd import hip_util
+    tape_f = _wide_tape(k)
+    tape = hip_util.Tape(tape_f)
+    assert tape.n_registers == k
+    dims = (20, 9, 7)
+    c4 = np.array([-1.0, -1.5, -1.2, 0], np.float32)
+    step = np.float32(0.93 * k / 20 + 0.15)
+    out = hip_util.Buffer(hip_util.Buffer.quad_dtype(np.float32), dims)
+    hip.k.grid_eval(dims, None, tape, c4, step, out).wait()
+    assert np.array_equal(out.read().view(np.float32).reshape(dims + (4,)), oracle.grid_eval(tape_f, c4[:3], step, dims))
+    flat = hip_util.Buffer(np.float32, dims)
+    hip.k.grid_eval_pymcubes(dims, None, tape, c4, step, flat).wait()
+    assert np.array_equal(flat.read().reshape(-1), oracle.grid_eval_pymcubes(tape_f, c4[:3], step, dims))
+
+
+def test_too_many_live_values_is_a_clean_error(hip):
+    from codecad_amd import hip_util
+    tape = hip_util.Tape(_wide_tape(200))
+    out = hip_util.Buffer(hip_util.Buffer.quad_dtype(np.float32), (4, 4, 4))
+    with pytest.raises(RuntimeError, match="live"):
+        hip.k.grid_eval((4, 4, 4), None, tape, np.zeros(4, np.float32), np.float32(1), out)
+    # the distance-only program needs 4 bytes per result, so the .w-only kernels still run
+    flat = hip_util.Buffer(np.float32, (4, 4, 4))
+    hip.k.grid_eval_pymcubes((4, 4, 4), None, tape, np.zeros(4, np.float32), np.float32(1), flat).wait()
+    assert np.array_equal(flat.read().reshape(-1), oracle.grid_eval_pymcubes(_wide_tape(200), [0, 0, 0], np.float32(1), (4, 4, 4)))
+    # and specialised code has no LDS register file at all
+    small = hip_util.Tape(_wide_tape(24)).specialize()
+    hip.k.grid_eval((4, 4, 4), None, small, np.zeros(4, np.float32), np.float32(1), out).wait()
+    assert np.array_equal(out.read().view(np.float32).reshape(4, 4, 4, 4), oracle.grid_eval(_wide_tape(24), [0, 0, 0], np.float32(1), (4, 4, 4)))
+
+
+def test_launches_are_graph_capturable(hip):
+    """include/hip_util.h promises launches neither allocate nor synchronise: capture the dense
+    kernel and a level launch into a hipGraph (through torch) and replay it."""
+    import torch
+    import codecad_amd as cc
+    from codecad_amd.hip_util import check
+    shape = cc.examples.sponge(2)
+    tape = cc.nodes.make_program_buffer(shape)
+    n = 48
+    corner = np.array([-0.5 + 0.5 / n] * 3 + [0.0], np.float32)
+    dims = (ctypes.c_uint32 * 3)(n, n, n)
+    out = torch.zeros((n, n, n, 4), dtype=torch.float32, device="cuda")
+    cptr = corner.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+    def launch(stream):
+        check(hip.lib.hu_grid_eval(tape.device_ptr, cptr, np.float32(1.0 / n), dims, out.data_ptr(), stream), "hu_grid_eval")
+
+    launch(None)                      # warm-up outside capture (one-time function attributes)
+    torch.cuda.synchronize()
+    want = out.clone()
+    out.zero_()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.graph(graph, stream=side):
+        launch(side.cuda_stream)
+    torch.cuda.synchronize()
+    assert float(out.abs().sum()) == 0.0          # captured, not executed
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
