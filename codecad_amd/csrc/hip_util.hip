@@ -146,12 +146,13 @@ bool distance_only(const hu_tape_s* t)
 // always for the distance-only program (48-52 B per voxel), for the full program up to 6 live
 // float4 values (sponge(4): 5.3 vs 5.8 ms; sponge(5), 7 values: 8.0 vs 7.7 ms -> one voxel).
 // HU_VOXELS_PER_LANE=1|2 forces a choice (the parity tests run both).
-int launch_shape(const hu_tape_s* t, LaunchShape& ls, bool distance_only_kernel)
+int launch_shape(const hu_tape_s* t, LaunchShape& ls, bool distance_only_kernel, int max_voxels_per_lane = 2)
 {
     static const int forced = [] { const char* e = getenv("HU_VOXELS_PER_LANE"); return e ? atoi(e) : 0; }();
     const size_t lane_bytes = distance_only_kernel ? (size_t)t->n_point_slots * 16 + (size_t)t->n_result_slots * 4
                                                    : (size_t)t->n_slots * 16;
-    const int wanted = (forced == 1 || forced == 2) ? forced : ((lane_bytes * 2 * 256 <= 48 * 1024) ? 2 : 1);
+    const int by_rule = (forced == 1 || forced == 2) ? forced : ((lane_bytes * 2 * 256 <= 48 * 1024) ? 2 : 1);
+    const int wanted = by_rule < max_voxels_per_lane ? by_rule : max_voxels_per_lane;
     const Rec* prog = distance_only_kernel ? t->recs_do_dev : t->recs_dev;
     ls.prog = prog;
     ls.n4 = (uint32_t)(distance_only_kernel ? t->n_point_slots : t->n_slots);
@@ -210,6 +211,9 @@ int ensure_attrs()
     int rc;
     if ((rc = ensure_attrs_n<1>())) return rc;
     if ((rc = ensure_attrs_n<2>())) return rc;
+    if ((rc = allow_big_lds(k_ray_caster<InterpEval<false>>))) return rc;
+    if ((rc = allow_big_lds(k_bitmap<InterpEval<false>>))) return rc;
+    if ((rc = allow_big_lds(k_bitmap<InterpEval<true>>))) return rc;
     done_for_device = dev;
     return HU_OK;
 }
@@ -729,6 +733,67 @@ int hu_mass_integrals(const double* parents_dev, const uint32_t* sums_dev, uint3
     if (!out10_dev || ((!parents_dev || !sums_dev) && n_parents)) return fail(HU_ERR_BAD_ARG, "NULL argument");
     hipLaunchKernelGGL(k_mass_integrals, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const double4*)parents_dev,
                        sums_dev, n_parents, s, out10_dev);
+    HU_HIP(hipGetLastError());
+    return HU_OK;
+}
+
+int hu_ray_caster(hu_tape t, const float origin[4], const float forward[4], const float up[4], const float right[4],
+                  float pixel_tolerance, float box_radius, float min_distance, float max_distance, float floor_z,
+                  uint32_t render_options, uint32_t width, uint32_t height, void* out_dev, void* stream)
+{
+    if (!t || !origin || !forward || !up || !right || !out_dev) return fail(HU_ERR_BAD_ARG, "NULL argument");
+    if (width == 0 || height == 0) return fail(HU_ERR_BAD_ARG, "image must have at least one pixel");
+    if (render_options > 3u) return fail(HU_ERR_BAD_ARG, "unknown render option bits");
+    const uint64_t tiles = (uint64_t)((width + 7u) / 8u) * ((height + 7u) / 8u);
+    LaunchShape ls;
+    int rc;
+    if ((rc = launch_shape(t, ls, false, 1))) return rc;  // directions steer the march: full program
+    if ((rc = ensure_attrs())) return rc;
+    const uint32_t waves_per_block = ls.block / 64u;
+    const uint64_t blocks = (tiles + waves_per_block - 1) / waves_per_block;
+    if (blocks > 0x7fffffffull) return fail(HU_ERR_BAD_ARG, "image too large for one launch");
+    RayCasterArgs a;
+    a.origin = mk3(origin[0], origin[1], origin[2]);
+    a.forward = mk3(forward[0], forward[1], forward[2]);
+    a.up = mk3(up[0], up[1], up[2]);
+    a.right = mk3(right[0], right[1], right[2]);
+    a.pixel_tolerance = pixel_tolerance;
+    a.box_radius = box_radius;
+    a.min_distance = min_distance;
+    a.max_distance = max_distance;
+    a.floor_z = floor_z;
+    a.options = render_options;
+    a.w = width;
+    a.h = height;
+    a.out = static_cast<uint8_t*>(out_dev);
+    hipLaunchKernelGGL((k_ray_caster<InterpEval<false>>), dim3((uint32_t)blocks), dim3(ls.block), ls.lds, (hipStream_t)stream,
+                       (InterpEval<false>{ls.prog, t->extra_dev, ls.n4}), a);
+    HU_HIP(hipGetLastError());
+    return HU_OK;
+}
+
+int hu_bitmap(hu_tape t, const float origin[4], float step_size, uint32_t width, uint32_t height, void* out_dev,
+              void* stream)
+{
+    if (!t || !origin || !out_dev) return fail(HU_ERR_BAD_ARG, "NULL argument");
+    if (width == 0 || height == 0) return fail(HU_ERR_BAD_ARG, "image must have at least one pixel");
+    const uint64_t pixels = (uint64_t)width * height;
+    if (pixels > 0x7fffffffull) return fail(HU_ERR_BAD_ARG, "image too large for one launch");
+    const bool d_only = distance_only(t);
+    LaunchShape ls;
+    int rc;
+    if ((rc = launch_shape(t, ls, d_only, 1))) return rc;
+    if ((rc = ensure_attrs())) return rc;
+    const dim3 grid((uint32_t)((pixels + ls.block - 1) / ls.block)), block(ls.block);
+    uint8_t* out = static_cast<uint8_t*>(out_dev);
+    if (d_only)
+        hipLaunchKernelGGL((k_bitmap<InterpEval<true>>), grid, block, ls.lds, (hipStream_t)stream,
+                           (InterpEval<true>{ls.prog, t->extra_dev, ls.n4}), origin[0], origin[1], origin[2], step_size,
+                           width, height, out);
+    else
+        hipLaunchKernelGGL((k_bitmap<InterpEval<false>>), grid, block, ls.lds, (hipStream_t)stream,
+                           (InterpEval<false>{ls.prog, t->extra_dev, ls.n4}), origin[0], origin[1], origin[2], step_size,
+                           width, height, out);
     HU_HIP(hipGetLastError());
     return HU_OK;
 }

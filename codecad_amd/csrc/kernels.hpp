@@ -8,6 +8,8 @@
 //   k_grid_eval_blocks     the per-leaf-block launches of rendering/mesh.py:53-60, batched
 //   k_classify<MASS,BATCH> subdivision.cl:12-30 and mass_properties.cl:7-56, either one block
 //                          (reference-shaped) or every parent of a level in one launch
+//   k_ray_caster           rendering/ray_caster.cl:146-256 as a per-lane state machine
+//   k_bitmap               rendering/bitmap.cl:1-18
 #pragma once
 
 #include "interp.hpp"
@@ -298,6 +300,264 @@ __global__ void __launch_bounds__(256) k_classify(const E ev, const ClassifyArgs
             if (v) atomicAdd(&a.sums[(size_t)b * 10 + threadIdx.x], v);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// renderers (reference rendering/ray_caster.cl, rendering/bitmap.cl)
+// ------------------------------------------------------------------------------------------
+// Plain binary32 in the order written (no fma: the build has -ffp-contract=off), the same
+// expression trees as oracle/sdf_oracle.c, so pixels compare equal byte for byte.
+struct F3 { float x, y, z; };
+__host__ __device__ __forceinline__ F3 mk3(float x, float y, float z) { F3 r = {x, y, z}; return r; }
+__device__ __forceinline__ F3 add3(F3 a, F3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ F3 sub3(F3 a, F3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ F3 mul3(F3 a, float k) { return mk3(a.x * k, a.y * k, a.z * k); }
+__device__ __forceinline__ float dot3(F3 a, F3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ F3 normalize3(F3 a) { return mul3(a, 1.0f / sdf::sqrt_(dot3(a, a))); }
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return __builtin_fminf(__builtin_fmaxf(v, lo), hi); }
+__device__ __forceinline__ float mixf(float a, float b, float t) { return a + (b - a) * t; }
+__device__ __forceinline__ float smoothstepf(float e0, float e1, float x)
+{
+    const float t = clampf((x - e0) / (e1 - e0), 0.0f, 1.0f);
+    return (t * t) * (3.0f - 2.0f * t);
+}
+__device__ __forceinline__ void store_rgb(uint8_t* out, F3 c)
+{
+    out[0] = (uint8_t)clampf(c.x, 0.0f, 255.0f);
+    out[1] = (uint8_t)clampf(c.y, 0.0f, 255.0f);
+    out[2] = (uint8_t)clampf(c.z, 0.0f, 255.0f);
+}
+
+struct RayCasterArgs {
+    F3 origin, forward, up, right;
+    float pixel_tolerance, box_radius, min_distance, max_distance, floor_z;
+    uint32_t options, w, h;
+    uint8_t* out;  // uchar RGB, index (y + h*x)*3 (INDEX2_GG, cl_util/indexing.h:5,9)
+};
+
+constexpr float kOverRelaxation = 0.5f;            // ray_caster.cl:5-11
+constexpr uint32_t kPrimaryMaxSteps = 1000, kLightMaxSteps = 100, kAoSteps = 4;
+constexpr float kLightMinInfluence = 1.0f / 128.0f;
+constexpr uint32_t kFalseColor = 1u, kZebra = 2u;
+
+// ray_caster.cl:13-26
+__device__ __forceinline__ float over_relaxation_step(F3 direction, float4 e)
+{
+    const float over = kOverRelaxation * __builtin_fminf(1.0f, 1.0f + dot3(direction, mk3(e.x, e.y, e.z)));
+    return e.w * (1.0f + over);
+}
+// ray_caster.cl:28-40
+__device__ __forceinline__ void light_no_trace(F3 normal, F3 to_light, F3 to_camera, float& diffuse, float& specular)
+{
+    const F3 halfway = normalize3(add3(to_light, to_camera));
+    diffuse = __builtin_fmaxf(0.0f, dot3(normal, to_light));
+    float s = __builtin_fmaxf(0.0f, dot3(normal, halfway));
+    s *= s; s *= s; s *= s;
+    specular = s;
+}
+// ray_caster.cl:118-131
+__device__ __forceinline__ F3 map_color(float ambient, float diffuse, float specular)
+{
+    const float saturation = 0.75f * smoothstepf(0.0f, 0.25f, diffuse);
+    const float value = 0.1f + 0.8f * mixf(diffuse, ambient, 0.3f);
+    const float chroma = value * saturation;
+    const float X = chroma * 0.7f;
+    const float m = value - chroma;
+    const float sp = specular * 128.0f;
+    return mk3(255.0f * (X + m) + sp, 255.0f * (chroma + m) + sp, 255.0f * (0.0f + m) + sp);
+}
+// ray_caster.cl:133-144
+__device__ __forceinline__ F3 map_color_zebra(F3 point, float ambient, float diffuse, float specular)
+{
+    const int white = ((int)__builtin_floorf(point.y)) & 1;
+    float color = 50.0f + 150.0f * (float)white;
+    color *= ambient + diffuse;
+    color += 128.0f * specular;
+    return mk3(color, color, color);
+}
+
+// One pixel per lane, 8x8 pixels per wavefront.  The reference kernel calls evaluate() from five
+// places (primary march, false-colour residual, ambient occlusion, shadow march, floor shadow);
+// here a pixel is a small state machine and the wavefront loops over ONE evaluate() site until
+// every lane is done: lanes in different phases share each pass through the tape, the
+// interpreter is instantiated once, and a pixel still sees exactly the reference's sequence of
+// evaluations (pixels are independent).
+template <class E> __global__ void __launch_bounds__(256) k_ray_caster(const E ev, const RayCasterArgs a)
+{
+    extern __shared__ float4 lds[];
+    enum Phase : uint32_t { PRIMARY, RESIDUAL, AO, LIGHT, FLOOR, DONE };
+    const uint32_t tiles_y = (a.h + 7u) >> 3;
+    const uint32_t tile = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    const uint32_t px = (tile / tiles_y) * 8u + (lane >> 3), py = (tile % tiles_y) * 8u + (lane & 7u);
+    const bool in_image = px < a.w && py < a.h;
+
+    const float filmx = (float)px - (float)(a.w - 1u) / 2.0f;
+    const float filmy = (float)py - (float)(a.h - 1u) / 2.0f;
+    const F3 direction = normalize3(sub3(add3(a.forward, mul3(a.right, filmx)), mul3(a.up, filmy)));
+    const F3 to_camera = mul3(direction, -1.0f);
+    const F3 to_light = mul3(normalize3(mk3(1.0f, 2.0f, -1.0f)), -1.0f);
+    const F3 to_light2 = mul3(normalize3(mk3(-1.0f, 1.0f, 0.0f)), -1.0f);
+    const bool false_color = (a.options & kFalseColor) != 0u;
+
+    uint32_t phase = in_image ? PRIMARY : DONE;
+    // primary march
+    float distance = a.min_distance, fallback = a.min_distance;
+    float4 pe = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // last primary evaluation
+    uint32_t step = 0;
+    bool hit = false;
+    // after the march
+    F3 point = mk3(0, 0, 0), normal = mk3(0, 0, 0), color = mk3(0, 0, 0);
+    float local_eps = 0.0f, residual = 0.0f, ambient = 0.0f;
+    // ambient occlusion
+    float occlusion = 0.0f, ao_scale = 1.0f, ao_distance = 0.0f;
+    uint32_t ao_i = 0;
+    // shadow march
+    float d0 = 0.0f, s0 = 0.0f, threshold = 0.0f, visibility = 1.0f, ldistance = 0.0f, lfallback = 0.0f;
+    uint32_t lstep = 0;
+    float floor_distance = 0.0f;
+
+    while (sdf::any_lane(phase != DONE)) {
+        F3 p = mk3(0.0f, 0.0f, 0.0f);
+        switch (phase) {
+        case PRIMARY: p = add3(a.origin, mul3(direction, distance)); break;
+        case RESIDUAL: p = point; break;
+        case AO: p = add3(point, mul3(normal, ao_distance)); break;
+        case LIGHT: p = add3(point, mul3(to_light, ldistance)); break;
+        case FLOOR: p = add3(a.origin, mul3(direction, floor_distance)); break;
+        default: break;
+        }
+        const float4 e = sdf::voxel(ev(p.x, p.y, p.z, lds), 0);
+
+        // 0 = stay in the phase; otherwise the transition this evaluation triggers
+        enum Next : uint32_t { STAY, END_PRIMARY, BEGIN_LIGHT, END_LIGHT, BEGIN_FLOOR, WRITE };
+        uint32_t next = STAY;
+        float diffuse = 0.0f, specular = 0.0f;  // result of the shadow march (END_LIGHT)
+
+        if (phase == PRIMARY) {  // ray_caster.cl:168-196
+            pe = e;
+            if (distance - fallback > e.w) {
+                distance = fallback;
+                if (++step == kPrimaryMaxSteps) next = END_PRIMARY;
+            } else {
+                hit = e.w < a.pixel_tolerance * distance;
+                if (hit) {
+                    distance += e.w * clampf(1.0f / dot3(mk3(e.x, e.y, e.z), to_camera), 0.0f, 2.0f);
+                    next = END_PRIMARY;
+                } else {
+                    fallback = distance + e.w;
+                    distance = distance + over_relaxation_step(direction, e);
+                    if (distance > a.max_distance) {
+                        distance = __builtin_inff();
+                        next = END_PRIMARY;
+                    } else if (++step == kPrimaryMaxSteps) {
+                        next = END_PRIMARY;
+                    }
+                }
+            }
+        } else if (phase == RESIDUAL) {
+            residual = sdf::abs_(e.w);
+            next = BEGIN_LIGHT;
+        } else if (phase == AO) {  // ray_caster.cl:100-116
+            occlusion += ao_scale * (ao_distance - e.w);
+            ao_scale /= 2.0f;
+            ao_distance += a.box_radius / 100.0f;
+            if (++ao_i == kAoSteps) {
+                ambient = clampf(1.0f - (occlusion * 0.5f) / (1.0f - ao_scale), 0.0f, 1.0f);
+                next = BEGIN_LIGHT;
+            }
+        } else if (phase == LIGHT) {  // ray_caster.cl:56-88
+            visibility = __builtin_fminf(visibility, e.w / ldistance);
+            bool finished = visibility < threshold;
+            if (!finished) {
+                if (ldistance - lfallback > e.w) {
+                    ldistance = lfallback;
+                    finished = ++lstep == kLightMaxSteps;
+                } else {
+                    lfallback = ldistance + e.w;
+                    ldistance = ldistance + over_relaxation_step(to_light, e);
+                    finished = ldistance > a.max_distance || ++lstep == kLightMaxSteps;
+                }
+            }
+            if (finished) {
+                diffuse = false_color ? (float)lstep : visibility * d0;
+                specular = false_color ? 0.0f : visibility * s0;
+                next = END_LIGHT;
+            }
+        } else if (phase == FLOOR) {  // ray_caster.cl:238-250
+            float shadow = clampf((2.0f * e.w) / a.box_radius, 0.0f, 1.0f);
+            shadow = 1.0f - shadow;
+            shadow *= shadow;
+            shadow = 1.0f - shadow;
+            const float k = 0.4f + 0.6f * shadow;
+            color = mk3(mixf(0.0f, color.x, k), mixf(0.0f, color.y, k), mixf(0.0f, color.z, k));
+            next = WRITE;
+        }
+
+        if (next == END_PRIMARY) {  // ray_caster.cl:198-236
+            local_eps = __builtin_fmaxf(1e-4f, 2.0f * sdf::abs_(pe.w));
+            point = add3(a.origin, mul3(direction, distance));
+            normal = mk3(pe.x, pe.y, pe.z);
+            if (false_color) {
+                if (hit) phase = RESIDUAL;
+                else next = BEGIN_LIGHT;
+            } else if (hit) {
+                ao_distance = a.box_radius / 100.0f;
+                phase = AO;
+            } else {
+                color = mk3(230.0f, 230.0f, 241.0f);
+                next = BEGIN_FLOOR;
+            }
+        }
+        if (next == BEGIN_LIGHT) {  // ray_caster.cl:42-55
+            light_no_trace(normal, to_light, to_camera, d0, s0);
+            if (d0 <= 0.0f && s0 <= 0.0f) {
+                next = END_LIGHT;  // diffuse = specular = 0
+            } else {
+                threshold = kLightMinInfluence / __builtin_fmaxf(d0, s0);
+                ldistance = lfallback = local_eps;
+                phase = LIGHT;
+            }
+        }
+        if (next == END_LIGHT) {
+            if (false_color) {
+                float steps = (float)step;
+                steps += diffuse;
+                steps += (float)kAoSteps;
+                color = mk3(steps, 1000.0f * residual, 0.0f);
+            } else {
+                float d2, s2;
+                light_no_trace(normal, to_light2, to_camera, d2, s2);
+                const float d = 0.8f * diffuse + 0.2f * d2;
+                const float s = 0.8f * specular + 0.2f * s2;
+                color = (a.options & kZebra) ? map_color_zebra(point, ambient, d, s) : map_color(ambient, d, s);
+            }
+            next = BEGIN_FLOOR;
+        }
+        if (next == BEGIN_FLOOR) {
+            floor_distance = (a.floor_z - a.origin.z) / direction.z;
+            if (floor_distance > 0.0f && floor_distance < distance) phase = FLOOR;
+            else next = WRITE;
+        }
+        if (next == WRITE) {
+            store_rgb(a.out + ((size_t)py + (size_t)a.h * px) * 3, color);
+            phase = DONE;
+        }
+    }
+}
+
+// bitmap.cl:1-18: one pixel per lane, y fastest like the output
+template <class E>
+__global__ void __launch_bounds__(256)
+k_bitmap(const E ev, float ox, float oy, float oz, float step_size, uint32_t w, uint32_t h, uint8_t* __restrict__ out)
+{
+    extern __shared__ float4 lds[];
+    const uint32_t lin = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = lin < w * h;
+    const uint32_t x = active ? lin / h : 0u, y = active ? lin % h : 0u;
+    const float v = ev(ox + step_size * (float)x, oy + step_size * (float)(h - y - 1u), oz + step_size * 0.0f, lds).w;
+    if (!active) return;
+    const float t = (v < 0.0f) ? 0.0f : 1.0f;  // step(0, v)
+    store_rgb(out + (size_t)lin * 3, mk3(mixf(125.0f, 230.0f, t), mixf(179.0f, 230.0f, t), mixf(0.0f, 241.0f, t)));
 }
 
 }  // namespace sdfk

@@ -49,6 +49,8 @@ PROTOTYPES = {
     "hu_subdivision_level": [_vp, _vp, _u32, _c.c_int32, _u3, _i, _d, _d3, _f, _f, _vp, _vp, _u32, _vp],
     "hu_mass_properties_level": [_vp, _vp, _u32, _d, _u3, _f, _f, _vp, _vp, _vp, _u32, _vp],
     "hu_mass_integrals": [_vp, _vp, _u32, _d, _vp, _vp],
+    "hu_ray_caster": [_vp, _f4, _f4, _f4, _f4, _f, _f, _f, _f, _f, _u32, _u32, _u32, _vp, _vp],
+    "hu_bitmap": [_vp, _f4, _f, _u32, _u32, _vp, _vp],
     "hu_tape_specialize": [_vp, _c.c_char_p],
     "hu_tape_specialized": [_vp, _c.POINTER(_i)],
 }

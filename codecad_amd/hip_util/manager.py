@@ -179,6 +179,22 @@ class _Kernels:
             _ptr(shape), c.ctypes.data_as(_lib._f4), float(box_step), float(distance_threshold), d,
             _ptr(sums), _ptr(intersecting_counter), _ptr(list_buffer), s), "hu_mass_properties"))
 
+    def ray_caster(self, global_size, local_size, scene, origin, forward, up, right, pixel_tolerance, box_radius,
+                   min_distance, max_distance, floor_z, render_options, output, wait_for=None, queue=None):
+        """rendering/ray_caster.cl:146-159; global_size = (width, height)."""
+        v = [_float4(x) for x in (origin, forward, up, right)]
+        return self._launch(wait_for, queue, lambda s: check(self._m.lib.hu_ray_caster(
+            _ptr(scene), *[x.ctypes.data_as(_lib._f4) for x in v], float(pixel_tolerance), float(box_radius),
+            float(min_distance), float(max_distance), float(floor_z), int(render_options), int(global_size[0]),
+            int(global_size[1]), _ptr(output), s), "hu_ray_caster"))
+
+    def bitmap(self, global_size, local_size, scene, origin, step_size, output, wait_for=None, queue=None):
+        """rendering/bitmap.cl:1-4; global_size = (width, height)."""
+        o = _float4(origin)
+        return self._launch(wait_for, queue, lambda s: check(self._m.lib.hu_bitmap(
+            _ptr(scene), o.ctypes.data_as(_lib._f4), float(step_size), int(global_size[0]), int(global_size[1]),
+            _ptr(output), s), "hu_bitmap"))
+
 
 class HipManager:
     """Lazy singleton: `.lib`, `.device`, `.queue`, `.k`, `.device_name`."""

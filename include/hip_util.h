@@ -136,6 +136,21 @@ int hu_mass_properties_level(hu_tape t, const double* parents_dev, uint32_t n_pa
 int hu_mass_integrals(const double* parents_dev, const uint32_t* sums_dev, uint32_t n_parents, double s,
                       double* out10_dev, void* stream);
 
+/* ---- renderers on the same evaluate() -------------------- */
+/* rendering/ray_caster.cl:146-159, launched by rendering/ray_caster.py:93-110 with global size
+ * (width, height).  origin/forward/up/right: float4 as the reference passes them (forward already
+ * scaled by the focal length; 4th component ignored).  render_options: bit0 false colour, bit1
+ * zebra (ray_caster.cl:9-10).  out_dev: uchar[width*height*3], pixel (x, y) at (y + height*x)*3.
+ * Tapes specialised with hu_tape_specialize still render through the interpreter. */
+int hu_ray_caster(hu_tape t, const float origin[4], const float forward[4], const float up[4],
+                  const float right[4], float pixel_tolerance, float box_radius, float min_distance,
+                  float max_distance, float floor_z, uint32_t render_options, uint32_t width,
+                  uint32_t height, void* out_dev, void* stream);
+/* rendering/bitmap.cl:1-4, launched by rendering/bitmap.py:22-26: inside/outside picture of a 2D
+ * shape, sample (x, y) at origin + step_size*(x, height-y-1).  out_dev as above. */
+int hu_bitmap(hu_tape t, const float origin[4], float step_size, uint32_t width, uint32_t height,
+              void* out_dev, void* stream);
+
 /* Per-tape specialisation (the reference's generate_fixed_eval_source_code, nodes/codegen.py:137-204):
  * unroll the decoded program into straight-line gfx950 code with hipRTC, using the op library
  * headers found in `include_dir` (codecad_amd/csrc).  Afterwards every launch with this tape runs

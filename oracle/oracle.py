@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
 _lib = None
 
-__all__ = ["build", "lib", "evaluate_points", "grid_eval", "grid_eval_pymcubes",
+__all__ = ["build", "lib", "evaluate_points", "grid_eval", "grid_eval_pymcubes", "ray_caster", "bitmap",
            "subdivision_step", "mass_properties", "det_math"]
 
 _f32p = ctypes.POINTER(ctypes.c_float)
@@ -141,3 +141,32 @@ def det_math(op, a, b=None):
                                  b.ctypes.data_as(_f32p), ctypes.c_int(a.size),
                                  out.ctypes.data_as(_f32p), out2.ctypes.data_as(_f32p)), "det_math")
     return (out, out2) if op == "sincos" else out
+
+
+def ray_caster(tape, origin, forward, up, right, pixel_tolerance, box_radius, min_distance, max_distance, floor_z,
+               options, size, threads=1):
+    """Reference kernel ray_caster (rendering/ray_caster.cl:146-256): uchar RGB in the kernel's
+    layout (w, h, 3) with index (y + h*x)*3."""
+    t, tp, tn = _tape(tape)
+    w, h = int(size[0]), int(size[1])
+    out = np.zeros((w, h, 3), dtype=np.uint8)
+    vec = [np.ascontiguousarray(np.asarray(v, dtype=np.float64)[:3], dtype=np.float32) for v in (origin, forward, up, right)]
+    lib().oracle_ray_caster.restype = ctypes.c_int
+    _check(lib().oracle_ray_caster(tp, tn, *[v.ctypes.data_as(_f32p) for v in vec], ctypes.c_float(pixel_tolerance),
+                                   ctypes.c_float(box_radius), ctypes.c_float(min_distance),
+                                   ctypes.c_float(max_distance), ctypes.c_float(floor_z), ctypes.c_uint32(int(options)),
+                                   ctypes.c_uint32(w), ctypes.c_uint32(h), out.ctypes.data_as(_u8p),
+                                   ctypes.c_int(threads)), "ray_caster")
+    return out
+
+
+def bitmap(tape, origin, step_size, size):
+    """Reference kernel bitmap (rendering/bitmap.cl:1-18), layout as ray_caster."""
+    t, tp, tn = _tape(tape)
+    w, h = int(size[0]), int(size[1])
+    out = np.zeros((w, h, 3), dtype=np.uint8)
+    o = np.ascontiguousarray(np.asarray(origin, dtype=np.float64)[:3], dtype=np.float32)
+    lib().oracle_bitmap.restype = ctypes.c_int
+    _check(lib().oracle_bitmap(tp, tn, o.ctypes.data_as(_f32p), ctypes.c_float(step_size), ctypes.c_uint32(w),
+                               ctypes.c_uint32(h), out.ctypes.data_as(_u8p)), "bitmap")
+    return out

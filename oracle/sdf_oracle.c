@@ -556,3 +556,231 @@ int oracle_det_math(int op, const float *a, const float *b, int n, float *out, f
     }
     return 0;
 }
+
+/* ====================================================================================
+ * Renderers on top of evaluate() -- SURVEY.md section 8(f) rank 3 (ray caster) and the 2D
+ * bitmap renderer.  Restated from reference rendering/ray_caster.cl:1-256 and
+ * rendering/bitmap.cl:1-18.  Pinned by the reference's own 32 baseline images
+ * (reference tests/baseline/rendered_*.png, tests/test_image.py:16-27, MSE <= 1e-3), which were
+ * produced by the reference itself: tests/test_render_baselines.py.
+ * Output: uchar RGB, index (y + h*x)*3 = INDEX2_GG*3 (cl_util/indexing.h:5,9).
+ * Arithmetic: plain IEEE binary32 in the order written (no fma except inside evaluate()).
+ * ================================================================================== */
+typedef struct { float x, y, z; } f3;
+static inline f3 mk3(float x, float y, float z) { f3 r = { x, y, z }; return r; }
+static inline f3 add3(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline f3 sub3(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline f3 mul3(f3 a, float k) { return mk3(a.x * k, a.y * k, a.z * k); }
+static inline float dot3f(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+static inline f3 normalize3(f3 a) { float inv = 1.0f / sqrtf(dot3f(a, a)); return mul3(a, inv); }
+static inline float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+static inline float mixf(float a, float b, float t) { return a + (b - a) * t; }
+static inline float smoothstepf(float e0, float e1, float x)
+{
+    float t = clampf((x - e0) / (e1 - e0), 0.0f, 1.0f);
+    return (t * t) * (3.0f - 2.0f * t);
+}
+
+#define RC_OVER_RELAXATION 0.5f
+#define RC_PRIMARY_MAX_STEPS 1000
+#define RC_LIGHT_MAX_STEPS 100
+#define RC_AO_STEPS 4
+#define RC_LIGHT_MIN_INFLUENCE (1.0f / 128.0f)
+#define RC_FALSE_COLOR 1u
+#define RC_ZEBRA 2u
+
+typedef struct { const float *tape, *end; } scene_t;
+
+static inline f4 scene_eval(const scene_t *s, f3 p)
+{
+    f4 r = mk4(0, 0, 0, 0);
+    evaluate(s->tape, s->end, mk4(p.x, p.y, p.z, 0), &r);
+    return r;
+}
+
+/* ray_caster.cl:13-26 */
+static inline float over_relaxation_step(f3 direction, f4 e)
+{
+    float over = RC_OVER_RELAXATION * fminf(1.0f, 1.0f + dot3f(direction, mk3(e.x, e.y, e.z)));
+    return e.w * (1.0f + over);
+}
+
+/* ray_caster.cl:28-40: (diffuse, specular) */
+static inline void light_no_trace(f3 normal, f3 to_light, f3 to_camera, float *diffuse, float *specular)
+{
+    f3 halfway = normalize3(add3(to_light, to_camera));
+    float d = fmaxf(0.0f, dot3f(normal, to_light));
+    float s = fmaxf(0.0f, dot3f(normal, halfway));
+    s *= s; s *= s; s *= s;
+    *diffuse = d; *specular = s;
+}
+
+/* ray_caster.cl:42-98 */
+static inline void light_contribution(const scene_t *sc, f3 point, f3 normal, f3 to_light, f3 to_camera,
+                                      float min_distance, float max_distance, uint32_t options,
+                                      float *diffuse, float *specular)
+{
+    float d0, s0;
+    light_no_trace(normal, to_light, to_camera, &d0, &s0);
+    if (d0 <= 0.0f && s0 <= 0.0f) { *diffuse = 0.0f; *specular = 0.0f; return; }
+    float threshold = RC_LIGHT_MIN_INFLUENCE / fmaxf(d0, s0);
+    float visibility = 1.0f;
+    float distance = min_distance, fallback = distance;
+    uint32_t step;
+    for (step = 0; step < RC_LIGHT_MAX_STEPS; ++step) {
+        f4 e = scene_eval(sc, add3(point, mul3(to_light, distance)));
+        visibility = fminf(visibility, e.w / distance);
+        if (visibility < threshold) break;
+        if (distance - fallback > e.w) { distance = fallback; continue; }
+        fallback = distance + e.w;
+        distance = distance + over_relaxation_step(to_light, e);
+        if (distance > max_distance) break;
+    }
+    if (options & RC_FALSE_COLOR) { *diffuse = (float)step; *specular = 0.0f; }
+    else { *diffuse = visibility * d0; *specular = visibility * s0; }
+}
+
+/* ray_caster.cl:100-116 */
+static inline float ambient_occlusion(const scene_t *sc, f3 point, f3 normal, float distance_step)
+{
+    float occlusion = 0.0f, scale = 1.0f, distance = distance_step;
+    for (uint32_t i = 0; i < RC_AO_STEPS; ++i) {
+        f4 e = scene_eval(sc, add3(point, mul3(normal, distance)));
+        occlusion += scale * (distance - e.w);
+        scale /= 2.0f;
+        distance += distance_step;
+    }
+    return clampf(1.0f - (occlusion * 0.5f) / (1.0f - scale), 0.0f, 1.0f);
+}
+
+/* ray_caster.cl:118-131 */
+static inline f3 map_color(float ambient, float diffuse, float specular)
+{
+    float saturation = 0.75f * smoothstepf(0.0f, 0.25f, diffuse);
+    float value = 0.1f + 0.8f * mixf(diffuse, ambient, 0.3f);
+    float chroma = value * saturation;
+    float X = chroma * 0.7f;
+    float m = value - chroma;
+    f3 color = mk3(255.0f * (X + m), 255.0f * (chroma + m), 255.0f * (0.0f + m));
+    float sp = specular * 128.0f;
+    return mk3(color.x + sp, color.y + sp, color.z + sp);
+}
+
+/* ray_caster.cl:133-144 */
+static inline f3 map_color_zebra(f3 point, float ambient, float diffuse, float specular)
+{
+    int white = ((int)floorf(point.y)) & 1;
+    float color = 50.0f + 150.0f * (float)white;
+    color *= ambient + diffuse;
+    color += 128.0f * specular;
+    return mk3(color, color, color);
+}
+
+/* ray_caster.cl:146-256, one pixel */
+static void ray_caster_pixel(const scene_t *sc, uint32_t x, uint32_t y, uint32_t w, uint32_t h, f3 origin,
+                             f3 forward, f3 up, f3 right, float pixel_tolerance, float box_radius,
+                             float min_distance, float max_distance, float floor_z, uint32_t options,
+                             uint8_t *out)
+{
+    float filmx = (float)x - (float)(w - 1) / 2.0f;
+    float filmy = (float)y - (float)(h - 1) / 2.0f;
+    f3 direction = normalize3(sub3(add3(forward, mul3(right, filmx)), mul3(up, filmy)));
+    const f3 light_dir = normalize3(mk3(1, 2, -1));
+    const f3 light2_dir = normalize3(mk3(-1, 1, 0));
+
+    float distance = min_distance, fallback = min_distance;
+    f4 e = mk4(0, 0, 0, 0);
+    int hit = 0;
+    uint32_t step;
+    for (step = 0; step < RC_PRIMARY_MAX_STEPS; ++step) {
+        e = scene_eval(sc, add3(origin, mul3(direction, distance)));
+        if (distance - fallback > e.w) { distance = fallback; continue; }
+        hit = e.w < pixel_tolerance * distance;
+        if (hit) {
+            f3 n = mk3(e.x, e.y, e.z);
+            distance += e.w * clampf(1.0f / dot3f(n, mul3(direction, -1.0f)), 0.0f, 2.0f);
+            break;
+        }
+        fallback = distance + e.w;
+        distance = distance + over_relaxation_step(direction, e);
+        if (distance > max_distance) { distance = INFINITY; break; }
+    }
+
+    f3 color;
+    float local_eps = fmaxf(1e-4f, 2.0f * fabsf(e.w));
+    f3 to_camera = mul3(direction, -1.0f);
+    if (options & RC_FALSE_COLOR) {
+        f3 point = add3(origin, mul3(direction, distance));
+        f3 normal = mk3(e.x, e.y, e.z);
+        float residual = hit ? fabsf(scene_eval(sc, point).w) : 0.0f;
+        float steps = (float)step, d, s;
+        light_contribution(sc, point, normal, mul3(light_dir, -1.0f), to_camera, local_eps, max_distance, options, &d, &s);
+        steps += d;
+        steps += (float)RC_AO_STEPS;
+        color = mk3(steps, 1000.0f * residual, 0.0f);
+    } else if (hit) {
+        f3 point = add3(origin, mul3(direction, distance));
+        f3 normal = mk3(e.x, e.y, e.z);
+        float ambient = ambient_occlusion(sc, point, normal, box_radius / 100.0f);
+        float d, s, d2, s2;
+        light_contribution(sc, point, normal, mul3(light_dir, -1.0f), to_camera, local_eps, max_distance, options, &d, &s);
+        light_no_trace(normal, mul3(light2_dir, -1.0f), to_camera, &d2, &s2);
+        d = 0.8f * d + 0.2f * d2;
+        s = 0.8f * s + 0.2f * s2;
+        color = (options & RC_ZEBRA) ? map_color_zebra(point, ambient, d, s) : map_color(ambient, d, s);
+    } else {
+        color = mk3(230, 230, 241);
+    }
+
+    float floor_distance = (floor_z - origin.z) / direction.z;
+    if (floor_distance > 0.0f && floor_distance < distance) {
+        f3 floor_point = add3(origin, mul3(direction, floor_distance));
+        float fd = scene_eval(sc, floor_point).w;
+        float shadow = clampf((2.0f * fd) / box_radius, 0.0f, 1.0f);
+        shadow = 1.0f - shadow;
+        shadow *= shadow;
+        shadow = 1.0f - shadow;
+        float k = 0.4f + 0.6f * shadow;
+        color = mk3(mixf(0.0f, color.x, k), mixf(0.0f, color.y, k), mixf(0.0f, color.z, k));
+    }
+    out[0] = (uint8_t)clampf(color.x, 0.0f, 255.0f);
+    out[1] = (uint8_t)clampf(color.y, 0.0f, 255.0f);
+    out[2] = (uint8_t)clampf(color.z, 0.0f, 255.0f);
+}
+
+int oracle_ray_caster(const float *tape, int n_tape, const float *origin, const float *forward, const float *up,
+                      const float *right, float pixel_tolerance, float box_radius, float min_distance,
+                      float max_distance, float floor_z, uint32_t options, uint32_t w, uint32_t h, uint8_t *out,
+                      int threads)
+{
+    scene_t sc = { tape, tape + n_tape };
+    f4 probe;
+    if (evaluate(tape, tape + n_tape, mk4(0, 0, 0, 0), &probe)) return -1;
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(dynamic, 4)
+    for (uint32_t x = 0; x < w; ++x)
+        for (uint32_t y = 0; y < h; ++y)
+            ray_caster_pixel(&sc, x, y, w, h, mk3(origin[0], origin[1], origin[2]), mk3(forward[0], forward[1], forward[2]),
+                             mk3(up[0], up[1], up[2]), mk3(right[0], right[1], right[2]), pixel_tolerance, box_radius,
+                             min_distance, max_distance, floor_z, options, out + ((size_t)y + (size_t)h * x) * 3);
+    return 0;
+}
+
+/* rendering/bitmap.cl:1-18 */
+int oracle_bitmap(const float *tape, int n_tape, const float *origin, float step_size, uint32_t w, uint32_t h,
+                  uint8_t *out)
+{
+    scene_t sc = { tape, tape + n_tape };
+    f4 probe;
+    if (evaluate(tape, tape + n_tape, mk4(0, 0, 0, 0), &probe)) return -1;
+    for (uint32_t x = 0; x < w; ++x)
+        for (uint32_t y = 0; y < h; ++y) {
+            f3 p = mk3(origin[0] + step_size * (float)x, origin[1] + step_size * (float)(h - y - 1), origin[2] + step_size * 0.0f);
+            float v = scene_eval(&sc, p).w;
+            float t = (v < 0.0f) ? 0.0f : 1.0f; /* step(0, v) */
+            uint8_t *o = out + ((size_t)y + (size_t)h * x) * 3;
+            o[0] = (uint8_t)clampf(mixf(125.0f, 230.0f, t), 0.0f, 255.0f);
+            o[1] = (uint8_t)clampf(mixf(179.0f, 230.0f, t), 0.0f, 255.0f);
+            o[2] = (uint8_t)clampf(mixf(0.0f, 241.0f, t), 0.0f, 255.0f);
+        }
+    return 0;
+}

@@ -1,0 +1,95 @@
+"""The renderers against the reference's OWN output: its 32 baseline images
+(tests/golden/baseline/, copied from reference tests/baseline/; compared like reference
+tests/tools.py:64-79, mean squared error <= 1e-3 on a 0..1 scale at 1024x768).
+
+On the CPU this runs the ORACLE's ray caster / bitmap on our tapes -- the one place where the
+oracle (and through it evaluate(), every op, the shape library and the tape compiler) is checked
+against pixels the reference itself produced.  On the GPU the HIP renderers are checked against the
+oracle (exactly) and against the same baselines."""
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+import oracle
+import shapes_zoo
+from codecad_amd import nodes
+from codecad_amd.rendering import ray_caster, bitmap
+from conftest import ROOT
+
+SIZE = (1024, 768)
+BASELINE = os.path.join(ROOT, "tests", "golden", "baseline")
+ALL = sorted(shapes_zoo.shapes_2d) + sorted(shapes_zoo.shapes_3d)
+CPU_SUBSET = ALL
+
+
+def baseline(name):
+    return np.asarray(Image.open(os.path.join(BASELINE, "rendered_%s.png" % name)).convert("RGB"), dtype=np.float32) / 255
+
+
+def mse(pixels, name):
+    ref = baseline(name)
+    assert pixels.shape == ref.shape
+    err = pixels.astype(np.float32) / 255 - ref
+    return float(np.mean(err * err))
+
+
+def oracle_render(name, size=SIZE, threads=None):
+    shape = {**shapes_zoo.shapes_2d, **shapes_zoo.shapes_3d}[name]
+    tape = nodes.make_program(shape)
+    if shape.dimension() == 2:
+        origin, step = bitmap.kernel_arguments(shape, size)
+        out = oracle.bitmap(tape, list(origin), np.float32(step), size)
+    else:
+        cam = ray_caster.get_camera_params(shape.bounding_box(), size, None)
+        a = ray_caster.kernel_arguments(shape, *cam)
+        out = oracle.ray_caster(tape, list(a["origin"]), list(a["forward"]), list(a["up"]), list(a["right"]),
+                                np.float32(a["pixel_tolerance"]), np.float32(a["box_radius"]),
+                                np.float32(a["min_distance"]), np.float32(a["max_distance"]), np.float32(a["floor_z"]),
+                                0, size, threads=threads or min(8, os.cpu_count() or 1))
+    return out.transpose((1, 0, 2))
+
+
+def test_all_baselines_present():
+    assert sorted(f[len("rendered_"):-4] for f in os.listdir(BASELINE) if f.endswith(".png")) == sorted(ALL)
+
+
+@pytest.mark.parametrize("name", CPU_SUBSET)
+def test_oracle_render_matches_reference_baseline(name):
+    assert mse(oracle_render(name), name) <= 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ALL)
+def test_hip_render_matches_oracle_and_baseline(hip, name):
+    from codecad_amd.rendering import image
+    shape = {**shapes_zoo.shapes_2d, **shapes_zoo.shapes_3d}[name]
+    pixels = image.render_pixels(shape, SIZE)
+    assert pixels.shape == (SIZE[1], SIZE[0], 3) and pixels.dtype == np.uint8
+    assert mse(pixels, name) <= 1e-3
+    small = (160, 120)
+    got = image.render_pixels(shape, small)
+    want = oracle_render(name, small, threads=16)
+    differing = np.count_nonzero(np.any(got != want, axis=-1))
+    assert differing == 0, "%d of %d pixels differ from the oracle" % (differing, small[0] * small[1])
+
+
+@pytest.mark.gpu
+def test_render_options(hip):
+    from codecad_amd import shapes
+    s = shapes.sphere(2) + shapes.box(1.5).translated_x(1)
+    cam = ray_caster.get_camera_params(s.bounding_box(), (96, 64), 40)
+    plain = ray_caster.render(s, *cam, size=(96, 64))
+    zebra = ray_caster.render(s, *cam, size=(96, 64), options=ray_caster.RenderOptions.zebra)
+    false_color = ray_caster.render(s, *cam, size=(96, 64), options=ray_caster.RenderOptions.false_color)
+    assert plain.shape == zebra.shape == false_color.shape == (64, 96, 3)
+    assert np.any(plain != zebra) and np.all(false_color[..., 2] == 0) and false_color[..., 0].max() > 4
+    a = ray_caster.kernel_arguments(s, *cam)
+    tape = nodes.make_program(s)
+    for opt, got in ((2, zebra), (1, false_color)):
+        want = oracle.ray_caster(tape, list(a["origin"]), list(a["forward"]), list(a["up"]), list(a["right"]),
+                                 np.float32(a["pixel_tolerance"]), np.float32(a["box_radius"]),
+                                 np.float32(a["min_distance"]), np.float32(a["max_distance"]), np.float32(a["floor_z"]),
+                                 opt, (96, 64), threads=8).transpose((1, 0, 2))
+        assert np.array_equal(got, want)
