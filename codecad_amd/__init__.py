@@ -18,6 +18,7 @@ from . import grid_eval  # noqa: F401
 from . import subdivision  # noqa: F401
 from .mass_properties import mass_properties, MassProperties  # noqa: F401
 from . import examples  # noqa: F401
+from . import rendering  # noqa: F401
 
 __all__ = ["util", "nodes", "shapes", "hip_util", "grid_eval", "subdivision", "mass_properties",
            "MassProperties", "examples"]
