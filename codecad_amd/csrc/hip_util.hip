@@ -279,6 +279,12 @@ std::string generate_source(const hu_tape_s* t)
 
 struct SpecEval { const float* extra; };  // same layout as the generated sdfk::JitEval
 
+const char* const kSpecKernelNames[8] = {
+    "sdfk::k_grid_eval<sdfk::JitEval, 0, 2>",           "sdfk::k_grid_eval<sdfk::JitEval, 1, 2>",
+    "sdfk::k_grid_eval_blocks<sdfk::JitEval, 0, 2>",    "sdfk::k_grid_eval_blocks<sdfk::JitEval, 1, 2>",
+    "sdfk::k_classify<sdfk::JitEval, false, false, 2>", "sdfk::k_classify<sdfk::JitEval, false, true, 2>",
+    "sdfk::k_classify<sdfk::JitEval, true, false, 2>",  "sdfk::k_classify<sdfk::JitEval, true, true, 2>"};
+
 }  // namespace
 
 extern "C" {
@@ -798,24 +804,24 @@ int hu_bitmap(hu_tape t, const float origin[4], float step_size, uint32_t width,
     return HU_OK;
 }
 
-int hu_tape_specialize(hu_tape t, const char* include_dir)
+// Compile `src` with hipRTC (needs no device).  On success *out holds the program, which the
+// caller destroys.
+static int compile_specialised(const std::string& src, const char* include_dir, hiprtcProgram* out)
 {
-    if (!t || !include_dir) return fail(HU_ERR_BAD_ARG, "NULL argument");
-    if (t->spec) return HU_OK;
-    const std::string src = generate_source(t);
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "tape_specialised.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
         return fail(HU_ERR_UNSUPPORTED, "hiprtcCreateProgram failed");
-    static const char* const names[8] = {
-        "sdfk::k_grid_eval<sdfk::JitEval, 0, 2>",          "sdfk::k_grid_eval<sdfk::JitEval, 1, 2>",
-        "sdfk::k_grid_eval_blocks<sdfk::JitEval, 0, 2>",   "sdfk::k_grid_eval_blocks<sdfk::JitEval, 1, 2>",
-        "sdfk::k_classify<sdfk::JitEval, false, false, 2>", "sdfk::k_classify<sdfk::JitEval, false, true, 2>",
-        "sdfk::k_classify<sdfk::JitEval, true, false, 2>",  "sdfk::k_classify<sdfk::JitEval, true, true, 2>"};
-    for (const char* n : names) (void)hiprtcAddNameExpression(prog, n);
+    for (const char* n : kSpecKernelNames) (void)hiprtcAddNameExpression(prog, n);
     const std::string inc = std::string("-I") + include_dir;
     // same numerical contract as the ahead-of-time build: no contraction, IEEE sqrt/divide (HIP default)
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", inc.c_str()};
-    const hiprtcResult rc = hiprtcCompileProgram(prog, 5, opts);
+    std::vector<std::string> extra;  // HU_RTC_FLAGS: extra compiler options, for tuning experiments
+    if (const char* e = getenv("HU_RTC_FLAGS")) {
+        std::istringstream in(e);
+        for (std::string w; in >> w;) extra.push_back(w);
+    }
+    std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", inc.c_str()};
+    for (const std::string& w : extra) opts.push_back(w.c_str());
+    const hiprtcResult rc = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
     if (rc != HIPRTC_SUCCESS) {
         size_t n = 0;
         std::string log;
@@ -826,6 +832,44 @@ int hu_tape_specialize(hu_tape t, const char* include_dir)
         (void)hiprtcDestroyProgram(&prog);
         return fail(HU_ERR_UNSUPPORTED, std::string("hipRTC compile failed: ") + hiprtcGetErrorString(rc) + "\n" + log.substr(0, 4000));
     }
+    *out = prog;
+    return HU_OK;
+}
+
+int hu_tape_compile_check(const float* tape, size_t n, const char* include_dir, size_t* code_bytes)
+{
+    if (!tape || !include_dir) return fail(HU_ERR_BAD_ARG, "NULL argument");
+    sdf::DecodedTape d;
+    const std::string err = sdf::decode_tape(tape, n, d);
+    if (!err.empty()) return fail(HU_ERR_BAD_TAPE, "malformed tape: " + err);
+    hu_tape_s t;  // host fields only
+    t.n_slots = d.n_slots;
+    t.recs_host = d.recs;
+    hiprtcProgram prog;
+    int rc;
+    if ((rc = compile_specialised(generate_source(&t), include_dir, &prog))) return rc;
+    size_t size = 0;
+    (void)hiprtcGetCodeSize(prog, &size);
+    if (code_bytes) *code_bytes = size;
+    for (const char* name : kSpecKernelNames) {
+        const char* lowered = nullptr;
+        if (hiprtcGetLoweredName(prog, name, &lowered) != HIPRTC_SUCCESS || !lowered) {
+            (void)hiprtcDestroyProgram(&prog);
+            return fail(HU_ERR_UNSUPPORTED, std::string("kernel missing from the specialised module: ") + name);
+        }
+    }
+    (void)hiprtcDestroyProgram(&prog);
+    return HU_OK;
+}
+
+int hu_tape_specialize(hu_tape t, const char* include_dir)
+{
+    if (!t || !include_dir) return fail(HU_ERR_BAD_ARG, "NULL argument");
+    if (t->spec) return HU_OK;
+    hiprtcProgram prog;
+    int crc;
+    if ((crc = compile_specialised(generate_source(t), include_dir, &prog))) return crc;
+    const char* const* names = kSpecKernelNames;
     size_t size = 0;
     (void)hiprtcGetCodeSize(prog, &size);
     std::vector<char> code(size);
@@ -849,6 +893,39 @@ int hu_tape_specialize(hu_tape t, const char* include_dir)
         return fail(HU_ERR_HIP, std::string("loading the specialised module: ") + hipGetErrorString(e));
     }
     t->spec = k;
+    return HU_OK;
+}
+
+int hu_selftest_math(uint64_t counts[4])
+{
+    if (!counts) return fail(HU_ERR_BAD_ARG, "counts is NULL");
+    unsigned long long* dev = nullptr;
+    HU_HIP(hipMalloc((void**)&dev, 4 * sizeof(unsigned long long)));
+    hipError_t e = hipMemset(dev, 0, 4 * sizeof(unsigned long long));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_selftest_math, dim3(256 * 32), dim3(256), 0, nullptr, dev);
+        e = hipGetLastError();
+    }
+    unsigned long long host[4] = {0, 0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpy(host, dev, sizeof host, hipMemcpyDeviceToHost);
+    (void)hipFree(dev);
+    if (e != hipSuccess) return fail(HU_ERR_HIP, std::string("hu_selftest_math: ") + hipGetErrorString(e));
+    for (int i = 0; i < 4; ++i) counts[i] = host[i];
+    return HU_OK;
+}
+
+int hu_tape_source(const float* tape, size_t n, char* buf, size_t capacity, size_t* needed)
+{
+    if (!tape || !needed || (!buf && capacity)) return fail(HU_ERR_BAD_ARG, "NULL argument");
+    sdf::DecodedTape d;
+    const std::string err = sdf::decode_tape(tape, n, d);
+    if (!err.empty()) return fail(HU_ERR_BAD_TAPE, "malformed tape: " + err);
+    hu_tape_s t;  // host fields only: nothing touches a device
+    t.n_slots = d.n_slots;
+    t.recs_host = d.recs;
+    const std::string src = generate_source(&t);
+    *needed = src.size() + 1;
+    if (capacity >= src.size() + 1) std::memcpy(buf, src.c_str(), src.size() + 1);
     return HU_OK;
 }
 

@@ -95,8 +95,67 @@ template <class T> __device__ __forceinline__ T dot3(T ax, T ay, T az, T bx, T b
 {
     return fma_(az, bz, fma_(ay, by, ax * bx));
 }
-template <class T> __device__ __forceinline__ T len2(T x, T y) { return sqrt_(fma_(y, y, x * x)); }
-template <class T> __device__ __forceinline__ T len3(T x, T y, T z) { return sqrt_(fma_(z, z, fma_(y, y, x * x))); }
+
+// ---- correctly rounded sqrt and reciprocal without the compiler's IEEE expansions ------------
+// sqrt(x) and 1/sqrt_rounded(x) are what the canonical arithmetic asks for (sdf_math.hpp,
+// oracle: sqrtf and 1.0f / s).  The compiler's correctly rounded expansions cost ~13 + ~10 VALU
+// instructions (input scaling for denormals, v_div_scale/v_div_fmas/v_div_fixup); for sponge-class
+// tapes that was a third of all VALU work.  For 2^-100 <= x <= 2^100 one Newton/Markstein step on
+// the hardware seeds gives the SAME bits:
+//     y = v_rsq(x); s0 = x*y; s = fma(fma(-s0, s0, x), y/2, s0)          == sqrtf(x)
+//     r0 = v_rcp(s);          r = fma(fma(-s, r0, 1), r0, r0)            == 1.0f / s
+// Not an approximation argument: tests/test_gpu_math.py runs hu_selftest_math, which compares
+// these functions with the IEEE expansions on ALL 2^32 inputs on the device.  Outside that range
+// (zeros, denormals, infinities, NaN, huge values) a wave-uniform branch takes the IEEE path.
+#ifndef SDF_FAST_CR_MATH
+#define SDF_FAST_CR_MATH 1
+#endif
+constexpr float kFastLo = 0x1p-100f, kFastHi = 0x1p100f;
+__device__ __forceinline__ float rsq_hw(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ f2 rsq_hw(f2 x) { return make_f2(__builtin_amdgcn_rsqf(x.x), __builtin_amdgcn_rsqf(x.y)); }
+__device__ __forceinline__ float rcp_hw(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ f2 rcp_hw(f2 x) { return make_f2(__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)); }
+__device__ __forceinline__ bool wave_any(bool m) { return __ballot(m) != 0ull; }
+__device__ __forceinline__ bool wave_any(i2 m) { return __ballot((m.x | m.y) != 0) != 0ull; }
+__device__ __forceinline__ bool outside_fast_range(float x) { return !(x >= kFastLo && x <= kFastHi); }
+__device__ __forceinline__ i2 outside_fast_range(f2 x) { return ~((x >= kFastLo) & (x <= kFastHi)); }
+template <class T> struct mask_of { using type = bool; static __device__ __forceinline__ bool all() { return true; } };
+template <> struct mask_of<f2> { using type = i2; static __device__ __forceinline__ i2 all() { i2 m; m.x = -1; m.y = -1; return m; } };
+
+// sqrt(x), identical to sqrt_(x) in every lane/voxel where `used` holds
+template <class T, class M> __device__ __forceinline__ T sqrt_cr(T x, M used)
+{
+#if SDF_FAST_CR_MATH
+    const T y = rsq_hw(x);
+    const T s0 = x * y, h = 0.5f * y;
+    T s = fma_(fma_(-s0, s0, x), h, s0);
+    if (wave_any(used & outside_fast_range(x))) s = sqrt_(x);
+    return s;
+#else
+    return sqrt_(x);
+#endif
+}
+// s = sqrt(x), r = 1.0f / s, identical to the plain operations where `used` holds
+template <class T, class M> __device__ __forceinline__ void sqrt_inv_cr(T x, M used, T& s, T& r)
+{
+#if SDF_FAST_CR_MATH
+    const T y = rsq_hw(x);
+    const T s0 = x * y, h = 0.5f * y;
+    s = fma_(fma_(-s0, s0, x), h, s0);
+    const T r0 = rcp_hw(s);
+    r = fma_(fma_(-s, r0, bc<T>(1.0f)), r0, r0);
+    if (wave_any(used & outside_fast_range(x))) {
+        s = sqrt_(x);
+        r = 1.0f / s;
+    }
+#else
+    s = sqrt_(x);
+    r = 1.0f / s;
+#endif
+}
+
+template <class T> __device__ __forceinline__ T len2(T x, T y) { return sqrt_cr(fma_(y, y, x * x), mask_of<T>::all()); }
+template <class T> __device__ __forceinline__ T len3(T x, T y, T z) { return sqrt_cr(fma_(z, z, fma_(y, y, x * x)), mask_of<T>::all()); }
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz)
 {
     return fma_(az, bz, fma_(ay, by, ax * bx));
@@ -133,10 +192,7 @@ template <class T> __device__ __forceinline__ V4<T> rectangle_op(float hw, float
     auto corner = (wx > 0.0f) & (wy > 0.0f);
     auto xs = wx > wy;
     T dist = wx, inv = wx;  // only read where `corner` holds
-    if (any_lane(corner)) {
-        dist = len2(wx, wy);
-        inv = 1.0f / dist;
-    }
+    if (any_lane(corner)) sqrt_inv_cr(fma_(wy, wy, wx * wx), corner, dist, inv);
     return v4<T>(sel(corner, sx * (wx * inv), sel(xs, sx, zero)), sel(corner, sy * (wy * inv), sel(xs, zero, sy)), zero,
                  sel(corner, dist, sel(xs, wx, wy)));
 }
@@ -148,7 +204,7 @@ template <class T> __device__ __forceinline__ T perp_w(T a, T b)
 {
     auto corner = (a > 0.0f) & (b > 0.0f);
     T dist = a;
-    if (any_lane(corner)) dist = len2(a, b);
+    if (any_lane(corner)) dist = sqrt_cr(fma_(b, b, a * a), corner);
     return sel(corner, dist, sel(a > b, a, b));
 }
 
@@ -161,10 +217,7 @@ template <class T> __device__ __forceinline__ V4<T> extrusion_op(float hh, V4<T>
     auto corner = (wz > 0.0f) & (in.w > 0.0f);
     auto cap = wz > in.w;
     T dist = wz, inv = wz;  // only read where `corner` holds
-    if (any_lane(corner)) {
-        dist = len2(wz, in.w);
-        inv = 1.0f / dist;
-    }
+    if (any_lane(corner)) sqrt_inv_cr(fma_(in.w, in.w, wz * wz), corner, dist, inv);
     T m1 = wz * inv, m2 = in.w * inv;
     return v4<T>(sel(corner, in.x * m2, sel(cap, zero, in.x)), sel(corner, in.y * m2, sel(cap, zero, in.y)),
                  sel(corner, fma_(in.z, m2, sz * m1), sel(cap, sz, in.z)), sel(corner, dist, sel(cap, wz, in.w)));
@@ -194,8 +247,8 @@ template <class T> __device__ __forceinline__ V4<T> rounded_union(float r, V4<T>
 // reference shapes/simple2d.cl:6-14
 template <class T> __device__ __forceinline__ V4<T> circle_op(float r, V4<T> c)
 {
-    T a = len2(c.x, c.y);
-    T inv = 1.0f / a;
+    T a, inv;
+    sqrt_inv_cr(fma_(c.y, c.y, c.x * c.x), mask_of<T>::all(), a, inv);
     auto zero = (a == 0.0f);
     return v4<T>(sel(zero, bc<T>(1.0f), c.x * inv), sel(zero, bc<T>(0.0f), c.y * inv), bc<T>(0.0f), a - r);
 }
@@ -203,8 +256,8 @@ template <class T> __device__ __forceinline__ V4<T> circle_op(float r, V4<T> c)
 // reference shapes/simple3d.cl:1-12
 template <class T> __device__ __forceinline__ V4<T> sphere_op(float r, V4<T> c)
 {
-    T a = len3(c.x, c.y, c.z);
-    T inv = 1.0f / a;
+    T a, inv;
+    sqrt_inv_cr(fma_(c.z, c.z, fma_(c.y, c.y, c.x * c.x)), mask_of<T>::all(), a, inv);
     auto zero = (a == 0.0f);
     return v4<T>(sel(zero, bc<T>(1.0f), c.x * inv), sel(zero, bc<T>(0.0f), c.y * inv), sel(zero, bc<T>(0.0f), c.z * inv),
                  a - r);

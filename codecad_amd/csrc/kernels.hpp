@@ -14,6 +14,13 @@
 
 #include "interp.hpp"
 
+// Occupancy hint for experiments (-DSDF_WAVES_PER_EU=n): waves per SIMD the register allocator aims for.
+#ifdef SDF_WAVES_PER_EU
+#define SDF_KERNEL_ATTRS __attribute__((amdgpu_waves_per_eu(SDF_WAVES_PER_EU, SDF_WAVES_PER_EU)))
+#else
+#define SDF_KERNEL_ATTRS
+#endif
+
 namespace sdfk {
 
 using sdf::Rec;
@@ -122,7 +129,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 // dense grid evaluation
 // ------------------------------------------------------------------------------------------
 template <class E, int LAYOUT, int N>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) SDF_KERNEL_ATTRS
 k_grid_eval(const E ev, float cx, float cy, float cz, float step, uint32_t sx, uint32_t sy, uint32_t sz, uint32_t x0,
             uint32_t n_cells, void* __restrict__ out)
 {
@@ -558,6 +565,45 @@ k_bitmap(const E ev, float ox, float oy, float oz, float step_size, uint32_t w, 
     if (!active) return;
     const float t = (v < 0.0f) ? 0.0f : 1.0f;  // step(0, v)
     store_rgb(out + (size_t)lin * 3, mk3(mixf(125.0f, 230.0f, t), mixf(179.0f, 230.0f, t), mixf(0.0f, 241.0f, t)));
+}
+
+// ------------------------------------------------------------------------------------------
+// self-test of the fast correctly rounded sqrt / reciprocal (interp.hpp sqrt_cr, sqrt_inv_cr):
+// every binary32 bit pattern, one voxel per lane (T = float) and two (T = f2), against the
+// compiler's IEEE expansions.  counts[0..3] = mismatches of {sqrt_cr, sqrt_inv_cr.s, sqrt_inv_cr.r}
+// and the number of inputs that took the fast path.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool same_bits(float a, float b)
+{
+    return __float_as_uint(a) == __float_as_uint(b) || (a != a && b != b);
+}
+__global__ void __launch_bounds__(256) k_selftest_math(unsigned long long* counts)
+{
+    unsigned long long bad[3] = {0, 0, 0}, fast = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += stride) {
+        const float x0 = __uint_as_float((uint32_t)i), x1 = __uint_as_float(~(uint32_t)i);
+        const float s_ref0 = sdf::sqrt_(x0), s_ref1 = sdf::sqrt_(x1);
+        const float r_ref0 = 1.0f / s_ref0, r_ref1 = 1.0f / s_ref1;
+        // one voxel per lane
+        float s, r;
+        sdf::sqrt_inv_cr(x0, true, s, r);
+        bad[0] += !same_bits(sdf::sqrt_cr(x0, true), s_ref0);
+        bad[1] += !same_bits(s, s_ref0);
+        bad[2] += !same_bits(r, r_ref0);
+        // two voxels per lane
+        const sdf::f2 x = sdf::make_f2(x0, x1);
+        sdf::f2 s2, r2;
+        sdf::sqrt_inv_cr(x, sdf::mask_of<sdf::f2>::all(), s2, r2);
+        const sdf::f2 q2 = sdf::sqrt_cr(x, sdf::mask_of<sdf::f2>::all());
+        bad[0] += !same_bits(q2.x, s_ref0) + !same_bits(q2.y, s_ref1);
+        bad[1] += !same_bits(s2.x, s_ref0) + !same_bits(s2.y, s_ref1);
+        bad[2] += !same_bits(r2.x, r_ref0) + !same_bits(r2.y, r_ref1);
+        fast += !sdf::outside_fast_range(x0);
+    }
+    for (int k = 0; k < 3; ++k)
+        if (bad[k]) atomicAdd(&counts[k], bad[k]);
+    atomicAdd(&counts[3], fast);
 }
 
 }  // namespace sdfk

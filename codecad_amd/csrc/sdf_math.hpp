@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #else
+using __hip_internal::uint8_t;
 using __hip_internal::int32_t;
 using __hip_internal::uint32_t;
 using __hip_internal::uint64_t;

@@ -53,6 +53,9 @@ PROTOTYPES = {
     "hu_bitmap": [_vp, _f4, _f, _u32, _u32, _vp, _vp],
     "hu_tape_specialize": [_vp, _c.c_char_p],
     "hu_tape_specialized": [_vp, _c.POINTER(_i)],
+    "hu_tape_compile_check": [_f4, _sz, _c.c_char_p, _c.POINTER(_sz)],
+    "hu_selftest_math": [_c.POINTER(_c.c_uint64)],
+    "hu_tape_source": [_f4, _sz, _c.c_char_p, _sz, _c.POINTER(_sz)],
 }
 
 HEADER = os.path.normpath(os.path.join(os.path.dirname(__file__), "..", "..", "include", "hip_util.h"))

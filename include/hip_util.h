@@ -158,6 +158,21 @@ int hu_bitmap(hu_tape t, const float origin[4], float step_size, uint32_t width,
  * (seconds); returns HU_ERR_UNSUPPORTED with the compiler log if hipRTC cannot build it. */
 int hu_tape_specialize(hu_tape t, const char* include_dir);
 int hu_tape_specialized(hu_tape t, int* out_flag);
+/* The HIP source hu_tape_specialize would compile for this tape (host only, no device needed):
+ * `*needed` receives its size including the terminator; it is copied when `capacity` suffices. */
+int hu_tape_source(const float* tape, size_t n_floats, char* buf, size_t capacity, size_t* needed);
+/* Compile that source with hipRTC without loading it (host only, no device needed): checks that the
+ * op library headers in `include_dir` build under hipRTC and that all eight kernels are present.
+ * `*code_bytes` (may be NULL) receives the code object size. */
+int hu_tape_compile_check(const float* tape, size_t n_floats, const char* include_dir, size_t* code_bytes);
+
+/* Device self-test of the arithmetic contract: the kernels compute sqrt(x) and 1/sqrt(x) with a
+ * short hardware-seeded sequence instead of the compiler's IEEE expansion (csrc/interp.hpp
+ * sqrt_cr / sqrt_inv_cr).  This runs both on ALL 2^32 binary32 inputs, one and two voxels per
+ * lane, and counts disagreements with the IEEE results: counts[0..2] = mismatches of sqrt_cr,
+ * sqrt_inv_cr's root, sqrt_inv_cr's reciprocal (all must be 0); counts[3] = inputs on the fast
+ * path.  Synchronous, about 0.1 s. */
+int hu_selftest_math(uint64_t counts[4]);
 
 #ifdef __cplusplus
 }

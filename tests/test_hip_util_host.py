@@ -116,3 +116,37 @@ def test_format_c_string_literal(s, tmp_path):
     subprocess.run(["gcc", "-o", str(exe), str(src)], check=True, capture_output=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True).stdout
     assert out == raw + b"\0"
+
+
+def _tape_ptr(tape):
+    import ctypes
+    import numpy
+    t = numpy.ascontiguousarray(tape, dtype=numpy.float32)
+    return t, t.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def test_specialised_source_builds_under_hiprtc_without_a_device():
+    """hipRTC needs no GPU: the generated straight-line source and the op library headers it includes
+    must compile for gfx950 and contain all eight kernels (catches header changes that only break
+    the run-time compiler, e.g. a type hipRTC's built-in runtime does not declare)."""
+    import ctypes
+    import os
+    import codecad_amd as cc
+    from codecad_amd.hip_util import _lib
+    lib = _lib.load()
+    include_dir = os.path.join(os.path.dirname(cc.__file__), "csrc").encode()
+    t, p = _tape_ptr(cc.nodes.make_program(cc.examples.sponge(2)))
+    needed = ctypes.c_size_t(0)
+    assert lib.hu_tape_source(p, t.size, None, 0, ctypes.byref(needed)) == 0
+    buf = ctypes.create_string_buffer(needed.value)
+    assert lib.hu_tape_source(p, t.size, buf, needed.value, ctypes.byref(needed)) == 0
+    src = buf.value.decode()
+    assert 0 < src.count("exec_one<T, false>") <= 52 and "struct JitEval" in src  # the decoder may fold records
+    size = ctypes.c_size_t(0)
+    rc = lib.hu_tape_compile_check(p, t.size, include_dir, ctypes.byref(size))
+    assert rc == 0, lib.hu_last_error().decode()
+    assert size.value > 10000
+    # a malformed tape is rejected before any compilation
+    bad, pb = _tape_ptr([99 * 512.0])
+    assert lib.hu_tape_compile_check(pb, bad.size, include_dir, None) != 0
+    assert b"malformed" in lib.hu_last_error()
