@@ -896,6 +896,63 @@ int hu_tape_specialize(hu_tape t, const char* include_dir)
     return HU_OK;
 }
 
+static int launch_process_polygon(bool batch, PolygonArgs& a, uint32_t n_blocks, void* stream)
+{
+    if (a.gx < 2 || a.gy < 2) return fail(HU_ERR_BAD_ARG, "the corner grid needs at least 2x2 samples");
+    if (a.gx > 512 || a.gy > 512) return fail(HU_ERR_BAD_ARG, "corner grids above 512 overflow the link encoding (polygon2d.py:46)");
+    if (n_blocks == 0) return HU_OK;
+    if (n_blocks > 65535u) return fail(HU_ERR_BAD_ARG, "at most 65535 blocks per launch");
+    const uint32_t cells = (a.gx - 1u) * (a.gy - 1u) * 2u;
+    const dim3 grid((cells + 255u) / 256u, n_blocks), block(256);
+    if (batch) hipLaunchKernelGGL(k_process_polygon<true>, grid, block, 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_process_polygon<false>, grid, block, 0, (hipStream_t)stream, a);
+    HU_HIP(hipGetLastError());
+    return HU_OK;
+}
+
+int hu_process_polygon(const float box_corner[2], float box_step, const void* corners_dev, const uint32_t grid[2],
+                       void* vertices_dev, uint32_t* links_dev, uint32_t* starts_dev, uint32_t* start_counter_dev,
+                       void* stream)
+{
+    if (!box_corner || !corners_dev || !grid || !vertices_dev || !links_dev || !starts_dev || !start_counter_dev)
+        return fail(HU_ERR_BAD_ARG, "NULL argument");
+    PolygonArgs a{};
+    a.corners = static_cast<const float4*>(corners_dev);
+    a.gx = grid[0] + 1u;  // the reference launches over (gx-1, gy-1, 2) triangles
+    a.gy = grid[1] + 1u;
+    a.cx = box_corner[0];
+    a.cy = box_corner[1];
+    a.step = box_step;
+    a.vertices = static_cast<float2*>(vertices_dev);
+    a.links = links_dev;
+    a.starts = starts_dev;
+    a.start_counter = start_counter_dev;
+    return launch_process_polygon(false, a, 1, stream);
+}
+
+int hu_process_polygon_blocks(const void* corners_dev, const int32_t* blocks_dev, uint32_t n_blocks, double resolution,
+                              const double origin[3], float step, const uint32_t dims[2], void* vertices_dev,
+                              uint32_t* links_dev, uint32_t* starts_dev, uint32_t* start_counters_dev, void* stream)
+{
+    if (!origin || !dims) return fail(HU_ERR_BAD_ARG, "NULL argument");
+    if (n_blocks && (!corners_dev || !blocks_dev || !vertices_dev || !links_dev || !starts_dev || !start_counters_dev))
+        return fail(HU_ERR_BAD_ARG, "NULL argument");
+    PolygonArgs a{};
+    a.corners = static_cast<const float4*>(corners_dev);
+    a.gx = dims[0];
+    a.gy = dims[1];
+    a.step = step;
+    a.blocks = reinterpret_cast<const int4*>(blocks_dev);
+    a.res = resolution;
+    a.ox = origin[0];
+    a.oy = origin[1];
+    a.vertices = static_cast<float2*>(vertices_dev);
+    a.links = links_dev;
+    a.starts = starts_dev;
+    a.start_counter = start_counters_dev;
+    return launch_process_polygon(true, a, n_blocks, stream);
+}
+
 int hu_selftest_math(uint64_t counts[4])
 {
     if (!counts) return fail(HU_ERR_BAD_ARG, "counts is NULL");

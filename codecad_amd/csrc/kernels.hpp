@@ -10,6 +10,7 @@
 //                          (reference-shaped) or every parent of a level in one launch
 //   k_ray_caster           rendering/ray_caster.cl:146-256 as a per-lane state machine
 //   k_bitmap               rendering/bitmap.cl:1-18
+//   k_process_polygon      rendering/polygon2d.cl:82-175, one block (reference-shaped) or all blocks
 #pragma once
 
 #include "interp.hpp"
@@ -565,6 +566,122 @@ k_bitmap(const E ev, float ox, float oy, float oz, float step_size, uint32_t w, 
     if (!active) return;
     const float t = (v < 0.0f) ? 0.0f : 1.0f;  // step(0, v)
     store_rgb(out + (size_t)lin * 3, mk3(mixf(125.0f, 230.0f, t), mixf(179.0f, 230.0f, t), mixf(0.0f, 241.0f, t)));
+}
+
+// ------------------------------------------------------------------------------------------
+// 2D contouring (reference rendering/polygon2d.cl)
+// ------------------------------------------------------------------------------------------
+// encode_index, polygon2d.cl:5-36: a cell index, or where a link leaves the block
+__device__ __forceinline__ uint32_t pp_encode_index(int32_t cx, int32_t cy, uint32_t size_x, uint32_t size_y, uint32_t index)
+{
+    constexpr uint32_t kIndexSize = 20;
+    index &= (1u << kIndexSize) - 1u;
+    bool y;
+    int32_t sx, sy;
+    if (cx < 0 || (uint32_t)cx >= size_x) { y = false; sx = cx; sy = cy; }
+    else if (cy < 0 || (uint32_t)cy >= size_y) { y = true; sx = cy; sy = cx; }
+    else return index;
+    return 0x80000000u | (y ? 0x40000000u : 0u) | (sx < 0 ? 0x20000000u : 0u) | ((uint32_t)sy << kIndexSize) | index;
+}
+
+// place_vertex, polygon2d.cl:38-80: weighted average of the corners, then <= 8 steps towards the
+// point where the three corners' tangent lines meet.  Plain binary32 in the oracle's order.
+__device__ __forceinline__ float2 pp_place_vertex(const float (&px)[3], const float (&py)[3], const float4 (&val)[3])
+{
+    float ax = 0.0f, ay = 0.0f, weight = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float w = 1.0f / (1.0f + sdf::abs_(val[i].w));
+        ax += px[i] * w;
+        ay += py[i] * w;
+        weight += w;
+    }
+    float x = ax / weight, y = ay / weight;
+    for (int i = 0; i < 8; ++i) {
+        float gx = 0.0f, gy = 0.0f, residual = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float tmp = (val[j].x * (x - px[j]) + val[j].y * (y - py[j])) + val[j].w;
+            residual += tmp * tmp;
+            gx += val[j].x * tmp;
+            gy += val[j].y * tmp;
+        }
+        if (residual < 1e-3f) break;
+        const float g2 = gx * gx + gy * gy;
+        if (g2 < 1e-8f) break;
+        const float k = residual / g2;
+        x -= gx * k;
+        y -= gy * k;
+    }
+    return make_float2(x, y);
+}
+
+struct PolygonArgs {
+    const float4* corners;   // float4[gx*gy] per block, index y + gy*x (grid_eval over (gx, gy, 1))
+    uint32_t gx, gy;         // corner samples per block; cells = (gx-1)*(gy-1)*2
+    float cx, cy, step;      // !BATCH: box corner as given
+    const int4* blocks;      // BATCH: integer block corners
+    double res, ox, oy;      // BATCH: corner = (float)(int_corner * res + origin)
+    float2* vertices;        // [cells] per block
+    uint32_t* links;         // [cells] per block
+    uint32_t* starts;        // [(gx-1)+(gy-1)] per block
+    uint32_t* start_counter; // one per block (caller zeroes)
+};
+
+// One lane per triangular half cell; lin = t + 2*(y + (gy-1)*x) = INDEX3_GG of the reference's
+// (gx-1, gy-1, 2) launch, so a wavefront reads/writes contiguous runs.
+template <bool BATCH> __global__ void __launch_bounds__(256) k_process_polygon(const PolygonArgs a)
+{
+    const uint32_t sx = a.gx - 1u, sy = a.gy - 1u, cells = sx * sy * 2u;
+    const uint32_t b = BATCH ? blockIdx.y : 0u;
+    const uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
+    if (index >= cells) return;
+    const uint32_t t = index & 1u, y = (index >> 1) % sy, x = (index >> 1) / sy;
+    const float4* corners = a.corners + (size_t)b * a.gx * a.gy;
+    float2* vertices = a.vertices + (size_t)b * cells;
+    uint32_t* links = a.links + (size_t)b * cells;
+    float bcx = a.cx, bcy = a.cy;
+    if (BATCH) {
+        const int4 ic = a.blocks[b];
+        bcx = (float)((double)ic.x * a.res + a.ox);
+        bcy = (float)((double)ic.y * a.res + a.oy);
+    }
+    const uint32_t offx[3] = {0u, 1u, t}, offy[3] = {0u, 1u, 1u - t};
+    float4 val[3];
+    uint32_t cell_type = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        val[i] = corners[(y + offy[i]) + (size_t)a.gy * (x + offx[i])];
+        cell_type = (cell_type << 1) | (val[i].w <= 0.0f ? 1u : 0u);
+    }
+    if (cell_type == 0u || cell_type == 7u) {
+        links[index] = 0xffffffffu;
+        return;
+    }
+    bool backwards = cell_type == 3u || cell_type == 5u || cell_type == 6u;
+    if (backwards) cell_type = 7u - cell_type;
+    const bool flip = t == 1u;
+    if (flip) backwards = !backwards;
+    // cell_type is now 1, 2 or 4 (polygon2d.cl:125-139)
+    int32_t fx = cell_type == 4u ? -1 : 0, fy = cell_type == 1u ? 1 : 0;
+    int32_t rx = cell_type == 1u ? -1 : 0, ry = cell_type == 2u ? 1 : 0;
+    if (backwards) { const int32_t u = fx, v = fy; fx = rx; fy = ry; rx = u; ry = v; }
+    if (flip) { int32_t u = fx; fx = fy; fy = u; u = rx; rx = ry; ry = u; }
+    fx += (int32_t)x; fy += (int32_t)y; rx += (int32_t)x; ry += (int32_t)y;
+    const uint32_t fwd_index = (1u - t) + 2u * ((uint32_t)fy + sy * (uint32_t)fx);  // INDEX3_G, wrapping like the size_t expression
+    links[index] = pp_encode_index(fx, fy, sx, sy, fwd_index);
+    const uint32_t start_index = pp_encode_index(rx, ry, sx, sy, index);
+    if (start_index & 0x80000000u) {
+        const uint32_t slot = atomicAdd(&a.start_counter[b], 1u);
+        if (slot < sx + sy) a.starts[(size_t)b * (sx + sy) + slot] = start_index ^ 0x20000000u;
+    }
+    float px[3], py[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        px[i] = bcx + (float)(x + offx[i]) * a.step;
+        py[i] = bcy + (float)(y + offy[i]) * a.step;
+    }
+    vertices[index] = pp_place_vertex(px, py, val);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -195,6 +195,16 @@ class _Kernels:
             _ptr(scene), o.ctypes.data_as(_lib._f4), float(step_size), int(global_size[0]), int(global_size[1]),
             _ptr(output), s), "hu_bitmap"))
 
+    def process_polygon(self, global_size, local_size, box_corner, box_step, corners, vertices, links, starts,
+                        start_counter, wait_for=None, queue=None):
+        """rendering/polygon2d.cl:82-93; global_size = (gx-1, gy-1, 2)."""
+        c = _float4(box_corner)
+        assert int(global_size[2]) == 2
+        g = (ctypes.c_uint32 * 2)(int(global_size[0]), int(global_size[1]))
+        return self._launch(wait_for, queue, lambda s: check(self._m.lib.hu_process_polygon(
+            c.ctypes.data_as(_lib._f4), float(box_step), _ptr(corners), g, _ptr(vertices), _ptr(links), _ptr(starts),
+            _ptr(start_counter), s), "hu_process_polygon"))
+
 
 class HipManager:
     """Lazy singleton: `.lib`, `.device`, `.queue`, `.k`, `.device_name`."""

@@ -151,6 +151,26 @@ int hu_ray_caster(hu_tape t, const float origin[4], const float forward[4], cons
 int hu_bitmap(hu_tape t, const float origin[4], float step_size, uint32_t width, uint32_t height,
               void* out_dev, void* stream);
 
+/* ---- 2D contouring ----------------------------------------- */
+/* rendering/polygon2d.cl:82-93, launched by rendering/polygon2d.py:101-112 with global size
+ * grid = (gx-1, gy-1, 2) over the float4 corner samples corners_dev[gx*gy] that hu_grid_eval wrote
+ * for dims (gx, gy, 1).  Per triangular half cell (index t + 2*(y + (gy-1)*x)): vertices_dev
+ * float2[cells] (written where the contour crosses the cell), links_dev uint32[cells] (next cell
+ * along the contour, 0xffffffff = empty cell, top bits = where it leaves the block,
+ * polygon2d.cl:5-36), starts_dev uint32[(gx-1)+(gy-1)] + *start_counter_dev (caller zeroes): cells
+ * that begin a chain entering through the block's boundary, in unspecified order. */
+int hu_process_polygon(const float box_corner[2], float box_step, const void* corners_dev,
+                       const uint32_t grid[2], void* vertices_dev, uint32_t* links_dev,
+                       uint32_t* starts_dev, uint32_t* start_counter_dev, void* stream);
+/* The same for ALL leaf blocks of a 2D subdivision in one launch (the per-block loop of
+ * polygon2d.py:84-126).  corners_dev: float4[n_blocks][dims[0]*dims[1]] as written by
+ * hu_grid_eval_blocks(layout 0) over dims (gx, gy, 1); block corner = (float)(int_corner *
+ * resolution + origin).  Outputs are per block, consecutive; start_counters_dev: uint32[n_blocks]. */
+int hu_process_polygon_blocks(const void* corners_dev, const int32_t* blocks_dev, uint32_t n_blocks,
+                              double resolution, const double origin[3], float step,
+                              const uint32_t dims[2], void* vertices_dev, uint32_t* links_dev,
+                              uint32_t* starts_dev, uint32_t* start_counters_dev, void* stream);
+
 /* Per-tape specialisation (the reference's generate_fixed_eval_source_code, nodes/codegen.py:137-204):
  * unroll the decoded program into straight-line gfx950 code with hipRTC, using the op library
  * headers found in `include_dir` (codecad_amd/csrc).  Afterwards every launch with this tape runs

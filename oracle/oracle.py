@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
 _lib = None
 
-__all__ = ["build", "lib", "evaluate_points", "grid_eval", "grid_eval_pymcubes", "ray_caster", "bitmap",
+__all__ = ["build", "lib", "evaluate_points", "grid_eval", "grid_eval_pymcubes", "ray_caster", "bitmap", "process_polygon",
            "subdivision_step", "mass_properties", "det_math"]
 
 _f32p = ctypes.POINTER(ctypes.c_float)
@@ -170,3 +170,24 @@ def bitmap(tape, origin, step_size, size):
     _check(lib().oracle_bitmap(tp, tn, o.ctypes.data_as(_f32p), ctypes.c_float(step_size), ctypes.c_uint32(w),
                                ctypes.c_uint32(h), out.ctypes.data_as(_u8p)), "bitmap")
     return out
+
+
+def process_polygon(corners, box_corner, box_step):
+    """Reference kernel process_polygon (rendering/polygon2d.cl:82-175) over a float4 corner grid of shape
+    (gx, gy, 4) -> (vertices float32 (cells, 2), links uint32 (cells,), starts uint32 (n,)), cells =
+    (gx-1)*(gy-1)*2, cell index t + 2*(y + (gy-1)*x).  Vertices of empty cells (link 0xffffffff) are NaN."""
+    c = np.ascontiguousarray(corners, dtype=np.float32)
+    gx, gy = int(c.shape[0]), int(c.shape[1])
+    assert c.shape == (gx, gy, 4)
+    cells = (gx - 1) * (gy - 1) * 2
+    vertices = np.full((cells, 2), np.nan, dtype=np.float32)
+    links = np.zeros(cells, dtype=np.uint32)
+    starts = np.zeros(max((gx - 1) + (gy - 1), 1) * 2, dtype=np.uint32)
+    count = ctypes.c_uint32(0)
+    o = np.ascontiguousarray(np.asarray(box_corner, dtype=np.float64)[:2], dtype=np.float32)
+    lib().oracle_process_polygon.restype = ctypes.c_int
+    _check(lib().oracle_process_polygon(c.ctypes.data_as(_f32p), ctypes.c_uint32(gx), ctypes.c_uint32(gy),
+                                        o.ctypes.data_as(_f32p), ctypes.c_float(box_step),
+                                        vertices.ctypes.data_as(_f32p), links.ctypes.data_as(_u32p),
+                                        starts.ctypes.data_as(_u32p), ctypes.byref(count)), "process_polygon")
+    return vertices, links, starts[:count.value].copy()

@@ -784,3 +784,104 @@ int oracle_bitmap(const float *tape, int n_tape, const float *origin, float step
         }
     return 0;
 }
+
+/* ====================================================================================
+ * 2D contouring -- SURVEY.md section 8(f) rank 4.  Restated from reference
+ * rendering/polygon2d.cl:1-175 (encode_index :5-36, place_vertex :38-80, process_polygon :82-175).
+ * The reference's tests never run this kernel (tests/test_polygons2d.py covers the polygon SHAPE
+ * only) and there are no fixtures for it: PARITY UNPINNED beyond this line-by-line restatement;
+ * tests/test_polygon2d_render.py checks geometric properties of the contours.
+ * `corners`: float4[gx*gy] as written by grid_eval over (gx, gy, 1), index y + gy*x.
+ * Global size of the reference launch = (gx-1, gy-1, 2); index = t + 2*(y + (gy-1)*x).
+ * `starts` are appended in (x, y, t) scan order here (the reference's atomic order is unspecified).
+ * Arithmetic: plain IEEE binary32 in the order written.
+ * ================================================================================== */
+static uint32_t pp_encode_index(int32_t cx, int32_t cy, uint32_t size_x, uint32_t size_y, uint32_t index)
+{
+    const uint32_t index_size = 20;
+    index &= (1u << index_size) - 1u;
+    int y;
+    int32_t sx, sy;
+    if (cx < 0 || (uint32_t)cx >= size_x) { y = 0; sx = cx; sy = cy; }
+    else if (cy < 0 || (uint32_t)cy >= size_y) { y = 1; sx = cy; sy = cx; }
+    else return index;
+    return 0x80000000u | (y ? 0x40000000u : 0u) | (sx < 0 ? 0x20000000u : 0u) | ((uint32_t)sy << index_size) | index;
+}
+
+static void pp_place_vertex(const float pos[3][2], const f4 val[3], float out[2])
+{
+    float ax = 0.0f, ay = 0.0f, weight = 0.0f;
+    for (int i = 0; i < 3; ++i) {
+        float w = 1.0f / (1.0f + fabsf(val[i].w));
+        ax += pos[i][0] * w;
+        ay += pos[i][1] * w;
+        weight += w;
+    }
+    ax /= weight;
+    ay /= weight;
+    float px = ax, py = ay;
+    for (int i = 0; i < 8; ++i) {
+        float gx = 0.0f, gy = 0.0f, residual = 0.0f;
+        for (int j = 0; j < 3; ++j) {
+            float nx = val[j].x, ny = val[j].y;
+            float tmp = (nx * (px - pos[j][0]) + ny * (py - pos[j][1])) + val[j].w;
+            residual += tmp * tmp;
+            gx += nx * tmp;
+            gy += ny * tmp;
+        }
+        if (residual < 1e-3f) break;
+        float g2 = gx * gx + gy * gy;
+        if (g2 < 1e-8f) break;
+        float k = residual / g2;
+        px -= gx * k;
+        py -= gy * k;
+    }
+    out[0] = px;
+    out[1] = py;
+}
+
+int oracle_process_polygon(const float *corners, uint32_t gx, uint32_t gy, const float *box_corner, float box_step,
+                           float *vertices, uint32_t *links, uint32_t *starts, uint32_t *start_counter)
+{
+    if (gx < 2 || gy < 2) return -1;
+    const uint32_t sx = gx - 1, sy = gy - 1;
+    const f4 *c = (const f4 *)corners;
+    for (uint32_t x = 0; x < sx; ++x)
+        for (uint32_t y = 0; y < sy; ++y)
+            for (uint32_t t = 0; t < 2; ++t) {
+                const uint32_t off[3][2] = { { 0, 0 }, { 1, 1 }, { t, 1 - t } };
+                uint32_t cell_type = 0;
+                for (int i = 0; i < 3; ++i)
+                    cell_type = (cell_type << 1) | (c[(y + off[i][1]) + (size_t)gy * (x + off[i][0])].w <= 0.0f ? 1u : 0u);
+                const uint32_t index = t + 2u * (y + sy * x);
+                if (cell_type == 0 || cell_type == 7) { links[index] = 0xffffffffu; continue; }
+                int backwards = cell_type == 3 || cell_type == 5 || cell_type == 6;
+                if (backwards) cell_type = 7 - cell_type;
+                const int flip = t == 1;
+                if (flip) backwards = !backwards;
+                int32_t fx = 0, fy = 0, rx = 0, ry = 0;
+                switch (cell_type) {
+                case 1: fx = 0; fy = 1; rx = -1; ry = 0; break;
+                case 2: fx = 0; fy = 0; rx = 0; ry = 1; break;
+                case 4: fx = -1; fy = 0; rx = 0; ry = 0; break;
+                }
+                if (backwards) { int32_t a = fx, b = fy; fx = rx; fy = ry; rx = a; ry = b; }
+                if (flip) { int32_t a = fx; fx = fy; fy = a; a = rx; rx = ry; ry = a; }
+                fx += (int32_t)x; fy += (int32_t)y; rx += (int32_t)x; ry += (int32_t)y;
+                /* INDEX3_G(fx, fy, 1 - t) in wrapping unsigned arithmetic, as the size_t expression truncates */
+                const uint32_t fwd_index = (1u - t) + 2u * ((uint32_t)fy + sy * (uint32_t)fx);
+                links[index] = pp_encode_index(fx, fy, sx, sy, fwd_index);
+                const uint32_t start_index = pp_encode_index(rx, ry, sx, sy, index);
+                if (start_index & 0x80000000u) starts[(*start_counter)++] = start_index ^ 0x20000000u;
+                float pos[3][2];
+                f4 val[3];
+                for (int i = 0; i < 3; ++i) {
+                    const uint32_t px = x + off[i][0], py = y + off[i][1];
+                    pos[i][0] = box_corner[0] + (float)px * box_step;
+                    pos[i][1] = box_corner[1] + (float)py * box_step;
+                    val[i] = c[py + (size_t)gy * px];
+                }
+                pp_place_vertex(pos, val, vertices + 2 * (size_t)index);
+            }
+    return 0;
+}
