@@ -20,6 +20,7 @@
 
 #include "../../include/hip_util.h"
 #include "kernels.hpp"
+#include "mesh_kernels.hpp"
 #include "tape.hpp"
 
 using sdf::Rec;
@@ -951,6 +952,81 @@ int hu_process_polygon_blocks(const void* corners_dev, const int32_t* blocks_dev
     a.starts = starts_dev;
     a.start_counter = start_counters_dev;
     return launch_process_polygon(true, a, n_blocks, stream);
+}
+
+static int mesh_shape(uint32_t n_blocks, const uint32_t dims[3], uint32_t& chunks, uint64_t& n_wg)
+{
+    uint64_t samples;
+    int rc;
+    if ((rc = check_dims(dims, samples))) return rc;
+    if (samples > (1ull << 24)) return fail(HU_ERR_BAD_ARG, "a block may have at most 2^24 samples (256^3)");
+    chunks = (uint32_t)((samples + kMcBlock - 1) / kMcBlock);
+    n_wg = (uint64_t)chunks * n_blocks;
+    if (n_wg > 0x7fffffffull) return fail(HU_ERR_BAD_ARG, "too many workgroups in one launch");
+    return HU_OK;
+}
+
+int hu_mesh_workgroups(uint32_t n_blocks, const uint32_t dims[3], uint64_t* n_workgroups)
+{
+    if (!n_workgroups) return fail(HU_ERR_BAD_ARG, "NULL argument");
+    uint32_t chunks;
+    return mesh_shape(n_blocks, dims, chunks, *n_workgroups);
+}
+
+int hu_mesh_count(const float* fields_dev, uint32_t n_blocks, const uint32_t dims[3], uint32_t* wg_counts_dev, void* stream)
+{
+    if (!wg_counts_dev || (!fields_dev && n_blocks)) return fail(HU_ERR_BAD_ARG, "NULL argument");
+    uint32_t chunks;
+    uint64_t n_wg;
+    int rc;
+    if ((rc = mesh_shape(n_blocks, dims, chunks, n_wg))) return rc;
+    McArgs a{};
+    a.fields = fields_dev;
+    a.A0 = dims[0];
+    a.A1 = dims[1];
+    a.A2 = dims[2];
+    a.chunks = chunks;
+    a.wg_counts = reinterpret_cast<uint2*>(wg_counts_dev);
+    if (n_wg) hipLaunchKernelGGL(k_mc_count, dim3((uint32_t)n_wg), dim3(kMcBlock), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_mc_scan, dim3(1), dim3(1024), 0, (hipStream_t)stream, a.wg_counts, (uint32_t)n_wg);
+    HU_HIP(hipGetLastError());
+    return HU_OK;
+}
+
+int hu_mesh_emit(const float* fields_dev, const int32_t* blocks_dev, uint32_t n_blocks, double resolution,
+                 const double origin[3], double step, const uint32_t dims[3], double y_offset,
+                 const uint32_t* wg_counts_dev, uint32_t* info_dev, double* vertices_dev, uint32_t* triangles_dev,
+                 void* stream)
+{
+    if (!origin) return fail(HU_ERR_BAD_ARG, "NULL argument");
+    if (n_blocks == 0) return HU_OK;
+    if (!fields_dev || !blocks_dev || !wg_counts_dev || !info_dev || !vertices_dev || !triangles_dev)
+        return fail(HU_ERR_BAD_ARG, "NULL argument");
+    uint32_t chunks;
+    uint64_t n_wg;
+    int rc;
+    if ((rc = mesh_shape(n_blocks, dims, chunks, n_wg))) return rc;
+    McArgs a{};
+    a.fields = fields_dev;
+    a.A0 = dims[0];
+    a.A1 = dims[1];
+    a.A2 = dims[2];
+    a.chunks = chunks;
+    a.blocks = reinterpret_cast<const int4*>(blocks_dev);
+    a.res = resolution;
+    a.ox = origin[0];
+    a.oy = origin[1];
+    a.oz = origin[2];
+    a.step = step;
+    a.y_offset = y_offset;
+    a.wg_counts = reinterpret_cast<uint2*>(const_cast<uint32_t*>(wg_counts_dev));
+    a.info = info_dev;
+    a.vertices = vertices_dev;
+    a.triangles = triangles_dev;
+    hipLaunchKernelGGL(k_mc_vertices, dim3((uint32_t)n_wg), dim3(kMcBlock), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_mc_triangles, dim3((uint32_t)n_wg), dim3(kMcBlock), 0, (hipStream_t)stream, a);
+    HU_HIP(hipGetLastError());
+    return HU_OK;
 }
 
 int hu_selftest_math(uint64_t counts[4])

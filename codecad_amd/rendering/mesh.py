@@ -1,0 +1,110 @@
+"""Triangular surface mesh of a 3D shape (reference rendering/mesh.py:10-74).
+
+The reference walks the leaf blocks of a subdivision one at a time: `grid_eval_pymcubes` of the block, a
+blocking copy to the host, PyMCubes on the CPU.  Here all leaf blocks are evaluated in one launch
+(`grid_eval_blocks`) and meshed on the device by marching cubes over all of them at once
+(`hu_mesh_count` / `hu_mesh_emit`): only the mesh travels to the host.
+
+PyMCubes 0.0.6 is not part of the reference tree; see DESIGN.md "Mesh" for what is and is not the same as its
+output.  Vertex positions follow mesh.py:65-68 literally, including that they sit `(sy-1)*step` lower in y than
+the samples they were computed from (a pure translation of the whole mesh; pass `true_positions=True` to
+`mesh_arrays` for the untranslated mesh).
+"""
+import ctypes
+
+import numpy
+
+from .. import hip_util
+from .. import subdivision
+from .. import util
+from ..hip_util import manager as hip_manager, check
+from .. import grid_eval as _grid_eval
+
+_BOX_TRIANGLES = [[0, 3, 1], [0, 2, 3], [1, 3, 5], [3, 7, 5], [4, 5, 6], [5, 7, 6],
+                  [0, 6, 2], [0, 4, 6], [0, 1, 5], [0, 5, 4], [3, 2, 6], [3, 6, 7]]
+
+
+class Mesh:
+    """Indexed mesh of all leaf blocks: `vertices` float64 (n, 3), `triangles` uint32 (m, 3) (global
+    vertex ids), and per block the first vertex / triangle (`block_vertex_start`, `block_triangle_start`,
+    length blocks + 1) so that block b is `vertices[vs[b]:vs[b+1]]`, `triangles[ts[b]:ts[b+1]] - vs[b]`."""
+
+    def __init__(self, vertices, triangles, block_vertex_start, block_triangle_start, samples, kernel_ms):
+        self.vertices = vertices
+        self.triangles = triangles
+        self.block_vertex_start = block_vertex_start
+        self.block_triangle_start = block_triangle_start
+        self.samples = samples
+        self.kernel_ms = kernel_ms
+
+
+def mesh_blocks(leaves, true_positions=False, queue=None, download=True):
+    """Marching cubes over the leaf blocks of `subdivision_device` -> Mesh (device work + one download)."""
+    queue = queue or hip_manager.queue
+    sx, sy, sz = (int(d) for d in leaves.dims)
+    n = leaves.count
+    lib = hip_manager.lib
+    if n == 0 or min(sx, sy, sz) < 2:
+        z = numpy.zeros(n + 1, dtype=numpy.int64)
+        return Mesh(numpy.zeros((0, 3)), numpy.zeros((0, 3), numpy.uint32), z, z, 0, 0.0)
+    fields = _grid_eval.grid_eval_blocks(leaves, pymcubes=True, queue=queue)
+    dims = (ctypes.c_uint32 * 3)(sy, sx, sz)    # array axes of the pymcubes layout: (flipped y, x, z)
+    n_wg = ctypes.c_uint64(0)
+    check(lib.hu_mesh_workgroups(n, dims, ctypes.byref(n_wg)), "hu_mesh_workgroups")
+    n_wg = n_wg.value
+    counts = hip_util.Buffer(numpy.uint32, (n_wg + 1, 2), queue=queue)
+    ev0 = hip_util.Event(hip_manager, queue)
+    check(lib.hu_mesh_count(fields.device_ptr, n, dims, counts.device_ptr, queue.handle), "hu_mesh_count")
+    ev0._done()
+    prefix = counts.read(wait_for=[ev0]).copy()
+    total_v, total_t = int(prefix[n_wg, 0]), int(prefix[n_wg, 1])
+    assert total_v < 2 ** 29, "too many vertices for one call"
+    chunks = n_wg // n
+    starts = numpy.concatenate([prefix[0:n_wg:chunks], prefix[n_wg:n_wg + 1]]).astype(numpy.int64)
+    info = hip_util.Buffer(numpy.uint32, (n, sx * sy * sz), queue=queue)
+    vertices = hip_util.Buffer(numpy.float64, (max(total_v, 1), 3), queue=queue)
+    triangles = hip_util.Buffer(numpy.uint32, (max(total_t, 1), 3), queue=queue)
+    o = (ctypes.c_double * 3)(leaves.origin.x, leaves.origin.y, leaves.origin.z)
+    step = float(leaves.step)
+    ev1 = hip_util.Event(hip_manager, queue)
+    check(lib.hu_mesh_emit(fields.device_ptr, leaves.blocks.device_ptr, n, float(leaves.resolution), o, step, dims,
+                           (sy - 1) * step if true_positions else 0.0, counts.device_ptr, info.device_ptr,
+                           vertices.device_ptr, triangles.device_ptr, queue.handle), "hu_mesh_emit")
+    ev1._done()
+    if download:
+        v = vertices.read(wait_for=[ev1])[:total_v].copy()
+        t = triangles.read()[:total_t].copy()
+    else:
+        ev1.wait()
+        v = t = None
+    ms = ev0.elapsed_ms() + ev1.elapsed_ms()
+    for b in (fields, counts, info, vertices, triangles):
+        b.release()
+    return Mesh(v, t, starts[:, 0].copy(), starts[:, 1].copy(), n * sx * sy * sz, ms)
+
+
+def mesh_arrays(obj, subdivision_grid_size=None, true_positions=False):
+    """-> Mesh of the whole shape (all blocks; vertices are shared inside a block, not between blocks)."""
+    obj.check_dimension(required=3)
+    leaves = subdivision.subdivision_device(obj, obj.feature_size() / 2, grid_size=subdivision_grid_size).sort()
+    mesh = mesh_blocks(leaves, true_positions=true_positions)
+    leaves.blocks.release()
+    return mesh
+
+
+def triangular_mesh(obj, subdivision_grid_size=None, debug_subdivision_boxes=False):
+    """Generate a triangular mesh of the surface of a 3D shape.  Yields (vertices, indices) per leaf block
+    that has any triangle, like the reference's generator."""
+    obj.check_dimension(required=3)
+    if debug_subdivision_boxes:
+        _tape, _dims, boxes = subdivision.subdivision(obj, obj.feature_size() / 2, grid_size=subdivision_grid_size)
+        for box_size, box_corner, box_resolution, *_ in boxes:
+            yield ([util.Vector(i, j, k).elementwise_mul(box_size) * box_resolution + box_corner
+                    for k in range(2) for j in range(2) for i in range(2)], _BOX_TRIANGLES)
+        return
+    mesh = mesh_arrays(obj, subdivision_grid_size)
+    vs, ts = mesh.block_vertex_start, mesh.block_triangle_start
+    for b in range(len(vs) - 1):
+        if ts[b + 1] == ts[b]:
+            continue
+        yield mesh.vertices[vs[b]:vs[b + 1]], (mesh.triangles[ts[b]:ts[b + 1]] - numpy.uint32(vs[b]))

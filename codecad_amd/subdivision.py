@@ -79,6 +79,18 @@ class LeafBlocks:
         self.level_counts = level_counts  # survivors after each evaluated level
         self.samples = samples          # SDF evaluations spent
 
+    def sort(self):
+        """Order the leaf list by integer corner (x, then y, then z).  The order the kernels leave depends on
+        how workgroups raced for list space; consumers that emit per-block output (meshes) sort first so that
+        their output is reproducible.  One small host round trip (16 B per block)."""
+        if self.count > 1:
+            host = numpy.empty((self.blocks.shape[0], 4), dtype=numpy.int32)
+            self.blocks.read(out=host)
+            a = host[:self.count]
+            host[:self.count] = a[numpy.lexsort((a[:, 2], a[:, 1], a[:, 0]))]
+            self.blocks.enqueue_write(host).wait()
+        return self
+
     def int_corners(self):
         """(count, 3) int32 numpy array, sorted lexicographically (deterministic order)."""
         if self.count == 0:

@@ -171,6 +171,31 @@ int hu_process_polygon_blocks(const void* corners_dev, const int32_t* blocks_dev
                               const uint32_t dims[2], void* vertices_dev, uint32_t* links_dev,
                               uint32_t* starts_dev, uint32_t* start_counters_dev, void* stream);
 
+/* ---- leaf-block consumer: marching cubes ------------------- */
+/* Replaces the per-block copy + `mcubes.marching_cubes(block, 0)` of rendering/mesh.py:53-63 (PyMCubes
+ * 0.0.6, a dependency that is not part of the reference tree) for ALL leaf blocks at once.
+ * fields_dev: float[n_blocks][dims[0]*dims[1]*dims[2]], each block an array [A0][A1][A2] (last index
+ * fastest), inside = value <= 0; for blocks written by hu_grid_eval_blocks(layout 1) over (sx, sy, sz)
+ * samples pass dims = (sy, sx, sz).  Work is split into workgroups of 256 samples:
+ * hu_mesh_workgroups gives their number n.
+ * hu_mesh_count: wg_counts_dev uint32[2*(n+1)] <- exclusive prefix of (vertices, triangles) per
+ * workgroup; entry n holds the totals (read it back to size the outputs; block b starts at
+ * workgroup b*n/n_blocks).  Asynchronous.
+ * hu_mesh_emit: vertices_dev double[total_vertices][3] in world coordinates exactly as mesh.py:65-68
+ * computes them (swap the first two array axes, negate y, * step, + block corner, all in fp64; block
+ * corner = int_corner*resolution + origin), plus y_offset on y (0 = the reference's placement, which
+ * sits (A0-1)*step below the true one; (A0-1)*step = true positions); triangles_dev
+ * uint32[total_triangles][3], global vertex ids, anticlockwise seen from outside the solid;
+ * info_dev: scratch uint32[n_blocks*samples].  Order: vertices by owning sample then axis, triangles by
+ * cell -- deterministic, no atomics.  At most 2^29 vertices per call. */
+int hu_mesh_workgroups(uint32_t n_blocks, const uint32_t dims[3], uint64_t* n_workgroups);
+int hu_mesh_count(const float* fields_dev, uint32_t n_blocks, const uint32_t dims[3],
+                  uint32_t* wg_counts_dev, void* stream);
+int hu_mesh_emit(const float* fields_dev, const int32_t* blocks_dev, uint32_t n_blocks,
+                 double resolution, const double origin[3], double step, const uint32_t dims[3],
+                 double y_offset, const uint32_t* wg_counts_dev, uint32_t* info_dev,
+                 double* vertices_dev, uint32_t* triangles_dev, void* stream);
+
 /* Per-tape specialisation (the reference's generate_fixed_eval_source_code, nodes/codegen.py:137-204):
  * unroll the decoded program into straight-line gfx950 code with hipRTC, using the op library
  * headers found in `include_dir` (codecad_amd/csrc).  Afterwards every launch with this tape runs

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
 _lib = None
 
-__all__ = ["build", "lib", "evaluate_points", "grid_eval", "grid_eval_pymcubes", "ray_caster", "bitmap", "process_polygon",
+__all__ = ["build", "lib", "evaluate_points", "grid_eval", "grid_eval_pymcubes", "ray_caster", "bitmap", "process_polygon", "marching_cubes",
            "subdivision_step", "mass_properties", "det_math"]
 
 _f32p = ctypes.POINTER(ctypes.c_float)
@@ -23,7 +23,7 @@ _u8p = ctypes.POINTER(ctypes.c_uint8)
 
 def build(force=False):
     """Compile the oracle with gcc (a few seconds).  Building the checker is not using it."""
-    src = [os.path.join(_HERE, f) for f in ("sdf_oracle.c", "det_math.h", "Makefile")]
+    src = [os.path.join(_HERE, f) for f in ("sdf_oracle.c", "det_math.h", "mc_table.h", "Makefile")]
     if (not force and os.path.exists(_LIB_PATH)
             and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in src)):
         return _LIB_PATH
@@ -191,3 +191,23 @@ def process_polygon(corners, box_corner, box_step):
                                         vertices.ctypes.data_as(_f32p), links.ctypes.data_as(_u32p),
                                         starts.ctypes.data_as(_u32p), ctypes.byref(count)), "process_polygon")
     return vertices, links, starts[:count.value].copy()
+
+
+def marching_cubes(field):
+    """Marching cubes of one block (3D float32 array, inside = value <= 0) -> (vertices float64 (n, 3) in array
+    coordinates, triangles uint32 (m, 3)); ordering and orientation as documented in sdf_oracle.c."""
+    f = np.ascontiguousarray(field, dtype=np.float32)
+    assert f.ndim == 3
+    fn = lib().oracle_marching_cubes
+    fn.restype = ctypes.c_int
+    nv, nt = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    dims = [ctypes.c_uint32(int(d)) for d in f.shape]
+    _f64p = ctypes.POINTER(ctypes.c_double)
+    _check(fn(f.ctypes.data_as(_f32p), *dims, ctypes.cast(None, _f64p), ctypes.c_uint64(0), ctypes.cast(None, _u32p),
+              ctypes.c_uint64(0), ctypes.byref(nv), ctypes.byref(nt)), "marching_cubes")
+    vertices = np.zeros((nv.value, 3), dtype=np.float64)
+    triangles = np.zeros((nt.value, 3), dtype=np.uint32)
+    _check(fn(f.ctypes.data_as(_f32p), *dims, vertices.ctypes.data_as(_f64p), ctypes.c_uint64(nv.value),
+              triangles.ctypes.data_as(_u32p), ctypes.c_uint64(nt.value), ctypes.byref(nv), ctypes.byref(nt)),
+           "marching_cubes")
+    return vertices, triangles

@@ -885,3 +885,84 @@ int oracle_process_polygon(const float *corners, uint32_t gx, uint32_t gy, const
             }
     return 0;
 }
+
+/* ====================================================================================
+ * Marching cubes over one block of samples -- SURVEY.md section 8(f) rank 2, the consumer of
+ * grid_eval_pymcubes (reference rendering/mesh.py:53-63: `mcubes.marching_cubes(block, 0)`).
+ * The algorithm lives in a third-party dependency that is NOT in /root/reference: PyMCubes 0.0.6
+ * (requirements.txt:11).  This restates the published algorithm (Lorensen & Cline 1987: one case
+ * index per cell from the 8 corner signs, a case table of triangles over the 12 cube edges, vertices
+ * by linear interpolation along edges, shared between cells) with a case table derived in
+ * tools/gen_mc_table.py.  PARITY UNPINNED against PyMCubes itself (its table's choices on
+ * ambiguous faces, its triangle order and its vertex order cannot be observed here); pinned by the
+ * reference's own mesh test (tests/test_mesh.py:12-29: the mesh must be watertight) and by geometric
+ * properties, tests/test_mesh.py.
+ *   field: float[A0*A1*A2], index a2 + A2*(a1 + A1*a0); inside = value <= 0.
+ *   vertices: array coordinates, double[.][3]; one per active edge, ordered by owning sample (linear
+ *     index, the edge's lower end point) then axis; position = owner + (0 - f1) / (f2 - f1) along the axis.
+ *   triangles: uint32[.][3] vertex ids, ordered by cell (linear index of its low corner) then table order;
+ *     anticlockwise seen from outside the solid (in right-handed array coordinates).
+ * Returns the counts; fills the arrays up to the given capacities.
+ * ================================================================================== */
+#include "mc_table.h"
+
+static const unsigned char kMcCorner[8][3] = { {0,0,0}, {1,0,0}, {1,1,0}, {0,1,0}, {0,0,1}, {1,0,1}, {1,1,1}, {0,1,1} };
+/* edge -> (owning corner, axis) */
+static const unsigned char kMcEdgeOwner[12][2] = { {0,0}, {1,1}, {3,0}, {0,1}, {4,0}, {5,1}, {7,0}, {4,1}, {0,2}, {1,2}, {2,2}, {3,2} };
+
+int oracle_marching_cubes(const float *field, uint32_t A0, uint32_t A1, uint32_t A2, double *vertices, uint64_t cap_v,
+                          uint32_t *triangles, uint64_t cap_t, uint64_t *n_vertices, uint64_t *n_triangles)
+{
+    const size_t n = (size_t)A0 * A1 * A2;
+    const size_t stride[3] = { (size_t)A1 * A2, A2, 1 };
+    const uint32_t dims[3] = { A0, A1, A2 };
+    uint32_t *info = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t)); /* first vertex id << 3 | active axes */
+    if (!info) return -1;
+    uint64_t nv = 0, nt = 0;
+    for (uint32_t a0 = 0; a0 < A0; ++a0)
+        for (uint32_t a1 = 0; a1 < A1; ++a1)
+            for (uint32_t a2 = 0; a2 < A2; ++a2) {
+                const size_t s = a2 + (size_t)A2 * (a1 + (size_t)A1 * a0);
+                const uint32_t a[3] = { a0, a1, a2 };
+                const float f1 = field[s];
+                const int in1 = f1 <= 0.0f;
+                uint32_t flags = 0;
+                info[s] = (uint32_t)nv << 3;
+                for (int axis = 0; axis < 3; ++axis) {
+                    if (a[axis] + 1 >= dims[axis]) continue;
+                    const float f2 = field[s + stride[axis]];
+                    if ((f2 <= 0.0f) == in1) continue;
+                    flags |= 1u << axis;
+                    if (nv < cap_v) {
+                        const double t = (1.0 * (0.0 - (double)f1)) / ((double)f2 - (double)f1);
+                        for (int k = 0; k < 3; ++k) vertices[3 * nv + k] = (double)a[k] + (k == axis ? t : 0.0);
+                    }
+                    ++nv;
+                }
+                info[s] |= flags;
+            }
+    for (uint32_t a0 = 0; a0 + 1 < A0; ++a0)
+        for (uint32_t a1 = 0; a1 + 1 < A1; ++a1)
+            for (uint32_t a2 = 0; a2 + 1 < A2; ++a2) {
+                const size_t s = a2 + (size_t)A2 * (a1 + (size_t)A1 * a0);
+                uint32_t cube = 0;
+                for (int m = 0; m < 8; ++m)
+                    if (field[s + kMcCorner[m][0] * stride[0] + kMcCorner[m][1] * stride[1] + kMcCorner[m][2] * stride[2]] <= 0.0f)
+                        cube |= 1u << m;
+                for (int k = 0; kMcTriangles[cube][k] >= 0; k += 3) {
+                    if (nt < cap_t)
+                        for (int j = 0; j < 3; ++j) {
+                            const int e = kMcTriangles[cube][k + j];
+                            const unsigned char *c = kMcCorner[kMcEdgeOwner[e][0]];
+                            const uint32_t axis = kMcEdgeOwner[e][1];
+                            const uint32_t w = info[s + c[0] * stride[0] + c[1] * stride[1] + c[2] * stride[2]];
+                            triangles[3 * nt + j] = (w >> 3) + (uint32_t)__builtin_popcount(w & ((1u << axis) - 1u));
+                        }
+                    ++nt;
+                }
+            }
+    free(info);
+    *n_vertices = nv;
+    *n_triangles = nt;
+    return 0;
+}
