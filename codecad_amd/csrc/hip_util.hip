@@ -447,7 +447,7 @@ int hu_tape_create(const float* tape, size_t n, hu_tape* out)
     std::string err = sdf::decode_tape(tape, n, d);
     if (!err.empty()) return fail(HU_ERR_BAD_TAPE, "malformed tape: " + err);
     hu_tape_s* t = new hu_tape_s();
-    t->n_instr = (int)d.recs.size() - sdf::kTapePadding;
+    t->n_instr = d.n_instructions;
     t->n_regs = d.n_regs;
     t->n_slots = d.n_slots;
     t->n_point_slots = d.n_point_slots;
@@ -960,17 +960,27 @@ static int mesh_shape(uint32_t n_blocks, const uint32_t dims[3], uint32_t& chunk
     int rc;
     if ((rc = check_dims(dims, samples))) return rc;
     if (samples > (1ull << 24)) return fail(HU_ERR_BAD_ARG, "a block may have at most 2^24 samples (256^3)");
-    chunks = (uint32_t)((samples + kMcBlock - 1) / kMcBlock);
+    if (dims[0] > 65535u || dims[1] > 65535u || dims[2] > 65535u) return fail(HU_ERR_BAD_ARG, "block dims must be below 65536");
+    chunks = (uint32_t)((samples + kMcPerGroup - 1) / kMcPerGroup);
     n_wg = (uint64_t)chunks * n_blocks;
     if (n_wg > 0x7fffffffull) return fail(HU_ERR_BAD_ARG, "too many workgroups in one launch");
     return HU_OK;
 }
 
-int hu_mesh_workgroups(uint32_t n_blocks, const uint32_t dims[3], uint64_t* n_workgroups)
+static void mesh_divisors(McArgs& a)
 {
-    if (!n_workgroups) return fail(HU_ERR_BAD_ARG, "NULL argument");
+    a.div_A1 = make_fast_div(a.A1);
+    a.div_A2 = make_fast_div(a.A2);
+}
+
+int hu_mesh_workgroups(uint32_t n_blocks, const uint32_t dims[3], uint64_t* n_workgroups, uint64_t* count_entries)
+{
+    if (!n_workgroups || !count_entries) return fail(HU_ERR_BAD_ARG, "NULL argument");
     uint32_t chunks;
-    return mesh_shape(n_blocks, dims, chunks, *n_workgroups);
+    int rc;
+    if ((rc = mesh_shape(n_blocks, dims, chunks, *n_workgroups))) return rc;
+    *count_entries = *n_workgroups + 1 + (*n_workgroups + kMcScanTile - 1) / kMcScanTile;
+    return HU_OK;
 }
 
 int hu_mesh_count(const float* fields_dev, uint32_t n_blocks, const uint32_t dims[3], uint32_t* wg_counts_dev, void* stream)
@@ -986,9 +996,17 @@ int hu_mesh_count(const float* fields_dev, uint32_t n_blocks, const uint32_t dim
     a.A1 = dims[1];
     a.A2 = dims[2];
     a.chunks = chunks;
+    mesh_divisors(a);
     a.wg_counts = reinterpret_cast<uint2*>(wg_counts_dev);
-    if (n_wg) hipLaunchKernelGGL(k_mc_count, dim3((uint32_t)n_wg), dim3(kMcBlock), 0, (hipStream_t)stream, a);
-    hipLaunchKernelGGL(k_mc_scan, dim3(1), dim3(1024), 0, (hipStream_t)stream, a.wg_counts, (uint32_t)n_wg);
+    // the tile totals of the scan live behind the totals entry: wg_counts_dev has n_wg + 1 + tiles entries
+    const uint32_t n = (uint32_t)n_wg, tiles = (n + kMcScanTile - 1) / kMcScanTile;
+    uint2* tile_totals = a.wg_counts + n + 1;
+    if (n) {
+        hipLaunchKernelGGL(k_mc_count, dim3(n), dim3(kMcBlock), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(k_mc_scan_tiles, dim3(tiles), dim3(kMcScanTile), 0, (hipStream_t)stream, a.wg_counts, n, tile_totals);
+    }
+    hipLaunchKernelGGL(k_mc_scan_totals, dim3(1), dim3(1024), 0, (hipStream_t)stream, tile_totals, tiles, a.wg_counts + n);
+    if (n) hipLaunchKernelGGL(k_mc_scan_add, dim3(tiles), dim3(kMcScanTile), 0, (hipStream_t)stream, a.wg_counts, n, tile_totals);
     HU_HIP(hipGetLastError());
     return HU_OK;
 }
@@ -1012,6 +1030,7 @@ int hu_mesh_emit(const float* fields_dev, const int32_t* blocks_dev, uint32_t n_
     a.A1 = dims[1];
     a.A2 = dims[2];
     a.chunks = chunks;
+    mesh_divisors(a);
     a.blocks = reinterpret_cast<const int4*>(blocks_dev);
     a.res = resolution;
     a.ox = origin[0];

@@ -180,6 +180,16 @@ __device__ __forceinline__ void quat_xform(float qx, float qy, float qz, float q
     oz = fma_(pz, K, tz + tz);
 }
 
+// Last step of the axis-rotation forms of transformation_to: p*k + 2t + offset, with k = w*w - q*q
+// (p[7]).  A quarter turn has k == 0 exactly; the product term is then an exact zero for finite p.
+template <class T> __device__ __forceinline__ V4<T> to_axis_finish(const V4<T>& in, T tx, T ty, T tz, const float* p)
+{
+    if (p[7] == 0.0f)  // wave-uniform: a tape constant
+        return v4<T>((tx + tx) + p[4], (ty + ty) + p[5], (tz + tz) + p[6], bc<T>(0.0f));
+    const T K = bc<T>(p[7]);
+    return v4<T>(fma_(in.x, K, tx + tx) + p[4], fma_(in.y, K, ty + ty) + p[5], fma_(in.z, K, tz + tz) + p[6], bc<T>(0.0f));
+}
+
 // reference shapes/simple2d.cl:1-4 (slab_x/slab_y of common.cl:33-39 inlined).  Equal to
 // perpendicular_intersection(slab_x, slab_y) (common.cl:15-31) under ==: the zero components
 // only drop exact zeros.  Written with selects, not branches: a divergent branch inside the
@@ -596,6 +606,28 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const floa
         T ox, oy, oz;
         quat_xform<T>(p[0], p[1], p[2], p[3], p[7], last.x, last.y, last.z, ox, oy, oz);
         last = v4<T>(ox + p[4], oy + p[5], oz + p[6], bc<T>(0.0f));
+        break;
+    }
+    case OPX_POINT: last = v4<T>(px, py, pz, bc<T>(0.0f)); break;
+    case OPX_TO_SCALE:  // p[7] = w*w; every cross/dot term is an exact zero
+        last = v4<T>(last.x * p[7] + p[4], last.y * p[7] + p[5], last.z * p[7] + p[6], bc<T>(0.0f));
+        break;
+    case OPX_TO_AXIS_X: {
+        const float q = p[0], qw = p[3];
+        const T d = last.x * q, cy = -(last.z * q), cz = last.y * q;
+        last = to_axis_finish<T>(last, d * q, cy * qw, cz * qw, p);
+        break;
+    }
+    case OPX_TO_AXIS_Y: {
+        const float q = p[1], qw = p[3];
+        const T d = last.y * q, cx = last.z * q, cz = -(last.x * q);
+        last = to_axis_finish<T>(last, cx * qw, d * q, cz * qw, p);
+        break;
+    }
+    case OPX_TO_AXIS_Z: {
+        const float q = p[2], qw = p[3];
+        const T d = last.z * q, cx = -(last.y * q), cy = last.x * q;
+        last = to_axis_finish<T>(last, cx * qw, cy * qw, d * q, p);
         break;
     }
     case OP_TRANSFORMATION_FROM: {

@@ -50,6 +50,7 @@ struct DecodedTape {
     std::vector<Rec> recs;        // full program: every slot is a float4 (direction + distance / point)
     std::vector<Rec> recs_do;     // distance-only program: point slots (float4) and result slots (float)
     std::vector<float> extra;     // polygon2d vertex data
+    int n_instructions = 0;       // instructions of the TAPE (the decoder may add internal records)
     int n_regs = 0;               // highest register index of the TAPE + 1 (what the reference allocates)
     int n_slots = 0;              // float4 slots the full program needs
     int n_point_slots = 0;        // distance-only program: float4 slots
@@ -63,6 +64,7 @@ inline bool produces_point(uint32_t op)
     switch (op) {
     case OP_INITIAL_TRANSFORMATION_TO: case OP_TRANSFORMATION_TO: case OP_SYMMETRICAL_TO: case OP_REPETITION:
     case OP_CIRCULAR_REPETITION_TO: case OP_REVOLUTION_TO: case OP_TWIST_REVOLUTION_TO:
+    case OPX_POINT: case OPX_TO_SCALE: case OPX_TO_AXIS_X: case OPX_TO_AXIS_Y: case OPX_TO_AXIS_Z:
         return true;
     default: return false;
     }
@@ -189,9 +191,32 @@ inline std::string decode_tape(const float* tape, size_t n, DecodedTape& out)
                 r.p[4] = -(p[1] * cos_(p[0]));
                 break;
             case OP_INITIAL_TRANSFORMATION_TO:
-            case OP_TRANSFORMATION_TO:
+            case OP_TRANSFORMATION_TO: {
                 r.p[7] = q_k(p);
+                // canonical arithmetic: a zero offset component is +0, so a transformed coordinate is
+                // never -0 whichever form computes it (the reference builds with -cl-no-signed-zeros)
+                for (int i = 4; i < 7; ++i) r.p[i] = p[i] + 0.0f;
+                const bool zx = p[0] == 0.0f, zy = p[1] == 0.0f, zz = p[2] == 0.0f;
+                uint32_t special = op;
+#ifndef SDF_TO_SPECIAL
+#define SDF_TO_SPECIAL 1
+#endif
+                if (!SDF_TO_SPECIAL) special = op;
+                else if (zx && zy && zz) special = OPX_TO_SCALE;
+                else if (zy && zz) special = OPX_TO_AXIS_X;
+                else if (zx && zz) special = OPX_TO_AXIS_Y;
+                else if (zx && zy) special = OPX_TO_AXIS_Z;
+                if (special != op) {
+                    if (op == OP_INITIAL_TRANSFORMATION_TO) {
+                        Rec point;
+                        std::memset(&point, 0, sizeof(point));
+                        point.hdr = OPX_POINT;
+                        out.recs.push_back(point);
+                    }
+                    r.hdr = special | (reg << 8);
+                }
                 break;
+            }
             case OP_TRANSFORMATION_FROM: {
                 float scale = q_scale(p);
                 r.p[4] = q_k(p);
@@ -247,6 +272,7 @@ inline std::string decode_tape(const float* tape, size_t n, DecodedTape& out)
         bool uses_reg = (op == OP_STORE || op == OP_LOAD || info.arity == 2);
         if (uses_reg && int(reg) + 1 > out.n_regs) out.n_regs = int(reg) + 1;
         out.recs.push_back(r);
+        ++out.n_instructions;
         if (op == OP_RETURN) { returned = true; break; }
     }
     if (!returned) return "tape does not end with _return";

@@ -22,7 +22,13 @@ enum Op : uint32_t {
     // provably equal (under ==) to the general op.  transformation_from rotates a DIRECTION by
     // the quaternion; when its vector part is zero (pure scale) or has a single non-zero
     // component (rotation about a coordinate axis) most products are exact zeros.
-    OPX_FROM_SCALE = 29, OPX_FROM_AXIS_X = 30, OPX_FROM_AXIS_Y = 31, OPX_FROM_AXIS_Z = 32
+    OPX_FROM_SCALE = 29, OPX_FROM_AXIS_X = 30, OPX_FROM_AXIS_Y = 31, OPX_FROM_AXIS_Z = 32,
+    // The same for transformation_to, which rotates the sample POINT: with a zero vector part the
+    // transform is a scaling, with one non-zero component a rotation about a coordinate axis, and
+    // the dropped terms are exact zeros for every finite point (DESIGN.md "Canonical arithmetic":
+    // this reduction is part of the arithmetic contract; the oracle applies it too).  OPX_POINT
+    // loads the sample point, so that initial_transformation_to can use the same reduced forms.
+    OPX_POINT = 33, OPX_TO_SCALE = 34, OPX_TO_AXIS_X = 35, OPX_TO_AXIS_Y = 36, OPX_TO_AXIS_Z = 37
 };
 
 

@@ -49,10 +49,10 @@ def mesh_blocks(leaves, true_positions=False, queue=None, download=True):
         return Mesh(numpy.zeros((0, 3)), numpy.zeros((0, 3), numpy.uint32), z, z, 0, 0.0)
     fields = _grid_eval.grid_eval_blocks(leaves, pymcubes=True, queue=queue)
     dims = (ctypes.c_uint32 * 3)(sy, sx, sz)    # array axes of the pymcubes layout: (flipped y, x, z)
-    n_wg = ctypes.c_uint64(0)
-    check(lib.hu_mesh_workgroups(n, dims, ctypes.byref(n_wg)), "hu_mesh_workgroups")
+    n_wg, entries = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    check(lib.hu_mesh_workgroups(n, dims, ctypes.byref(n_wg), ctypes.byref(entries)), "hu_mesh_workgroups")
     n_wg = n_wg.value
-    counts = hip_util.Buffer(numpy.uint32, (n_wg + 1, 2), queue=queue)
+    counts = hip_util.Buffer(numpy.uint32, (entries.value, 2), queue=queue)
     ev0 = hip_util.Event(hip_manager, queue)
     check(lib.hu_mesh_count(fields.device_ptr, n, dims, counts.device_ptr, queue.handle), "hu_mesh_count")
     ev0._done()

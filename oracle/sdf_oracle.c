@@ -102,12 +102,36 @@ static inline f4 union_op(float r, f4 a, f4 b) { return rounded_union(r, a, b); 
 static inline f4 intersection_op(float r, f4 a, f4 b) { return neg4(rounded_union(r, neg4(a), neg4(b))); }
 static inline f4 subtraction_op(float r, f4 a, f4 b) { return neg4(rounded_union(r, neg4(a), b)); }
 
-/* shapes/common.cl:78-98 (initial_)transformation_to_op */
+/* shapes/common.cl:78-98 (initial_)transformation_to_op.
+ * Canonical arithmetic: a zero offset component counts as +0, so a transformed
+ * coordinate is never -0 (the reference builds with -cl-no-signed-zeros and cannot tell); and when
+ * the quaternion's vector part is zero, or has a single non-zero component, the terms that are
+ * products with those zeros are dropped -- for every finite point they are exact zeros, so this is
+ * the general formula's value; it only differs for infinite / NaN points (0 * inf). */
 static inline f4 transformation_to_op(const float *p, f4 point)
 {
+    const float ox = p[4] + 0.0f, oy = p[5] + 0.0f, oz = p[6] + 0.0f;
+    const int zx = p[0] == 0.0f, zy = p[1] == 0.0f, zz = p[2] == 0.0f;
     f4 q = mk4(p[0], p[1], p[2], p[3]);
-    f4 t = quaternion_transform(q, point);
-    return mk4(t.x + p[4], t.y + p[5], t.z + p[6], 0.0f);
+    if (!(zx + zy + zz >= 2)) {
+        f4 t = quaternion_transform(q, point);
+        return mk4(t.x + ox, t.y + oy, t.z + oz, 0.0f);
+    }
+    const float k = fmaf(q.w, q.w, -dot3(q, q));
+    if (zx && zy && zz) return mk4(point.x * k + ox, point.y * k + oy, point.z * k + oz, 0.0f);
+    float tx, ty, tz;
+    if (zy && zz) {          /* rotation about x */
+        float d = point.x * q.x, cy = -(point.z * q.x), cz = point.y * q.x;
+        tx = d * q.x; ty = cy * q.w; tz = cz * q.w;
+    } else if (zx && zz) {   /* about y */
+        float d = point.y * q.y, cx = point.z * q.y, cz = -(point.x * q.y);
+        tx = cx * q.w; ty = d * q.y; tz = cz * q.w;
+    } else {                 /* about z */
+        float d = point.z * q.z, cx = -(point.y * q.z), cy = point.x * q.z;
+        tx = cx * q.w; ty = cy * q.w; tz = d * q.z;
+    }
+    if (k == 0.0f) return mk4((tx + tx) + ox, (ty + ty) + oy, (tz + tz) + oz, 0.0f);
+    return mk4(fmaf(point.x, k, tx + tx) + ox, fmaf(point.y, k, ty + ty) + oy, fmaf(point.z, k, tz + tz) + oz, 0.0f);
 }
 
 /* shapes/common.cl:100-110 transformation_from_op */

@@ -161,12 +161,12 @@ def hip_marching_cubes(hip, fields, true_positions=False):
     blocks = hip_util.Buffer(np.int32, (n, 4))
     blocks.enqueue_write(np.zeros((n, 4), np.int32)).wait()
     dims = (ctypes.c_uint32 * 3)(a0, a1, a2)
-    n_wg = ctypes.c_uint64(0)
-    assert lib.hu_mesh_workgroups(n, dims, ctypes.byref(n_wg)) == 0
-    counts = hip_util.Buffer(np.uint32, (n_wg.value + 1, 2))
+    n_wg, entries = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    assert lib.hu_mesh_workgroups(n, dims, ctypes.byref(n_wg), ctypes.byref(entries)) == 0
+    counts = hip_util.Buffer(np.uint32, (entries.value, 2))
     assert lib.hu_mesh_count(fields_dev.device_ptr, n, dims, counts.device_ptr, hip.queue.handle) == 0, lib.hu_last_error()
     prefix = counts.read().copy()
-    tv, tt = int(prefix[-1, 0]), int(prefix[-1, 1])
+    tv, tt = int(prefix[n_wg.value, 0]), int(prefix[n_wg.value, 1])
     info = hip_util.Buffer(np.uint32, (n, a0 * a1 * a2))
     vertices = hip_util.Buffer(np.float64, (max(tv, 1), 3))
     triangles = hip_util.Buffer(np.uint32, (max(tt, 1), 3))
@@ -175,7 +175,7 @@ def hip_marching_cubes(hip, fields, true_positions=False):
                             info.device_ptr, vertices.device_ptr, triangles.device_ptr, hip.queue.handle) == 0, lib.hu_last_error()
     v, t = vertices.read()[:tv].copy(), triangles.read()[:tt].copy()
     chunks = n_wg.value // n
-    starts = np.concatenate([prefix[0:n_wg.value:chunks], prefix[-1:]]).astype(np.int64)
+    starts = np.concatenate([prefix[0:n_wg.value:chunks], prefix[n_wg.value:n_wg.value + 1]]).astype(np.int64)
     for b in (fields_dev, blocks, counts, info, vertices, triangles):
         b.release()
     return v, t, starts
