@@ -511,7 +511,8 @@ int hu_grid_eval_slab(hu_tape t, const float corner[4], float step, const uint32
         const uint32_t max_x = (uint32_t)((1ull << 30) / plane);
         SpecEval ev{t->extra_dev};
         float cx = corner[0], cy = corner[1], cz = corner[2];
-        uint32_t sx = dims[0], sy = dims[1], sz = dims[2];
+        uint32_t sx = dims[0];
+        Dim sy = make_dim(dims[1]), sz = make_dim(dims[2]);
         for (uint32_t done = 0; done < x_count;) {
             const uint32_t nx = (x_count - done < max_x) ? (x_count - done) : max_x;
             uint32_t n_cells = (uint32_t)(nx * plane), xs = x0 + done;
@@ -538,7 +539,7 @@ int hu_grid_eval_slab(hu_tape t, const float corner[4], float step, const uint32
 #define HU_LAUNCH_DENSE(L, D, NV)                                                                                  \
     hipLaunchKernelGGL((k_grid_eval<InterpEval<D>, L, NV>), dim3(blocks), dim3(ls.block), ls.lds, (hipStream_t)stream, \
                        (InterpEval<D>{ls.prog, t->extra_dev, ls.n4}), corner[0], corner[1], corner[2], step, dims[0],  \
-                       dims[1], dims[2], x0 + done, n_cells, o)
+                       make_dim(dims[1]), make_dim(dims[2]), x0 + done, n_cells, o)
         const bool d_only = layout == 1 && distance_only(t);
         if (ls.voxels_per_lane == 2) {
             if (layout == 0) HU_LAUNCH_DENSE(0, false, 2);
@@ -586,7 +587,8 @@ int hu_grid_eval_blocks(hu_tape t, const int32_t* blocks_dev, uint32_t n_blocks,
         SpecEval ev{t->extra_dev};
         const int4* b = (const int4*)blocks_dev;
         double res = resolution, ox = origin[0], oy = origin[1], oz = origin[2];
-        uint32_t sx = dims[0], sy = dims[1], sz = dims[2];
+        uint32_t sx = dims[0];
+        Dim sy = make_dim(dims[1]), sz = make_dim(dims[2]);
         void* args[] = {&ev, &b, &chunks, &res, &ox, &oy, &oz, &step, &sx, &sy, &sz, &out_dev};
         HU_HIP(hipModuleLaunchKernel(t->spec->blocks[layout], chunks * n_blocks, 1, 1, kSpecBlock, 1, 1, 0, (hipStream_t)stream,
                                      args, nullptr));
@@ -602,7 +604,7 @@ int hu_grid_eval_blocks(hu_tape t, const int32_t* blocks_dev, uint32_t n_blocks,
 #define HU_LAUNCH_BLOCKS(L, D, NV)                                                                                 \
     hipLaunchKernelGGL((k_grid_eval_blocks<InterpEval<D>, L, NV>), grid, block, ls.lds, (hipStream_t)stream,           \
                        (InterpEval<D>{ls.prog, t->extra_dev, ls.n4}), (const int4*)blocks_dev, chunks, resolution,        \
-                       origin[0], origin[1], origin[2], step, dims[0], dims[1], dims[2], out_dev)
+                       origin[0], origin[1], origin[2], step, dims[0], make_dim(dims[1]), make_dim(dims[2]), out_dev)
     const bool d_only = layout == 1 && distance_only(t);
     if (ls.voxels_per_lane == 2) {
         if (layout == 0) HU_LAUNCH_BLOCKS(0, false, 2);
@@ -635,6 +637,7 @@ int launch_classify(hu_tape t, ClassifyArgs& a, uint32_t n_parents, const uint32
     if (t->spec) {
         const uint32_t per_block = kSpecBlock * kSpecVoxelsPerLane;
         a.sx = dims[0]; a.sy = dims[1]; a.sz = dims[2];
+        a.dy = make_dim(dims[1]); a.dz = make_dim(dims[2]);
         a.chunks = (uint32_t)((cells + per_block - 1) / per_block);
         a.scratch_offset = 0;
         if ((uint64_t)a.chunks * n_parents > 0x7fffffffull) return fail(HU_ERR_BAD_ARG, "too many workgroups in one launch");
@@ -650,6 +653,8 @@ int launch_classify(hu_tape t, ClassifyArgs& a, uint32_t n_parents, const uint32
     a.sx = dims[0];
     a.sy = dims[1];
     a.sz = dims[2];
+    a.dy = make_dim(dims[1]);
+    a.dz = make_dim(dims[2]);
     const uint32_t per_block = ls.block * ls.voxels_per_lane;
     a.chunks = (uint32_t)((cells + per_block - 1) / per_block);
     a.scratch_offset = (uint32_t)ls.regfile_bytes;

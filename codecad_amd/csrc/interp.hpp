@@ -40,8 +40,44 @@ __device__ __forceinline__ f2 abs_(f2 x) { return __builtin_elementwise_abs(x); 
 __device__ __forceinline__ f2 copysign_(f2 m, f2 s) { return __builtin_elementwise_copysign(m, s); }
 __device__ __forceinline__ float rint_(float x) { return __builtin_rintf(x); }
 __device__ __forceinline__ f2 rint_(f2 x) { return __builtin_elementwise_rint(x); }
-__device__ __forceinline__ float sel(bool m, float a, float b) { return m ? a : b; }
-__device__ __forceinline__ f2 sel(i2 m, f2 a, f2 b) { return m ? a : b; }
+// Per-voxel predicates: the lane's own flag(s) PLUS the wavefront mask of each flag, built up
+// alongside (`w` = ballot of `v`).  Every flag starts as a float compare, whose result IS its
+// wavefront mask in an SGPR pair, and &, | combine the masks with scalar instructions; so
+// "does any lane of the wavefront..." costs no vector instruction.  Asking the compiler for
+// ballot(a && b) instead makes it rebuild the mask through a v_cndmask + v_cmp pair (measured: 4 VALU
+// instructions per test in the rectangle op).  Unused masks are dead code.
+struct m1 { bool v; uint64_t w; };
+struct m2 { bool x, y; uint64_t wx, wy; };
+__device__ __forceinline__ m1 mk(bool c) { return m1{c, __builtin_amdgcn_ballot_w64(c)}; }
+__device__ __forceinline__ m2 mk(bool cx, bool cy) { return m2{cx, cy, __builtin_amdgcn_ballot_w64(cx), __builtin_amdgcn_ballot_w64(cy)}; }
+__device__ __forceinline__ m1 operator&(m1 a, m1 b) { return m1{a.v && b.v, a.w & b.w}; }
+__device__ __forceinline__ m1 operator|(m1 a, m1 b) { return m1{a.v || b.v, a.w | b.w}; }
+__device__ __forceinline__ m2 operator&(m2 a, m2 b) { return m2{a.x && b.x, a.y && b.y, a.wx & b.wx, a.wy & b.wy}; }
+__device__ __forceinline__ m2 operator|(m2 a, m2 b) { return m2{a.x || b.x, a.y || b.y, a.wx | b.wx, a.wy | b.wy}; }
+__device__ __forceinline__ m1 gt(float a, float b) { return mk(a > b); }
+__device__ __forceinline__ m1 lt(float a, float b) { return mk(a < b); }
+__device__ __forceinline__ m1 ge(float a, float b) { return mk(a >= b); }
+__device__ __forceinline__ m1 eq(float a, float b) { return mk(a == b); }
+__device__ __forceinline__ m1 not_ge(float a, float b) { return mk(!(a >= b)); }  // true for NaN
+__device__ __forceinline__ m1 not_le(float a, float b) { return mk(!(a <= b)); }
+__device__ __forceinline__ m2 gt(f2 a, f2 b) { return mk(a.x > b.x, a.y > b.y); }
+__device__ __forceinline__ m2 lt(f2 a, f2 b) { return mk(a.x < b.x, a.y < b.y); }
+__device__ __forceinline__ m2 ge(f2 a, f2 b) { return mk(a.x >= b.x, a.y >= b.y); }
+__device__ __forceinline__ m2 eq(f2 a, f2 b) { return mk(a.x == b.x, a.y == b.y); }
+__device__ __forceinline__ m2 gt(f2 a, float b) { return mk(a.x > b, a.y > b); }
+__device__ __forceinline__ m2 lt(f2 a, float b) { return mk(a.x < b, a.y < b); }
+__device__ __forceinline__ m2 ge(f2 a, float b) { return mk(a.x >= b, a.y >= b); }
+__device__ __forceinline__ m2 eq(f2 a, float b) { return mk(a.x == b, a.y == b); }
+__device__ __forceinline__ m2 not_ge(f2 a, float b) { return mk(!(a.x >= b), !(a.y >= b)); }
+__device__ __forceinline__ m2 not_le(f2 a, float b) { return mk(!(a.x <= b), !(a.y <= b)); }
+__device__ __forceinline__ float sel(m1 m, float a, float b) { return m.v ? a : b; }
+__device__ __forceinline__ f2 sel(m2 m, f2 a, f2 b)
+{
+    f2 r;
+    r.x = m.x ? a.x : b.x;
+    r.y = m.y ? a.y : b.y;
+    return r;
+}
 __device__ __forceinline__ float get(float v, int) { return v; }
 __device__ __forceinline__ float get(f2 v, int i) { return i ? v.y : v.x; }
 __device__ __forceinline__ f2 make_f2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }  // NOT (f2)(a, b): in C++ that casts a comma expression
@@ -53,11 +89,11 @@ __device__ __forceinline__ f2 make_f2(float a, float b) { f2 r; r.x = a; r.y = b
 #define SDF_SKIP_CORNER 1
 #endif
 #if SDF_SKIP_CORNER
-__device__ __forceinline__ bool any_lane(bool m) { return __ballot(m) != 0ull; }
-__device__ __forceinline__ bool any_lane(i2 m) { return __ballot((m.x | m.y) != 0) != 0ull; }
+__device__ __forceinline__ bool any_lane(m1 m) { return m.w != 0ull; }
+__device__ __forceinline__ bool any_lane(m2 m) { return (m.wx | m.wy) != 0ull; }
 #else
-__device__ __forceinline__ bool any_lane(bool) { return true; }
-__device__ __forceinline__ bool any_lane(i2) { return true; }
+__device__ __forceinline__ bool any_lane(m1) { return true; }
+__device__ __forceinline__ bool any_lane(m2) { return true; }
 #endif
 
 template <class T> struct V4 { T x, y, z, w; };
@@ -110,17 +146,25 @@ template <class T> __device__ __forceinline__ T dot3(T ax, T ay, T az, T bx, T b
 #ifndef SDF_FAST_CR_MATH
 #define SDF_FAST_CR_MATH 1
 #endif
+// In straight-line (per-tape) code the compiler otherwise speculates the small IEEE sqrt block and pays its
+// 13 VALU instructions per voxel every time (measured: sponge(4) distance-only 1.35 -> 1.02 ms with the
+// branch kept).  Inside the interpreter's dispatch loop the same marker has the opposite effect (3.0 ->
+// 5.5 ms: it defeats the loop's uniform-region layout), so only the run-time-compiled code uses it.
+#ifdef __HIPCC_RTC__
+#define SDF_KEEP_BRANCH(why) asm volatile("; " why)
+#else
+#define SDF_KEEP_BRANCH(why)
+#endif
 constexpr float kFastLo = 0x1p-100f, kFastHi = 0x1p100f;
 __device__ __forceinline__ float rsq_hw(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ f2 rsq_hw(f2 x) { return make_f2(__builtin_amdgcn_rsqf(x.x), __builtin_amdgcn_rsqf(x.y)); }
 __device__ __forceinline__ float rcp_hw(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ f2 rcp_hw(f2 x) { return make_f2(__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)); }
-__device__ __forceinline__ bool wave_any(bool m) { return __ballot(m) != 0ull; }
-__device__ __forceinline__ bool wave_any(i2 m) { return __ballot((m.x | m.y) != 0) != 0ull; }
-__device__ __forceinline__ bool outside_fast_range(float x) { return !(x >= kFastLo && x <= kFastHi); }
-__device__ __forceinline__ i2 outside_fast_range(f2 x) { return ~((x >= kFastLo) & (x <= kFastHi)); }
-template <class T> struct mask_of { using type = bool; static __device__ __forceinline__ bool all() { return true; } };
-template <> struct mask_of<f2> { using type = i2; static __device__ __forceinline__ i2 all() { i2 m; m.x = -1; m.y = -1; return m; } };
+__device__ __forceinline__ bool wave_any(m1 m) { return m.w != 0ull; }
+__device__ __forceinline__ bool wave_any(m2 m) { return (m.wx | m.wy) != 0ull; }
+template <class T> __device__ __forceinline__ auto outside_fast_range(T x) { return not_ge(x, kFastLo) | not_le(x, kFastHi); }
+template <class T> struct mask_of { using type = m1; static __device__ __forceinline__ m1 all() { return m1{true, ~0ull}; } };
+template <> struct mask_of<f2> { using type = m2; static __device__ __forceinline__ m2 all() { return m2{true, true, ~0ull, ~0ull}; } };
 
 // sqrt(x), identical to sqrt_(x) in every lane/voxel where `used` holds
 template <class T, class M> __device__ __forceinline__ T sqrt_cr(T x, M used)
@@ -129,7 +173,10 @@ template <class T, class M> __device__ __forceinline__ T sqrt_cr(T x, M used)
     const T y = rsq_hw(x);
     const T s0 = x * y, h = 0.5f * y;
     T s = fma_(fma_(-s0, s0, x), h, s0);
-    if (wave_any(used & outside_fast_range(x))) s = sqrt_(x);
+    if (wave_any(used & outside_fast_range(x))) {
+        SDF_KEEP_BRANCH("IEEE sqrt for out-of-range input");
+        s = sqrt_(x);
+    }
     return s;
 #else
     return sqrt_(x);
@@ -145,6 +192,7 @@ template <class T, class M> __device__ __forceinline__ void sqrt_inv_cr(T x, M u
     const T r0 = rcp_hw(s);
     r = fma_(fma_(-s, r0, bc<T>(1.0f)), r0, r0);
     if (wave_any(used & outside_fast_range(x))) {
+        SDF_KEEP_BRANCH("IEEE sqrt and divide for out-of-range input");
         s = sqrt_(x);
         r = 1.0f / s;
     }
@@ -199,12 +247,19 @@ template <class T> __device__ __forceinline__ V4<T> rectangle_op(float hw, float
     const T one = bc<T>(1.0f), zero = bc<T>(0.0f);
     T sx = copysign_(one, c.x), sy = copysign_(one, c.y);
     T wx = abs_(c.x) - hw, wy = abs_(c.y) - hh;
-    auto corner = (wx > 0.0f) & (wy > 0.0f);
-    auto xs = wx > wy;
-    T dist = wx, inv = wx;  // only read where `corner` holds
-    if (any_lane(corner)) sqrt_inv_cr(fma_(wy, wy, wx * wx), corner, dist, inv);
-    return v4<T>(sel(corner, sx * (wx * inv), sel(xs, sx, zero)), sel(corner, sy * (wy * inv), sel(xs, zero, sy)), zero,
-                 sel(corner, dist, sel(xs, wx, wy)));
+    auto corner = gt(wx, 0.0f) & gt(wy, 0.0f);
+    auto xs = gt(wx, wy);
+    // the nearer slab everywhere; the corner region (outside both slabs) is patched in only when some
+    // lane of the wavefront is in it, so the common case pays three selects per voxel, not six
+    V4<T> r = v4<T>(sel(xs, sx, zero), sel(xs, zero, sy), zero, sel(xs, wx, wy));
+    if (any_lane(corner)) {
+        T dist, inv;
+        sqrt_inv_cr(fma_(wy, wy, wx * wx), corner, dist, inv);
+        r.x = sel(corner, sx * (wx * inv), r.x);
+        r.y = sel(corner, sy * (wy * inv), r.y);
+        r.w = sel(corner, dist, r.w);
+    }
+    return r;
 }
 
 // Distance-only forms (DISTANCE_ONLY interpreter): the same operations that produce .w above,
@@ -212,25 +267,31 @@ template <class T> __device__ __forceinline__ V4<T> rectangle_op(float hw, float
 // distance (tape.hpp: direction_feeds_distance).
 template <class T> __device__ __forceinline__ T perp_w(T a, T b)
 {
-    auto corner = (a > 0.0f) & (b > 0.0f);
+    auto corner = gt(a, 0.0f) & gt(b, 0.0f);
     T dist = a;
     if (any_lane(corner)) dist = sqrt_cr(fma_(b, b, a * a), corner);
-    return sel(corner, dist, sel(a > b, a, b));
+    return sel(corner, dist, sel(gt(a, b), a, b));
 }
 
 // reference shapes/simple3d.cl:18-21 = perpendicular_intersection(slab_z(h, coords), in)
 template <class T> __device__ __forceinline__ V4<T> extrusion_op(float hh, V4<T> in, V4<T> coords)
 {
-    const T one = bc<T>(1.0f), zero = bc<T>(0.0f);
-    T sz = copysign_(one, coords.z);
+    const T zero = bc<T>(0.0f);
+    T sz = copysign_(bc<T>(1.0f), coords.z);
     T wz = abs_(coords.z) - hh;
-    auto corner = (wz > 0.0f) & (in.w > 0.0f);
-    auto cap = wz > in.w;
-    T dist = wz, inv = wz;  // only read where `corner` holds
-    if (any_lane(corner)) sqrt_inv_cr(fma_(in.w, in.w, wz * wz), corner, dist, inv);
-    T m1 = wz * inv, m2 = in.w * inv;
-    return v4<T>(sel(corner, in.x * m2, sel(cap, zero, in.x)), sel(corner, in.y * m2, sel(cap, zero, in.y)),
-                 sel(corner, fma_(in.z, m2, sz * m1), sel(cap, sz, in.z)), sel(corner, dist, sel(cap, wz, in.w)));
+    auto corner = gt(wz, 0.0f) & gt(in.w, 0.0f);
+    auto cap = gt(wz, in.w);
+    V4<T> r = v4<T>(sel(cap, zero, in.x), sel(cap, zero, in.y), sel(cap, sz, in.z), sel(cap, wz, in.w));
+    if (any_lane(corner)) {
+        T dist, inv;
+        sqrt_inv_cr(fma_(in.w, in.w, wz * wz), corner, dist, inv);
+        T m1 = wz * inv, m2 = in.w * inv;
+        r.x = sel(corner, in.x * m2, r.x);
+        r.y = sel(corner, in.y * m2, r.y);
+        r.z = sel(corner, fma_(in.z, m2, sz * m1), r.z);
+        r.w = sel(corner, dist, r.w);
+    }
+    return r;
 }
 
 // reference shapes/common.cl:45-64
@@ -251,7 +312,7 @@ template <class T> __device__ __forceinline__ V4<T> rounded_union(float r, V4<T>
 {
     if (r >= 0.0f)  // wave-uniform: r is a tape constant
         return per_voxel(a, b, [r](float4 x, float4 y) { return rounded_blend(r, x, y); });
-    return sel4(a.w < b.w, a, b);
+    return sel4(lt(a.w, b.w), a, b);
 }
 
 // reference shapes/simple2d.cl:6-14
@@ -259,7 +320,7 @@ template <class T> __device__ __forceinline__ V4<T> circle_op(float r, V4<T> c)
 {
     T a, inv;
     sqrt_inv_cr(fma_(c.y, c.y, c.x * c.x), mask_of<T>::all(), a, inv);
-    auto zero = (a == 0.0f);
+    auto zero = eq(a, 0.0f);
     return v4<T>(sel(zero, bc<T>(1.0f), c.x * inv), sel(zero, bc<T>(0.0f), c.y * inv), bc<T>(0.0f), a - r);
 }
 
@@ -268,7 +329,7 @@ template <class T> __device__ __forceinline__ V4<T> sphere_op(float r, V4<T> c)
 {
     T a, inv;
     sqrt_inv_cr(fma_(c.z, c.z, fma_(c.y, c.y, c.x * c.x)), mask_of<T>::all(), a, inv);
-    auto zero = (a == 0.0f);
+    auto zero = eq(a, 0.0f);
     return v4<T>(sel(zero, bc<T>(1.0f), c.x * inv), sel(zero, bc<T>(0.0f), c.y * inv), sel(zero, bc<T>(0.0f), c.z * inv),
                  a - r);
 }
@@ -681,10 +742,10 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const floa
     case OP_OFFSET: last.w = last.w - p[0]; break;
     case OP_SHELL: {
         if (DISTANCE_ONLY) {
-            last.w = sel(last.w >= 0.0f, last.w, -last.w) - p[0];
+            last.w = sel(ge(last.w, 0.0f), last.w, -last.w) - p[0];
             break;
         }
-        V4<T> s = sel4(last.w >= 0.0f, last, neg(last));
+        V4<T> s = sel4(ge(last.w, 0.0f), last, neg(last));
         last = v4<T>(s.x, s.y, s.z, s.w - p[0]);
         break;
     }
@@ -724,19 +785,19 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const floa
     case OP_SYMMETRICAL_FROM: {
         if (DISTANCE_ONLY) break;
         T ptx = regs.load_x(reg);
-        last.x = sel(ptx < 0.0f, -last.x, last.x);
+        last.x = sel(lt(ptx, 0.0f), -last.x, last.x);
         break;
     }
     case OP_UNION:
-        if (DISTANCE_ONLY) { T b = regs.load_res(reg); last.w = sel(last.w < b, last.w, b); }
+        if (DISTANCE_ONLY) { T b = regs.load_res(reg); last.w = sel(lt(last.w, b), last.w, b); }
         else last = rounded_union(p[0], last, regs.load(reg));
         break;
     case OP_INTERSECTION:
-        if (DISTANCE_ONLY) { T a = -last.w, b = -regs.load_res(reg); last.w = -sel(a < b, a, b); }
+        if (DISTANCE_ONLY) { T a = -last.w, b = -regs.load_res(reg); last.w = -sel(lt(a, b), a, b); }
         else last = neg(rounded_union(p[0], neg(last), neg(regs.load(reg))));
         break;
     case OP_SUBTRACTION:
-        if (DISTANCE_ONLY) { T a = -last.w, b = regs.load_res(reg); last.w = -sel(a < b, a, b); }
+        if (DISTANCE_ONLY) { T a = -last.w, b = regs.load_res(reg); last.w = -sel(lt(a, b), a, b); }
         else last = neg(rounded_union(p[0], neg(last), regs.load(reg)));
         break;
     default: return true;  // unreachable: tapes are validated at upload

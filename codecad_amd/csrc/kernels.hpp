@@ -46,6 +46,26 @@ template <bool DO> struct InterpEval {
 // corner + step * (float)gid, multiply then add, not fused.
 __device__ __forceinline__ float sample(float corner, float step, uint32_t i) { return corner + step * (float)i; }
 
+// A grid extent with the constants that divide by it: the kernels turn a linear cell index into (x, y, z)
+// per lane, and a 32-bit division by a run-time value costs ~22 VALU instructions where
+// multiply-high + shifts cost 5 (round-up method of Granlund & Montgomery, exact for every 32-bit x).
+struct Dim {
+    uint32_t n, m, s;
+};
+inline Dim make_dim(uint32_t n)
+{
+    if (n <= 1u) return Dim{n, 0u, 0u};
+    uint32_t L = 0;
+    while ((1ull << L) < n) ++L;
+    return Dim{n, (uint32_t)((((1ull << L) - n) << 32) / n + 1ull), L - 1u};
+}
+__device__ __forceinline__ uint32_t div(uint32_t x, Dim d)
+{
+    const uint32_t t = __umulhi(d.m, x);
+    const uint32_t q = (t + ((x - t) >> 1)) >> d.s;
+    return d.n == 1u ? x : q;  // kernel-uniform select
+}
+
 // N = voxels per lane (1: T = float, 2: T = packed float2, see interp.hpp)
 template <int N> struct Pack { using T = float; };
 template <> struct Pack<2> { using T = sdf::f2; };
@@ -57,14 +77,15 @@ __device__ __forceinline__ sdf::f2 pack(const float (&v)[2]) { return sdf::make_
 template <int N> struct Cells {
     uint32_t x[N], y[N], z[N];
     bool active[N];
-    __device__ __forceinline__ Cells(uint32_t lin0, uint32_t n_cells, uint32_t sy, uint32_t sz)
+    __device__ __forceinline__ Cells(uint32_t lin0, uint32_t n_cells, Dim dy, Dim dz)
     {
+        const uint32_t sy = dy.n, sz = dz.n;
         active[0] = lin0 < n_cells;
         const uint32_t l = active[0] ? lin0 : 0u;  // idle tail lanes follow the (uniform) tape harmlessly
-        z[0] = l % sz;
-        const uint32_t t = l / sz;
-        y[0] = t % sy;
-        x[0] = t / sy;
+        const uint32_t t = div(l, dz);
+        z[0] = l - t * sz;
+        x[0] = div(t, dy);
+        y[0] = t - x[0] * sy;
 #pragma unroll
         for (int i = 1; i < N; ++i) {
             active[i] = active[0] && (lin0 + i < n_cells);
@@ -131,13 +152,14 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 // ------------------------------------------------------------------------------------------
 template <class E, int LAYOUT, int N>
 __global__ void __launch_bounds__(256) SDF_KERNEL_ATTRS
-k_grid_eval(const E ev, float cx, float cy, float cz, float step, uint32_t sx, uint32_t sy, uint32_t sz, uint32_t x0,
+k_grid_eval(const E ev, float cx, float cy, float cz, float step, uint32_t sx, Dim dy, Dim dz, uint32_t x0,
             uint32_t n_cells, void* __restrict__ out)
 {
+    const uint32_t sy = dy.n, sz = dz.n;
     using T = typename Pack<N>::T;
     extern __shared__ float4 lds[];
     const uint32_t lin0 = (blockIdx.x * blockDim.x + threadIdx.x) * N;
-    const Cells<N> c(lin0, n_cells, sy, sz);
+    const Cells<N> c(lin0, n_cells, dy, dz);
     const sdf::V4<T> r = ev(c.position(cx, step, c.x, x0), c.position(cy, step, c.y), c.position(cz, step, c.z), lds);
 #pragma unroll
     for (int i = 0; i < N; ++i) {
@@ -157,9 +179,10 @@ k_grid_eval(const E ev, float cx, float cy, float cz, float step, uint32_t sx, u
 template <class E, int LAYOUT, int N>
 __global__ void __launch_bounds__(256)
 k_grid_eval_blocks(const E ev, const int4* __restrict__ blocks, uint32_t chunks, double res, double ox,
-                   double oy, double oz, float step, uint32_t sx, uint32_t sy, uint32_t sz,
+                   double oy, double oz, float step, uint32_t sx, Dim dy, Dim dz,
                    void* __restrict__ out)
 {
+    const uint32_t sy = dy.n, sz = dz.n;
     using T = typename Pack<N>::T;
     extern __shared__ float4 lds[];
     const uint32_t b = blockIdx.x / chunks, chunk = blockIdx.x - b * chunks;
@@ -170,7 +193,7 @@ k_grid_eval_blocks(const E ev, const int4* __restrict__ blocks, uint32_t chunks,
     const float cy = (float)((double)ic.y * res + oy);
     const float cz = (float)((double)ic.z * res + oz);
     const uint32_t lin0 = (chunk * blockDim.x + threadIdx.x) * N;
-    const Cells<N> c(lin0, cells, sy, sz);
+    const Cells<N> c(lin0, cells, dy, dz);
     const sdf::V4<T> r = ev(c.position(cx, step, c.x), c.position(cy, step, c.y), c.position(cz, step, c.z), lds);
     const size_t base = (size_t)b * cells;
 #pragma unroll
@@ -191,6 +214,7 @@ struct ClassifyArgs {
     const void* parents;   // BATCH: int4[] (subdivision) or double4[] (mass); else unused
     uint32_t chunks;       // workgroups per parent
     uint32_t sx, sy, sz;
+    Dim dy, dz;            // sy, sz with their division constants
     float cx, cy, cz;      // !BATCH: sample corner as given by the caller
     float step, thr;
     int32_t int_step;      // BATCH subdivision: cell size of this level in resolution units
@@ -239,7 +263,7 @@ __global__ void __launch_bounds__(256) k_classify(const E ev, const ClassifyArgs
     }
 
     const uint32_t lin0 = (chunk * blockDim.x + threadIdx.x) * N;
-    const Cells<N> c(lin0, cells, a.sy, a.sz);
+    const Cells<N> c(lin0, cells, a.dy, a.dz);
     const T w = ev(c.position(cx, a.step, c.x), c.position(cy, a.step, c.y), c.position(cz, a.step, c.z), lds).w;
 
     bool ambiguous[N];
@@ -424,7 +448,7 @@ template <class E> __global__ void __launch_bounds__(256) k_ray_caster(const E e
     uint32_t lstep = 0;
     float floor_distance = 0.0f;
 
-    while (sdf::any_lane(phase != DONE)) {
+    while (sdf::any_lane(sdf::mk(phase != DONE))) {
         F3 p = mk3(0.0f, 0.0f, 0.0f);
         switch (phase) {
         case PRIMARY: p = add3(a.origin, mul3(direction, distance)); break;
@@ -694,6 +718,7 @@ __device__ __forceinline__ bool same_bits(float a, float b)
 {
     return __float_as_uint(a) == __float_as_uint(b) || (a != a && b != b);
 }
+#ifndef __HIPCC_RTC__  // not part of the per-tape modules
 __global__ void __launch_bounds__(256) k_selftest_math(unsigned long long* counts)
 {
     unsigned long long bad[3] = {0, 0, 0}, fast = 0;
@@ -704,8 +729,8 @@ __global__ void __launch_bounds__(256) k_selftest_math(unsigned long long* count
         const float r_ref0 = 1.0f / s_ref0, r_ref1 = 1.0f / s_ref1;
         // one voxel per lane
         float s, r;
-        sdf::sqrt_inv_cr(x0, true, s, r);
-        bad[0] += !same_bits(sdf::sqrt_cr(x0, true), s_ref0);
+        sdf::sqrt_inv_cr(x0, sdf::mask_of<float>::all(), s, r);
+        bad[0] += !same_bits(sdf::sqrt_cr(x0, sdf::mask_of<float>::all()), s_ref0);
         bad[1] += !same_bits(s, s_ref0);
         bad[2] += !same_bits(r, r_ref0);
         // two voxels per lane
@@ -716,11 +741,12 @@ __global__ void __launch_bounds__(256) k_selftest_math(unsigned long long* count
         bad[0] += !same_bits(q2.x, s_ref0) + !same_bits(q2.y, s_ref1);
         bad[1] += !same_bits(s2.x, s_ref0) + !same_bits(s2.y, s_ref1);
         bad[2] += !same_bits(r2.x, r_ref0) + !same_bits(r2.y, r_ref1);
-        fast += !sdf::outside_fast_range(x0);
+        fast += !sdf::outside_fast_range(x0).v;
     }
     for (int k = 0; k < 3; ++k)
         if (bad[k]) atomicAdd(&counts[k], bad[k]);
     atomicAdd(&counts[3], fast);
 }
+#endif
 
 }  // namespace sdfk

@@ -33,10 +33,11 @@ def main():
         tape = cc.nodes.make_program(cc.examples.sponge(int(name[6:])))
     else:
         import json
-        tape = json.load(open(os.path.join(ROOT, "tests/golden/ref_tapes.json")))[name]["tape"]
+        shapes = json.load(open(os.path.join(ROOT, "tests/golden/ref_tapes.json")))["shapes"]
+        tape = np.array({s["name"]: s for s in shapes}[name]["tape_u32"], dtype=np.uint32).view(np.float32)
     out = "/tmp/spec_isa"
     os.makedirs(out, exist_ok=True)
-    src = source_of(tape) + "\ntemplate __global__ void sdfk::k_grid_eval<sdfk::JitEval, %d, 2>(const sdfk::JitEval, float, float, float, float, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, void*);\n" % layout
+    src = source_of(tape) + "\ntemplate __global__ void sdfk::k_grid_eval<sdfk::JitEval, %d, 2>(const sdfk::JitEval, float, float, float, float, uint32_t, sdfk::Dim, sdfk::Dim, uint32_t, uint32_t, void*);\n" % layout
     open(out + "/spec.hip", "w").write(src)
     extra = [a for a in sys.argv[3:]]
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I", ROOT + "/codecad_amd/csrc",
@@ -54,10 +55,10 @@ def main():
     print("VALU %d  SALU %d  packed %d" % (valu, salu, sum(c for o, c in ops.items() if o.startswith("v_pk_"))))
     for o, c in ops.most_common(40):
         print("  %-28s %d" % (o, c))
-    for key in ("vgpr_count", "sgpr_count", "scratch", "NumVgprs", "ScratchSize", "Occupancy"):
-        for m in re.finditer(r".*%s.*" % key, text):
+    for key in ("NumVgprs", "NumSgprs", "ScratchSize", "Occupancy"):
+        m = re.search(r"; %s: .*" % key, body)
+        if m:
             print(m.group(0).strip())
-            break
 
 
 if __name__ == "__main__":
