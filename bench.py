@@ -220,7 +220,9 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": measured_traffic(n, evaluator), "kernel_ms": round(dense_avg_ms, 4),
                          "voxels_per_s": round(dense_voxels / (dense_avg_ms * 1e-3), 0),
-                         "note": "this tape is FP32-VALU-bound, not HBM-bound: see valu_* fields",
+                         "note": "this tape is FP32-VALU-bound, not HBM-bound: see valu_* fields; valu_flop_per_voxel is the "
+                                 "ALGORITHMIC count of the reference's formulas (SURVEY.md section 8(d) convention, FMA = 2), "
+                                 "not instructions executed: the kernel's reduced transformation forms execute fewer",
                          "valu_flop_per_voxel": flop,
                          "valu_achieved_tflops": round(dense_voxels * flop / (dense_avg_ms * 1e-3) / 1e12, 2),
                          "valu_peak_tflops": FP32_PEAK_TFLOPS,
