@@ -966,10 +966,20 @@ static int mesh_shape(uint32_t n_blocks, const uint32_t dims[3], uint32_t& chunk
     if ((rc = check_dims(dims, samples))) return rc;
     if (samples > (1ull << 24)) return fail(HU_ERR_BAD_ARG, "a block may have at most 2^24 samples (256^3)");
     if (dims[0] > 65535u || dims[1] > 65535u || dims[2] > 65535u) return fail(HU_ERR_BAD_ARG, "block dims must be below 65536");
-    chunks = (uint32_t)((samples + kMcPerGroup - 1) / kMcPerGroup);
+    chunks = (uint32_t)((samples + kMcBlock - 1) / kMcBlock);
     n_wg = (uint64_t)chunks * n_blocks;
     if (n_wg > 0x7fffffffull) return fail(HU_ERR_BAD_ARG, "too many workgroups in one launch");
     return HU_OK;
+}
+
+// 64-bit words of inside bits per block: every window a wavefront reads (its samples shifted by up to one
+// plane + one row + one sample, plus the next word for the funnel shift) and every word k_mc_bits writes
+static uint32_t mesh_words_per_block(const uint32_t dims[3], uint32_t chunks)
+{
+    const uint64_t n = (uint64_t)dims[0] * dims[1] * dims[2], max_off = (uint64_t)dims[1] * dims[2] + dims[2] + 1;
+    // the last workgroup's wavefronts may start up to kMcBlock - 1 samples past the end of the block
+    const uint64_t read = ((n + kMcBlock + max_off) >> 6) + 2, written = (uint64_t)chunks * (kMcBlock / 64);
+    return (uint32_t)(read > written ? read : written);
 }
 
 static void mesh_divisors(McArgs& a)
@@ -978,19 +988,22 @@ static void mesh_divisors(McArgs& a)
     a.div_A2 = make_fast_div(a.A2);
 }
 
-int hu_mesh_workgroups(uint32_t n_blocks, const uint32_t dims[3], uint64_t* n_workgroups, uint64_t* count_entries)
+int hu_mesh_workgroups(uint32_t n_blocks, const uint32_t dims[3], uint64_t* n_workgroups, uint64_t* count_entries,
+                       uint64_t* bit_words)
 {
-    if (!n_workgroups || !count_entries) return fail(HU_ERR_BAD_ARG, "NULL argument");
+    if (!n_workgroups || !count_entries || !bit_words) return fail(HU_ERR_BAD_ARG, "NULL argument");
     uint32_t chunks;
     int rc;
     if ((rc = mesh_shape(n_blocks, dims, chunks, *n_workgroups))) return rc;
     *count_entries = *n_workgroups + 1 + (*n_workgroups + kMcScanTile - 1) / kMcScanTile;
+    *bit_words = (uint64_t)mesh_words_per_block(dims, chunks) * n_blocks;
     return HU_OK;
 }
 
-int hu_mesh_count(const float* fields_dev, uint32_t n_blocks, const uint32_t dims[3], uint32_t* wg_counts_dev, void* stream)
+int hu_mesh_count(const float* fields_dev, uint32_t n_blocks, const uint32_t dims[3], uint64_t* bits_dev,
+                  uint32_t* wg_counts_dev, void* stream)
 {
-    if (!wg_counts_dev || (!fields_dev && n_blocks)) return fail(HU_ERR_BAD_ARG, "NULL argument");
+    if (!wg_counts_dev || ((!fields_dev || !bits_dev) && n_blocks)) return fail(HU_ERR_BAD_ARG, "NULL argument");
     uint32_t chunks;
     uint64_t n_wg;
     int rc;
@@ -1007,6 +1020,10 @@ int hu_mesh_count(const float* fields_dev, uint32_t n_blocks, const uint32_t dim
     const uint32_t n = (uint32_t)n_wg, tiles = (n + kMcScanTile - 1) / kMcScanTile;
     uint2* tile_totals = a.wg_counts + n + 1;
     if (n) {
+        a.words_per_block = mesh_words_per_block(dims, chunks);
+        a.bits = bits_dev;
+        HU_HIP(hipMemsetAsync(bits_dev, 0, (size_t)a.words_per_block * n_blocks * sizeof(uint64_t), (hipStream_t)stream));
+        hipLaunchKernelGGL(k_mc_bits, dim3(n), dim3(kMcBlock), 0, (hipStream_t)stream, a, bits_dev);
         hipLaunchKernelGGL(k_mc_count, dim3(n), dim3(kMcBlock), 0, (hipStream_t)stream, a);
         hipLaunchKernelGGL(k_mc_scan_tiles, dim3(tiles), dim3(kMcScanTile), 0, (hipStream_t)stream, a.wg_counts, n, tile_totals);
     }
@@ -1018,12 +1035,12 @@ int hu_mesh_count(const float* fields_dev, uint32_t n_blocks, const uint32_t dim
 
 int hu_mesh_emit(const float* fields_dev, const int32_t* blocks_dev, uint32_t n_blocks, double resolution,
                  const double origin[3], double step, const uint32_t dims[3], double y_offset,
-                 const uint32_t* wg_counts_dev, uint32_t* info_dev, double* vertices_dev, uint32_t* triangles_dev,
-                 void* stream)
+                 const uint64_t* bits_dev, const uint32_t* wg_counts_dev, uint32_t* info_dev, double* vertices_dev,
+                 uint32_t* triangles_dev, void* stream)
 {
     if (!origin) return fail(HU_ERR_BAD_ARG, "NULL argument");
     if (n_blocks == 0) return HU_OK;
-    if (!fields_dev || !blocks_dev || !wg_counts_dev || !info_dev || !vertices_dev || !triangles_dev)
+    if (!fields_dev || !blocks_dev || !bits_dev || !wg_counts_dev || !info_dev || !vertices_dev || !triangles_dev)
         return fail(HU_ERR_BAD_ARG, "NULL argument");
     uint32_t chunks;
     uint64_t n_wg;
@@ -1043,6 +1060,8 @@ int hu_mesh_emit(const float* fields_dev, const int32_t* blocks_dev, uint32_t n_
     a.oz = origin[2];
     a.step = step;
     a.y_offset = y_offset;
+    a.bits = bits_dev;
+    a.words_per_block = mesh_words_per_block(dims, chunks);
     a.wg_counts = reinterpret_cast<uint2*>(const_cast<uint32_t*>(wg_counts_dev));
     a.info = info_dev;
     a.vertices = vertices_dev;

@@ -6,15 +6,23 @@
 // 1987), case table derived in tools/gen_mc_table.py; output ordering and arithmetic are those of
 // the oracle's restatement (oracle/sdf_oracle.c oracle_marching_cubes), so meshes compare equal.
 //
-// Indexed, deterministic output without atomics -- three passes over the samples, all HBM-bound:
+// Indexed, deterministic output without atomics.  All passes are over the samples, 64 consecutive
+// samples of a block per wavefront:
+//   k_mc_bits       one INSIDE bit per sample (value <= 0): each wavefront's ballot is one 64-bit word
 //   k_mc_count      per workgroup: number of vertices (active edges owned by its samples) and of
 //                   triangles (cells whose low corner it owns)
 //   k_mc_scan_*     exclusive scan of the workgroup counts (tiles of 1024, their totals, add back)
 //   k_mc_vertices   recompute, scan inside the workgroup, write vertex positions (fp64, world
 //                   coordinates as mesh.py:65-68 computes them) and each sample's first vertex id
 //   k_mc_triangles  recompute the case, scan, write triangles as global vertex ids
+// The three counting/emitting passes never touch the float samples to classify: a wavefront fetches
+// the eight 64-bit WINDOWS of the bit array that hold its lanes' eight cube corners (uniform loads),
+// and if no corner differs from the lane's own sample anywhere in the wavefront -- most wavefronts: the
+// surface crosses few of them -- it is done after a dozen scalar instructions.  Only surface wavefronts
+// extract per-lane case indices (shifts of the windows), and only active edges load float samples.
+// (The first version loaded 12 floats per sample in every pass and ran at 8 % of the HBM roofline.)
 // A block is an array [A0][A1][A2] (a2 fastest): for the pymcubes layout A0 = sy (y flipped),
-// A1 = sx, A2 = sz.  A lane owns kMcPerLane consecutive samples, a workgroup 256 times that, of one block.
+// A1 = sx, A2 = sz.  One lane per sample; a workgroup owns 256 consecutive samples of one block.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -49,39 +57,27 @@ struct McArgs {
     double res, ox, oy, oz;   // block corner = int_corner * res + origin  (subdivision.py:100)
     double step;              // sample spacing of the block (box_resolution)
     double y_offset;          // added to y: 0 reproduces mesh.py:65-68, (A0-1)*step gives true positions
+    const uint64_t* bits;     // inside bits: words_per_block 64-bit words per block (zero padded at the end)
+    uint32_t words_per_block;
     uint2* wg_counts;         // per workgroup (vertices, triangles); exclusive prefix after k_mc_scan
     uint32_t* info;           // per sample: first vertex id << 3 | active axes
     double* vertices;         // [.][3]
     uint32_t* triangles;      // [.][3]
 };
 
-// Samples per lane.  Measured on MI355X over the 126 M samples of the bench's leaf blocks (16^3):
-// 1 per lane: count 0.84 ms, vertices 0.88 ms, triangles 1.62 ms; 4 per lane: 1.14 / 0.79 / 1.79 ms.
-// The passes are bound by integer/address instructions (12 loads, 8 compares and the index math per
-// sample), not by HBM (0.5 GB of samples per pass) nor by workgroup latency; the next step would be one
-// inside-bit per sample shared through LDS row masks instead of 12 loads per sample.
-constexpr uint32_t kMcPerLane = 1;
-constexpr uint32_t kMcPerGroup = kMcBlock * kMcPerLane;
-
 struct McSample {
-    uint32_t s, a0, a1, a2;
+    uint32_t b, s, a0, a1, a2;
     bool valid;
 };
 
-// block of this workgroup and the first sample of this lane
-__device__ __forceinline__ void mc_lane(const McArgs& a, uint32_t& b, uint32_t& s0)
-{
-    b = blockIdx.x / a.chunks;  // wave-uniform
-    const uint32_t chunk = blockIdx.x - b * a.chunks;
-    s0 = (chunk * kMcBlock + threadIdx.x) * kMcPerLane;
-}
-
-__device__ __forceinline__ McSample mc_sample(const McArgs& a, uint32_t s)
+__device__ __forceinline__ McSample mc_sample(const McArgs& a)
 {
     McSample m;
-    m.s = s;
-    m.valid = s < a.A0 * a.A1 * a.A2;
-    const uint32_t v = m.valid ? s : 0u;
+    m.b = blockIdx.x / a.chunks;  // wave-uniform
+    const uint32_t chunk = blockIdx.x - m.b * a.chunks;
+    m.s = chunk * kMcBlock + threadIdx.x;
+    m.valid = m.s < a.A0 * a.A1 * a.A2;
+    const uint32_t v = m.valid ? m.s : 0u;
     const uint32_t t = a.div_A2.div(v);
     m.a2 = v - t * a.A2;
     m.a0 = a.div_A1.div(t);
@@ -89,39 +85,56 @@ __device__ __forceinline__ McSample mc_sample(const McArgs& a, uint32_t s)
     return m;
 }
 
-// active axes of the sample's three owned edges, and the values needed to place their vertices
-__device__ __forceinline__ uint32_t mc_edge_flags(const McArgs& a, const McSample& m, const float* f, float& f1, float (&f2)[3])
+// Inside bits of the 64 samples at linear offset `off` from this wavefront's samples (bit i = sample
+// first + i + off): two uniform word loads and a funnel shift.
+__device__ __forceinline__ uint64_t mc_window(const uint64_t* words, uint32_t first, uint32_t off)
 {
-    f1 = 0.0f;
-    f2[0] = f2[1] = f2[2] = 0.0f;
-    if (!m.valid) return 0u;
-    const uint32_t stride[3] = {a.A1 * a.A2, a.A2, 1u};
-    const uint32_t pos[3] = {m.a0, m.a1, m.a2}, dims[3] = {a.A0, a.A1, a.A2};
-    f1 = f[m.s];
-    const bool in1 = f1 <= 0.0f;
-    uint32_t flags = 0;
-#pragma unroll
-    for (int axis = 0; axis < 3; ++axis) {
-        if (pos[axis] + 1u >= dims[axis]) continue;
-        f2[axis] = f[m.s + stride[axis]];
-        if ((f2[axis] <= 0.0f) != in1) flags |= 1u << axis;
-    }
-    return flags;
+    const uint32_t bit = first + off, w = bit >> 6, sh = bit & 63u;
+    const uint64_t lo = words[w], hi = words[w + 1];
+    return sh ? (lo >> sh) | (hi << (64u - sh)) : lo;
 }
 
-// case index of the cell whose low corner is the sample (0 when the sample owns no cell)
-__device__ __forceinline__ uint32_t mc_case(const McArgs& a, const McSample& m, const float* f)
+// The wavefront's eight corner windows (cube corner numbering of the table) and whether any corner
+// anywhere in the wavefront differs from the lane's own sample -- conservative: it ignores which
+// neighbours exist, so a wavefront may be kept for nothing, never dropped wrongly.
+struct McWindows {
+    uint64_t w[8];
+    bool any;
+};
+__device__ __forceinline__ McWindows mc_windows(const McArgs& a, const McSample& m)
 {
-    if (!m.valid || m.a0 + 1u >= a.A0 || m.a1 + 1u >= a.A1 || m.a2 + 1u >= a.A2) return 0u;
+    const uint64_t* words = a.bits + (size_t)m.b * a.words_per_block;
+    const uint32_t first = __builtin_amdgcn_readfirstlane(m.s) & ~63u;  // the wavefront's first sample
     const uint32_t s0 = a.A1 * a.A2, s1 = a.A2;
-    uint32_t cube = 0;
+    McWindows r;
+    uint64_t diff = 0;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const uint32_t off = ((c == 1 || c == 2 || c == 5 || c == 6) ? s0 : 0u) + ((c == 2 || c == 3 || c == 6 || c == 7) ? s1 : 0u) +
                              (c >= 4 ? 1u : 0u);
-        if (f[m.s + off] <= 0.0f) cube |= 1u << c;
+        r.w[c] = mc_window(words, first, off);
+        diff |= r.w[c] ^ r.w[0];
     }
-    return cube;
+    r.any = diff != 0ull;
+    return r;
+}
+
+// The lane's case index (0 when it owns no cell) and the active axes of its three owned edges.
+__device__ __forceinline__ void mc_classify(const McArgs& a, const McSample& m, const McWindows& win, uint32_t& cube, uint32_t& flags)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t bits = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) bits |= (uint32_t)((win.w[c] >> lane) & 1ull) << c;
+    const bool e0 = m.a0 + 1u < a.A0, e1 = m.a1 + 1u < a.A1, e2 = m.a2 + 1u < a.A2;
+    const uint32_t own = bits & 1u;
+    flags = 0;
+    if (m.valid) {
+        if (e0 && ((bits >> 1) & 1u) != own) flags |= 1u;  // corner 1 = +a0
+        if (e1 && ((bits >> 3) & 1u) != own) flags |= 2u;  // corner 3 = +a1
+        if (e2 && ((bits >> 4) & 1u) != own) flags |= 4u;  // corner 4 = +a2
+    }
+    cube = (m.valid && e0 && e1 && e2) ? bits : 0u;
 }
 
 // exclusive scan of one value per lane over the workgroup; `total` = sum.  scratch: >= 8 uint32 of LDS.
@@ -148,23 +161,27 @@ __device__ __forceinline__ uint32_t wg_exclusive_scan(uint32_t v, uint32_t* scra
     return base + incl - v;
 }
 
+__global__ void __launch_bounds__(256) k_mc_bits(const McArgs a, uint64_t* __restrict__ bits)
+{
+    const McSample m = mc_sample(a);
+    const float* f = a.fields + (size_t)m.b * a.A0 * a.A1 * a.A2;
+    const bool inside = m.valid && f[m.s] <= 0.0f;
+    const uint64_t word = __builtin_amdgcn_ballot_w64(inside);
+    if ((threadIdx.x & 63u) == 0u) bits[(size_t)m.b * a.words_per_block + (m.s >> 6)] = word;
+}
+
 __global__ void __launch_bounds__(256) k_mc_count(const McArgs a)
 {
     __shared__ uint32_t scratch[8];
-    uint32_t b, s0;
-    mc_lane(a, b, s0);
-    const float* f = a.fields + (size_t)b * a.A0 * a.A1 * a.A2;
-    uint32_t nv = 0, cube[kMcPerLane];
-#pragma unroll
-    for (uint32_t i = 0; i < kMcPerLane; ++i) {
-        const McSample m = mc_sample(a, s0 + i);
-        float f1, f2[3];
-        nv += __popc(mc_edge_flags(a, m, f, f1, f2));
-        cube[i] = mc_case(a, m, f);
+    const McSample m = mc_sample(a);
+    const McWindows win = mc_windows(a, m);
+    uint32_t nv = 0, nt = 0;
+    if (win.any) {  // wave-uniform
+        uint32_t cube, flags;
+        mc_classify(a, m, win, cube, flags);
+        nv = __popc(flags);
+        nt = kMcTriangleCountDev[cube];
     }
-    uint32_t nt = 0;
-#pragma unroll
-    for (uint32_t i = 0; i < kMcPerLane; ++i) nt += kMcTriangleCountDev[cube[i]];
     uint32_t total_v, total_t;
     wg_exclusive_scan(nv, scratch, total_v);
     wg_exclusive_scan(nt, scratch, total_t);
@@ -217,75 +234,62 @@ __global__ void __launch_bounds__(1024) k_mc_scan_add(uint2* counts, uint32_t n,
 __global__ void __launch_bounds__(256) k_mc_vertices(const McArgs a)
 {
     __shared__ uint32_t scratch[8];
-    uint32_t b, s0;
-    mc_lane(a, b, s0);
-    const size_t block_base = (size_t)b * a.A0 * a.A1 * a.A2;
-    const float* f = a.fields + block_base;
-    McSample m[kMcPerLane];
-    uint32_t flags[kMcPerLane], count = 0;
-    float f1[kMcPerLane], f2[kMcPerLane][3];
-#pragma unroll
-    for (uint32_t i = 0; i < kMcPerLane; ++i) {
-        m[i] = mc_sample(a, s0 + i);
-        flags[i] = mc_edge_flags(a, m[i], f, f1[i], f2[i]);
-        count += __popc(flags[i]);
-    }
+    const McSample m = mc_sample(a);
+    const size_t block_base = (size_t)m.b * a.A0 * a.A1 * a.A2;
+    const McWindows win = mc_windows(a, m);
+    uint32_t cube = 0, flags = 0;
+    if (win.any) mc_classify(a, m, win, cube, flags);
     uint32_t total;
-    uint32_t id = a.wg_counts[blockIdx.x].x + wg_exclusive_scan(count, scratch, total);
+    const uint32_t first = a.wg_counts[blockIdx.x].x + wg_exclusive_scan(__popc(flags), scratch, total);
+    if (!m.valid) return;
+    a.info[block_base + m.s] = (first << 3) | flags;
+    if (!flags) return;
     // mesh.py:65-68 in numpy float64: swap the first two array axes, negate y, scale, add the corner
-    const int4 ic = a.blocks[b];
+    const float* f = a.fields + block_base;
+    const float f1 = f[m.s];
+    const int4 ic = a.blocks[m.b];
     const double cx = (double)ic.x * a.res + a.ox, cy = (double)ic.y * a.res + a.oy, cz = (double)ic.z * a.res + a.oz;
+    const uint32_t pos[3] = {m.a0, m.a1, m.a2}, stride[3] = {a.A1 * a.A2, a.A2, 1u};
+    uint32_t id = first;
 #pragma unroll
-    for (uint32_t i = 0; i < kMcPerLane; ++i) {
-        if (!m[i].valid) continue;
-        a.info[block_base + m[i].s] = (id << 3) | flags[i];
-        const uint32_t pos[3] = {m[i].a0, m[i].a1, m[i].a2};
+    for (int axis = 0; axis < 3; ++axis) {
+        if (!(flags & (1u << axis))) continue;
+        const float f2 = f[m.s + stride[axis]];
+        const double t = (1.0 * (0.0 - (double)f1)) / ((double)f2 - (double)f1);
+        double v[3];
 #pragma unroll
-        for (int axis = 0; axis < 3; ++axis) {
-            if (!(flags[i] & (1u << axis))) continue;
-            const double t = (1.0 * (0.0 - (double)f1[i])) / ((double)f2[i][axis] - (double)f1[i]);
-            double v[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) v[k] = (double)pos[k] + (k == axis ? t : 0.0);
-            double* out = a.vertices + 3 * (size_t)id;
-            out[0] = v[1] * a.step + cx;
-            out[1] = ((-v[0]) * a.step + cy) + a.y_offset;
-            out[2] = v[2] * a.step + cz;
-            ++id;
-        }
+        for (int k = 0; k < 3; ++k) v[k] = (double)pos[k] + (k == axis ? t : 0.0);
+        double* out = a.vertices + 3 * (size_t)id;
+        out[0] = v[1] * a.step + cx;
+        out[1] = ((-v[0]) * a.step + cy) + a.y_offset;
+        out[2] = v[2] * a.step + cz;
+        ++id;
     }
 }
 
 __global__ void __launch_bounds__(256) k_mc_triangles(const McArgs a)
 {
     __shared__ uint32_t scratch[8];
-    uint32_t b, s0;
-    mc_lane(a, b, s0);
-    const size_t block_base = (size_t)b * a.A0 * a.A1 * a.A2;
-    const float* f = a.fields + block_base;
-    uint32_t cube[kMcPerLane], count = 0;
-#pragma unroll
-    for (uint32_t i = 0; i < kMcPerLane; ++i) cube[i] = mc_case(a, mc_sample(a, s0 + i), f);
-#pragma unroll
-    for (uint32_t i = 0; i < kMcPerLane; ++i) count += kMcTriangleCountDev[cube[i]];
+    const McSample m = mc_sample(a);
+    const size_t block_base = (size_t)m.b * a.A0 * a.A1 * a.A2;
+    const McWindows win = mc_windows(a, m);
+    uint32_t cube = 0, flags = 0;
+    if (win.any) mc_classify(a, m, win, cube, flags);
+    const uint32_t nt = kMcTriangleCountDev[cube];
     uint32_t total;
-    uint32_t slot = a.wg_counts[blockIdx.x].y + wg_exclusive_scan(count, scratch, total);
-    if (!count) return;
+    uint32_t slot = a.wg_counts[blockIdx.x].y + wg_exclusive_scan(nt, scratch, total);
+    if (!nt) return;
     const uint32_t stride[3] = {a.A1 * a.A2, a.A2, 1u};
+    const uint32_t* info = a.info + block_base + m.s;
+    for (uint32_t k = 0; k < 3u * nt; k += 3, ++slot) {
+        uint32_t* out = a.triangles + 3 * (size_t)slot;
 #pragma unroll
-    for (uint32_t i = 0; i < kMcPerLane; ++i) {
-        const uint32_t nt = kMcTriangleCountDev[cube[i]];
-        const uint32_t* info = a.info + block_base + s0 + i;
-        for (uint32_t k = 0; k < 3u * nt; k += 3, ++slot) {
-            uint32_t* out = a.triangles + 3 * (size_t)slot;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int e = kMcTrianglesDev[cube[i]][k + j];
-                const unsigned char* c = kMcCornerDev[kMcEdgeOwnerDev[e][0]];
-                const uint32_t axis = kMcEdgeOwnerDev[e][1];
-                const uint32_t w = info[c[0] * stride[0] + c[1] * stride[1] + c[2] * stride[2]];
-                out[j] = (w >> 3) + __popc(w & ((1u << axis) - 1u));
-            }
+        for (int j = 0; j < 3; ++j) {
+            const int e = kMcTrianglesDev[cube][k + j];
+            const unsigned char* c = kMcCornerDev[kMcEdgeOwnerDev[e][0]];
+            const uint32_t axis = kMcEdgeOwnerDev[e][1];
+            const uint32_t w = info[c[0] * stride[0] + c[1] * stride[1] + c[2] * stride[2]];
+            out[j] = (w >> 3) + __popc(w & ((1u << axis) - 1u));
         }
     }
 }

@@ -49,12 +49,14 @@ def mesh_blocks(leaves, true_positions=False, queue=None, download=True):
         return Mesh(numpy.zeros((0, 3)), numpy.zeros((0, 3), numpy.uint32), z, z, 0, 0.0)
     fields = _grid_eval.grid_eval_blocks(leaves, pymcubes=True, queue=queue)
     dims = (ctypes.c_uint32 * 3)(sy, sx, sz)    # array axes of the pymcubes layout: (flipped y, x, z)
-    n_wg, entries = ctypes.c_uint64(0), ctypes.c_uint64(0)
-    check(lib.hu_mesh_workgroups(n, dims, ctypes.byref(n_wg), ctypes.byref(entries)), "hu_mesh_workgroups")
+    n_wg, entries, words = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint64(0)
+    check(lib.hu_mesh_workgroups(n, dims, ctypes.byref(n_wg), ctypes.byref(entries), ctypes.byref(words)),
+          "hu_mesh_workgroups")
     n_wg = n_wg.value
     counts = hip_util.Buffer(numpy.uint32, (entries.value, 2), queue=queue)
+    bits = hip_util.Buffer(numpy.uint64, (words.value,), queue=queue)
     ev0 = hip_util.Event(hip_manager, queue)
-    check(lib.hu_mesh_count(fields.device_ptr, n, dims, counts.device_ptr, queue.handle), "hu_mesh_count")
+    check(lib.hu_mesh_count(fields.device_ptr, n, dims, bits.device_ptr, counts.device_ptr, queue.handle), "hu_mesh_count")
     ev0._done()
     prefix = counts.read(wait_for=[ev0]).copy()
     total_v, total_t = int(prefix[n_wg, 0]), int(prefix[n_wg, 1])
@@ -68,7 +70,7 @@ def mesh_blocks(leaves, true_positions=False, queue=None, download=True):
     step = float(leaves.step)
     ev1 = hip_util.Event(hip_manager, queue)
     check(lib.hu_mesh_emit(fields.device_ptr, leaves.blocks.device_ptr, n, float(leaves.resolution), o, step, dims,
-                           (sy - 1) * step if true_positions else 0.0, counts.device_ptr, info.device_ptr,
+                           (sy - 1) * step if true_positions else 0.0, bits.device_ptr, counts.device_ptr, info.device_ptr,
                            vertices.device_ptr, triangles.device_ptr, queue.handle), "hu_mesh_emit")
     ev1._done()
     if download:
@@ -78,7 +80,7 @@ def mesh_blocks(leaves, true_positions=False, queue=None, download=True):
         ev1.wait()
         v = t = None
     ms = ev0.elapsed_ms() + ev1.elapsed_ms()
-    for b in (fields, counts, info, vertices, triangles):
+    for b in (fields, counts, bits, info, vertices, triangles):
         b.release()
     return Mesh(v, t, starts[:, 0].copy(), starts[:, 1].copy(), n * sx * sy * sz, ms)
 
