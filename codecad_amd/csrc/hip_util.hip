@@ -959,71 +959,55 @@ int hu_process_polygon_blocks(const void* corners_dev, const int32_t* blocks_dev
     return launch_process_polygon(true, a, n_blocks, stream);
 }
 
-static int mesh_shape(uint32_t n_blocks, const uint32_t dims[3], uint32_t& chunks, uint64_t& n_wg)
+// Fills the shape part of McArgs; n_wg = workgroups of 256 segments over all blocks.
+static int mesh_shape(uint32_t n_blocks, const uint32_t dims[3], McArgs& a, uint64_t& n_wg)
 {
     uint64_t samples;
     int rc;
     if ((rc = check_dims(dims, samples))) return rc;
     if (samples > (1ull << 24)) return fail(HU_ERR_BAD_ARG, "a block may have at most 2^24 samples (256^3)");
     if (dims[0] > 65535u || dims[1] > 65535u || dims[2] > 65535u) return fail(HU_ERR_BAD_ARG, "block dims must be below 65536");
-    chunks = (uint32_t)((samples + kMcBlock - 1) / kMcBlock);
-    n_wg = (uint64_t)chunks * n_blocks;
+    a.A0 = dims[0];
+    a.A1 = dims[1];
+    a.A2 = dims[2];
+    a.spr = mc_segments_per_row(dims[2]);
+    a.segments = dims[0] * dims[1] * a.spr;
+    a.div_A1 = make_fast_div(a.A1);
+    a.div_spr = make_fast_div(a.spr);
+    a.chunks = (a.segments + kMcBlock - 1) / kMcBlock;
+    n_wg = (uint64_t)a.chunks * n_blocks;
     if (n_wg > 0x7fffffffull) return fail(HU_ERR_BAD_ARG, "too many workgroups in one launch");
     return HU_OK;
 }
 
-// 64-bit words of inside bits per block: every window a wavefront reads (its samples shifted by up to one
-// plane + one row + one sample, plus the next word for the funnel shift) and every word k_mc_bits writes
-static uint32_t mesh_words_per_block(const uint32_t dims[3], uint32_t chunks)
-{
-    const uint64_t n = (uint64_t)dims[0] * dims[1] * dims[2], max_off = (uint64_t)dims[1] * dims[2] + dims[2] + 1;
-    // the last workgroup's wavefronts may start up to kMcBlock - 1 samples past the end of the block
-    const uint64_t read = ((n + kMcBlock + max_off) >> 6) + 2, written = (uint64_t)chunks * (kMcBlock / 64);
-    return (uint32_t)(read > written ? read : written);
-}
-
-static void mesh_divisors(McArgs& a)
-{
-    a.div_A1 = make_fast_div(a.A1);
-    a.div_A2 = make_fast_div(a.A2);
-}
-
 int hu_mesh_workgroups(uint32_t n_blocks, const uint32_t dims[3], uint64_t* n_workgroups, uint64_t* count_entries,
-                       uint64_t* bit_words)
+                       uint64_t* segments)
 {
-    if (!n_workgroups || !count_entries || !bit_words) return fail(HU_ERR_BAD_ARG, "NULL argument");
-    uint32_t chunks;
+    if (!n_workgroups || !count_entries || !segments) return fail(HU_ERR_BAD_ARG, "NULL argument");
+    McArgs a{};
     int rc;
-    if ((rc = mesh_shape(n_blocks, dims, chunks, *n_workgroups))) return rc;
+    if ((rc = mesh_shape(n_blocks, dims, a, *n_workgroups))) return rc;
     *count_entries = *n_workgroups + 1 + (*n_workgroups + kMcScanTile - 1) / kMcScanTile;
-    *bit_words = (uint64_t)mesh_words_per_block(dims, chunks) * n_blocks;
+    *segments = (uint64_t)a.segments * n_blocks;
     return HU_OK;
 }
 
-int hu_mesh_count(const float* fields_dev, uint32_t n_blocks, const uint32_t dims[3], uint64_t* bits_dev,
+int hu_mesh_count(const float* fields_dev, uint32_t n_blocks, const uint32_t dims[3], uint32_t* masks_dev,
                   uint32_t* wg_counts_dev, void* stream)
 {
-    if (!wg_counts_dev || ((!fields_dev || !bits_dev) && n_blocks)) return fail(HU_ERR_BAD_ARG, "NULL argument");
-    uint32_t chunks;
+    if (!wg_counts_dev || ((!fields_dev || !masks_dev) && n_blocks)) return fail(HU_ERR_BAD_ARG, "NULL argument");
+    McArgs a{};
     uint64_t n_wg;
     int rc;
-    if ((rc = mesh_shape(n_blocks, dims, chunks, n_wg))) return rc;
-    McArgs a{};
+    if ((rc = mesh_shape(n_blocks, dims, a, n_wg))) return rc;
     a.fields = fields_dev;
-    a.A0 = dims[0];
-    a.A1 = dims[1];
-    a.A2 = dims[2];
-    a.chunks = chunks;
-    mesh_divisors(a);
+    a.masks = masks_dev;
     a.wg_counts = reinterpret_cast<uint2*>(wg_counts_dev);
     // the tile totals of the scan live behind the totals entry: wg_counts_dev has n_wg + 1 + tiles entries
     const uint32_t n = (uint32_t)n_wg, tiles = (n + kMcScanTile - 1) / kMcScanTile;
     uint2* tile_totals = a.wg_counts + n + 1;
     if (n) {
-        a.words_per_block = mesh_words_per_block(dims, chunks);
-        a.bits = bits_dev;
-        HU_HIP(hipMemsetAsync(bits_dev, 0, (size_t)a.words_per_block * n_blocks * sizeof(uint64_t), (hipStream_t)stream));
-        hipLaunchKernelGGL(k_mc_bits, dim3(n), dim3(kMcBlock), 0, (hipStream_t)stream, a, bits_dev);
+        hipLaunchKernelGGL(k_mc_masks, dim3(n), dim3(kMcBlock), 0, (hipStream_t)stream, a);
         hipLaunchKernelGGL(k_mc_count, dim3(n), dim3(kMcBlock), 0, (hipStream_t)stream, a);
         hipLaunchKernelGGL(k_mc_scan_tiles, dim3(tiles), dim3(kMcScanTile), 0, (hipStream_t)stream, a.wg_counts, n, tile_totals);
     }
@@ -1035,24 +1019,18 @@ int hu_mesh_count(const float* fields_dev, uint32_t n_blocks, const uint32_t dim
 
 int hu_mesh_emit(const float* fields_dev, const int32_t* blocks_dev, uint32_t n_blocks, double resolution,
                  const double origin[3], double step, const uint32_t dims[3], double y_offset,
-                 const uint64_t* bits_dev, const uint32_t* wg_counts_dev, uint32_t* info_dev, double* vertices_dev,
+                 const uint32_t* masks_dev, const uint32_t* wg_counts_dev, uint32_t* seg_info_dev, double* vertices_dev,
                  uint32_t* triangles_dev, void* stream)
 {
     if (!origin) return fail(HU_ERR_BAD_ARG, "NULL argument");
     if (n_blocks == 0) return HU_OK;
-    if (!fields_dev || !blocks_dev || !bits_dev || !wg_counts_dev || !info_dev || !vertices_dev || !triangles_dev)
+    if (!fields_dev || !blocks_dev || !masks_dev || !wg_counts_dev || !seg_info_dev || !vertices_dev || !triangles_dev)
         return fail(HU_ERR_BAD_ARG, "NULL argument");
-    uint32_t chunks;
+    McArgs a{};
     uint64_t n_wg;
     int rc;
-    if ((rc = mesh_shape(n_blocks, dims, chunks, n_wg))) return rc;
-    McArgs a{};
+    if ((rc = mesh_shape(n_blocks, dims, a, n_wg))) return rc;
     a.fields = fields_dev;
-    a.A0 = dims[0];
-    a.A1 = dims[1];
-    a.A2 = dims[2];
-    a.chunks = chunks;
-    mesh_divisors(a);
     a.blocks = reinterpret_cast<const int4*>(blocks_dev);
     a.res = resolution;
     a.ox = origin[0];
@@ -1060,10 +1038,9 @@ int hu_mesh_emit(const float* fields_dev, const int32_t* blocks_dev, uint32_t n_
     a.oz = origin[2];
     a.step = step;
     a.y_offset = y_offset;
-    a.bits = bits_dev;
-    a.words_per_block = mesh_words_per_block(dims, chunks);
+    a.masks = const_cast<uint32_t*>(masks_dev);
     a.wg_counts = reinterpret_cast<uint2*>(const_cast<uint32_t*>(wg_counts_dev));
-    a.info = info_dev;
+    a.seg_info = reinterpret_cast<uint4*>(seg_info_dev);
     a.vertices = vertices_dev;
     a.triangles = triangles_dev;
     hipLaunchKernelGGL(k_mc_vertices, dim3((uint32_t)n_wg), dim3(kMcBlock), 0, (hipStream_t)stream, a);

@@ -6,23 +6,24 @@
 // 1987), case table derived in tools/gen_mc_table.py; output ordering and arithmetic are those of
 // the oracle's restatement (oracle/sdf_oracle.c oracle_marching_cubes), so meshes compare equal.
 //
-// Indexed, deterministic output without atomics.  All passes are over the samples, 64 consecutive
-// samples of a block per wavefront:
-//   k_mc_bits       one INSIDE bit per sample (value <= 0): each wavefront's ballot is one 64-bit word
-//   k_mc_count      per workgroup: number of vertices (active edges owned by its samples) and of
-//                   triangles (cells whose low corner it owns)
+// Indexed, deterministic output without atomics.  The unit of work is a SEGMENT: up to 32 consecutive
+// samples along the fastest axis of a block (31 cells; a row of a 16^3 block is one segment), one
+// segment per lane, 256 consecutive segments of one block per workgroup:
+//   k_mc_masks      the only pass over the float samples: one inside bit per sample (value <= 0),
+//                   a 32-bit mask per segment
+//   k_mc_count      from the masks of a segment and of its +a0 / +a1 / +a0+a1 neighbours: the segment's
+//                   active edges (three XORs, three popcounts) and its cells' triangles (only cells whose
+//                   eight corner bits differ are looked up); reduced per workgroup
 //   k_mc_scan_*     exclusive scan of the workgroup counts (tiles of 1024, their totals, add back)
-//   k_mc_vertices   recompute, scan inside the workgroup, write vertex positions (fp64, world
-//                   coordinates as mesh.py:65-68 computes them) and each sample's first vertex id
-//   k_mc_triangles  recompute the case, scan, write triangles as global vertex ids
-// The three counting/emitting passes never touch the float samples to classify: a wavefront fetches
-// the eight 64-bit WINDOWS of the bit array that hold its lanes' eight cube corners (uniform loads),
-// and if no corner differs from the lane's own sample anywhere in the wavefront -- most wavefronts: the
-// surface crosses few of them -- it is done after a dozen scalar instructions.  Only surface wavefronts
-// extract per-lane case indices (shifts of the windows), and only active edges load float samples.
-// (The first version loaded 12 floats per sample in every pass and ran at 8 % of the HBM roofline.)
+//   k_mc_vertices   vertex ids from one scan per workgroup; per segment {first id, x/y/z edge masks};
+//                   positions (fp64, as mesh.py:65-68 computes them) from the two samples of each ACTIVE edge
+//   k_mc_triangles  per active cell the case, its triangles; a vertex id is the owning segment's first
+//                   id plus popcounts of its edge masks
+// The first version classified every sample from 12 float loads in each of three passes with one sample
+// per lane: 3.4 ms for the bench's 126 M samples, 8 % of the HBM roofline, bound by work per thread
+// (DESIGN.md).  Here the floats are read once, everything else works on 4 bytes per 16-32 samples.
 // A block is an array [A0][A1][A2] (a2 fastest): for the pymcubes layout A0 = sy (y flipped),
-// A1 = sx, A2 = sz.  One lane per sample; a workgroup owns 256 consecutive samples of one block.
+// A1 = sx, A2 = sz.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -33,11 +34,33 @@
 namespace sdfk {
 
 constexpr uint32_t kMcBlock = 256;
+constexpr uint32_t kMcSegCells = 31;  // cells per segment; a segment spans kMcSegCells + 1 samples
 
-__device__ __constant__ unsigned char kMcCornerDev[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0}, {0, 0, 1}, {1, 0, 1}, {1, 1, 1}, {0, 1, 1}};
-__device__ __constant__ unsigned char kMcEdgeOwnerDev[12][2] = {{0, 0}, {1, 1}, {3, 0}, {0, 1}, {4, 0}, {5, 1}, {7, 0}, {4, 1}, {0, 2}, {1, 2}, {2, 2}, {3, 2}};
-__device__ __constant__ signed char kMcTrianglesDev[256][MC_TABLE_WIDTH] = MC_TRIANGLES_INIT;
 __device__ __constant__ unsigned char kMcTriangleCountDev[256] = MC_TRIANGLE_COUNT_INIT;
+
+// The triangle table with each edge replaced by where its vertex lives: bits 0-2 = owning cube corner's
+// offset along a0, a1, a2, bits 3-4 = the edge's axis; 0xff ends the list.  One 16-byte row per case,
+// so a cell's triangles cost one load instead of a chain of three byte lookups per triangle edge.
+struct McPackedTable {
+    unsigned char row[256][MC_TABLE_WIDTH];
+};
+constexpr McPackedTable mc_make_packed_table()
+{
+    constexpr signed char tri[256][MC_TABLE_WIDTH] = MC_TRIANGLES_INIT;
+    constexpr unsigned char corner[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0}, {0, 0, 1}, {1, 0, 1}, {1, 1, 1}, {0, 1, 1}};
+    constexpr unsigned char owner[12][2] = {{0, 0}, {1, 1}, {3, 0}, {0, 1}, {4, 0}, {5, 1}, {7, 0}, {4, 1}, {0, 2}, {1, 2}, {2, 2}, {3, 2}};
+    McPackedTable p{};
+    for (int c = 0; c < 256; ++c)
+        for (int k = 0; k < MC_TABLE_WIDTH; ++k) {
+            const int e = tri[c][k];
+            p.row[c][k] = e < 0 ? 0xffu
+                                : (unsigned char)(corner[owner[e][0]][0] | (corner[owner[e][0]][1] << 1) |
+                                                  (corner[owner[e][0]][2] << 2) | (owner[e][1] << 3));
+        }
+    return p;
+}
+static_assert(MC_TABLE_WIDTH == 16, "a table row is loaded as one 16-byte vector");
+__device__ __constant__ McPackedTable kMcPackedDev = mc_make_packed_table();
 
 // x / d for x < 2^24 and d < 2^16 by one 64-bit multiply and a shift: m = floor(2^40 / d) + 1 is exact
 // while x*d < 2^40 (the host checks both bounds), instead of a ~40-instruction division per lane.
@@ -48,93 +71,87 @@ struct FastDiv {
 };
 inline FastDiv make_fast_div(uint32_t d) { return FastDiv{d, d > 1u ? (1ull << 40) / d + 1ull : 0ull}; }
 
+inline uint32_t mc_segments_per_row(uint32_t A2) { return A2 <= kMcSegCells + 1u ? 1u : (A2 - 1u + kMcSegCells - 1u) / kMcSegCells; }
+
 struct McArgs {
     const float* fields;      // float[n_blocks][A0*A1*A2]
     uint32_t A0, A1, A2;
-    FastDiv div_A1, div_A2;
-    uint32_t chunks;          // workgroups per block
+    uint32_t spr;             // segments per row (of A2 samples)
+    uint32_t segments;        // per block = A0*A1*spr
+    FastDiv div_A1, div_spr;
+    uint32_t chunks;          // workgroups per block = ceil(segments / 256)
     const int4* blocks;       // integer block corners
     double res, ox, oy, oz;   // block corner = int_corner * res + origin  (subdivision.py:100)
     double step;              // sample spacing of the block (box_resolution)
     double y_offset;          // added to y: 0 reproduces mesh.py:65-68, (A0-1)*step gives true positions
-    const uint64_t* bits;     // inside bits: words_per_block 64-bit words per block (zero padded at the end)
-    uint32_t words_per_block;
+    uint32_t* masks;          // [n_blocks][segments] inside bits
     uint2* wg_counts;         // per workgroup (vertices, triangles); exclusive prefix after k_mc_scan
-    uint32_t* info;           // per sample: first vertex id << 3 | active axes
+    uint4* seg_info;          // [n_blocks][segments] {first vertex id, x-edge mask, y-edge mask, z-edge mask}
     double* vertices;         // [.][3]
     uint32_t* triangles;      // [.][3]
 };
 
-struct McSample {
-    uint32_t b, s, a0, a1, a2;
-    bool valid;
+__device__ __forceinline__ uint32_t low_bits(uint32_t n) { return n >= 32u ? 0xffffffffu : (1u << n) - 1u; }
+
+// One lane's segment: where it is, which samples it spans, which neighbours exist.
+struct McSeg {
+    uint32_t b, seg, a0, a1, z0, cnt;   // block, segment index in the block, position, first sample, samples
+    bool valid, e0, e1, last;           // inside the block; +a0 / +a1 neighbour exists; last segment of its row
+    uint32_t xy_own, z_own;             // samples whose x/y edges, z edges this segment owns
 };
-
-__device__ __forceinline__ McSample mc_sample(const McArgs& a)
+__device__ __forceinline__ McSeg mc_segment(const McArgs& a)
 {
-    McSample m;
-    m.b = blockIdx.x / a.chunks;  // wave-uniform
-    const uint32_t chunk = blockIdx.x - m.b * a.chunks;
-    m.s = chunk * kMcBlock + threadIdx.x;
-    m.valid = m.s < a.A0 * a.A1 * a.A2;
-    const uint32_t v = m.valid ? m.s : 0u;
-    const uint32_t t = a.div_A2.div(v);
-    m.a2 = v - t * a.A2;
-    m.a0 = a.div_A1.div(t);
-    m.a1 = t - m.a0 * a.A1;
-    return m;
+    McSeg g;
+    g.b = blockIdx.x / a.chunks;  // wave-uniform
+    const uint32_t chunk = blockIdx.x - g.b * a.chunks;
+    g.seg = chunk * kMcBlock + threadIdx.x;
+    g.valid = g.seg < a.segments;
+    const uint32_t v = g.valid ? g.seg : 0u;
+    const uint32_t row = a.div_spr.div(v), sg = v - row * a.spr;
+    g.a0 = a.div_A1.div(row);
+    g.a1 = row - g.a0 * a.A1;
+    g.z0 = sg * kMcSegCells;
+    const uint32_t left = a.A2 - g.z0;
+    g.cnt = left < kMcSegCells + 1u ? left : kMcSegCells + 1u;
+    g.last = g.z0 + g.cnt == a.A2;
+    g.e0 = g.valid && g.a0 + 1u < a.A0;
+    g.e1 = g.valid && g.a1 + 1u < a.A1;
+    // the last sample of a segment that is not the last of its row is the first sample of the next one,
+    // which owns its edges
+    g.xy_own = g.valid ? low_bits(g.last ? g.cnt : g.cnt - 1u) : 0u;
+    g.z_own = g.valid ? low_bits(g.cnt - 1u) : 0u;
+    return g;
 }
+__device__ __forceinline__ uint32_t mc_first_sample(const McArgs& a, const McSeg& g) { return g.z0 + a.A2 * (g.a1 + a.A1 * g.a0); }
 
-// Inside bits of the 64 samples at linear offset `off` from this wavefront's samples (bit i = sample
-// first + i + off): two uniform word loads and a funnel shift.
-__device__ __forceinline__ uint64_t mc_window(const uint64_t* words, uint32_t first, uint32_t off)
-{
-    const uint32_t bit = first + off, w = bit >> 6, sh = bit & 63u;
-    const uint64_t lo = words[w], hi = words[w + 1];
-    return sh ? (lo >> sh) | (hi << (64u - sh)) : lo;
-}
-
-// The wavefront's eight corner windows (cube corner numbering of the table) and whether any corner
-// anywhere in the wavefront differs from the lane's own sample -- conservative: it ignores which
-// neighbours exist, so a wavefront may be kept for nothing, never dropped wrongly.
-struct McWindows {
-    uint64_t w[8];
-    bool any;
+// masks of the segment and its three neighbours, and what follows from them
+struct McMasks {
+    uint32_t m00, m10, m01, m11;  // (a0, a1), (a0+1, a1), (a0, a1+1), (a0+1, a1+1)
+    uint32_t ex, ey, ez;          // active owned edges along a0, a1, a2, one bit per sample of the segment
+    uint32_t cells;               // cells (bit i: between samples i and i+1) whose eight corners differ
 };
-__device__ __forceinline__ McWindows mc_windows(const McArgs& a, const McSample& m)
+__device__ __forceinline__ McMasks mc_masks(const McArgs& a, const McSeg& g)
 {
-    const uint64_t* words = a.bits + (size_t)m.b * a.words_per_block;
-    const uint32_t first = __builtin_amdgcn_readfirstlane(m.s) & ~63u;  // the wavefront's first sample
-    const uint32_t s0 = a.A1 * a.A2, s1 = a.A2;
-    McWindows r;
-    uint64_t diff = 0;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const uint32_t off = ((c == 1 || c == 2 || c == 5 || c == 6) ? s0 : 0u) + ((c == 2 || c == 3 || c == 6 || c == 7) ? s1 : 0u) +
-                             (c >= 4 ? 1u : 0u);
-        r.w[c] = mc_window(words, first, off);
-        diff |= r.w[c] ^ r.w[0];
-    }
-    r.any = diff != 0ull;
+    const uint32_t* m = a.masks + (size_t)g.b * a.segments + g.seg;
+    const uint32_t d0 = a.spr * a.A1, d1 = a.spr;
+    McMasks r;
+    r.m00 = g.valid ? m[0] : 0u;
+    r.m10 = g.e0 ? m[d0] : r.m00;
+    r.m01 = g.e1 ? m[d1] : r.m00;
+    r.m11 = (g.e0 && g.e1) ? m[d0 + d1] : r.m00;
+    r.ex = (r.m00 ^ r.m10) & g.xy_own;   // a missing neighbour was replaced by the segment itself: no edge
+    r.ey = (r.m00 ^ r.m01) & g.xy_own;
+    r.ez = (r.m00 ^ (r.m00 >> 1)) & g.z_own;
+    const uint32_t any = r.m00 | r.m10 | r.m01 | r.m11, all = r.m00 & r.m10 & r.m01 & r.m11;
+    r.cells = (g.e0 && g.e1) ? ((any | (any >> 1)) ^ (all & (all >> 1))) & g.z_own : 0u;
     return r;
 }
-
-// The lane's case index (0 when it owns no cell) and the active axes of its three owned edges.
-__device__ __forceinline__ void mc_classify(const McArgs& a, const McSample& m, const McWindows& win, uint32_t& cube, uint32_t& flags)
+// case index of cell i of the segment (corner numbering of the table)
+__device__ __forceinline__ uint32_t mc_cube(const McMasks& k, uint32_t i)
 {
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t bits = 0;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) bits |= (uint32_t)((win.w[c] >> lane) & 1ull) << c;
-    const bool e0 = m.a0 + 1u < a.A0, e1 = m.a1 + 1u < a.A1, e2 = m.a2 + 1u < a.A2;
-    const uint32_t own = bits & 1u;
-    flags = 0;
-    if (m.valid) {
-        if (e0 && ((bits >> 1) & 1u) != own) flags |= 1u;  // corner 1 = +a0
-        if (e1 && ((bits >> 3) & 1u) != own) flags |= 2u;  // corner 3 = +a1
-        if (e2 && ((bits >> 4) & 1u) != own) flags |= 4u;  // corner 4 = +a2
-    }
-    cube = (m.valid && e0 && e1 && e2) ? bits : 0u;
+    const uint32_t p00 = (k.m00 >> i) & 3u, p10 = (k.m10 >> i) & 3u, p11 = (k.m11 >> i) & 3u, p01 = (k.m01 >> i) & 3u;
+    return (p00 & 1u) | ((p10 & 1u) << 1) | ((p11 & 1u) << 2) | ((p01 & 1u) << 3) | ((p00 >> 1) << 4) | ((p10 >> 1) << 5) |
+           ((p11 >> 1) << 6) | ((p01 >> 1) << 7);
 }
 
 // exclusive scan of one value per lane over the workgroup; `total` = sum.  scratch: >= 8 uint32 of LDS.
@@ -161,30 +178,47 @@ __device__ __forceinline__ uint32_t wg_exclusive_scan(uint32_t v, uint32_t* scra
     return base + incl - v;
 }
 
-__global__ void __launch_bounds__(256) k_mc_bits(const McArgs a, uint64_t* __restrict__ bits)
+// sum of one value per lane over the workgroup (every lane gets it).  scratch: >= 8 uint32 of LDS.
+__device__ __forceinline__ uint32_t wg_sum(uint32_t v, uint32_t* scratch)
 {
-    const McSample m = mc_sample(a);
-    const float* f = a.fields + (size_t)m.b * a.A0 * a.A1 * a.A2;
-    const bool inside = m.valid && f[m.s] <= 0.0f;
-    const uint64_t word = __builtin_amdgcn_ballot_w64(inside);
-    if ((threadIdx.x & 63u) == 0u) bits[(size_t)m.b * a.words_per_block + (m.s >> 6)] = word;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63u) == 0u) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    uint32_t total = 0;
+    const uint32_t nw = (blockDim.x + 63u) >> 6;
+    for (uint32_t w = 0; w < nw; ++w) total += scratch[w];
+    return total;
+}
+
+__global__ void __launch_bounds__(256) k_mc_masks(const McArgs a)
+{
+    const McSeg g = mc_segment(a);
+    if (!g.valid) return;
+    const float* f = a.fields + (size_t)g.b * a.A0 * a.A1 * a.A2 + mc_first_sample(a, g);
+    uint32_t mask = 0;
+    if (g.cnt == 16u && (a.A2 & 3u) == 0u) {  // a row of a 16^3 block: four 16-byte loads in flight
+        const float4* f4 = reinterpret_cast<const float4*>(f);
+        const float4 v0 = f4[0], v1 = f4[1], v2 = f4[2], v3 = f4[3];
+        const float v[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mask |= (v[i] <= 0.0f ? 1u : 0u) << i;
+    } else {
+        for (uint32_t i = 0; i < g.cnt; ++i) mask |= (f[i] <= 0.0f ? 1u : 0u) << i;
+    }
+    a.masks[(size_t)g.b * a.segments + g.seg] = mask;
 }
 
 __global__ void __launch_bounds__(256) k_mc_count(const McArgs a)
 {
     __shared__ uint32_t scratch[8];
-    const McSample m = mc_sample(a);
-    const McWindows win = mc_windows(a, m);
-    uint32_t nv = 0, nt = 0;
-    if (win.any) {  // wave-uniform
-        uint32_t cube, flags;
-        mc_classify(a, m, win, cube, flags);
-        nv = __popc(flags);
-        nt = kMcTriangleCountDev[cube];
-    }
-    uint32_t total_v, total_t;
-    wg_exclusive_scan(nv, scratch, total_v);
-    wg_exclusive_scan(nt, scratch, total_t);
+    const McSeg g = mc_segment(a);
+    const McMasks k = mc_masks(a, g);
+    const uint32_t nv = __popc(k.ex) + __popc(k.ey) + __popc(k.ez);
+    uint32_t nt = 0;
+    for (uint32_t cells = k.cells; cells; cells &= cells - 1u) nt += kMcTriangleCountDev[mc_cube(k, __ffs(cells) - 1)];
+    const uint32_t total_v = wg_sum(nv, scratch), total_t = wg_sum(nt, scratch);
     if (threadIdx.x == 0) a.wg_counts[blockIdx.x] = make_uint2(total_v, total_t);
 }
 
@@ -234,62 +268,78 @@ __global__ void __launch_bounds__(1024) k_mc_scan_add(uint2* counts, uint32_t n,
 __global__ void __launch_bounds__(256) k_mc_vertices(const McArgs a)
 {
     __shared__ uint32_t scratch[8];
-    const McSample m = mc_sample(a);
-    const size_t block_base = (size_t)m.b * a.A0 * a.A1 * a.A2;
-    const McWindows win = mc_windows(a, m);
-    uint32_t cube = 0, flags = 0;
-    if (win.any) mc_classify(a, m, win, cube, flags);
+    const McSeg g = mc_segment(a);
+    const McMasks k = mc_masks(a, g);
     uint32_t total;
-    const uint32_t first = a.wg_counts[blockIdx.x].x + wg_exclusive_scan(__popc(flags), scratch, total);
-    if (!m.valid) return;
-    a.info[block_base + m.s] = (first << 3) | flags;
-    if (!flags) return;
+    uint32_t id = a.wg_counts[blockIdx.x].x + wg_exclusive_scan(__popc(k.ex) + __popc(k.ey) + __popc(k.ez), scratch, total);
+    if (!g.valid) return;
+    a.seg_info[(size_t)g.b * a.segments + g.seg] = make_uint4(id, k.ex, k.ey, k.ez);
+    uint32_t active = k.ex | k.ey | k.ez;
+    if (!active) return;
     // mesh.py:65-68 in numpy float64: swap the first two array axes, negate y, scale, add the corner
-    const float* f = a.fields + block_base;
-    const float f1 = f[m.s];
-    const int4 ic = a.blocks[m.b];
+    const float* f = a.fields + (size_t)g.b * a.A0 * a.A1 * a.A2 + mc_first_sample(a, g);
+    const int4 ic = a.blocks[g.b];
     const double cx = (double)ic.x * a.res + a.ox, cy = (double)ic.y * a.res + a.oy, cz = (double)ic.z * a.res + a.oz;
-    const uint32_t pos[3] = {m.a0, m.a1, m.a2}, stride[3] = {a.A1 * a.A2, a.A2, 1u};
-    uint32_t id = first;
+    const uint32_t stride[3] = {a.A1 * a.A2, a.A2, 1u}, edges[3] = {k.ex, k.ey, k.ez};
+    for (; active; active &= active - 1u) {
+        const uint32_t i = __ffs(active) - 1;
+        const float f1 = f[i];
+        const uint32_t pos[3] = {g.a0, g.a1, g.z0 + i};
 #pragma unroll
-    for (int axis = 0; axis < 3; ++axis) {
-        if (!(flags & (1u << axis))) continue;
-        const float f2 = f[m.s + stride[axis]];
-        const double t = (1.0 * (0.0 - (double)f1)) / ((double)f2 - (double)f1);
-        double v[3];
+        for (int axis = 0; axis < 3; ++axis) {
+            if (!((edges[axis] >> i) & 1u)) continue;
+            const float f2 = f[i + stride[axis]];
+            const double t = (1.0 * (0.0 - (double)f1)) / ((double)f2 - (double)f1);
+            double v[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) v[k] = (double)pos[k] + (k == axis ? t : 0.0);
-        double* out = a.vertices + 3 * (size_t)id;
-        out[0] = v[1] * a.step + cx;
-        out[1] = ((-v[0]) * a.step + cy) + a.y_offset;
-        out[2] = v[2] * a.step + cz;
-        ++id;
+            for (int c = 0; c < 3; ++c) v[c] = (double)pos[c] + (c == axis ? t : 0.0);
+            double* out = a.vertices + 3 * (size_t)id;
+            out[0] = v[1] * a.step + cx;
+            out[1] = ((-v[0]) * a.step + cy) + a.y_offset;
+            out[2] = v[2] * a.step + cz;
+            ++id;
+        }
     }
 }
 
 __global__ void __launch_bounds__(256) k_mc_triangles(const McArgs a)
 {
     __shared__ uint32_t scratch[8];
-    const McSample m = mc_sample(a);
-    const size_t block_base = (size_t)m.b * a.A0 * a.A1 * a.A2;
-    const McWindows win = mc_windows(a, m);
-    uint32_t cube = 0, flags = 0;
-    if (win.any) mc_classify(a, m, win, cube, flags);
-    const uint32_t nt = kMcTriangleCountDev[cube];
+    const McSeg g = mc_segment(a);
+    const McMasks k = mc_masks(a, g);
+    uint32_t nt = 0;
+    for (uint32_t cells = k.cells; cells; cells &= cells - 1u) nt += kMcTriangleCountDev[mc_cube(k, __ffs(cells) - 1)];
     uint32_t total;
     uint32_t slot = a.wg_counts[blockIdx.x].y + wg_exclusive_scan(nt, scratch, total);
     if (!nt) return;
-    const uint32_t stride[3] = {a.A1 * a.A2, a.A2, 1u};
-    const uint32_t* info = a.info + block_base + m.s;
-    for (uint32_t k = 0; k < 3u * nt; k += 3, ++slot) {
-        uint32_t* out = a.triangles + 3 * (size_t)slot;
+    const uint4* info = a.seg_info + (size_t)g.b * a.segments + g.seg;
+    const uint32_t d0 = a.spr * a.A1, d1 = a.spr;
+    for (uint32_t cells = k.cells; cells; cells &= cells - 1u) {
+        const uint32_t i = __ffs(cells) - 1;
+        const uint32_t cube = mc_cube(k, i);
+        const uint4 row4 = *reinterpret_cast<const uint4*>(kMcPackedDev.row[cube]);
+        const uint32_t row[4] = {row4.x, row4.y, row4.z, row4.w};
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int e = kMcTrianglesDev[cube][k + j];
-            const unsigned char* c = kMcCornerDev[kMcEdgeOwnerDev[e][0]];
-            const uint32_t axis = kMcEdgeOwnerDev[e][1];
-            const uint32_t w = info[c[0] * stride[0] + c[1] * stride[1] + c[2] * stride[2]];
-            out[j] = (w >> 3) + __popc(w & ((1u << axis) - 1u));
+        for (int t = 0; t < 15; t += 3) {  // at most five triangles per case
+            if (((row[t >> 2] >> (8 * (t & 3))) & 0xffu) == 0xffu) break;
+            uint32_t* out = a.triangles + 3 * (size_t)slot;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const uint32_t pk = (row[(t + j) >> 2] >> (8 * ((t + j) & 3))) & 0xffu;
+                const uint32_t axis = pk >> 3;
+                // the owning segment's record is fetched per use: the four candidates held in registers and
+                // selected per lane measured slower (1.26 vs 0.96 ms), the loads hit the cache
+                uint32_t q = ((pk & 1u) ? d0 : 0u) + ((pk & 2u) ? d1 : 0u), li = i + ((pk >> 2) & 1u);
+                if (li == g.cnt - 1u && !g.last) {  // that sample's edges belong to the next segment of the row
+                    q += 1u;
+                    li = 0u;
+                }
+                const uint4 w = info[q];
+                const uint32_t below = low_bits(li);
+                out[j] = w.x + __popc(w.y & below) + __popc(w.z & below) + __popc(w.w & below) +
+                         (axis >= 1u ? (w.y >> li) & 1u : 0u) + (axis == 2u ? (w.z >> li) & 1u : 0u);
+            }
+            ++slot;
         }
     }
 }

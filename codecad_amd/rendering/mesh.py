@@ -54,16 +54,16 @@ def mesh_blocks(leaves, true_positions=False, queue=None, download=True):
           "hu_mesh_workgroups")
     n_wg = n_wg.value
     counts = hip_util.Buffer(numpy.uint32, (entries.value, 2), queue=queue)
-    bits = hip_util.Buffer(numpy.uint64, (words.value,), queue=queue)
+    bits = hip_util.Buffer(numpy.uint32, (words.value,), queue=queue)   # one inside bit per sample, a mask per segment
     ev0 = hip_util.Event(hip_manager, queue)
     check(lib.hu_mesh_count(fields.device_ptr, n, dims, bits.device_ptr, counts.device_ptr, queue.handle), "hu_mesh_count")
     ev0._done()
     prefix = counts.read(wait_for=[ev0]).copy()
     total_v, total_t = int(prefix[n_wg, 0]), int(prefix[n_wg, 1])
-    assert total_v < 2 ** 29, "too many vertices for one call"
+    assert total_v < 2 ** 32, "too many vertices for one call"
     chunks = n_wg // n
     starts = numpy.concatenate([prefix[0:n_wg:chunks], prefix[n_wg:n_wg + 1]]).astype(numpy.int64)
-    info = hip_util.Buffer(numpy.uint32, (n, sx * sy * sz), queue=queue)
+    info = hip_util.Buffer(numpy.uint32, (words.value, 4), queue=queue)   # per segment: first vertex id, edge masks
     vertices = hip_util.Buffer(numpy.float64, (max(total_v, 1), 3), queue=queue)
     triangles = hip_util.Buffer(numpy.uint32, (max(total_t, 1), 3), queue=queue)
     o = (ctypes.c_double * 3)(leaves.origin.x, leaves.origin.y, leaves.origin.z)

@@ -176,27 +176,28 @@ int hu_process_polygon_blocks(const void* corners_dev, const int32_t* blocks_dev
  * 0.0.6, a dependency that is not part of the reference tree) for ALL leaf blocks at once.
  * fields_dev: float[n_blocks][dims[0]*dims[1]*dims[2]], each block an array [A0][A1][A2] (last index
  * fastest), inside = value <= 0; for blocks written by hu_grid_eval_blocks(layout 1) over (sx, sy, sz)
- * samples pass dims = (sy, sx, sz).  Work is split into workgroups of 256 samples:
- * hu_mesh_workgroups gives their number n, the number of (uint32, uint32) entries wg_counts_dev must
- * hold (n + 1 + scan scratch) and the number of 64-bit words bits_dev must hold.
- * hu_mesh_count: bits_dev <- one inside bit per sample; wg_counts_dev[0..n) <- exclusive prefix of
- * (vertices, triangles) per workgroup; entry n holds the totals (read it back to size the outputs;
- * block b starts at workgroup b*n/n_blocks).  Asynchronous.
- * hu_mesh_emit (same fields, bits and counts): vertices_dev double[total_vertices][3] in world
+ * samples pass dims = (sy, sx, sz).  The unit of work is a segment (up to 32 consecutive samples along
+ * the last axis: a row of a 16^3 block), 256 segments per workgroup: hu_mesh_workgroups gives the
+ * number n of workgroups, the number of (uint32, uint32) entries wg_counts_dev must hold (n + 1 + scan
+ * scratch) and the total number of segments.
+ * hu_mesh_count: masks_dev uint32[segments] <- one inside bit per sample; wg_counts_dev[0..n) <-
+ * exclusive prefix of (vertices, triangles) per workgroup; entry n holds the totals (read it back to
+ * size the outputs; block b starts at workgroup b*n/n_blocks).  Asynchronous.
+ * hu_mesh_emit (same fields, masks and counts): vertices_dev double[total_vertices][3] in world
  * coordinates exactly as mesh.py:65-68 computes them (swap the first two array axes, negate y, * step,
  * + block corner, all in fp64; block corner = int_corner*resolution + origin), plus y_offset on y (0 =
  * the reference's placement, which sits (A0-1)*step below the true one; (A0-1)*step = true positions);
  * triangles_dev uint32[total_triangles][3], global vertex ids, anticlockwise seen from outside the solid;
- * info_dev: scratch uint32[n_blocks*samples].  Order: vertices by owning sample then axis, triangles by
- * cell -- deterministic, no atomics.  At most 2^29 vertices per call. */
+ * seg_info_dev: scratch uint32[4*segments].  Order: vertices by owning sample then axis, triangles by
+ * cell -- deterministic, no atomics.  At most 2^32 - 1 vertices per call. */
 int hu_mesh_workgroups(uint32_t n_blocks, const uint32_t dims[3], uint64_t* n_workgroups,
-                       uint64_t* count_entries, uint64_t* bit_words);
+                       uint64_t* count_entries, uint64_t* segments);
 int hu_mesh_count(const float* fields_dev, uint32_t n_blocks, const uint32_t dims[3],
-                  uint64_t* bits_dev, uint32_t* wg_counts_dev, void* stream);
+                  uint32_t* masks_dev, uint32_t* wg_counts_dev, void* stream);
 int hu_mesh_emit(const float* fields_dev, const int32_t* blocks_dev, uint32_t n_blocks,
                  double resolution, const double origin[3], double step, const uint32_t dims[3],
-                 double y_offset, const uint64_t* bits_dev, const uint32_t* wg_counts_dev,
-                 uint32_t* info_dev, double* vertices_dev, uint32_t* triangles_dev, void* stream);
+                 double y_offset, const uint32_t* masks_dev, const uint32_t* wg_counts_dev,
+                 uint32_t* seg_info_dev, double* vertices_dev, uint32_t* triangles_dev, void* stream);
 
 /* Per-tape specialisation (the reference's generate_fixed_eval_source_code, nodes/codegen.py:137-204):
  * unroll the decoded program into straight-line gfx950 code with hipRTC, using the op library

@@ -164,11 +164,11 @@ def hip_marching_cubes(hip, fields, true_positions=False):
     n_wg, entries, words = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint64(0)
     assert lib.hu_mesh_workgroups(n, dims, ctypes.byref(n_wg), ctypes.byref(entries), ctypes.byref(words)) == 0
     counts = hip_util.Buffer(np.uint32, (entries.value, 2))
-    bits = hip_util.Buffer(np.uint64, (words.value,))
+    bits = hip_util.Buffer(np.uint32, (words.value,))
     assert lib.hu_mesh_count(fields_dev.device_ptr, n, dims, bits.device_ptr, counts.device_ptr, hip.queue.handle) == 0, lib.hu_last_error()
     prefix = counts.read().copy()
     tv, tt = int(prefix[n_wg.value, 0]), int(prefix[n_wg.value, 1])
-    info = hip_util.Buffer(np.uint32, (n, a0 * a1 * a2))
+    info = hip_util.Buffer(np.uint32, (words.value, 4))
     vertices = hip_util.Buffer(np.float64, (max(tv, 1), 3))
     triangles = hip_util.Buffer(np.uint32, (max(tt, 1), 3))
     o = (ctypes.c_double * 3)(0.0, 0.0, 0.0)
@@ -210,7 +210,9 @@ def test_hip_marching_cubes_matches_oracle_on_noise_and_spheres(hip):
 def test_hip_marching_cubes_sizes_that_split_a_block_over_workgroups(hip):
     """257 and 1000+ samples per block: vertex ids and triangle slots cross workgroup boundaries."""
     rng = np.random.default_rng(5)
-    for shape in ((2, 1, 257, 1), (3, 10, 10, 11), (1, 2, 2, 2), (2, 33, 5, 17)):
+    # ... and rows longer than one 32-sample segment (33, 63, 70, 100 samples: segments share their end samples)
+    for shape in ((2, 1, 257, 1), (3, 10, 10, 11), (1, 2, 2, 2), (2, 33, 5, 17), (2, 3, 4, 32), (2, 3, 4, 33),
+                  (1, 5, 3, 63), (2, 4, 5, 70), (1, 20, 20, 100), (1, 1, 1, 40), (1, 2, 1, 40)):
         fields = rng.uniform(-1, 1, shape).astype(np.float32)
         v, t, starts = hip_marching_cubes(hip, fields)
         for b in range(shape[0]):
