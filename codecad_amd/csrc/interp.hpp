@@ -614,6 +614,11 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const floa
     const bool scalar_slot = DISTANCE_ONLY && (cur.hdr & kResultKind);  // wave-uniform
     const float* p = cur.p;
     const V4<T> none = v4<T>(bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f));
+    const uint32_t fold = __float_as_uint(cur.p[kFoldParam]);  // wave-uniform (tape.hpp fold_moves)
+    if (fold & kFoldLoad) {
+        if (DISTANCE_ONLY && (fold & kFoldLoadResult)) last.w = regs.load_res(fold & 0xffu);
+        else last = regs.load(fold & 0xffu);
+    }
     switch (op) {
     case OP_RETURN: return true;
     case OP_STORE:
@@ -801,6 +806,10 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const floa
         else last = neg(rounded_union(p[0], neg(last), regs.load(reg)));
         break;
     default: return true;  // unreachable: tapes are validated at upload
+    }
+    if (fold & kFoldStore) {
+        if (DISTANCE_ONLY && (fold & kFoldStoreResult)) regs.store_res((fold >> 16) & 0xffu, last.w);
+        else regs.store((fold >> 16) & 0xffu, last);
     }
     return false;
 }

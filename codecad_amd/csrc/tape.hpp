@@ -153,6 +153,44 @@ inline bool allocate_slots(DecodedTape& d, std::string& err)
 inline float q_k(const float* q) { return fma_(q[3], q[3], -fma_(q[2], q[2], fma_(q[1], q[1], q[0] * q[0]))); }
 inline float q_scale(const float* q) { return fma_(q[3], q[3], fma_(q[2], q[2], fma_(q[1], q[1], q[0] * q[0]))); }
 
+// Fold _load into the record that follows it and _store into the record before it (tape_format.hpp
+// kFold*).  Order of effects is unchanged: the load happens first, the store last.
+inline void fold_moves(std::vector<Rec>& prog)
+{
+#ifndef SDF_FOLD_MOVES
+#define SDF_FOLD_MOVES 1
+#endif
+    if (!SDF_FOLD_MOVES) return;
+    auto fold_of = [](Rec& r) -> uint32_t& { return reinterpret_cast<uint32_t&>(r.p[kFoldParam]); };
+    std::vector<Rec> out;
+    out.reserve(prog.size());
+    uint32_t pending_load = 0;  // fold word bits for the next real record
+    bool last_foldable = false; // the previous emitted record can still take a store
+    for (size_t i = 0; i < prog.size(); ++i) {
+        Rec r = prog[i];
+        const uint32_t op = r.hdr & 0xffu, slot = (r.hdr >> 8) & 0xffffu;
+        const bool result = (r.hdr & kResultKind) != 0;
+        const bool next_is_real = i + 1 < prog.size() && (prog[i + 1].hdr & 0xffu) != OP_STORE && (prog[i + 1].hdr & 0xffu) != OP_LOAD;
+        if (op == OP_LOAD && slot < 256u && next_is_real && !pending_load) {
+            pending_load = kFoldLoad | (result ? kFoldLoadResult : 0u) | slot;
+            last_foldable = false;
+            continue;
+        }
+        if (op == OP_STORE && slot < 256u && last_foldable && !(fold_of(out.back()) & kFoldStore)) {
+            fold_of(out.back()) |= kFoldStore | (result ? kFoldStoreResult : 0u) | (slot << 16);
+            continue;
+        }
+        if (op != OP_STORE && op != OP_LOAD) {
+            fold_of(r) = pending_load;
+            pending_load = 0;
+        }
+        out.push_back(r);
+        last_foldable = op != OP_STORE && op != OP_LOAD && op != OP_RETURN;
+        if (op == OP_RETURN) break;
+    }
+    prog.swap(out);
+}
+
 // Validate + decode.  Returns "" on success, otherwise the reason the tape is malformed.
 inline std::string decode_tape(const float* tape, size_t n, DecodedTape& out)
 {
@@ -281,6 +319,8 @@ inline std::string decode_tape(const float* tape, size_t n, DecodedTape& out)
         std::string err;
         if (!allocate_slots(out, err)) return err;
     }
+    fold_moves(out.recs);
+    if (!out.recs_do.empty()) fold_moves(out.recs_do);
     // Zero (= _return) records of padding: the interpreter fetches records in groups.
     Rec pad;
     std::memset(&pad, 0, sizeof(pad));

@@ -42,6 +42,12 @@ constexpr int kTapePadding = 8;         // >= interp.hpp kFetchGroup
 // `slot` is NOT the tape's register number: registers are renamed at decode time
 // (allocate_slots below) to the smallest set of LDS slots that liveness allows.
 constexpr uint32_t kResultKind = 0x80000000u;  // distance-only program: the slot holds a bare distance
+// _load / _store folded into the neighbouring record (tape.hpp fold_moves): the last parameter dword
+// says "first load `last` from a slot" and/or "afterwards store `last` to a slot".  A third of the
+// sponge's instructions are such moves; folded, they cost two uniform tests instead of a dispatch each.
+constexpr int kFoldParam = 10;   // p[10]: no op uses it (records have 11 parameter dwords)
+constexpr uint32_t kFoldLoad = 0x100u, kFoldLoadResult = 0x200u;          // bits 0-7: slot
+constexpr uint32_t kFoldStore = 0x1000000u, kFoldStoreResult = 0x2000000u;  // bits 16-23: slot
 #ifndef SDF_REC_DWORDS
 #define SDF_REC_DWORDS 12
 #endif
