@@ -239,6 +239,9 @@ int check_dims(const uint32_t dims[3], uint64_t& cells)
 // removed by dead-code elimination.  The arithmetic is the interpreter's, operation for
 // operation, so results are identical (tests run the parity suite on specialised tapes).
 // ------------------------------------------------------------------------------------------
+// All eight per-tape kernels are compiled together in one module: measured, hipRTC spends its time on the
+// shared straight-line tape function, not per kernel (sponge(4): 0.9 s for eight kernels, 0.56 s for one;
+// planetary: 18 s either way), so compiling lazily, kernel by kernel, costs more whenever two are used.
 struct SpecKernels {
     hipModule_t module = nullptr;
     hipFunction_t dense[2] = {nullptr, nullptr};
