@@ -272,7 +272,7 @@ std::string generate_source(const hu_tape_s* t)
             std::snprintf(buf, sizeof buf, "0x%08xu", bits);
             o << (i ? ", " : "") << "__builtin_bit_cast(float, " << buf << ")";
         }
-        o << "}}; exec_one<T, false>(r, last, extra, px, py, pz, regs); }\n";
+        o << "}}; exec_one<T, false, decltype(regs), " << (r.hdr & 0xffu) << ">(r, last, extra, px, py, pz, regs); }\n";
     }
     o << "    return last;\n}\n"
       << "struct JitEval {\n    const float* extra;\n"

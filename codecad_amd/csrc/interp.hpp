@@ -605,11 +605,16 @@ template <class T, int SLOTS> struct RegsV {
 #endif
 constexpr int kFetchGroup = SDF_FETCH_GROUP;  // tape.hpp pads the program with kTapePadding _return records
 
-template <class T, bool DISTANCE_ONLY, class R>
+// STATIC_OP >= 0 (per-tape code, where the generator knows each record's opcode): the switch below is on a
+// compile-time constant, so the front end emits only that case.  Leaving it to the optimiser to discover
+// that a literal record selects one case of 38 made hipRTC spend 94 % of its time in the inliner and in
+// correlated-value-propagation over dead cases (planetary, 467 records: 18 s -> see DESIGN.md).
+template <class T, bool DISTANCE_ONLY, class R, int STATIC_OP = -1>
 __device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const float* __restrict__ extra, T px, T py,
                                          T pz, R& regs)
 {
-    const uint32_t op = cur.hdr & 0xffu;
+    constexpr bool kStaticOp = STATIC_OP >= 0;
+    const uint32_t op = kStaticOp ? (uint32_t)STATIC_OP : (cur.hdr & 0xffu);
     const uint32_t reg = (cur.hdr >> 8) & 0xffffu;
     const bool scalar_slot = DISTANCE_ONLY && (cur.hdr & kResultKind);  // wave-uniform
     const float* p = cur.p;
