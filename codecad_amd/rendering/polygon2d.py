@@ -122,3 +122,29 @@ def polygon(obj, subdivision_grid_size=None):
     ic, vertices, links, starts = contour_blocks(leaves)
     leaves.blocks.release()
     yield from stitch([(ic[i], vertices[i], links[i], starts[i]) for i in range(len(ic))], int_box_step)
+
+
+# ---- SVG export (reference rendering/svg.py:4-36) ------------------------------------------------
+_SVG_STYLE = ('<style type="text/css">path{stroke:#000;stroke-width:1px;vector-effect:non-scaling-stroke;'
+              'fill:#BBF23C;}</style>')
+
+
+def svg_document(obj, polygons=None):
+    """The SVG text of a 2D shape: one path, a sub-path per boundary polygon, in millimetres, y up."""
+    polygons = polygon(obj) if polygons is None else polygons
+    box = obj.bounding_box()
+    width, height = box.size().x, box.size().y
+    parts = ['<svg xmlns="http://www.w3.org/2000/svg" width="%smm" height="%smm" viewBox="%s %s %s %s">'
+             % (width, height, box.a.x, -box.b.y, width, height), _SVG_STYLE, '<path d="']
+    for chain in polygons:
+        # flipping y flips the winding, so walk the chain backwards; close on its last point
+        points = list(reversed(chain)) + [chain[-1]]
+        parts.append("M%s,%s" % (points[0][0], -points[0][1]))
+        parts.extend("L%s,%s" % (x, -y) for x, y in points[1:])
+    parts.append('"/></svg>')
+    return "".join(parts)
+
+
+def render_svg(obj, filename):
+    with open(filename, "w") as fp:
+        fp.write(svg_document(obj))

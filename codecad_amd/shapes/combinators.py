@@ -359,3 +359,28 @@ class InvoluteGear(Union2D):
         if backlash != 0:
             profile = profile.offset(-backlash)
         super().__init__([profile & Circle(r=outer), Circle(r=inner)])
+
+
+# ---------------------------------------------------------------------------------------------
+# n-ary constructors (exported by the package)
+# ---------------------------------------------------------------------------------------------
+def _group(shapes, what, cls2, cls3, r):
+    shapes = list(shapes)
+    if not shapes:
+        raise ValueError(what + " of empty set objects doesn't make much sense, does it?")
+    if len(shapes) == 1:
+        return shapes[0]
+    dim = shapes[0].dimension()
+    if any(s.dimension() != dim for s in shapes):
+        raise ValueError(what + " needs shapes of identical dimensions")
+    return (cls2 if dim == 2 else cls3)(shapes, r=r)
+
+
+def union(shapes, r=-1):
+    """Union; r >= 0 rounds the seams with that radius."""
+    return _group(shapes, "Union", Union2D, Union, r)
+
+
+def intersection(shapes, r=-1):
+    """Intersection; r >= 0 rounds the seams with that radius."""
+    return _group(shapes, "Intersection", Intersection2D, Intersection, r)

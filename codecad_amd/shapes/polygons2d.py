@@ -176,3 +176,13 @@ class Polygon2DBuilder:
     def print(self, file=sys.stdout):
         print(str(self.points), file=file)
         return self
+
+
+def polygon2d(points):
+    """Simple polygon from (x, y) points, either winding; rejects self-intersections."""
+    return Polygon2D(points)
+
+
+def polygon2d_builder(origin_x, origin_y):
+    """Turtle-style builder: `.dx(..).dy(..).angle(..).close()` -> polygon."""
+    return Polygon2D.build(origin_x, origin_y)

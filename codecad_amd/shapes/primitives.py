@@ -199,3 +199,61 @@ class Revolution(base.Shape3D):
         flat_point = cache.make_node("twist_revolution_to", [self.r, self.twist], [point])
         return cache.make_node("twist_revolution_from", [self.minor_r, self.r, self.twist],
                                [self.s.get_node(flat_point, cache), point])
+
+
+# ---------------------------------------------------------------------------------------------
+# Constructor functions: the user-facing spelling of the classes above (exported by the package).
+# ---------------------------------------------------------------------------------------------
+def rectangle(x=1, y=None):
+    """Axis-aligned rectangle centred on the origin; one argument gives a square.
+    Tape op `rectangle(half_w, half_h)`: exact distance, outward unit direction."""
+    return Rectangle(x, x if y is None else y)
+
+
+def circle(d=1, r=None):
+    """Circle centred on the origin by diameter `d` or radius `r` (tape op `circle(r)`)."""
+    return Circle(d, r)
+
+
+def half_plane():
+    """The half plane y > 0 (tape op `half_space`, shared with the 3D half space)."""
+    return HalfPlane()
+
+
+def regular_polygon2d(n, d=1, r=None, side_length=None, across_flats=None):
+    """Regular n-gon with a vertex on +x, sized by exactly one of circumscribed diameter `d`,
+    circumscribed radius `r`, `side_length` or `across_flats`."""
+    return RegularPolygon2D(n, d, r, side_length, across_flats)
+
+
+def capsule(x1, y1, x2, y2, width):
+    """Stadium between two points: a zero-height rectangle offset by width/2."""
+    dx, dy = x2 - x1, y2 - y1
+    return (rectangle(math.hypot(dx, dy), 0).offset(width / 2)
+            .rotated(math.degrees(math.atan2(dy, dx))).translated((x1 + x2) / 2, (y1 + y2) / 2))
+
+
+def box(x=1, y=None, z=None):
+    """Cuboid centred on the origin (a rectangle extruded symmetrically); one argument gives a cube.
+    `float("inf")` along z gives an infinite prism (the extrusion node is then omitted)."""
+    if (y is None) != (z is None):
+        raise ValueError("y and z must either both be None, or both be number")
+    if y is None:
+        y = z = x
+    return rectangle(x, y).extruded(z)
+
+
+def sphere(d=1, r=None):
+    """Sphere centred on the origin by diameter or radius (tape op `sphere(r)`)."""
+    return Sphere(2 * r if r is not None else d)
+
+
+def cylinder(h=1, d=1, r=None, symmetrical=True):
+    """Cylinder along z: a circle extruded by `h`, centred on z = 0 unless symmetrical=False
+    (then it stands on the z = 0 plane)."""
+    return circle(d=d, r=r).extruded(h, symmetrical)
+
+
+def half_space():
+    """The half space y > 0."""
+    return HalfSpace()

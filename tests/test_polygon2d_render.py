@@ -164,10 +164,9 @@ def test_hip_polygons_match_the_oracle_pipeline(hip, name, grid):
 
 @pytest.mark.gpu
 def test_svg_export(hip, tmp_path):
-    from codecad_amd.rendering import svg
     shape = shapes_zoo.shapes_2d["gear"]
     path = tmp_path / "gear.svg"
-    svg.render_svg(shape, str(path))
+    polygon2d.render_svg(shape, str(path))
     text = path.read_text()
     assert text.startswith('<svg xmlns="http://www.w3.org/2000/svg"') and text.endswith('"/></svg>')
     assert text.count("M") == len(list(polygon2d.polygon(shape))) and text.count("L") > 100

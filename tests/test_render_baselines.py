@@ -15,7 +15,7 @@ from PIL import Image
 import oracle
 import shapes_zoo
 from codecad_amd import nodes
-from codecad_amd.rendering import ray_caster, bitmap
+from codecad_amd.rendering import ray_caster, pictures
 from conftest import ROOT
 
 SIZE = (1024, 768)
@@ -39,7 +39,7 @@ def oracle_render(name, size=SIZE, threads=None):
     shape = {**shapes_zoo.shapes_2d, **shapes_zoo.shapes_3d}[name]
     tape = nodes.make_program(shape)
     if shape.dimension() == 2:
-        origin, step = bitmap.kernel_arguments(shape, size)
+        origin, step = pictures.bitmap_arguments(shape, size)
         out = oracle.bitmap(tape, list(origin), np.float32(step), size)
     else:
         cam = ray_caster.get_camera_params(shape.bounding_box(), size, None)
@@ -63,13 +63,12 @@ def test_oracle_render_matches_reference_baseline(name):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ALL)
 def test_hip_render_matches_oracle_and_baseline(hip, name):
-    from codecad_amd.rendering import image
     shape = {**shapes_zoo.shapes_2d, **shapes_zoo.shapes_3d}[name]
-    pixels = image.render_pixels(shape, SIZE)
+    pixels = pictures.render_pixels(shape, SIZE)
     assert pixels.shape == (SIZE[1], SIZE[0], 3) and pixels.dtype == np.uint8
     assert mse(pixels, name) <= 1e-3
     small = (160, 120)
-    got = image.render_pixels(shape, small)
+    got = pictures.render_pixels(shape, small)
     want = oracle_render(name, small, threads=16)
     differing = np.count_nonzero(np.any(got != want, axis=-1))
     assert differing == 0, "%d of %d pixels differ from the oracle" % (differing, small[0] * small[1])

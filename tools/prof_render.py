@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import shapes_zoo  # noqa: E402
 from codecad_amd import nodes, hip_util  # noqa: E402
 from codecad_amd.hip_util import manager as m  # noqa: E402
-from codecad_amd.rendering import ray_caster, bitmap  # noqa: E402
+from codecad_amd.rendering import ray_caster, pictures  # noqa: E402
 from codecad_amd import examples  # noqa: E402
 
 SIZE = (1024, 768)
@@ -23,7 +23,7 @@ def time_shape(name, shape, reps=5):
     tape = nodes.make_program_buffer(shape)
     out = hip_util.Buffer(np.uint8, SIZE + (3,))
     if shape.dimension() == 2:
-        origin, step = bitmap.kernel_arguments(shape, SIZE)
+        origin, step = pictures.bitmap_arguments(shape, SIZE)
         launch = lambda: m.k.bitmap(SIZE, None, tape, origin.as_float4(), np.float32(step), out)
     else:
         cam = ray_caster.get_camera_params(shape.bounding_box(), SIZE, None)
