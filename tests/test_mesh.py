@@ -222,10 +222,18 @@ def test_hip_marching_cubes_sizes_that_split_a_block_over_workgroups(hip):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,grid", [("box", 12), ("sphere", 16), ("csg_thing", 16), ("torus", 12), ("symmetrical_xyz", 16)])
+def _tall_shape():
+    """A thin tall box with a ball on it: with the default 128^3 blocks its rows (z is the fastest axis)
+    are ~100 samples long, i.e. several 32-sample segments each."""
+    return shapes.box(4, 4, 200) + shapes.sphere(6).translated_z(30)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,grid", [("box", 12), ("sphere", 16), ("csg_thing", 16), ("torus", 12), ("symmetrical_xyz", 16),
+                                       ("csg_thing", None), ("tall", None), ("tall", 40)])
 def test_hip_mesh_pipeline_matches_oracle_pipeline(hip, name, grid):
     from codecad_amd.rendering import mesh
-    shape = shapes_zoo.shapes_3d[name]
+    shape = _tall_shape() if name == "tall" else shapes_zoo.shapes_3d[name]
     got = list(mesh.triangular_mesh(shape, subdivision_grid_size=grid))
     want = [(c, v, t) for c, v, t in oracle_mesh(shape, grid)[0] if len(t)]
     assert len(got) == len(want) > 0
