@@ -31,14 +31,13 @@ class map_flags:
 
 
 class _PinnedBlock:
-    """Owns one hipHostMalloc allocation; freed when the last numpy view of it dies, so an
-    array returned by Buffer.read() stays valid after the Buffer itself is gone."""
+    """Owns one pinned host allocation (from the manager's pool); given back when the last numpy view of
+    it dies, so an array returned by Buffer.read() stays valid after the Buffer itself is gone."""
 
-    def __init__(self, manager, nbytes):
+    def __init__(self, manager, nbytes, stream_key):
         self.manager = manager
-        p = ctypes.c_void_p()
-        check(manager.lib.hu_host_alloc(ctypes.byref(p), max(nbytes, 1)), "hu_host_alloc")
-        self.ptr = p.value
+        self.stream_key = stream_key
+        self.ptr, self.size_class = manager.pinned_pool.take(stream_key, nbytes)
 
     def view(self, dtype, nitems, shape, nbytes):
         raw = (ctypes.c_char * max(nbytes, 1)).from_address(self.ptr)
@@ -48,7 +47,7 @@ class _PinnedBlock:
     def __del__(self):
         try:
             if self.ptr:
-                self.manager.lib.hu_host_free(self.ptr)
+                self.manager.pinned_pool.give(self.stream_key, self.ptr, self.size_class)
                 self.ptr = None
         except Exception:
             pass
@@ -78,14 +77,13 @@ class Buffer:
         self.size = self.nitems * self.dtype.itemsize  # bytes
         self.array = None
         self._pinned = None
-        p = ctypes.c_void_p()
-        check(m.lib.hu_malloc(ctypes.byref(p), self.size), "hu_malloc")
-        self.device_ptr = p.value
+        self._stream_key = self.queue.handle
+        self.device_ptr, self._size_class = m.device_pool.take(self._stream_key, self.size)
 
     # -- host shadow ---------------------------------------------------------------------
     def create_host_side_array(self):
         """Allocate the pinned shadow array `self.array` (uninitialised)."""
-        self._pinned = _PinnedBlock(self.manager, self.size)
+        self._pinned = _PinnedBlock(self.manager, self.size, self._stream_key)
         self.array = self._pinned.view(self.dtype, self.nitems, self.shape, self.size)
 
     def _host(self, array):
@@ -166,11 +164,10 @@ class Buffer:
         return self.nitems
 
     def release(self):
-        """Free the device memory now (idempotent).  The pinned shadow is freed when the last
-        array that views it is gone."""
-        lib = self.manager.lib
+        """Give the device memory back now (idempotent): to the manager's pool, for the next buffer used on
+        the same stream.  The pinned shadow follows when the last array that views it is gone."""
         if self.device_ptr:
-            check(lib.hu_free(self.device_ptr), "hu_free")
+            self.manager.device_pool.give(self._stream_key, self.device_ptr, self._size_class)
             self.device_ptr = None
         self._pinned = None
 

@@ -206,6 +206,54 @@ class _Kernels:
             _ptr(start_counter), s), "hu_process_polygon"))
 
 
+class _BlockPool:
+    """Recycles device (or pinned host) allocations.
+
+    hipMalloc / hipFree cost 0.1-1 ms each and hipFree synchronises the device; the level-synchronous
+    drivers allocate a handful of lists per level, which made `mass_properties` spend two thirds of its
+    wall time in the allocator (sponge(4) at 1/512: 1.1 ms of kernels, 3.4 ms wall).  Blocks are
+    rounded up to a size class and returned to the pool of the STREAM they were used on: the next user
+    enqueues on the same in-order stream, so work still in flight on the block finishes first.
+    CODECAD_AMD_POOL_MB caps the cached bytes (default 4096, 0 disables pooling)."""
+
+    def __init__(self, alloc, free, limit_bytes):
+        self._alloc, self._free, self.limit = alloc, free, limit_bytes
+        self.blocks = {}   # (stream key, size class) -> [pointers]
+        self.cached = 0
+
+    @staticmethod
+    def size_class(nbytes):
+        nbytes = max(int(nbytes), 1)
+        if nbytes <= (1 << 20):
+            return max(256, 1 << (nbytes - 1).bit_length())
+        return (nbytes + (1 << 20) - 1) & ~((1 << 20) - 1)
+
+    def take(self, stream_key, nbytes):
+        cls = self.size_class(nbytes)
+        stack = self.blocks.get((stream_key, cls))
+        if stack:
+            self.cached -= cls
+            return stack.pop(), cls
+        try:
+            return self._alloc(cls), cls
+        except RuntimeError:
+            self.trim()          # out of memory with blocks cached: give them back and retry once
+            return self._alloc(cls), cls
+
+    def give(self, stream_key, ptr, cls):
+        if self.cached + cls <= self.limit:
+            self.blocks.setdefault((stream_key, cls), []).append(ptr)
+            self.cached += cls
+        else:
+            self._free(ptr)
+
+    def trim(self):
+        for stack in self.blocks.values():
+            for ptr in stack:
+                self._free(ptr)
+        self.blocks, self.cached = {}, 0
+
+
 class HipManager:
     """Lazy singleton: `.lib`, `.device`, `.queue`, `.k`, `.device_name`."""
 
@@ -218,6 +266,9 @@ class HipManager:
         self._free_events = []
         self.device = None
         self.k = _Kernels(self)
+        limit = int(float(os.environ.get("CODECAD_AMD_POOL_MB", "4096")) * (1 << 20))
+        self.device_pool = _BlockPool(self._raw_malloc, self._raw_free, limit)
+        self.pinned_pool = _BlockPool(self._raw_host_alloc, self._raw_host_free, min(limit, 256 << 20))
 
     # -- lifecycle -----------------------------------------------------------------------
     @property
@@ -244,9 +295,33 @@ class HipManager:
         self._epoch = self._new_event()
         check(lib.hu_event_record(self._epoch, None), "hu_event_record")
 
+    # -- raw allocation (the pools call these) -----------------------------------------------
+    def _raw_malloc(self, nbytes):
+        p = ctypes.c_void_p()
+        check(self.lib.hu_malloc(ctypes.byref(p), nbytes), "hu_malloc")
+        return p.value
+
+    def _raw_free(self, ptr):
+        check(self.lib.hu_free(ptr), "hu_free")
+
+    def _raw_host_alloc(self, nbytes):
+        p = ctypes.c_void_p()
+        check(self.lib.hu_host_alloc(ctypes.byref(p), nbytes), "hu_host_alloc")
+        return p.value
+
+    def _raw_host_free(self, ptr):
+        check(self.lib.hu_host_free(ptr), "hu_host_free")
+
+    def empty_cache(self):
+        """Return every pooled block to the driver."""
+        self.device_pool.trim()
+        self.pinned_pool.trim()
+
     def use_device(self, device):
         """Select the GPU ordinal for this process (before any allocation)."""
         if self._lib is not None and device != self.device:
+            self.synchronize()
+            self.empty_cache()   # pooled blocks belong to the device we are leaving
             self._queue = None
             self._free_events = []
         self._open(device)

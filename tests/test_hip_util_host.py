@@ -150,3 +150,44 @@ def test_specialised_source_builds_under_hiprtc_without_a_device():
     bad, pb = _tape_ptr([99 * 512.0])
     assert lib.hu_tape_compile_check(pb, bad.size, include_dir, None) != 0
     assert b"malformed" in lib.hu_last_error()
+
+
+def test_block_pool_recycles_per_stream_and_respects_its_limit():
+    from codecad_amd.hip_util.manager import _BlockPool
+    live, counter = set(), [0]
+
+    def alloc(n):
+        counter[0] += 1
+        live.add(counter[0])
+        return counter[0]
+
+    pool = _BlockPool(alloc, live.remove, limit_bytes=3 << 20)
+    assert [pool.size_class(n) for n in (0, 1, 256, 257, 1 << 20, (1 << 20) + 1)] == [256, 256, 256, 512, 1 << 20, 2 << 20]
+    a, ca = pool.take("s1", 1000)
+    b, cb = pool.take("s1", 1000)
+    assert a != b and ca == cb == 1024
+    pool.give("s1", a, ca)
+    assert pool.take("s2", 1000)[0] not in (a, b)          # another stream never sees s1's block
+    assert pool.take("s1", 600)[0] == a                     # same stream, same size class: recycled
+    big = [pool.take("s1", 2 << 20) for _ in range(3)]
+    for p, c in big:
+        pool.give("s1", p, c)                               # 2 MiB + 2 MiB > 3 MiB limit: the second is freed
+    assert pool.cached == 2 << 20 and big[1][0] not in live and big[0][0] in live
+    pool.trim()
+    assert pool.cached == 0 and big[0][0] not in live
+
+
+def test_block_pool_trims_and_retries_when_the_allocator_fails():
+    from codecad_amd.hip_util.manager import _BlockPool
+    freed, fail_once = [], [True]
+
+    def alloc(n):
+        if n == 4096 and fail_once[0]:
+            fail_once[0] = False
+            raise RuntimeError("out of memory")
+        return n
+
+    pool = _BlockPool(alloc, freed.append, limit_bytes=1 << 30)
+    p, c = pool.take("s", 300)
+    pool.give("s", p, c)
+    assert pool.take("s", 4000) == (4096, 4096) and freed == [512] and pool.cached == 0
