@@ -268,7 +268,7 @@ class HipManager:
         self.k = _Kernels(self)
         limit = int(float(os.environ.get("CODECAD_AMD_POOL_MB", "4096")) * (1 << 20))
         self.device_pool = _BlockPool(self._raw_malloc, self._raw_free, limit)
-        self.pinned_pool = _BlockPool(self._raw_host_alloc, self._raw_host_free, min(limit, 256 << 20))
+        self.pinned_pool = _BlockPool(self._raw_host_alloc, self._raw_host_free, min(limit, 1 << 30))
 
     # -- lifecycle -----------------------------------------------------------------------
     @property
