@@ -239,7 +239,7 @@ int check_dims(const uint32_t dims[3], uint64_t& cells)
 // removed by dead-code elimination.  The arithmetic is the interpreter's, operation for
 // operation, so results are identical (tests run the parity suite on specialised tapes).
 // ------------------------------------------------------------------------------------------
-// All eight per-tape kernels are compiled together in one module: measured, hipRTC spends its time on the
+// All per-tape kernels are compiled together in one module: measured, hipRTC spends its time on the
 // shared straight-line tape function, not per kernel (sponge(4): 0.9 s for eight kernels, 0.56 s for one;
 // planetary: 18 s either way), so compiling lazily, kernel by kernel, costs more whenever two are used.
 struct SpecKernels {
@@ -247,6 +247,7 @@ struct SpecKernels {
     hipFunction_t dense[2] = {nullptr, nullptr};
     hipFunction_t blocks[2] = {nullptr, nullptr};
     hipFunction_t classify[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [MASS][BATCH]
+    hipFunction_t ray_caster = nullptr, bitmap = nullptr;
 };
 
 namespace {
@@ -283,11 +284,13 @@ std::string generate_source(const hu_tape_s* t)
 
 struct SpecEval { const float* extra; };  // same layout as the generated sdfk::JitEval
 
-const char* const kSpecKernelNames[8] = {
+constexpr int kSpecKernelCount = 10;
+const char* const kSpecKernelNames[kSpecKernelCount] = {
     "sdfk::k_grid_eval<sdfk::JitEval, 0, 2>",           "sdfk::k_grid_eval<sdfk::JitEval, 1, 2>",
     "sdfk::k_grid_eval_blocks<sdfk::JitEval, 0, 2>",    "sdfk::k_grid_eval_blocks<sdfk::JitEval, 1, 2>",
     "sdfk::k_classify<sdfk::JitEval, false, false, 2>", "sdfk::k_classify<sdfk::JitEval, false, true, 2>",
-    "sdfk::k_classify<sdfk::JitEval, true, false, 2>",  "sdfk::k_classify<sdfk::JitEval, true, true, 2>"};
+    "sdfk::k_classify<sdfk::JitEval, true, false, 2>",  "sdfk::k_classify<sdfk::JitEval, true, true, 2>",
+    "sdfk::k_ray_caster<sdfk::JitEval>",                "sdfk::k_bitmap<sdfk::JitEval>"};
 
 }  // namespace
 
@@ -781,6 +784,14 @@ int hu_ray_caster(hu_tape t, const float origin[4], const float forward[4], cons
     a.w = width;
     a.h = height;
     a.out = static_cast<uint8_t*>(out_dev);
+    if (t->spec) {
+        SpecEval ev{t->extra_dev};
+        void* args[] = {&ev, &a};
+        const uint64_t spec_blocks = (tiles + kSpecBlock / 64u - 1) / (kSpecBlock / 64u);
+        HU_HIP(hipModuleLaunchKernel(t->spec->ray_caster, (uint32_t)spec_blocks, 1, 1, kSpecBlock, 1, 1, 0, (hipStream_t)stream,
+                                     args, nullptr));
+        return HU_OK;
+    }
     hipLaunchKernelGGL((k_ray_caster<InterpEval<false>>), dim3((uint32_t)blocks), dim3(ls.block), ls.lds, (hipStream_t)stream,
                        (InterpEval<false>{ls.prog, t->extra_dev, ls.n4}), a);
     HU_HIP(hipGetLastError());
@@ -794,13 +805,21 @@ int hu_bitmap(hu_tape t, const float origin[4], float step_size, uint32_t width,
     if (width == 0 || height == 0) return fail(HU_ERR_BAD_ARG, "image must have at least one pixel");
     const uint64_t pixels = (uint64_t)width * height;
     if (pixels > 0x7fffffffull) return fail(HU_ERR_BAD_ARG, "image too large for one launch");
+    uint8_t* out = static_cast<uint8_t*>(out_dev);
+    if (t->spec) {
+        SpecEval ev{t->extra_dev};
+        float ox = origin[0], oy = origin[1], oz = origin[2];
+        void* args[] = {&ev, &ox, &oy, &oz, &step_size, &width, &height, &out};
+        HU_HIP(hipModuleLaunchKernel(t->spec->bitmap, (uint32_t)((pixels + kSpecBlock - 1) / kSpecBlock), 1, 1, kSpecBlock, 1, 1, 0,
+                                     (hipStream_t)stream, args, nullptr));
+        return HU_OK;
+    }
     const bool d_only = distance_only(t);
     LaunchShape ls;
     int rc;
     if ((rc = launch_shape(t, ls, d_only, 1))) return rc;
     if ((rc = ensure_attrs())) return rc;
     const dim3 grid((uint32_t)((pixels + ls.block - 1) / ls.block)), block(ls.block);
-    uint8_t* out = static_cast<uint8_t*>(out_dev);
     if (d_only)
         hipLaunchKernelGGL((k_bitmap<InterpEval<true>>), grid, block, ls.lds, (hipStream_t)stream,
                            (InterpEval<true>{ls.prog, t->extra_dev, ls.n4}), origin[0], origin[1], origin[2], step_size,
@@ -885,9 +904,10 @@ int hu_tape_specialize(hu_tape t, const char* include_dir)
     (void)hiprtcGetCode(prog, code.data());
     SpecKernels* k = new SpecKernels();
     hipError_t e = hipModuleLoadData(&k->module, code.data());
-    hipFunction_t* slots[8] = {&k->dense[0], &k->dense[1], &k->blocks[0], &k->blocks[1],
-                               &k->classify[0][0], &k->classify[0][1], &k->classify[1][0], &k->classify[1][1]};
-    for (int i = 0; i < 8 && e == hipSuccess; ++i) {
+    hipFunction_t* slots[kSpecKernelCount] = {&k->dense[0], &k->dense[1], &k->blocks[0], &k->blocks[1],
+                                              &k->classify[0][0], &k->classify[0][1], &k->classify[1][0], &k->classify[1][1],
+                                              &k->ray_caster, &k->bitmap};
+    for (int i = 0; i < kSpecKernelCount && e == hipSuccess; ++i) {
         const char* lowered = nullptr;
         if (hiprtcGetLoweredName(prog, names[i], &lowered) != HIPRTC_SUCCESS || !lowered) {
             e = hipErrorNotFound;

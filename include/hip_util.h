@@ -140,8 +140,7 @@ int hu_mass_integrals(const double* parents_dev, const uint32_t* sums_dev, uint3
 /* rendering/ray_caster.cl:146-159, launched by rendering/ray_caster.py:93-110 with global size
  * (width, height).  origin/forward/up/right: float4 as the reference passes them (forward already
  * scaled by the focal length; 4th component ignored).  render_options: bit0 false colour, bit1
- * zebra (ray_caster.cl:9-10).  out_dev: uchar[width*height*3], pixel (x, y) at (y + height*x)*3.
- * Tapes specialised with hu_tape_specialize still render through the interpreter. */
+ * zebra (ray_caster.cl:9-10).  out_dev: uchar[width*height*3], pixel (x, y) at (y + height*x)*3. */
 int hu_ray_caster(hu_tape t, const float origin[4], const float forward[4], const float up[4],
                   const float right[4], float pixel_tolerance, float box_radius, float min_distance,
                   float max_distance, float floor_z, uint32_t render_options, uint32_t width,
@@ -210,7 +209,7 @@ int hu_tape_specialized(hu_tape t, int* out_flag);
  * `*needed` receives its size including the terminator; it is copied when `capacity` suffices. */
 int hu_tape_source(const float* tape, size_t n_floats, char* buf, size_t capacity, size_t* needed);
 /* Compile that source with hipRTC without loading it (host only, no device needed): checks that the
- * op library headers in `include_dir` build under hipRTC and that all eight kernels are present.
+ * op library headers in `include_dir` build under hipRTC and that all ten kernels are present.
  * `*code_bytes` (may be NULL) receives the code object size. */
 int hu_tape_compile_check(const float* tape, size_t n_floats, const char* include_dir, size_t* code_bytes);
 

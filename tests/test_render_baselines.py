@@ -92,3 +92,27 @@ def test_render_options(hip):
                                  np.float32(a["min_distance"]), np.float32(a["max_distance"]), np.float32(a["floor_z"]),
                                  opt, (96, 64), threads=8).transpose((1, 0, 2))
         assert np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["csg_thing", "torus", "mirror_3d", "gear", "nonconvex_shell2"])
+def test_specialised_tapes_render_the_same_bytes(hip, name):
+    """hu_tape_specialize also builds the ray caster / bitmap kernels for the tape: same pixels, faster."""
+    from codecad_amd import hip_util
+    from codecad_amd.hip_util import manager as m
+    shape = {**shapes_zoo.shapes_2d, **shapes_zoo.shapes_3d}[name]
+    size = (200, 150)
+    interpreted = pictures.render_pixels(shape, size)
+    spec = hip_util.Tape(nodes.make_program(shape)).specialize()
+    out = hip_util.Buffer(np.uint8, size + (3,))
+    if shape.dimension() == 2:
+        origin, step = pictures.bitmap_arguments(shape, size)
+        m.k.bitmap(size, None, spec, origin.as_float4(), np.float32(step), out).wait()
+    else:
+        cam = ray_caster.get_camera_params(shape.bounding_box(), size, None)
+        a = ray_caster.kernel_arguments(shape, *cam)
+        m.k.ray_caster(size, None, spec, a["origin"].as_float4(), a["forward"].as_float4(), a["up"].as_float4(),
+                       a["right"].as_float4(), a["pixel_tolerance"], a["box_radius"], a["min_distance"], a["max_distance"],
+                       a["floor_z"], 0, out).wait()
+    assert np.array_equal(out.read().transpose((1, 0, 2)), interpreted)
+    out.release()
