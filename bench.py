@@ -129,10 +129,10 @@ def main():
     ld = (ctypes.c_uint32 * 3)(int(leaf_dims[0]), int(leaf_dims[1]), int(leaf_dims[2]))
     leaf_out = [None]
 
-    ev0, ev1 = ctypes.c_void_p(), ctypes.c_void_p()
-    check(lib.hu_event_create(ctypes.byref(ev0)), "event")
-    check(lib.hu_event_create(ctypes.byref(ev1)), "event")
-    dense_ms = []
+    ev0, ev1, ev2 = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    for ev in (ev0, ev1, ev2):
+        check(lib.hu_event_create(ctypes.byref(ev)), "event")
+    dense_ms, adaptive_ms = [], []
 
     def one_step(timed):
         # A
@@ -154,11 +154,14 @@ def main():
         check(lib.hu_grid_eval_blocks(tape.device_ptr, mine.data_ptr(), k, resolution, origin,
                                       np.float32(leaf_int_step * resolution), ld, 1, leaf_out[0].data_ptr(), stream),
               "hu_grid_eval_blocks")
+        check(lib.hu_event_record(ev2, stream), "record")
         if timed:
-            check(lib.hu_event_synchronize(ev1), "sync")
+            check(lib.hu_event_synchronize(ev2), "sync")
             ms = ctypes.c_float()
             check(lib.hu_event_elapsed_ms(ev0, ev1, ctypes.byref(ms)), "elapsed")
             dense_ms.append(ms.value)
+            check(lib.hu_event_elapsed_ms(ev1, ev2, ctypes.byref(ms)), "elapsed")
+            adaptive_ms.append(ms.value)   # B + C: subdivision (with its per-level counter reads) + leaf blocks
 
     def barrier():
         queue.synchronize()
@@ -215,6 +218,14 @@ def main():
                                          "leaf_blocks": stats["leaves"] * leaf_cells,
                                          "survivors_per_level_global": stats["level_counts"]},
             "interpreter_dense_kernel_ms": round(sum(interp_ms) / len(interp_ms), 4),
+            # adaptive runs report effective voxels/s (N^3 / time) beside evaluated samples/s
+            "adaptive": {"what": "B + C on this rank: subdivision to the leaf blocks, then every sample of every leaf block",
+                         "ms": round(sum(adaptive_ms) / len(adaptive_ms), 4),
+                         "evaluated_samples": stats["samples"] + stats["leaves"] * leaf_cells,
+                         "evaluated_msamples_per_s": round((stats["samples"] + stats["leaves"] * leaf_cells)
+                                                           / (sum(adaptive_ms) / len(adaptive_ms)) / 1e3, 1),
+                         "effective_voxels": n ** 3,
+                         "effective_mvoxels_per_s": round(n ** 3 / (sum(adaptive_ms) / len(adaptive_ms)) / 1e3, 1)},
             "roofline": {"bound": "hbm", "kernel": "k_grid_eval<%s, 0, 2>" % ("JitEval" if evaluator == "specialised" else "InterpEval<false>"),
                          "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),

@@ -191,3 +191,50 @@ def test_block_pool_trims_and_retries_when_the_allocator_fails():
     p, c = pool.take("s", 300)
     pool.give("s", p, c)
     assert pool.take("s", 4000) == (4096, 4096) and freed == [512] and pool.cached == 0
+
+
+def test_tape_decoder_survives_mutated_tapes():
+    """The decoder is the trust boundary of the C ABI (a malformed tape must be refused at upload, the
+    kernels never validate): mutate golden tapes -- truncations, corrupted words, wild registers, NaNs --
+    and decode each through hu_tape_source (host only).  Every call must return, with OK or a
+    'malformed tape' error; the process surviving is the assertion."""
+    import ctypes
+    import json
+    import os
+    import numpy as np
+    from conftest import ROOT
+    from codecad_amd.hip_util import _lib
+    lib = _lib.load()
+    shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_tapes.json")))["shapes"]
+    tapes = [np.array(s["tape_u32"], dtype=np.uint32).view(np.float32) for s in shapes if s["tape_len"] < 400]
+    rng = np.random.default_rng(11)
+    needed = ctypes.c_size_t(0)
+    ok = refused = 0
+    for trial in range(3000):
+        t = tapes[trial % len(tapes)].copy()
+        kind = trial % 6
+        if kind == 0:
+            t = t[:rng.integers(0, len(t))]
+        elif kind == 1:
+            t[rng.integers(0, len(t))] = rng.choice([np.nan, np.inf, -1.0, 1e9, 0.5, 29 * 512.0, 6 * 512.0 + 3])
+        elif kind == 2:
+            i = rng.integers(0, len(t))
+            t[i] = float(int(rng.integers(0, 29)) * 512 + int(rng.integers(0, 512)))
+        elif kind == 3:
+            t = np.concatenate([t[:rng.integers(0, len(t))], t[rng.integers(0, len(t)):]])
+        elif kind == 4:
+            t = rng.uniform(0, 29 * 512, size=rng.integers(1, 60)).astype(np.float32).round()
+        else:
+            t = t.view(np.uint32).copy()
+            t[rng.integers(0, len(t))] ^= np.uint32(1 << int(rng.integers(0, 32)))
+            t = t.view(np.float32)
+        t = np.ascontiguousarray(t, dtype=np.float32)
+        if t.size == 0:
+            continue
+        rc = lib.hu_tape_source(t.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), t.size, None, 0, ctypes.byref(needed))
+        if rc == 0:
+            ok += 1
+        else:
+            refused += 1
+            assert b"malformed" in lib.hu_last_error()
+    assert ok > 50 and refused > 500, (ok, refused)
