@@ -49,28 +49,28 @@ def mesh_blocks(leaves, true_positions=False, queue=None, download=True):
         return Mesh(numpy.zeros((0, 3)), numpy.zeros((0, 3), numpy.uint32), z, z, 0, 0.0)
     fields = _grid_eval.grid_eval_blocks(leaves, pymcubes=True, queue=queue)
     dims = (ctypes.c_uint32 * 3)(sy, sx, sz)    # array axes of the pymcubes layout: (flipped y, x, z)
-    n_wg, entries, words = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint64(0)
-    check(lib.hu_mesh_workgroups(n, dims, ctypes.byref(n_wg), ctypes.byref(entries), ctypes.byref(words)),
+    n_wg, entries, segments = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint64(0)
+    check(lib.hu_mesh_workgroups(n, dims, ctypes.byref(n_wg), ctypes.byref(entries), ctypes.byref(segments)),
           "hu_mesh_workgroups")
     n_wg = n_wg.value
     counts = hip_util.Buffer(numpy.uint32, (entries.value, 2), queue=queue)
-    bits = hip_util.Buffer(numpy.uint32, (words.value,), queue=queue)   # one inside bit per sample, a mask per segment
+    masks = hip_util.Buffer(numpy.uint32, (segments.value,), queue=queue)   # one inside bit per sample, a mask per segment
     ev0 = hip_util.Event(hip_manager, queue)
-    check(lib.hu_mesh_count(fields.device_ptr, n, dims, bits.device_ptr, counts.device_ptr, queue.handle), "hu_mesh_count")
+    check(lib.hu_mesh_count(fields.device_ptr, n, dims, masks.device_ptr, counts.device_ptr, queue.handle), "hu_mesh_count")
     ev0._done()
     prefix = counts.read(wait_for=[ev0]).copy()
     total_v, total_t = int(prefix[n_wg, 0]), int(prefix[n_wg, 1])
     assert total_v < 2 ** 32, "too many vertices for one call"
     chunks = n_wg // n
     starts = numpy.concatenate([prefix[0:n_wg:chunks], prefix[n_wg:n_wg + 1]]).astype(numpy.int64)
-    info = hip_util.Buffer(numpy.uint32, (words.value, 4), queue=queue)   # per segment: first vertex id, edge masks
+    info = hip_util.Buffer(numpy.uint32, (segments.value, 4), queue=queue)   # per segment: first vertex id, edge masks
     vertices = hip_util.Buffer(numpy.float64, (max(total_v, 1), 3), queue=queue)
     triangles = hip_util.Buffer(numpy.uint32, (max(total_t, 1), 3), queue=queue)
     o = (ctypes.c_double * 3)(leaves.origin.x, leaves.origin.y, leaves.origin.z)
     step = float(leaves.step)
     ev1 = hip_util.Event(hip_manager, queue)
     check(lib.hu_mesh_emit(fields.device_ptr, leaves.blocks.device_ptr, n, float(leaves.resolution), o, step, dims,
-                           (sy - 1) * step if true_positions else 0.0, bits.device_ptr, counts.device_ptr, info.device_ptr,
+                           (sy - 1) * step if true_positions else 0.0, masks.device_ptr, counts.device_ptr, info.device_ptr,
                            vertices.device_ptr, triangles.device_ptr, queue.handle), "hu_mesh_emit")
     ev1._done()
     if download:
@@ -81,7 +81,7 @@ def mesh_blocks(leaves, true_positions=False, queue=None, download=True):
         ev1.wait()
         v = t = None
     ms = ev0.elapsed_ms() + ev1.elapsed_ms()
-    for b in (fields, counts, bits, info, vertices, triangles):
+    for b in (fields, counts, masks, info, vertices, triangles):
         b.release()
     return Mesh(v, t, starts[:, 0].copy(), starts[:, 1].copy(), n * sx * sy * sz, ms)
 

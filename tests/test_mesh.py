@@ -161,23 +161,23 @@ def hip_marching_cubes(hip, fields, true_positions=False):
     blocks = hip_util.Buffer(np.int32, (n, 4))
     blocks.enqueue_write(np.zeros((n, 4), np.int32)).wait()
     dims = (ctypes.c_uint32 * 3)(a0, a1, a2)
-    n_wg, entries, words = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint64(0)
-    assert lib.hu_mesh_workgroups(n, dims, ctypes.byref(n_wg), ctypes.byref(entries), ctypes.byref(words)) == 0
+    n_wg, entries, segments = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint64(0)
+    assert lib.hu_mesh_workgroups(n, dims, ctypes.byref(n_wg), ctypes.byref(entries), ctypes.byref(segments)) == 0
     counts = hip_util.Buffer(np.uint32, (entries.value, 2))
-    bits = hip_util.Buffer(np.uint32, (words.value,))
-    assert lib.hu_mesh_count(fields_dev.device_ptr, n, dims, bits.device_ptr, counts.device_ptr, hip.queue.handle) == 0, lib.hu_last_error()
+    masks = hip_util.Buffer(np.uint32, (segments.value,))
+    assert lib.hu_mesh_count(fields_dev.device_ptr, n, dims, masks.device_ptr, counts.device_ptr, hip.queue.handle) == 0, lib.hu_last_error()
     prefix = counts.read().copy()
     tv, tt = int(prefix[n_wg.value, 0]), int(prefix[n_wg.value, 1])
-    info = hip_util.Buffer(np.uint32, (words.value, 4))
+    info = hip_util.Buffer(np.uint32, (segments.value, 4))
     vertices = hip_util.Buffer(np.float64, (max(tv, 1), 3))
     triangles = hip_util.Buffer(np.uint32, (max(tt, 1), 3))
     o = (ctypes.c_double * 3)(0.0, 0.0, 0.0)
-    assert lib.hu_mesh_emit(fields_dev.device_ptr, blocks.device_ptr, n, 1.0, o, 1.0, dims, 0.0, bits.device_ptr, counts.device_ptr,
+    assert lib.hu_mesh_emit(fields_dev.device_ptr, blocks.device_ptr, n, 1.0, o, 1.0, dims, 0.0, masks.device_ptr, counts.device_ptr,
                             info.device_ptr, vertices.device_ptr, triangles.device_ptr, hip.queue.handle) == 0, lib.hu_last_error()
     v, t = vertices.read()[:tv].copy(), triangles.read()[:tt].copy()
     chunks = n_wg.value // n
     starts = np.concatenate([prefix[0:n_wg.value:chunks], prefix[n_wg.value:n_wg.value + 1]]).astype(np.int64)
-    for b in (fields_dev, blocks, counts, bits, info, vertices, triangles):
+    for b in (fields_dev, blocks, counts, masks, info, vertices, triangles):
         b.release()
     return v, t, starts
 
