@@ -46,6 +46,47 @@ def _traverse(tape, levels, resolution, origin, n_objects):
     return dist.run_levels(top, len(levels) - 1, classify)
 
 
+def _integrate(tape, box_a, levels):
+    """Sharded mass-properties integration with the oracle's kernel as the per-level worker."""
+    import math
+    import oracle
+    from codecad_amd import dist
+    from codecad_amd.mass_properties import integrals_host, _KEYS
+
+    def level_fn(level, parents):
+        s, dims = levels[level]
+        leaf = level + 1 == len(levels)
+        thr = 0.0 if leaf else s * math.sqrt(3) / 2
+        children, corners, sums = [], [], []
+        for cx, cy, cz, tag in parents.tolist():
+            shifted = np.array([cx + s / 2, cy + s / 2, cz + s / 2])
+            su, n, cells = oracle.mass_properties(tape, shifted.astype(np.float32), np.float32(s), np.float32(thr), dims)
+            corners.append([cx, cy, cz])
+            sums.append(su)
+            if not leaf:
+                for i, j, k, _ in cells.tolist():
+                    children.append([i * s + cx, j * s + cy, k * s + cz, tag])
+        part = torch.zeros(10, dtype=torch.float64)
+        if corners:
+            d = integrals_host(np.array(sums, dtype=np.uint32), np.array(corners, dtype=np.float64), s)
+            part = torch.tensor([d[k] for k in _KEYS], dtype=torch.float64)
+        return torch.tensor(children, dtype=torch.float64).reshape(-1, 4), part
+
+    top = torch.tensor([[box_a[0], box_a[1], box_a[2], 0.0]], dtype=torch.float64)
+    return dist.integrate_levels(top, len(levels), level_fn)
+
+
+def _setup_mass():
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from codecad_amd import examples, nodes, subdivision
+    shape = examples.sponge(2)
+    res = 1.0 / 27
+    box = shape.bounding_box()
+    levels = [(res * c, tuple(int(v) for v in d)) for c, d in subdivision.calculate_block_sizes(box, 3, res, 3, False)]
+    return nodes.make_program(shape), tuple(box.a), levels
+
+
 def _setup():
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -77,8 +118,10 @@ def _worker(rank, world, port, queue):
     leaves, counts = _traverse(tape, levels, res, origin, n_objects=world)
     total = dist.allreduce_sum(torch.tensor([leaves.shape[0]], dtype=torch.int64))
     assert int(total.item()) == world * leaves.shape[0]
+    mtape, box_a, mlevels = _setup_mass()
+    integrals = _integrate(mtape, box_a, mlevels)
     if rank == 0:
-        queue.put((leaves.numpy().tolist(), counts))
+        queue.put((leaves.numpy().tolist(), counts, integrals.tolist()))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -91,7 +134,7 @@ def test_two_rank_traversal_equals_single_rank():
     procs = [ctx.Process(target=_worker, args=(r, world, port, queue)) for r in range(world)]
     for p in procs:
         p.start()
-    got_leaves, got_counts = queue.get(timeout=180)
+    got_leaves, got_counts, got_integrals = queue.get(timeout=180)
     for p in procs:
         p.join(timeout=180)
         assert p.exitcode == 0
@@ -105,6 +148,11 @@ def test_two_rank_traversal_equals_single_rank():
     # both objects have identical hierarchies
     per_obj = [sorted(t[:3] for t in got_leaves if t[3] == k) for k in range(world)]
     assert per_obj[0] == per_obj[1] and len(per_obj[0]) > 0
+    # the sharded integration (slices + all-gather of ambiguous cells + one all-reduce) equals the 1-rank one
+    mtape, box_a, mlevels = _setup_mass()
+    single = _integrate(mtape, box_a, mlevels).tolist()
+    assert np.allclose(got_integrals, single, rtol=1e-13, atol=1e-15)   # first moments are 0 up to rounding noise
+    assert got_integrals[0] == pytest.approx((20 / 27) ** 2, rel=1e-12)   # the sponge's exact volume at this resolution
 
 
 def test_single_process_helpers():
