@@ -223,3 +223,64 @@ def mass_properties(shape, resolution, grid_size=None):
     top = torch.tensor([[box.a.x, box.a.y, box.a.z, 0.0]], dtype=torch.float64, device=device)
     totals = integrate_levels(top, len(levels), level_fn)
     return finish(dict(zip(_KEYS, totals.tolist())))
+
+
+def subdivision(shape, resolution, overlap_edge_samples=True, grid_size=None):
+    """`codecad_amd.subdivision.subdivision_device` sharded over the ranks of the process group: every
+    level's parent list is cut into balanced slices, `hu_subdivision_level` classifies and compacts the
+    slice, the survivors are all-gathered.  Returns (leaves, info): `leaves` an (n, 4) int32 device tensor of
+    integer leaf corners, identical (as a set; ordered by rank slice) on every rank, and `info` with
+    `dims`, `int_step`, `step`, `resolution`, `origin`, `level_counts` like LeafBlocks.  A consumer takes
+    `leaves[balanced_slice(n, rank, world)]` (e.g. hu_grid_eval_blocks: bench.py step C)."""
+    import ctypes
+    import math
+    import numpy
+    from . import nodes
+    from . import subdivision as sub
+    from .hip_util import manager as hip_manager, check
+
+    if grid_size is None:
+        grid_size = 128
+    assert resolution > 0 and 1 < grid_size <= 256
+    device = torch.device("cuda", local_device())
+    hip_manager.use_device(device.index)
+    lib = hip_manager.lib
+    stream = torch.cuda.current_stream(device).cuda_stream
+    tape = nodes.make_program_buffer(shape)
+    dimension = shape.dimension()
+    box = shape.bounding_box().expanded_additive(resolution / 2)
+    if dimension == 2:
+        box = box.flattened()
+    levels = sub.calculate_block_sizes(box, dimension, resolution, grid_size, overlap_edge_samples)
+    origin = (ctypes.c_double * 3)(box.a.x, box.a.y, box.a.z)
+    counter = torch.zeros(1, dtype=torch.int32, device=device)
+    capacity = {}
+
+    def classify(level, parents):
+        int_step, dims = levels[level]
+        k = int(parents.shape[0])
+        if k == 0:
+            return parents[:0]
+        parents = parents.contiguous()
+        d = (ctypes.c_uint32 * 3)(int(dims[0]), int(dims[1]), int(dims[2]))
+        box_step = int_step * resolution
+        thr = box_step * math.sqrt(dimension) / 2
+        cap = capacity.get(level, max(1 << 14, 8 * k))
+        while True:
+            children = torch.empty((cap, 4), dtype=torch.int32, device=device)
+            counter.zero_()
+            check(lib.hu_subdivision_level(tape.device_ptr, parents.data_ptr(), k, int(int_step), d, dimension,
+                                           resolution, origin, numpy.float32(box_step), numpy.float32(thr),
+                                           counter.data_ptr(), children.data_ptr(), cap, stream), "hu_subdivision_level")
+            count = int(counter.item())
+            if count <= cap:
+                capacity[level] = cap
+                return children[:count]
+            cap = int(count * 1.25)
+
+    top = torch.zeros((1, 4), dtype=torch.int32, device=device)
+    leaves, counts = run_levels(top, len(levels) - 1, classify)
+    leaf_int_step, leaf_dims = levels[-1]
+    info = {"tape": tape, "dims": leaf_dims, "int_step": leaf_int_step, "step": leaf_int_step * resolution,
+            "resolution": resolution, "origin": box.a, "level_counts": counts}
+    return leaves, info

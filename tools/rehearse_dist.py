@@ -21,5 +21,12 @@ if rank == 0:
     assert abs(got.volume - want.volume) <= 1e-13 * want.volume
     assert np.allclose(got.inertia_tensor, want.inertia_tensor, rtol=1e-11, atol=1e-16)
     assert abs(got.centroid - want.centroid) < 1e-14
+leaves, info = dist.subdivision(shape, 1.0 / 243, grid_size=9)
+if rank == 0:
+    single = cc.subdivision.subdivision_device(shape, 1.0 / 243, grid_size=9)
+    a = sorted(map(tuple, leaves.cpu().numpy()[:, :3].tolist()))
+    b = sorted(map(tuple, single.int_corners().tolist()))
+    print("leaf blocks: %d sharded, %d single GPU, levels %s" % (len(a), len(b), info["level_counts"]))
+    assert a == b and list(info["level_counts"]) == list(single.level_counts)
     print("rehearsal ok")
 dist.barrier()
