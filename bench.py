@@ -128,6 +128,7 @@ def main():
     leaf_cells = int(leaf_dims[0]) * int(leaf_dims[1]) * int(leaf_dims[2])
     ld = (ctypes.c_uint32 * 3)(int(leaf_dims[0]), int(leaf_dims[1]), int(leaf_dims[2]))
     leaf_out = [None]
+    level_hints = []   # per-level survivor counts of the previous step: one collective per level (dist.allgather_rows)
 
     ev0, ev1, ev2 = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
     for ev in (ev0, ev1, ev2):
@@ -142,7 +143,7 @@ def main():
         check(lib.hu_event_record(ev1, stream), "record")
         # B
         stats["samples"] = 0
-        leaves, counts = dist.run_levels(top, len(levels) - 1, classify)
+        leaves, counts = dist.run_levels(top, len(levels) - 1, classify, hints=level_hints)
         stats["level_counts"] = counts
         # C: this rank's balanced share of the global leaf list
         b, e = dist.balanced_slice(int(leaves.shape[0]), rank, world)

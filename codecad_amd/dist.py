@@ -67,23 +67,47 @@ def x_slab(sx, rank, world):
     return balanced_slice(sx, rank, world)
 
 
-def allgather_rows(rows, group=None):
-    """Variable-length all-gather: every rank passes a (n_i, k) tensor and gets the
-    concatenation over ranks in rank order.  Two collectives: counts, then padded rows."""
+def allgather_rows(rows, group=None, hint=None, return_counts=False):
+    """Variable-length all-gather: every rank passes a (n_i, k) tensor and gets the concatenation over
+    ranks in rank order.
+
+    Two collectives (counts, then rows padded to the longest) -- or ONE when the caller passes `hint`, an
+    upper bound on every rank's row count it expects to hold (e.g. the counts of the previous, identical
+    step): rows are padded to `hint` and the true count rides in an extra header row; if some rank has more
+    rows than the hint, every rank sees that in the gathered headers and all fall back to the two-step
+    form together.  With return_counts the per-rank row counts come back too: (rows, [n_0, ..])."""
     rank, world = rank_world()
     if world == 1:
-        return rows
+        return (rows, [int(rows.shape[0])]) if return_counts else rows
     device = rows.device
     if device.type != "cpu" and _host_staged():
-        return allgather_rows(rows.cpu(), group).to(device)
+        out, counts = allgather_rows(rows.cpu(), group, hint, True)
+        return (out.to(device), counts) if return_counts else out.to(device)
+    k = tuple(rows.shape[1:])
+    if hint is not None and len(k) == 1 and not rows.dtype.is_floating_point:
+        hint = int(hint)
+        packed = torch.zeros((hint + 1,) + k, dtype=rows.dtype, device=device)
+        packed[0, 0] = rows.shape[0]
+        fits = rows.shape[0] <= hint
+        if fits:
+            packed[1:1 + rows.shape[0]] = rows
+        gathered = [torch.empty_like(packed) for _ in range(world)]
+        dist.all_gather(gathered, packed, group=group)
+        counts = torch.stack([g[0, 0] for g in gathered]).tolist()   # one synchronisation
+        if max(counts) <= hint:
+            out = torch.cat([g[1:1 + c] for g, c in zip(gathered, counts)], dim=0)
+            if out.is_cuda:
+                torch.cuda.current_stream(out.device).synchronize()
+            return (out, counts) if return_counts else out
+        # someone overflowed the hint (every rank knows): the general path below
     n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device)
     counts = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(counts, n, group=group)
-    counts = [int(c.item()) for c in counts]
+    counts = torch.cat(counts).tolist()   # one synchronisation, not one per rank
     longest = max(counts)
     if longest == 0:
-        return rows[:0]
-    padded = torch.zeros((longest,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+        return (rows[:0], counts) if return_counts else rows[:0]
+    padded = torch.zeros((longest,) + k, dtype=rows.dtype, device=rows.device)
     padded[:rows.shape[0]] = rows
     gathered = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(gathered, padded, group=group)
@@ -92,7 +116,7 @@ def allgather_rows(rows, group=None):
         # the list is handed to kernels launched through the C ABI by data_ptr(): make sure the
         # collective and the concatenation have finished, whatever stream they ran on
         torch.cuda.current_stream(out.device).synchronize()
-    return out
+    return (out, counts) if return_counts else out
 
 
 def allreduce_sum(t, group=None):
@@ -125,11 +149,14 @@ def barrier():
         dist.barrier()
 
 
-def run_levels(top_parents, n_levels, classify_level):
+def run_levels(top_parents, n_levels, classify_level, hints=None):
     """Level-synchronous traversal with a balanced slice per rank and one exchange per level.
 
     top_parents: (n, k) tensor, identical on every rank (the global top-level parent list).
     classify_level(level, my_parents) -> (m, k) tensor of that slice's surviving children.
+    hints: optional list, one entry per level, updated in place: the largest per-rank survivor count seen
+    at that level (+ slack, raised whenever a level overflows it); a caller that repeats the same traversal passes the same list again and
+    each level's exchange becomes a single collective (allgather_rows).
     Returns (global leaf list, [global survivor count per level]).
     """
     rank, world = rank_world()
@@ -137,7 +164,14 @@ def run_levels(top_parents, n_levels, classify_level):
     for level in range(n_levels):
         begin, end = balanced_slice(parents.shape[0], rank, world)
         mine = classify_level(level, parents[begin:end])
-        parents = allgather_rows(mine)
+        hint = hints[level] if hints is not None and level < len(hints) else None
+        parents, per_rank = allgather_rows(mine, hint=hint, return_counts=True)
+        if hints is not None:   # the same list on every rank: per_rank is global knowledge
+            while len(hints) <= level:
+                hints.append(None)
+            biggest = max(per_rank)
+            if hints[level] is None or biggest > hints[level]:
+                hints[level] = biggest + biggest // 8 + 16
         counts.append(int(parents.shape[0]))
         if parents.shape[0] == 0:
             break

@@ -22,7 +22,7 @@ def _free_port():
     return port
 
 
-def _traverse(tape, levels, resolution, origin, n_objects):
+def _traverse(tape, levels, resolution, origin, n_objects, hints=None):
     import math
     import oracle
     from codecad_amd import dist
@@ -43,7 +43,7 @@ def _traverse(tape, levels, resolution, origin, n_objects):
 
     top = torch.zeros((n_objects, 4), dtype=torch.int32)
     top[:, 3] = torch.arange(n_objects, dtype=torch.int32)
-    return dist.run_levels(top, len(levels) - 1, classify)
+    return dist.run_levels(top, len(levels) - 1, classify, hints=hints)
 
 
 def _integrate(tape, box_a, levels):
@@ -115,7 +115,16 @@ def _worker(rank, world, port, queue):
     allrows = dist.allgather_rows(mine)
     want = torch.cat([torch.arange(k * 3 * 2, dtype=torch.int32).reshape(-1, 2) + 100 * k for k in range(world)])
     assert torch.equal(allrows, want)
+    # the single-collective form: exact hint, generous hint, and a hint that is too small (falls back)
+    for hint in (6, 50, 2):
+        assert torch.equal(dist.allgather_rows(mine, hint=hint), want)
     leaves, counts = _traverse(tape, levels, res, origin, n_objects=world)
+    # repeating the traversal with remembered hints gives the same result through one collective per level
+    hints = []
+    first = _traverse(tape, levels, res, origin, n_objects=world, hints=hints)
+    again = _traverse(tape, levels, res, origin, n_objects=world, hints=hints)
+    assert len(hints) == len(counts) and all(h is not None for h in hints)
+    assert torch.equal(first[0], leaves) and torch.equal(again[0], leaves) and again[1] == counts
     total = dist.allreduce_sum(torch.tensor([leaves.shape[0]], dtype=torch.int64))
     assert int(total.item()) == world * leaves.shape[0]
     mtape, box_a, mlevels = _setup_mass()
