@@ -29,6 +29,16 @@ def check(rc, what=""):
         raise HipError("%s failed (%d): %s" % (what or "hip_util call", rc, msg.decode() if msg else "?"))
 
 
+def _note(scene, global_size, factor=1):
+    """Tell a Tape how many samples a launch is about to evaluate (Tape.note_samples: tiered specialisation)."""
+    note = getattr(scene, "note_samples", None)
+    if note is not None:
+        n = factor
+        for v in global_size:
+            n *= int(v)
+        note(n)
+
+
 def _ptr(obj):
     """Device pointer of a Buffer / Tape / torch tensor / int."""
     if obj is None:
@@ -156,17 +166,20 @@ class _Kernels:
         return ev._done()
 
     def grid_eval(self, global_size, local_size, scene, box_corner, box_step, output, wait_for=None, queue=None):
+        _note(scene, global_size)
         c, d = _float4(box_corner), _dims3(global_size)
         return self._launch(wait_for, queue, lambda s: check(self._m.lib.hu_grid_eval(
             _ptr(scene), c.ctypes.data_as(_lib._f4), float(box_step), d, _ptr(output), s), "hu_grid_eval"))
 
     def grid_eval_pymcubes(self, global_size, local_size, scene, box_corner, box_step, output, wait_for=None, queue=None):
+        _note(scene, global_size)
         c, d = _float4(box_corner), _dims3(global_size)
         return self._launch(wait_for, queue, lambda s: check(self._m.lib.hu_grid_eval_pymcubes(
             _ptr(scene), c.ctypes.data_as(_lib._f4), float(box_step), d, _ptr(output), s), "hu_grid_eval_pymcubes"))
 
     def subdivision_step(self, global_size, local_size, scene, box_corner, box_step, distance_threshold,
                          intersecting_counter, list_buffer, wait_for=None, queue=None):
+        _note(scene, global_size)
         c, d = _float4(box_corner), _dims3(global_size)
         return self._launch(wait_for, queue, lambda s: check(self._m.lib.hu_subdivision_step(
             _ptr(scene), c.ctypes.data_as(_lib._f4), float(box_step), float(distance_threshold), d,
@@ -174,6 +187,7 @@ class _Kernels:
 
     def mass_properties(self, global_size, local_size, shape, box_corner, box_step, distance_threshold,
                         sums, intersecting_counter, list_buffer, wait_for=None, queue=None):
+        _note(shape, global_size)
         c, d = _float4(box_corner), _dims3(global_size)
         return self._launch(wait_for, queue, lambda s: check(self._m.lib.hu_mass_properties(
             _ptr(shape), c.ctypes.data_as(_lib._f4), float(box_step), float(distance_threshold), d,
@@ -182,6 +196,7 @@ class _Kernels:
     def ray_caster(self, global_size, local_size, scene, origin, forward, up, right, pixel_tolerance, box_radius,
                    min_distance, max_distance, floor_z, render_options, output, wait_for=None, queue=None):
         """rendering/ray_caster.cl:146-159; global_size = (width, height)."""
+        _note(scene, global_size, 50)   # a march is tens of evaluations per pixel
         v = [_float4(x) for x in (origin, forward, up, right)]
         return self._launch(wait_for, queue, lambda s: check(self._m.lib.hu_ray_caster(
             _ptr(scene), *[x.ctypes.data_as(_lib._f4) for x in v], float(pixel_tolerance), float(box_radius),
@@ -190,6 +205,7 @@ class _Kernels:
 
     def bitmap(self, global_size, local_size, scene, origin, step_size, output, wait_for=None, queue=None):
         """rendering/bitmap.cl:1-4; global_size = (width, height)."""
+        _note(scene, global_size)
         o = _float4(origin)
         return self._launch(wait_for, queue, lambda s: check(self._m.lib.hu_bitmap(
             _ptr(scene), o.ctypes.data_as(_lib._f4), float(step_size), int(global_size[0]), int(global_size[1]),

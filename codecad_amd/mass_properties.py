@@ -97,6 +97,7 @@ def level_integrals(tape, parents, n_parents, s, dims, leaf, queue, counter):
         children = hip_util.Buffer(numpy.float64, (max(capacity, 1), 4), queue=queue)
         sums.enqueue_fill(0)
         counter.enqueue_fill(0)
+        tape.note_samples(n_parents * cells)
         check(lib.hu_mass_properties_level(tape.device_ptr, parents.device_ptr, n_parents, float(s), d,
                                            numpy.float32(s), numpy.float32(thr), sums.device_ptr,
                                            counter.device_ptr, children.device_ptr, capacity, queue.handle),

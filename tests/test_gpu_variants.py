@@ -92,3 +92,31 @@ def test_specialised_tape_is_bit_identical_to_the_interpreter(hip, name):
         results.append(got)
     for x, y in zip(*results):
         assert np.array_equal(x, y)
+
+
+@pytest.mark.gpu
+def test_tiered_specialisation_policy(hip, monkeypatch):
+    """Default policy: a tape is compiled once the interpreter has spent on it about what hipRTC costs."""
+    import numpy as np
+    from codecad_amd import hip_util, examples, nodes, grid_eval
+    tape = nodes.make_program(examples.sponge(2))
+    c = np.zeros(4, np.float32)
+    c[:3] = -0.5
+    out = hip_util.Buffer(grid_eval.FLOAT4, (24, 24, 24))
+
+    t = hip_util.Tape(tape)
+    assert t._policy == "auto" and not t.specialized
+    hip.k.grid_eval((24, 24, 24), None, t, c, np.float32(1 / 24), out).wait()
+    assert not t.specialized and t._work == 24 ** 3 * t.n_instructions      # far below the break-even point
+    interpreted = out.read().copy()
+    t._JIT_SECONDS = (0.0, 0.0)                                              # pretend hipRTC is free
+    hip.k.grid_eval((24, 24, 24), None, t, c, np.float32(1 / 24), out).wait()
+    assert t.specialized                                                     # compiled before this launch
+    assert np.array_equal(out.read().view(np.uint32), interpreted.view(np.uint32))
+
+    monkeypatch.setenv("CODECAD_AMD_SPECIALIZE", "0")
+    never = hip_util.Tape(tape)
+    never._JIT_SECONDS = (0.0, 0.0)
+    hip.k.grid_eval((24, 24, 24), None, never, c, np.float32(1 / 24), out).wait()
+    assert not never.specialized
+    out.release()
