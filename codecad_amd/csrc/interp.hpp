@@ -356,8 +356,8 @@ __device__ __noinline__ float4 regular_polygon2d_op(float pi_over_n, float r, fl
 {
     float len = length2(c.x, c.y);
     float alpha = sector_alpha(c.y, c.x, pi_over_n);
-    int side = (int)__builtin_floorf(alpha / two_pi_over_n);
-    float side2 = (float)(side * 2);
+    int side = to_int_(__builtin_floorf(alpha / two_pi_over_n));
+    float side2 = (2.0f * (float)side);
     float mod_alpha = (alpha - side2 * pi_over_n) - pi_over_n;
     float s, co;
     sincos_(mod_alpha, s, co);
@@ -488,8 +488,8 @@ __device__ __noinline__ float4 circular_repetition_to_op(float pi_over_n, float 
     const float p[2] = {pi_over_n, two_pi_over_n};
     float len = length2(c.x, c.y);
     float alpha = sector_alpha(c.y, c.x, p[0]);
-    int side = (int)__builtin_floorf(alpha / p[1]);
-    float mod_alpha = (alpha - (float)(side * 2) * p[0]) - p[0];
+    int side = to_int_(__builtin_floorf(alpha / p[1]));
+    float mod_alpha = (alpha - (2.0f * (float)side) * p[0]) - p[0];
     float s, co;
     sincos_(mod_alpha, s, co);
     return f4(len * co, len * s, c.z, 0.0f);
@@ -500,9 +500,9 @@ __device__ __noinline__ float4 circular_repetition_from_op(float pi_over_n, floa
 {
     const float p[2] = {pi_over_n, two_pi_over_n};
     float alpha = sector_alpha(c.y, c.x, p[0]);
-    int side = (int)__builtin_floorf(alpha / p[1]);
+    int side = to_int_(__builtin_floorf(alpha / p[1]));
     float s, co, ox, oy;
-    sincos_((float)(side * 2) * p[0], s, co);
+    sincos_((2.0f * (float)side) * p[0], s, co);
     rot2(co, s, dist.x, dist.y, ox, oy);
     return f4(ox, oy, dist.z, dist.w);
 }

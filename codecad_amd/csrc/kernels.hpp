@@ -401,7 +401,7 @@ __device__ __forceinline__ F3 map_color(float ambient, float diffuse, float spec
 // ray_caster.cl:133-144
 __device__ __forceinline__ F3 map_color_zebra(F3 point, float ambient, float diffuse, float specular)
 {
-    const int white = ((int)__builtin_floorf(point.y)) & 1;
+    const int white = sdf::to_int_(__builtin_floorf(point.y)) & 1;
     float color = 50.0f + 150.0f * (float)white;
     color *= ambient + diffuse;
     color += 128.0f * specular;

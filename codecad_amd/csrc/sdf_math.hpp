@@ -38,6 +38,11 @@ SDF_HD float sqrt_(float x) { return __builtin_sqrtf(x); }
 SDF_HD float abs_(float x) { return __builtin_fabsf(x); }
 SDF_HD float copysign_(float m, float s) { return __builtin_copysignf(m, s); }
 
+// float -> int32 that is defined for every input: NaN and values outside (-2^31, 2^31) give 0 (a plain cast
+// is undefined behaviour there, and x86 and gfx950 disagree about it: INT_MIN vs 0 / saturation).  The
+// oracle has the same function, so even garbage in (a NaN sample point) gives the same garbage out.
+SDF_HD int32_t to_int_(float v) { return (v > -2147483648.0f && v < 2147483648.0f) ? (int32_t)v : 0; }
+
 SDF_HD float length2(float x, float y) { return sqrt_(fma_(y, y, x * x)); }
 SDF_HD float length3(float x, float y, float z) { return sqrt_(fma_(z, z, fma_(y, y, x * x))); }
 
@@ -77,7 +82,7 @@ SDF_HD float atan2_(float y, float x)
 
 SDF_HD float reduce_pio4(float ax, int32_t& j_out)
 {
-    int32_t j = (int32_t)(ax * 1.27323954473516f);
+    int32_t j = to_int_(ax * 1.27323954473516f);
     j += (j & 1);
     float y = (float)j;
     float r = fma_(-y, 0.78515625f, ax);

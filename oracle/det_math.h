@@ -78,11 +78,15 @@ static inline float dm_atan2(float y, float x)
     return copysignf(t, y);
 }
 
+/* float -> int32 defined for every input: NaN and values outside (-2^31, 2^31) give 0 (a plain cast is
+ * undefined behaviour there; x86 gives INT_MIN, gfx950 0 or saturation).  Same rule in the kernels. */
+static inline int32_t dm_to_int(float v) { return (v > -2147483648.0f && v < 2147483648.0f) ? (int32_t)v : 0; }
+
 /* Cody-Waite reduction by pi/4 octants (Cephes sinf.c constants).  Returns r in
  * [-pi/4, pi/4] and the (even) octant count j so that |x| = r + j*pi/4. */
 static inline float dm_reduce_pio4(float ax, int32_t *j_out)
 {
-    int32_t j = (int32_t)(ax * 1.27323954473516f); /* 4/pi */
+    int32_t j = dm_to_int(ax * 1.27323954473516f); /* 4/pi */
     j += (j & 1);
     float y = (float)j;
     float r = fmaf(-y, 0.78515625f, ax);

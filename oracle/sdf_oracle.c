@@ -191,8 +191,8 @@ static inline f4 regular_polygon2d_op(float pi_over_n, float r, f4 c)
 {
     float len = dm_hypot(c.x, c.y);
     float alpha = sector_alpha(c.y, c.x, pi_over_n);
-    int side = (int)floorf(alpha / (2.0f * pi_over_n));
-    float side2 = (float)(side * 2);
+    int side = dm_to_int(floorf(alpha / (2.0f * pi_over_n)));
+    float side2 = (2.0f * (float)side);
     float mod_alpha = (alpha - side2 * pi_over_n) - pi_over_n;
     float s, co;
     dm_sincos(mod_alpha, &s, &co);
@@ -355,8 +355,8 @@ static inline f4 circular_repetition_to_op(float pi_over_n, f4 c)
 {
     float len = dm_length2(c.x, c.y);
     float alpha = sector_alpha(c.y, c.x, pi_over_n);
-    int side = (int)floorf(alpha / (2.0f * pi_over_n));
-    float mod_alpha = (alpha - (float)(side * 2) * pi_over_n) - pi_over_n;
+    int side = dm_to_int(floorf(alpha / (2.0f * pi_over_n)));
+    float mod_alpha = (alpha - (2.0f * (float)side) * pi_over_n) - pi_over_n;
     float s, co;
     dm_sincos(mod_alpha, &s, &co);
     return mk4(len * co, len * s, c.z, 0.0f);
@@ -366,9 +366,9 @@ static inline f4 circular_repetition_to_op(float pi_over_n, f4 c)
 static inline f4 circular_repetition_from_op(float pi_over_n, f4 dist, f4 c)
 {
     float alpha = sector_alpha(c.y, c.x, pi_over_n);
-    int side = (int)floorf(alpha / (2.0f * pi_over_n));
+    int side = dm_to_int(floorf(alpha / (2.0f * pi_over_n)));
     float s, co, ox, oy;
-    dm_sincos((float)(side * 2) * pi_over_n, &s, &co);
+    dm_sincos((2.0f * (float)side) * pi_over_n, &s, &co);
     rot2(co, s, dist.x, dist.y, &ox, &oy);
     return mk4(ox, oy, dist.z, dist.w);
 }
@@ -693,7 +693,7 @@ static inline f3 map_color(float ambient, float diffuse, float specular)
 /* ray_caster.cl:133-144 */
 static inline f3 map_color_zebra(f3 point, float ambient, float diffuse, float specular)
 {
-    int white = ((int)floorf(point.y)) & 1;
+    int white = dm_to_int(floorf(point.y)) & 1;
     float color = 50.0f + 150.0f * (float)white;
     color *= ambient + diffuse;
     color += 128.0f * specular;

@@ -116,3 +116,29 @@ def test_specialised_tapes_render_the_same_bytes(hip, name):
                        a["floor_z"], 0, out).wait()
     assert np.array_equal(out.read().transpose((1, 0, 2)), interpreted)
     out.release()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["extruded_pentagon", "gear_wheel", "ring_of_balls", "twisted"])
+def test_false_colour_agrees_where_rays_miss(hip, name):
+    """False colour evaluates the shape at points at infinity (missed rays march to INFINITY, 0 * inf = NaN):
+    garbage in, but the SAME garbage out of the kernels and the oracle -- in particular float -> int
+    conversions of NaN are defined identically (sdf_math.hpp to_int_ / det_math.h dm_to_int)."""
+    from codecad_amd import shapes
+    shape = {
+        "extruded_pentagon": lambda: shapes.regular_polygon2d(5, d=3).extruded(2).rotated_x(30),
+        "gear_wheel": lambda: shapes_zoo.shapes_2d["gear"].extruded(1).rotated_x(60),
+        "ring_of_balls": lambda: shapes.unsafe.CircularRepetition(shapes.sphere(1).translated_x(3), 7).rotated_x(50),
+        "twisted": lambda: shapes.rectangle(1, 2).revolved(r=4, twist=90).rotated_x(40),
+    }[name]()
+    size = (96, 72)
+    cam = ray_caster.get_camera_params(shape.bounding_box(), size, 50)
+    a = ray_caster.kernel_arguments(shape, *cam)
+    tape = nodes.make_program(shape)
+    for options in (1, 0):
+        got = ray_caster.render(shape, *cam, size=size, options=ray_caster.RenderOptions(options))
+        want = oracle.ray_caster(tape, list(a["origin"]), list(a["forward"]), list(a["up"]), list(a["right"]),
+                                 np.float32(a["pixel_tolerance"]), np.float32(a["box_radius"]),
+                                 np.float32(a["min_distance"]), np.float32(a["max_distance"]), np.float32(a["floor_z"]),
+                                 options, size, threads=8).transpose((1, 0, 2))
+        assert np.array_equal(got, want), "%d pixels differ" % np.count_nonzero(np.any(got != want, axis=-1))
