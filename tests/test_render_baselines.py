@@ -119,7 +119,7 @@ def test_specialised_tapes_render_the_same_bytes(hip, name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["extruded_pentagon", "gear_wheel", "ring_of_balls", "twisted"])
+@pytest.mark.parametrize("name", ["extruded_pentagon", "gear_wheel", "ring_of_balls", "twisted", "quarter_turns"])
 def test_false_colour_agrees_where_rays_miss(hip, name):
     """False colour evaluates the shape at points at infinity (missed rays march to INFINITY, 0 * inf = NaN):
     garbage in, but the SAME garbage out of the kernels and the oracle -- in particular float -> int
@@ -130,6 +130,8 @@ def test_false_colour_agrees_where_rays_miss(hip, name):
         "gear_wheel": lambda: shapes_zoo.shapes_2d["gear"].extruded(1).rotated_x(60),
         "ring_of_balls": lambda: shapes.unsafe.CircularRepetition(shapes.sphere(1).translated_x(3), 7).rotated_x(50),
         "twisted": lambda: shapes.rectangle(1, 2).revolved(r=4, twist=90).rotated_x(40),
+        "quarter_turns": lambda: (shapes.box(1, 2, 3).rotated_x(90).scaled(2) + shapes.cylinder(h=4, d=1).rotated_y(90)
+                                  + shapes.sphere(1).translated_z(3).rotated_z(180)),   # no general rotation on top
     }[name]()
     size = (96, 72)
     cam = ray_caster.get_camera_params(shape.bounding_box(), size, 50)
