@@ -19,6 +19,7 @@
 //                   positions (fp64, as mesh.py:65-68 computes them) from the two samples of each ACTIVE edge
 //   k_mc_triangles  per active cell the case, its triangles; a vertex id is the owning segment's first
 //                   id plus popcounts of its edge masks
+//                   (both emit through a workgroup queue in LDS: one vertex / one cell per lane)
 // The first version classified every sample from 12 float loads in each of three passes with one sample
 // per lane: 3.4 ms for the bench's 126 M samples, 8 % of the HBM roofline, bound by work per thread
 // (DESIGN.md).  Here the floats are read once, everything else works on 4 bytes per 16-32 samples.
@@ -265,82 +266,127 @@ __global__ void __launch_bounds__(1024) k_mc_scan_add(uint2* counts, uint32_t n,
     counts[i] = make_uint2(c.x + base.x, c.y + base.y);
 }
 
+// The emitting passes balance their work inside the workgroup: a lane first ENUMERATES what its
+// segment produces (active edges / cells with triangles) into an LDS queue -- positions from one scan,
+// so the global output order is unchanged -- and then every lane takes queue entries round robin: one
+// vertex, or one cell's triangles, per lane.  Emitting straight from the per-segment loops left most
+// lanes idle behind the busiest row of the wavefront (0.39 + 0.66 ms for the bench's leaf blocks).
+constexpr uint32_t kMcQueue = 2048;   // entries per window; a workgroup with more loops over windows
+
 __global__ void __launch_bounds__(256) k_mc_vertices(const McArgs a)
 {
     __shared__ uint32_t scratch[8];
+    __shared__ uint32_t queue[kMcQueue];
     const McSeg g = mc_segment(a);
     const McMasks k = mc_masks(a, g);
     uint32_t total;
-    uint32_t id = a.wg_counts[blockIdx.x].x + wg_exclusive_scan(__popc(k.ex) + __popc(k.ey) + __popc(k.ez), scratch, total);
-    if (!g.valid) return;
-    a.seg_info[(size_t)g.b * a.segments + g.seg] = make_uint4(id, k.ex, k.ey, k.ez);
-    uint32_t active = k.ex | k.ey | k.ez;
-    if (!active) return;
+    const uint32_t mine = wg_exclusive_scan(__popc(k.ex) + __popc(k.ey) + __popc(k.ez), scratch, total);
+    const uint32_t wg_first = a.wg_counts[blockIdx.x].x;
+    if (g.valid) a.seg_info[(size_t)g.b * a.segments + g.seg] = make_uint4(wg_first + mine, k.ex, k.ey, k.ez);
+    if (total == 0u) return;  // workgroup-uniform
     // mesh.py:65-68 in numpy float64: swap the first two array axes, negate y, scale, add the corner
-    const float* f = a.fields + (size_t)g.b * a.A0 * a.A1 * a.A2 + mc_first_sample(a, g);
-    const int4 ic = a.blocks[g.b];
+    const uint32_t b = blockIdx.x / a.chunks, seg0 = (blockIdx.x - b * a.chunks) * kMcBlock;
+    const float* block_f = a.fields + (size_t)b * a.A0 * a.A1 * a.A2;
+    const int4 ic = a.blocks[b];
     const double cx = (double)ic.x * a.res + a.ox, cy = (double)ic.y * a.res + a.oy, cz = (double)ic.z * a.res + a.oz;
     const uint32_t stride[3] = {a.A1 * a.A2, a.A2, 1u}, edges[3] = {k.ex, k.ey, k.ez};
-    for (; active; active &= active - 1u) {
-        const uint32_t i = __ffs(active) - 1;
-        const float f1 = f[i];
-        const uint32_t pos[3] = {g.a0, g.a1, g.z0 + i};
+    for (uint32_t w0 = 0; w0 < total; w0 += kMcQueue) {
+        // enumerate: sample by sample, axis by axis -- the order of the vertex ids
+        uint32_t idx = mine;
+        for (uint32_t active = k.ex | k.ey | k.ez; active; active &= active - 1u) {
+            const uint32_t i = __ffs(active) - 1;
 #pragma unroll
-        for (int axis = 0; axis < 3; ++axis) {
-            if (!((edges[axis] >> i) & 1u)) continue;
-            const float f2 = f[i + stride[axis]];
+            for (uint32_t axis = 0; axis < 3; ++axis)
+                if ((edges[axis] >> i) & 1u) {
+                    if (idx - w0 < kMcQueue) queue[idx - w0] = threadIdx.x | (i << 8) | (axis << 13);  // unsigned: also idx >= w0
+                    ++idx;
+                }
+        }
+        __syncthreads();
+        const uint32_t n = total - w0 < kMcQueue ? total - w0 : kMcQueue;
+        for (uint32_t e = threadIdx.x; e < n; e += kMcBlock) {
+            const uint32_t entry = queue[e], ls = entry & 255u, i = (entry >> 8) & 31u, axis = entry >> 13;
+            // the owning segment's position (the division is cheap next to the fp64 work below)
+            const uint32_t seg = seg0 + ls, row = a.div_spr.div(seg), sg = seg - row * a.spr;
+            const uint32_t a0 = a.div_A1.div(row), a1 = row - a0 * a.A1, z = sg * kMcSegCells + i;
+            const uint32_t s = z + a.A2 * (a1 + a.A1 * a0);
+            const float f1 = block_f[s], f2 = block_f[s + stride[axis]];
             const double t = (1.0 * (0.0 - (double)f1)) / ((double)f2 - (double)f1);
+            const uint32_t pos[3] = {a0, a1, z};
             double v[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) v[c] = (double)pos[c] + (c == axis ? t : 0.0);
-            double* out = a.vertices + 3 * (size_t)id;
+            for (uint32_t c = 0; c < 3; ++c) v[c] = (double)pos[c] + (c == axis ? t : 0.0);
+            double* out = a.vertices + 3 * (size_t)(wg_first + w0 + e);
             out[0] = v[1] * a.step + cx;
             out[1] = ((-v[0]) * a.step + cy) + a.y_offset;
             out[2] = v[2] * a.step + cz;
-            ++id;
         }
+        __syncthreads();
     }
 }
 
 __global__ void __launch_bounds__(256) k_mc_triangles(const McArgs a)
 {
     __shared__ uint32_t scratch[8];
+    __shared__ uint2 queue[kMcQueue];
     const McSeg g = mc_segment(a);
     const McMasks k = mc_masks(a, g);
-    uint32_t nt = 0;
-    for (uint32_t cells = k.cells; cells; cells &= cells - 1u) nt += kMcTriangleCountDev[mc_cube(k, __ffs(cells) - 1)];
-    uint32_t total;
-    uint32_t slot = a.wg_counts[blockIdx.x].y + wg_exclusive_scan(nt, scratch, total);
-    if (!nt) return;
-    const uint4* info = a.seg_info + (size_t)g.b * a.segments + g.seg;
-    const uint32_t d0 = a.spr * a.A1, d1 = a.spr;
+    uint32_t nt = 0, ncell = 0;
     for (uint32_t cells = k.cells; cells; cells &= cells - 1u) {
-        const uint32_t i = __ffs(cells) - 1;
-        const uint32_t cube = mc_cube(k, i);
-        const uint4 row4 = *reinterpret_cast<const uint4*>(kMcPackedDev.row[cube]);
-        const uint32_t row[4] = {row4.x, row4.y, row4.z, row4.w};
-#pragma unroll
-        for (int t = 0; t < 15; t += 3) {  // at most five triangles per case
-            if (((row[t >> 2] >> (8 * (t & 3))) & 0xffu) == 0xffu) break;
-            uint32_t* out = a.triangles + 3 * (size_t)slot;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const uint32_t pk = (row[(t + j) >> 2] >> (8 * ((t + j) & 3))) & 0xffu;
-                const uint32_t axis = pk >> 3;
-                // the owning segment's record is fetched per use: the four candidates held in registers and
-                // selected per lane measured slower (1.26 vs 0.96 ms), the loads hit the cache
-                uint32_t q = ((pk & 1u) ? d0 : 0u) + ((pk & 2u) ? d1 : 0u), li = i + ((pk >> 2) & 1u);
-                if (li == g.cnt - 1u && !g.last) {  // that sample's edges belong to the next segment of the row
-                    q += 1u;
-                    li = 0u;
-                }
-                const uint4 w = info[q];
-                const uint32_t below = low_bits(li);
-                out[j] = w.x + __popc(w.y & below) + __popc(w.z & below) + __popc(w.w & below) +
-                         (axis >= 1u ? (w.y >> li) & 1u : 0u) + (axis == 2u ? (w.z >> li) & 1u : 0u);
-            }
-            ++slot;
+        const uint32_t c = kMcTriangleCountDev[mc_cube(k, __ffs(cells) - 1)];
+        nt += c;
+        ncell += c ? 1u : 0u;
+    }
+    uint32_t total_t, total_c;
+    const uint32_t my_slot = a.wg_counts[blockIdx.x].y + wg_exclusive_scan(nt, scratch, total_t);
+    const uint32_t my_cell = wg_exclusive_scan(ncell, scratch, total_c);
+    if (total_c == 0u) return;  // workgroup-uniform
+    const uint32_t b = blockIdx.x / a.chunks, seg0 = (blockIdx.x - b * a.chunks) * kMcBlock;
+    const uint4* block_info = a.seg_info + (size_t)b * a.segments;
+    const uint32_t d0 = a.spr * a.A1, d1 = a.spr;
+    for (uint32_t w0 = 0; w0 < total_c; w0 += kMcQueue) {
+        uint32_t idx = my_cell, slot = my_slot;
+        for (uint32_t cells = k.cells; cells; cells &= cells - 1u) {
+            const uint32_t i = __ffs(cells) - 1, cube = mc_cube(k, i), c = kMcTriangleCountDev[cube];
+            if (!c) continue;
+            if (idx - w0 < kMcQueue)
+                queue[idx - w0] = make_uint2(threadIdx.x | (i << 8) | (cube << 13) | (g.cnt << 21) | ((g.last ? 1u : 0u) << 27), slot);
+            ++idx;
+            slot += c;
         }
+        __syncthreads();
+        const uint32_t n = total_c - w0 < kMcQueue ? total_c - w0 : kMcQueue;
+        for (uint32_t e = threadIdx.x; e < n; e += kMcBlock) {
+            const uint2 entry = queue[e];
+            const uint32_t ls = entry.x & 255u, i = (entry.x >> 8) & 31u, cube = (entry.x >> 13) & 255u;
+            const uint32_t cnt = (entry.x >> 21) & 63u;
+            const bool last = (entry.x >> 27) & 1u;
+            const uint4* info = block_info + seg0 + ls;
+            const uint4 row4 = *reinterpret_cast<const uint4*>(kMcPackedDev.row[cube]);
+            const uint32_t row[4] = {row4.x, row4.y, row4.z, row4.w};
+            uint32_t slot = entry.y;
+#pragma unroll
+            for (int t = 0; t < 15; t += 3) {  // at most five triangles per case
+                if (((row[t >> 2] >> (8 * (t & 3))) & 0xffu) == 0xffu) break;
+                uint32_t* out = a.triangles + 3 * (size_t)slot;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const uint32_t pk = (row[(t + j) >> 2] >> (8 * ((t + j) & 3))) & 0xffu;
+                    const uint32_t axis = pk >> 3;
+                    uint32_t q = ((pk & 1u) ? d0 : 0u) + ((pk & 2u) ? d1 : 0u), li = i + ((pk >> 2) & 1u);
+                    if (li == cnt - 1u && !last) {  // that sample's edges belong to the next segment of the row
+                        q += 1u;
+                        li = 0u;
+                    }
+                    const uint4 w = info[q];
+                    const uint32_t below = low_bits(li);
+                    out[j] = w.x + __popc(w.y & below) + __popc(w.z & below) + __popc(w.w & below) +
+                             (axis >= 1u ? (w.y >> li) & 1u : 0u) + (axis == 2u ? (w.z >> li) & 1u : 0u);
+                }
+                ++slot;
+            }
+        }
+        __syncthreads();
     }
 }
 
