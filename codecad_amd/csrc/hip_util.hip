@@ -294,6 +294,9 @@ const char* const kSpecKernelNames[kSpecKernelCount] = {
 
 }  // namespace
 
+// for the other translation units of the library (sort.hip)
+int hu_fail_external(int code, const char* message) { return fail(code, message); }
+
 extern "C" {
 
 int hu_abi_version(void) { return HU_ABI_VERSION; }

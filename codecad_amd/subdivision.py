@@ -80,15 +80,17 @@ class LeafBlocks:
         self.samples = samples          # SDF evaluations spent
 
     def sort(self):
-        """Order the leaf list by integer corner (x, then y, then z).  The order the kernels leave depends on
-        how workgroups raced for list space; consumers that emit per-block output (meshes) sort first so that
-        their output is reproducible.  One small host round trip (16 B per block)."""
+        """Order the leaf list by integer corner (x, then y, then z), on the device (`hu_sort_blocks`).  The order
+        the kernels leave depends on how workgroups raced for list space; consumers that emit per-block
+        output (meshes, contours) sort first so that their output is reproducible."""
         if self.count > 1:
-            host = numpy.empty((self.blocks.shape[0], 4), dtype=numpy.int32)
-            self.blocks.read(out=host)
-            a = host[:self.count]
-            host[:self.count] = a[numpy.lexsort((a[:, 2], a[:, 1], a[:, 0]))]
-            self.blocks.enqueue_write(host).wait()
+            lib = hip_manager.lib
+            needed = ctypes.c_size_t(0)
+            check(lib.hu_sort_blocks(self.blocks.device_ptr, self.count, None, 0, ctypes.byref(needed), None), "hu_sort_blocks")
+            scratch = hip_util.Buffer(numpy.uint8, needed.value, queue=self.blocks.queue)
+            check(lib.hu_sort_blocks(self.blocks.device_ptr, self.count, scratch.device_ptr, needed.value,
+                                     ctypes.byref(needed), self.blocks.queue.handle), "hu_sort_blocks")
+            scratch.release()
         return self
 
     def int_corners(self):

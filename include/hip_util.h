@@ -198,6 +198,14 @@ int hu_mesh_emit(const float* fields_dev, const int32_t* blocks_dev, uint32_t n_
                  double y_offset, const uint32_t* masks_dev, const uint32_t* wg_counts_dev,
                  uint32_t* seg_info_dev, double* vertices_dev, uint32_t* triangles_dev, void* stream);
 
+/* Order a list of integer block corners (int32[4] rows, e.g. the leaf list of hu_subdivision_level) by
+ * (x, y, z) on the device, in place, so that per-block output comes out in a reproducible order (the
+ * kernels append survivors in the order workgroups finished).  Two calls: with scratch_dev NULL (or too
+ * small) only *needed is set; then with scratch_bytes >= *needed the list is sorted; synchronises the
+ * stream.  Corners must lie within +-2^20 resolution units. */
+int hu_sort_blocks(int32_t* blocks_dev, uint32_t n_blocks, void* scratch_dev, size_t scratch_bytes,
+                   size_t* needed, void* stream);
+
 /* Per-tape specialisation (the reference's generate_fixed_eval_source_code, nodes/codegen.py:137-204):
  * unroll the decoded program into straight-line gfx950 code with hipRTC, using the op library
  * headers found in `include_dir` (codecad_amd/csrc).  Afterwards every launch with this tape runs

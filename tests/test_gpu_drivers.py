@@ -380,3 +380,40 @@ def test_launches_are_graph_capturable(hip):
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, want)
+
+
+@pytest.mark.gpu
+def test_device_sort_of_block_lists(hip):
+    """hu_sort_blocks orders int4 rows by (x, y, z) like numpy.lexsort; tags travel with their rows."""
+    import ctypes
+    import numpy as np
+    from codecad_amd import hip_util
+    rng = np.random.default_rng(9)
+    for n in (2, 3, 257, 30800, 200001):
+        rows = rng.integers(-5000, 5000, size=(n, 4)).astype(np.int32)
+        rows[:, 3] = np.arange(n)
+        rows[: n // 3, 0] = rows[0, 0]              # ties on x, then on (x, y)
+        rows[: n // 7, 1] = rows[0, 1]
+        # (x, y, z) must be unique for a unique expected order
+        _, first = np.unique(rows[:, :3], axis=0, return_index=True)
+        rows = rows[np.sort(first)]
+        m = len(rows)
+        buf = hip_util.Buffer(np.int32, (m, 4))
+        buf.enqueue_write(rows).wait()
+        needed = ctypes.c_size_t(0)
+        assert hip.lib.hu_sort_blocks(buf.device_ptr, m, None, 0, ctypes.byref(needed), None) == 0
+        scratch = hip_util.Buffer(np.uint8, needed.value)
+        assert hip.lib.hu_sort_blocks(buf.device_ptr, m, scratch.device_ptr, needed.value, ctypes.byref(needed),
+                                      hip.queue.handle) == 0, hip.lib.hu_last_error()
+        want = rows[np.lexsort((rows[:, 2], rows[:, 1], rows[:, 0]))]
+        assert np.array_equal(buf.read(), want)
+        scratch.release()
+        buf.release()
+    # corners that do not fit the 21-bit key fields are refused, not mis-sorted
+    rows = np.array([[0, 0, 0, 0], [1 << 21, 0, 0, 1]], dtype=np.int32)
+    buf = hip_util.Buffer(np.int32, (2, 4))
+    buf.enqueue_write(rows).wait()
+    scratch = hip_util.Buffer(np.uint8, 1 << 20)
+    needed = ctypes.c_size_t(0)
+    assert hip.lib.hu_sort_blocks(buf.device_ptr, 2, scratch.device_ptr, 1 << 20, ctypes.byref(needed), hip.queue.handle) != 0
+    assert b"2^20" in hip.lib.hu_last_error()
