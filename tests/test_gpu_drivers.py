@@ -417,3 +417,24 @@ def test_device_sort_of_block_lists(hip):
     needed = ctypes.c_size_t(0)
     assert hip.lib.hu_sort_blocks(buf.device_ptr, 2, scratch.device_ptr, 1 << 20, ctypes.byref(needed), hip.queue.handle) != 0
     assert b"2^20" in hip.lib.hu_last_error()
+
+
+@pytest.mark.gpu
+def test_config_c5_sponge5_at_2048_single_gpu_form(hip):
+    """BASELINE config C5 (sponge(5), effective 2048^3, grid 16) in its single-GPU form: the level-batched
+    traversal against the per-block reference traversal on the oracle (sorted leaf corners equal), and the
+    size-independent property that the leaf blocks cover exactly the ambiguous cells' volume."""
+    import ref_driver
+    from codecad_amd import examples, nodes, subdivision
+    shape = examples.sponge(5)
+    res = 1.0 / 2048
+    leaves = subdivision.subdivision_device(shape, res, grid_size=16).sort()
+    assert leaves.level_counts == [704, 1340721] and tuple(int(d) for d in leaves.dims) == (16, 16, 16)
+    got = leaves.int_corners()
+    dims, want = ref_driver.subdivision(nodes.make_program(shape), shape.bounding_box(), 3, res, overlap=True, grid_size=16)
+    want = np.array(sorted(b[2] for b in want), dtype=np.int32)
+    assert tuple(int(d) for d in dims) == (16, 16, 16)
+    assert np.array_equal(got, want)
+    # every leaf corner sits on the lattice of its level (15 cells apart: blocks share their edge samples)
+    assert np.all(got % 15 == 0)
+    leaves.blocks.release()
