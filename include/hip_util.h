@@ -6,14 +6,16 @@
  *   - cl_util/cl_buffer.py:9-131        `Buffer` (device allocation + host transfers)
  *   - nodes/program.py:79-84            `make_program_buffer` (tape upload)
  *   - grid_eval.cl, subdivision.cl, mass_properties.cl and the generated evaluate()
+ *   - rendering/ray_caster.cl, bitmap.cl, polygon2d.cl, and the PyMCubes call of rendering/mesh.py
  *
  * Conventions: every function returns 0 on success or a negative hu_status code; the
  * message for the last failure on the calling thread is hu_last_error().  All pointers
  * named *_dev are device pointers (from hu_malloc or any hipMalloc-compatible allocator,
  * e.g. a torch tensor's data_ptr()).  `stream` is a hipStream_t passed as void*
  * (NULL = the legacy default stream).  Launch functions are asynchronous and perform no
- * allocation or synchronisation, so they can be captured into a hipGraph.
- * The caller owns every handle; there are no hidden global allocations.
+ * allocation or synchronisation, so they can be captured into a hipGraph (exceptions, each
+ * documented at its declaration: hu_tape_create/specialize, hu_sort_blocks and hu_selftest_math
+ * synchronise).  The caller owns every handle; there are no hidden global allocations.
  */
 #ifndef HIP_UTIL_H
 #define HIP_UTIL_H
