@@ -130,13 +130,18 @@ def check(shape, hip, specialise):
     handle.release()
 
 
-@pytest.mark.parametrize("seed", range(60))
+import os
+
+_EXTRA = int(os.environ.get("CODECAD_AMD_RANDOM_TREES", "0"))   # a one-off soak run: many more seeds
+
+
+@pytest.mark.parametrize("seed", range(60 + _EXTRA))
 def test_random_3d_tree_matches_oracle(hip, seed):
     rng = random.Random(1000 + seed)
     check(random_3d(rng, rng.choice([2, 3, 4])), hip, specialise=seed % 4 == 0)
 
 
-@pytest.mark.parametrize("seed", range(36))
+@pytest.mark.parametrize("seed", range(36 + _EXTRA))
 def test_random_2d_tree_matches_oracle(hip, seed):
     rng = random.Random(2000 + seed)
     check(random_2d(rng, rng.choice([2, 3, 4])), hip, specialise=seed % 4 == 0)
