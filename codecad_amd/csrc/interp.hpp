@@ -286,8 +286,10 @@ template <class T> __device__ __forceinline__ V4<T> extrusion_op(float hh, V4<T>
         T dist, inv;
         sqrt_inv_cr(fma_(in.w, in.w, wz * wz), corner, dist, inv);
         T m1 = wz * inv, m2 = in.w * inv;
-        r.x = sel(corner, in.x * m2, r.x);
-        r.y = sel(corner, in.y * m2, r.y);
+        // + 0: the slab's direction has x = y = +0, and (+0)*m1 added to a product that is -0 gives +0
+        // (perpendicular_intersection, common.cl:15-31, adds both terms); zero signs are observable
+        r.x = sel(corner, in.x * m2 + 0.0f, r.x);
+        r.y = sel(corner, in.y * m2 + 0.0f, r.y);
         r.z = sel(corner, fma_(in.z, m2, sz * m1), r.z);
         r.w = sel(corner, dist, r.w);
     }

@@ -134,14 +134,35 @@ static inline f4 transformation_to_op(const float *p, f4 point)
     return mk4(fmaf(point.x, k, tx + tx) + ox, fmaf(point.y, k, ty + ty) + oy, fmaf(point.z, k, tz + tz) + oz, 0.0f);
 }
 
-/* shapes/common.cl:100-110 transformation_from_op */
+/* shapes/common.cl:100-110 transformation_from_op.
+ * Canonical arithmetic, like transformation_to_op: when the quaternion's vector part is
+ * zero, or has a single non-zero component, the terms that are products with those zeros are dropped.  For
+ * finite directions the VALUE is the general formula's; what it pins is the sign of zero components, which is
+ * observable: a rounded blend returns the direction (0, 0, 0), and the ray caster divides by dot(normal, ray). */
 static inline f4 transformation_from_op(const float *p, f4 in)
 {
     f4 q = mk4(p[0], p[1], p[2], p[3]);
     float scale = quaternion_scale(q);
     float inv = 1.0f / scale;
-    f4 t = quaternion_transform(q, in);
-    return mk4(t.x * inv, t.y * inv, t.z * inv, in.w * scale);
+    const int zx = p[0] == 0.0f, zy = p[1] == 0.0f, zz = p[2] == 0.0f;
+    if (!(zx + zy + zz >= 2)) {
+        f4 t = quaternion_transform(q, in);
+        return mk4(t.x * inv, t.y * inv, t.z * inv, in.w * scale);
+    }
+    const float k = fmaf(q.w, q.w, -dot3(q, q));
+    if (zx && zy && zz) return mk4((in.x * k) * inv, (in.y * k) * inv, (in.z * k) * inv, in.w * scale);
+    float tx, ty, tz;
+    if (zy && zz) {          /* rotation about x */
+        float d = in.x * q.x, cy = -(in.z * q.x), cz = in.y * q.x;
+        tx = d * q.x; ty = cy * q.w; tz = cz * q.w;
+    } else if (zx && zz) {   /* about y */
+        float d = in.y * q.y, cx = in.z * q.y, cz = -(in.x * q.y);
+        tx = cx * q.w; ty = d * q.y; tz = cz * q.w;
+    } else {                 /* about z */
+        float d = in.z * q.z, cx = -(in.y * q.z), cy = in.x * q.z;
+        tx = cx * q.w; ty = cy * q.w; tz = d * q.z;
+    }
+    return mk4(fmaf(in.x, k, tx + tx) * inv, fmaf(in.y, k, ty + ty) * inv, fmaf(in.z, k, tz + tz) * inv, in.w * scale);
 }
 
 /* shapes/common.cl:112-131 */

@@ -45,3 +45,15 @@ def hip():
     from codecad_amd import hip_util
     hip_util.manager.lib  # raises loudly if the extension or the device is missing
     return hip_util.manager
+
+
+def same_bits(a, b):
+    """Every float identical BIT FOR BIT (so -0 differs from +0), except that any NaN matches any NaN.
+    The sign of a zero is observable downstream (copysign in the slab ops, 1/dot(normal, ray) in the ray
+    caster), so the parity tests hold the kernels to it."""
+    import numpy as np
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    if a.shape != b.shape:
+        return False
+    return bool(np.all((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))))

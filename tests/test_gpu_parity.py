@@ -11,7 +11,7 @@ import pytest
 
 import oracle
 import shapes_zoo
-from conftest import load_golden_tapes
+from conftest import load_golden_tapes, same_bits
 
 pytestmark = pytest.mark.gpu
 
@@ -36,7 +36,7 @@ def _grid_for(ref, n):
 
 
 def _same(a, b):
-    return np.array_equal(a, b, equal_nan=True)
+    return same_bits(a, b)
 
 
 @pytest.mark.parametrize("name", ZOO)

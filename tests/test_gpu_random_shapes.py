@@ -10,6 +10,7 @@ import pytest
 
 import oracle
 from codecad_amd import nodes, shapes, grid_eval, hip_util
+from conftest import same_bits
 
 pytestmark = pytest.mark.gpu
 
@@ -120,11 +121,11 @@ def check(shape, hip, specialise):
         out = hip_util.Buffer(grid_eval.FLOAT4, dims)
         hip.k.grid_eval(dims, None, handle, c4, step, out).wait()
         got = out.read().view(np.float32).reshape(dims + (4,))
-        assert np.array_equal(got, want, equal_nan=True), "float4 grid differs"
+        assert same_bits(got, want), "float4 grid differs"
         want_w = oracle.grid_eval_pymcubes(tape, corner, step, dims)
         outw = hip_util.Buffer(np.float32, dims)
         hip.k.grid_eval_pymcubes(dims, None, handle, c4, step, outw).wait()
-        assert np.array_equal(outw.read().reshape(-1), want_w, equal_nan=True), "distance grid differs"
+        assert same_bits(outw.read().reshape(-1), want_w), "distance grid differs"
         out.release()
         outw.release()
     handle.release()
