@@ -9,7 +9,7 @@ import oracle
 import ref_driver
 import shapes_zoo
 from codecad_amd import util
-from conftest import load_golden_tapes
+from conftest import load_golden_tapes, same_bits
 
 pytestmark = pytest.mark.gpu
 GOLDEN = load_golden_tapes()
@@ -98,8 +98,8 @@ def test_leaf_block_grid_eval_matches_oracle(hip):
     for i in list(range(0, len(corners), max(1, len(corners) // 25))):
         corner = util.Vector(*corners[i].tolist()) * leaves.resolution + leaves.origin
         c32 = np.array(tuple(corner), np.float64).astype(np.float32)
-        assert np.array_equal(g4[i], oracle.grid_eval(tape, c32, np.float32(leaves.step), dims))
-        assert np.array_equal(g1[i], oracle.grid_eval_pymcubes(tape, c32, np.float32(leaves.step), dims))
+        assert same_bits(g4[i], oracle.grid_eval(tape, c32, np.float32(leaves.step), dims))
+        assert same_bits(g1[i], oracle.grid_eval_pymcubes(tape, c32, np.float32(leaves.step), dims).reshape(g1[i].shape))
 
 
 def _dense_torch(hip, tape_obj, n, x0=0, x_count=None, layout=0):
@@ -137,7 +137,7 @@ def test_full_size_512_dense_properties(hip):
     want = oracle.evaluate_points(tape.host_tape, pts)
     ti = torch.from_numpy(idx).cuda()
     got = whole[ti[:, 0], ti[:, 1], ti[:, 2]].cpu().numpy()
-    assert np.array_equal(got, want)
+    assert same_bits(got, want)
     # (c) volume fraction: cell centres of a 512 grid are never on a sponge(4) face
     inside = float((whole[..., 3] <= 0).double().mean().item())
     assert inside == pytest.approx((20 / 27) ** 4, rel=2e-3)
@@ -173,7 +173,7 @@ def test_more_than_2_pow_30_cells_in_one_call(hip):
     want = oracle.evaluate_points(ref["tape"], pts)[:, 3]
     lin = idx[:, 2] + (idx[:, 0] + (dims_t[1] - 1 - idx[:, 1]) * dims_t[0]) * dims_t[2]
     got = out[torch.from_numpy(lin).cuda()].cpu().numpy()
-    assert np.array_equal(got, want)
+    assert same_bits(got, want)
 
 
 def test_object_tags_and_torch_interop(hip):
@@ -328,7 +328,7 @@ def test_wide_register_files(hip, k):
     step = np.float32(0.93 * k / 20 + 0.15)
     out = hip_util.Buffer(hip_util.Buffer.quad_dtype(np.float32), dims)
     hip.k.grid_eval(dims, None, tape, c4, step, out).wait()
-    assert np.array_equal(out.read().view(np.float32).reshape(dims + (4,)), oracle.grid_eval(tape_f, c4[:3], step, dims))
+    assert same_bits(out.read().view(np.float32).reshape(dims + (4,)), oracle.grid_eval(tape_f, c4[:3], step, dims))
     flat = hip_util.Buffer(np.float32, dims)
     hip.k.grid_eval_pymcubes(dims, None, tape, c4, step, flat).wait()
     assert np.array_equal(flat.read().reshape(-1), oracle.grid_eval_pymcubes(tape_f, c4[:3], step, dims))
@@ -347,7 +347,7 @@ def test_too_many_live_values_is_a_clean_error(hip):
     # and specialised code has no LDS register file at all
     small = hip_util.Tape(_wide_tape(24)).specialize()
     hip.k.grid_eval((4, 4, 4), None, small, np.zeros(4, np.float32), np.float32(1), out).wait()
-    assert np.array_equal(out.read().view(np.float32).reshape(4, 4, 4, 4), oracle.grid_eval(_wide_tape(24), [0, 0, 0], np.float32(1), (4, 4, 4)))
+    assert same_bits(out.read().view(np.float32).reshape(4, 4, 4, 4), oracle.grid_eval(_wide_tape(24), [0, 0, 0], np.float32(1), (4, 4, 4)))
 
 
 def test_launches_are_graph_capturable(hip):

@@ -15,6 +15,7 @@ import ref_driver
 import shapes_zoo
 from codecad_amd import nodes, util
 from codecad_amd.rendering import polygon2d
+from conftest import same_bits
 
 SHAPES = sorted(shapes_zoo.shapes_2d)
 
@@ -140,7 +141,7 @@ def test_hip_process_polygon_matches_oracle_cell_by_cell(hip, name):
     n = int(counter.read()[0])
     got_s = np.sort(starts.read()[:n].copy())
     c_host = oracle.grid_eval(tape, ref_driver.f32_corner(corner), step, (g, g, 1)).reshape(g, g, 4)
-    assert np.array_equal(corners.read().view(np.float32).reshape(g, g, 4), c_host, equal_nan=True)
+    assert same_bits(corners.read().view(np.float32).reshape(g, g, 4), c_host)
     want_v, want_l, want_s = oracle.process_polygon(c_host, ref_driver.f32_corner(corner)[:2], step)
     assert np.array_equal(got_l, want_l)
     live = want_l != 0xffffffff
