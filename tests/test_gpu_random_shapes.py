@@ -17,7 +17,13 @@ pytestmark = pytest.mark.gpu
 
 def random_2d(rng, depth):
     if depth == 0 or rng.random() < 0.25:
-        kind = rng.choice(["rectangle", "circle", "ngon", "polygon"])
+        kind = rng.choice(["rectangle", "circle", "ngon", "polygon", "gear", "capsule", "half_plane"])
+        if kind == "gear":
+            return shapes.gears.InvoluteGear(rng.choice([9, 12]), rng.choice([0.5, 1])).scaled(0.5)
+        if kind == "capsule":
+            return shapes.capsule(-1, 0, 1, rng.choice([0, 1]), 0.5)
+        if kind == "half_plane":
+            return shapes.half_plane().translated_y(-0.5) & shapes.circle(d=3)
         if kind == "rectangle":
             return shapes.rectangle(rng.choice([1, 2, 3.5]), rng.choice([1, 2.5, 4]))
         if kind == "circle":
@@ -57,7 +63,11 @@ def random_2d(rng, depth):
 
 def random_3d(rng, depth):
     if depth == 0 or rng.random() < 0.2:
-        kind = rng.choice(["box", "sphere", "cylinder", "extrude", "revolve"])
+        kind = rng.choice(["box", "sphere", "cylinder", "extrude", "revolve", "twist", "half_space"])
+        if kind == "twist":
+            return shapes.rectangle(1, 2).revolved(r=rng.choice([3, 4]), twist=rng.choice([90, 180, 360]))
+        if kind == "half_space":
+            return shapes.half_space().translated_y(-0.5) & shapes.sphere(d=3)
         if kind == "box":
             return shapes.box(rng.choice([1, 2, 3]), rng.choice([1, 2.5]), rng.choice([1, 4]))
         if kind == "sphere":
