@@ -1075,6 +1075,20 @@ int hu_mesh_emit(const float* fields_dev, const int32_t* blocks_dev, uint32_t n_
     return HU_OK;
 }
 
+int hu_mesh_stl(const double* vertices_dev, const uint32_t* triangles_dev, uint64_t n_triangles, void* records_dev,
+                void* stream)
+{
+    if (n_triangles == 0) return HU_OK;
+    if (!vertices_dev || !triangles_dev || !records_dev) return fail(HU_ERR_BAD_ARG, "NULL argument");
+    if (reinterpret_cast<uintptr_t>(records_dev) & 15u) return fail(HU_ERR_BAD_ARG, "records_dev must be 16-byte aligned");
+    const uint64_t n_wg = (n_triangles + kStlBlock - 1) / kStlBlock;
+    if (n_wg > 0x7fffffffull) return fail(HU_ERR_BAD_ARG, "too many triangles for one call");
+    hipLaunchKernelGGL(k_stl_records, dim3((uint32_t)n_wg), dim3(kStlBlock), 0, (hipStream_t)stream, vertices_dev,
+                       triangles_dev, n_triangles, static_cast<uint8_t*>(records_dev));
+    HU_HIP(hipGetLastError());
+    return HU_OK;
+}
+
 int hu_selftest_math(uint64_t counts[4])
 {
     if (!counts) return fail(HU_ERR_BAD_ARG, "counts is NULL");

@@ -390,4 +390,49 @@ __global__ void __launch_bounds__(256) k_mc_triangles(const McArgs a)
     }
 }
 
+// ---- binary STL records (reference rendering/stl_renderer.py:8-24 through numpy-stl 1.8.0) -------------
+// One 50-byte record per triangle: normal, three corners (float32, little endian), a zero attribute word.
+// Corners are the fp64 vertices rounded to float32 (the reference's assignment into the float32 `vectors`);
+// normal = (v1 - v0) x (v2 - v0) in float32, not normalised, each component fl(fl(a*b) - fl(c*d)) as
+// numpy.cross evaluates it (numpy-stl's update_normals on save).  Records are 2-byte aligned, so a workgroup
+// assembles its 256 records in LDS as 16-bit halves and writes them out as aligned 16-byte words.
+constexpr uint32_t kStlBlock = 256, kStlRecordBytes = 50;
+
+__global__ __launch_bounds__(kStlBlock) void k_stl_records(const double* __restrict__ vertices,
+                                                           const uint32_t* __restrict__ triangles, uint64_t n_triangles,
+                                                           uint8_t* __restrict__ records)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t rec[kStlBlock * (kStlRecordBytes / 2)];
+    const uint64_t first = (uint64_t)blockIdx.x * kStlBlock, t = first + threadIdx.x;
+    if (t < n_triangles) {
+        float v[3][3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double* src = vertices + 3 * (size_t)triangles[3 * t + c];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v[c][k] = (float)src[k];
+        }
+        const float ax = v[1][0] - v[0][0], ay = v[1][1] - v[0][1], az = v[1][2] - v[0][2];
+        const float bx = v[2][0] - v[0][0], by = v[2][1] - v[0][1], bz = v[2][2] - v[0][2];
+        const float f[12] = {ay * bz - az * by, az * bx - ax * bz, ax * by - ay * bx,
+                             v[0][0], v[0][1], v[0][2], v[1][0], v[1][1], v[1][2], v[2][0], v[2][1], v[2][2]};
+        uint16_t* r = rec + threadIdx.x * (kStlRecordBytes / 2);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const uint32_t u = __float_as_uint(f[i]);
+            r[2 * i] = (uint16_t)(u & 0xffffu);
+            r[2 * i + 1] = (uint16_t)(u >> 16);
+        }
+        r[24] = 0;
+    }
+    __syncthreads();
+    const uint64_t left = n_triangles - first;
+    const uint32_t bytes = (uint32_t)(left < kStlBlock ? left : kStlBlock) * kStlRecordBytes;
+    uint8_t* out = records + first * kStlRecordBytes;   // a multiple of 12800: 16-byte aligned with the buffer
+    const uint4* src16 = reinterpret_cast<const uint4*>(rec);
+    for (uint32_t i = threadIdx.x; i < bytes / 16u; i += kStlBlock) reinterpret_cast<uint4*>(out)[i] = src16[i];
+    const uint8_t* src8 = reinterpret_cast<const uint8_t*>(rec);
+    for (uint32_t i = (bytes & ~15u) + threadIdx.x; i < bytes; i += kStlBlock) out[i] = src8[i];
+}
+
 }  // namespace sdfk

@@ -56,6 +56,7 @@ PROTOTYPES = {
     "hu_mesh_workgroups": [_u32, _u3, _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint64)],
     "hu_mesh_count": [_vp, _u32, _u3, _vp, _vp, _vp],
     "hu_mesh_emit": [_vp, _vp, _u32, _d, _d3, _d, _u3, _d, _vp, _vp, _vp, _vp, _vp, _vp],
+    "hu_mesh_stl": [_vp, _vp, _c.c_uint64, _vp, _vp],
     "hu_sort_blocks": [_vp, _u32, _vp, _sz, _c.POINTER(_sz), _vp],
     "hu_tape_specialize": [_vp, _c.c_char_p],
     "hu_tape_specialized": [_vp, _c.POINTER(_i)],

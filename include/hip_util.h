@@ -199,6 +199,14 @@ int hu_mesh_emit(const float* fields_dev, const int32_t* blocks_dev, uint32_t n_
                  double resolution, const double origin[3], double step, const uint32_t dims[3],
                  double y_offset, const uint32_t* masks_dev, const uint32_t* wg_counts_dev,
                  uint32_t* seg_info_dev, double* vertices_dev, uint32_t* triangles_dev, void* stream);
+/* Binary STL records of an indexed mesh (rendering/stl_renderer.py:8-24, which fills a numpy-stl 1.8.0 mesh
+ * triangle by triangle on the host and saves it): records_dev (16-byte aligned, 50*n_triangles bytes) <-
+ * per triangle the normal, the three corners -- vertices_dev rounded to float32 -- and a zero attribute
+ * word, little endian, i.e. the body of the file after its 80-byte header and uint32 count.  normal =
+ * (v1-v0) x (v2-v0) in float32, unnormalised, as numpy-stl's update_normals computes it on save.  Every
+ * index in triangles_dev must be a valid vertex.  Asynchronous. */
+int hu_mesh_stl(const double* vertices_dev, const uint32_t* triangles_dev, uint64_t n_triangles,
+                void* records_dev, void* stream);
 
 /* Order a list of integer block corners (int32[4] rows, e.g. the leaf list of hu_subdivision_level) by
  * (x, y, z) on the device, in place, so that per-block output comes out in a reproducible order (the

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
 _lib = None
 
-__all__ = ["build", "lib", "evaluate_points", "grid_eval", "grid_eval_pymcubes", "ray_caster", "bitmap", "process_polygon", "marching_cubes",
+__all__ = ["build", "lib", "evaluate_points", "grid_eval", "grid_eval_pymcubes", "ray_caster", "bitmap", "process_polygon", "marching_cubes", "stl_records", "STL_RECORD",
            "subdivision_step", "mass_properties", "det_math"]
 
 _f32p = ctypes.POINTER(ctypes.c_float)
@@ -211,3 +211,21 @@ def marching_cubes(field):
               triangles.ctypes.data_as(_u32p), ctypes.c_uint64(nt.value), ctypes.byref(nv), ctypes.byref(nt)),
            "marching_cubes")
     return vertices, triangles
+
+
+STL_RECORD = np.dtype([("normal", "<f4", 3), ("vectors", "<f4", (3, 3)), ("attr", "<u2")])
+
+
+def stl_records(vertices, triangles):
+    """Binary STL records of an indexed mesh, as the reference's exporter produces them (reference
+    rendering/stl_renderer.py:14-24): every corner assigned into numpy-stl 1.8.0's float32 `vectors`
+    (round to nearest), normals from `Mesh.update_normals` on save = numpy.cross(v1 - v0, v2 - v0) in float32,
+    unnormalised, attribute word 0.  numpy-stl is a pinned dependency (requirements.txt:12) that is not in the
+    reference tree: this restates its published record layout (50 bytes, little endian)."""
+    vertices = np.asarray(vertices, dtype=np.float64).reshape(-1, 3)
+    triangles = np.asarray(triangles, dtype=np.int64).reshape(-1, 3)
+    rec = np.zeros(len(triangles), dtype=STL_RECORD)
+    rec["vectors"] = vertices[triangles].astype(np.float32)
+    v = rec["vectors"]
+    rec["normal"] = np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0])
+    return rec

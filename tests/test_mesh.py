@@ -260,12 +260,60 @@ def test_hip_watertight_like_the_reference_test(hip, name, grid_size):
 
 @pytest.mark.gpu
 def test_stl_export(hip, tmp_path):
-    from codecad_amd.rendering import stl_renderer
+    from codecad_amd.rendering import stl_renderer, mesh
     path = tmp_path / "sphere.stl"
     n = stl_renderer.render_stl(shapes.sphere(10), str(path), subdivision_grid_size=16)
     data = path.read_bytes()
     assert n >= 20 and len(data) == 84 + 50 * n and struct.unpack("<I", data[80:84])[0] == n
-    rec = np.frombuffer(data[84:], dtype=stl_renderer._RECORD)
+    rec = np.frombuffer(data[84:], dtype=stl_renderer.RECORD)
     centre = rec["vectors"].reshape(-1, 3).mean(axis=0)
     out = rec["vectors"].mean(axis=1) - centre
     assert np.all(np.einsum("ij,ij->i", rec["normal"], out) > 0)   # normals point out of the sphere
+    # the file is the oracle's records of the indexed mesh, byte for byte
+    m = mesh.mesh_arrays(shapes.sphere(10), subdivision_grid_size=16)
+    assert data[84:] == oracle.stl_records(m.vertices, m.triangles).tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunk", [32, 100, 129])
+def test_stl_streams_in_pieces(hip, tmp_path, monkeypatch, chunk):
+    """render_stl with pieces much smaller than the mesh (ragged last piece, pieces that are not multiples of
+    a workgroup): the file does not depend on the piece size."""
+    from codecad_amd.rendering import stl_renderer, mesh
+    shape = shapes.sphere(20) - shapes.cylinder(h=30, d=8)
+    m = mesh.mesh_arrays(shape, subdivision_grid_size=16)
+    want = oracle.stl_records(m.vertices, m.triangles).tobytes()
+    assert len(m.triangles) > 2 * chunk
+    monkeypatch.setattr(mesh, "_STL_CHUNK", chunk)
+    path = tmp_path / "piece.stl"
+    n = stl_renderer.render_stl(shape, str(path), subdivision_grid_size=16)
+    data = path.read_bytes()
+    assert n == len(m.triangles) and struct.unpack("<I", data[80:84])[0] == n
+    assert data[84:] == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_triangles", [1, 7, 255, 256, 257, 1000, 70001])
+def test_stl_records_parity(hip, n_triangles):
+    """hu_mesh_stl == the oracle's records byte for byte: ragged last workgroup, shared and repeated
+    vertices, values that round differently in float32, large / tiny / negative-zero coordinates (cross products
+    stay finite: the sign of an inf - inf NaN is the one thing x86 and the GPU do not share)."""
+    from codecad_amd.rendering import stl_renderer
+    rng = np.random.default_rng(n_triangles)
+    n_vertices = max(3, n_triangles // 2)
+    v = rng.standard_normal((n_vertices, 3)) * 10.0 ** rng.integers(-3, 4, (n_vertices, 1))
+    v[rng.integers(0, n_vertices, n_vertices // 8 + 1)] = np.array([-0.0, 1e-320, 1e15])
+    v[rng.integers(0, n_vertices, n_vertices // 8 + 1)] *= 1e-20     # products that are float32 denormals
+    v[0] = [1 + 2.0 ** -24, 1 + 2.0 ** -24 + 2.0 ** -50, -(1 + 3 * 2.0 ** -24)]   # ties and near-ties of the rounding
+    t = rng.integers(0, n_vertices, (n_triangles, 3)).astype(np.uint32)
+    got = stl_renderer.stl_records(v, t)
+    want = oracle.stl_records(v, t)
+    assert got.tobytes() == want.tobytes()
+
+
+@pytest.mark.gpu
+def test_stl_records_errors(hip):
+    from codecad_amd.rendering import stl_renderer
+    assert len(stl_renderer.stl_records(np.zeros((3, 3)), np.zeros((0, 3), np.uint32))) == 0
+    with pytest.raises(ValueError):
+        stl_renderer.stl_records(np.zeros((3, 3)), np.array([[0, 1, 3]], np.uint32))
