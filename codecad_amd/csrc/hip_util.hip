@@ -11,12 +11,17 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <sstream>
 #include <string>
 #include <vector>
+
+#include <dirent.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "../../include/hip_util.h"
 #include "kernels.hpp"
@@ -835,23 +840,175 @@ int hu_bitmap(hu_tape t, const float origin[4], float step_size, uint32_t width,
     return HU_OK;
 }
 
-// Compile `src` with hipRTC (needs no device).  On success *out holds the program, which the
-// caller destroys.
-static int compile_specialised(const std::string& src, const char* include_dir, hiprtcProgram* out)
+// ---- specialised code objects: hipRTC build + optional on-disk cache ------------------------
+// What hu_tape_specialize needs from a build: the code object and, per kernel of kSpecKernelNames, its
+// lowered (mangled) name.  With a cache directory the image is stored under a key made of everything the
+// build depends on -- generated source, the op library headers it includes, the compiler options, the
+// hipRTC / HIP versions -- so a later process (or a later tape with the same program) loads it in
+// milliseconds instead of compiling for seconds.  The cache is best effort: unreadable, truncated or
+// foreign files are ignored and rebuilt, an unwritable directory is not an error.
+struct SpecImage {
+    std::vector<std::string> lowered;
+    std::vector<char> code;
+};
+
+static const char* const kSpecHeaders[] = {"kernels.hpp", "interp.hpp", "tape_format.hpp", "sdf_math.hpp"};
+static const char kSpecMagic[8] = {'H', 'U', 'S', 'P', 'E', 'C', '1', 0};
+
+static uint64_t fnv1a(uint64_t h, const void* data, size_t n)
+{
+    const unsigned char* p = static_cast<const unsigned char*>(data);
+    for (size_t i = 0; i < n; ++i) h = (h ^ p[i]) * 0x100000001b3ull;
+    return h;
+}
+
+static bool read_file(const std::string& path, std::string& out)
+{
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    out.clear();
+    char buf[65536];
+    size_t n;
+    while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) out.append(buf, n);
+    const bool ok = !std::ferror(f);
+    std::fclose(f);
+    return ok;
+}
+
+static std::vector<std::string> spec_options(const char* include_dir)
+{
+    // same numerical contract as the ahead-of-time build: no contraction, IEEE sqrt/divide (HIP default)
+    std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                                     std::string("-I") + include_dir};
+    if (const char* e = getenv("HU_RTC_FLAGS")) {  // extra compiler options, for tuning experiments
+        std::istringstream in(e);
+        for (std::string w; in >> w;) opts.push_back(w);
+    }
+    return opts;
+}
+
+// Two independent 64-bit hashes over everything the build depends on; false if a header cannot be read
+// (then nothing is cached).
+static bool spec_cache_key(const std::string& src, const char* include_dir, const std::vector<std::string>& opts,
+                           uint64_t key[2])
+{
+    uint64_t h[2] = {0xcbf29ce484222325ull, 0x84222325cbf29ce4ull};
+    auto mix = [&](const void* p, size_t n) {
+        const uint64_t len = n;
+        for (int i = 0; i < 2; ++i) {
+            h[i] = fnv1a(h[i], &len, sizeof len);
+            h[i] = fnv1a(h[i], p, n);
+        }
+    };
+    int version[3] = {0, 0, HIP_VERSION};
+    (void)hiprtcVersion(&version[0], &version[1]);
+    mix(version, sizeof version);
+    mix(src.data(), src.size());
+    for (size_t i = 0; i < opts.size(); ++i)  // the include path itself does not matter, the headers' bytes do
+        if (opts[i].compare(0, 2, "-I") != 0) mix(opts[i].data(), opts[i].size());
+    for (const char* name : kSpecKernelNames) mix(name, std::strlen(name));
+    std::string text;
+    for (const char* name : kSpecHeaders) {
+        if (!read_file(std::string(include_dir) + "/" + name, text)) return false;
+        mix(text.data(), text.size());
+    }
+    key[0] = h[0];
+    key[1] = h[1] ^ 0x9e3779b97f4a7c15ull;
+    return true;
+}
+
+static std::string spec_cache_path(const char* cache_dir, const uint64_t key[2])
+{
+    char name[64];
+    std::snprintf(name, sizeof name, "/%016llx%016llx.huspec", (unsigned long long)key[0], (unsigned long long)key[1]);
+    return std::string(cache_dir) + name;
+}
+
+static bool spec_cache_load(const std::string& path, const uint64_t key[2], SpecImage& img)
+{
+    std::string blob;
+    if (!read_file(path, blob)) return false;
+    size_t pos = 0;
+    auto take = [&](void* dst, size_t n) {
+        if (blob.size() - pos < n) return false;
+        std::memcpy(dst, blob.data() + pos, n);
+        pos += n;
+        return true;
+    };
+    char magic[8];
+    uint64_t k[2], code_size, sum;
+    uint32_t names;
+    if (!take(magic, 8) || std::memcmp(magic, kSpecMagic, 8) != 0 || !take(k, 16) || k[0] != key[0] || k[1] != key[1] ||
+        !take(&names, 4) || names != (uint32_t)kSpecKernelCount)
+        return false;
+    img.lowered.clear();
+    for (uint32_t i = 0; i < names; ++i) {
+        uint32_t len;
+        if (!take(&len, 4) || len == 0 || len > 4096 || blob.size() - pos < len) return false;
+        img.lowered.emplace_back(blob.data() + pos, len);
+        pos += len;
+    }
+    if (!take(&code_size, 8) || code_size == 0 || blob.size() - pos != code_size + 8) return false;
+    img.code.assign(blob.begin() + pos, blob.begin() + pos + code_size);
+    pos += code_size;
+    return take(&sum, 8) && sum == fnv1a(0xcbf29ce484222325ull, blob.data(), blob.size() - 8);  // covers names and code
+}
+
+static void spec_cache_store(const char* cache_dir, const std::string& path, const uint64_t key[2], const SpecImage& img)
+{
+    (void)mkdir(cache_dir, 0700);  // one level; the caller creates parents
+    const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+    std::string blob(kSpecMagic, 8);
+    auto put = [&](const void* p, size_t n) { blob.append(static_cast<const char*>(p), n); };
+    put(key, 16);
+    const uint32_t names = (uint32_t)img.lowered.size();
+    put(&names, 4);
+    for (const std::string& n : img.lowered) {
+        const uint32_t len = (uint32_t)n.size();
+        put(&len, 4);
+        put(n.data(), len);
+    }
+    const uint64_t code_size = img.code.size();
+    put(&code_size, 8);
+    put(img.code.data(), img.code.size());
+    const uint64_t sum = fnv1a(0xcbf29ce484222325ull, blob.data(), blob.size());
+    put(&sum, 8);
+    FILE* f = std::fopen(tmp.c_str(), "wb");
+    if (!f) return;
+    bool ok = std::fwrite(blob.data(), 1, blob.size(), f) == blob.size();
+    ok = (std::fclose(f) == 0) && ok;
+    if (!ok || std::rename(tmp.c_str(), path.c_str()) != 0) (void)std::remove(tmp.c_str());  // atomic publish
+}
+
+// Keep the cache bounded: beyond kSpecCacheFiles entries the oldest (by modification time) are removed.
+constexpr size_t kSpecCacheFiles = 1024;
+static void spec_cache_prune(const char* cache_dir)
+{
+    DIR* d = opendir(cache_dir);
+    if (!d) return;
+    std::vector<std::pair<int64_t, std::string>> files;
+    while (const dirent* e = readdir(d)) {
+        const std::string name = e->d_name;
+        if (name.size() < 8 || name.compare(name.size() - 7, 7, ".huspec") != 0) continue;
+        struct stat st;
+        const std::string path = std::string(cache_dir) + "/" + name;
+        if (stat(path.c_str(), &st) == 0) files.emplace_back((int64_t)st.st_mtime, path);
+    }
+    closedir(d);
+    if (files.size() <= kSpecCacheFiles) return;
+    std::sort(files.begin(), files.end());
+    for (size_t i = 0; i + kSpecCacheFiles * 3 / 4 < files.size(); ++i) (void)std::remove(files[i].second.c_str());
+}
+
+// Compile `src` with hipRTC (needs no device) into an image.
+static int compile_specialised(const std::string& src, const std::vector<std::string>& options, SpecImage& img)
 {
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "tape_specialised.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
         return fail(HU_ERR_UNSUPPORTED, "hiprtcCreateProgram failed");
     for (const char* n : kSpecKernelNames) (void)hiprtcAddNameExpression(prog, n);
-    const std::string inc = std::string("-I") + include_dir;
-    // same numerical contract as the ahead-of-time build: no contraction, IEEE sqrt/divide (HIP default)
-    std::vector<std::string> extra;  // HU_RTC_FLAGS: extra compiler options, for tuning experiments
-    if (const char* e = getenv("HU_RTC_FLAGS")) {
-        std::istringstream in(e);
-        for (std::string w; in >> w;) extra.push_back(w);
-    }
-    std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", inc.c_str()};
-    for (const std::string& w : extra) opts.push_back(w.c_str());
+    std::vector<const char*> opts;
+    for (const std::string& w : options) opts.push_back(w.c_str());
     const hiprtcResult rc = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
     if (rc != HIPRTC_SUCCESS) {
         size_t n = 0;
@@ -863,11 +1020,54 @@ static int compile_specialised(const std::string& src, const char* include_dir, 
         (void)hiprtcDestroyProgram(&prog);
         return fail(HU_ERR_UNSUPPORTED, std::string("hipRTC compile failed: ") + hiprtcGetErrorString(rc) + "\n" + log.substr(0, 4000));
     }
-    *out = prog;
+    size_t size = 0;
+    (void)hiprtcGetCodeSize(prog, &size);
+    img.code.resize(size);
+    (void)hiprtcGetCode(prog, img.code.data());
+    img.lowered.clear();
+    for (const char* name : kSpecKernelNames) {
+        const char* lowered = nullptr;
+        if (hiprtcGetLoweredName(prog, name, &lowered) != HIPRTC_SUCCESS || !lowered) {
+            (void)hiprtcDestroyProgram(&prog);
+            return fail(HU_ERR_UNSUPPORTED, std::string("kernel missing from the specialised module: ") + name);
+        }
+        img.lowered.emplace_back(lowered);
+    }
+    (void)hiprtcDestroyProgram(&prog);
     return HU_OK;
 }
 
-int hu_tape_compile_check(const float* tape, size_t n, const char* include_dir, size_t* code_bytes)
+// The image of `src`: from the cache when it is there, else built (and stored).  With only_if_cached a miss
+// leaves img.code empty and is not an error.
+static int specialised_image(const std::string& src, const char* include_dir, const char* cache_dir, bool only_if_cached,
+                             SpecImage& img, int* from_cache)
+{
+    if (from_cache) *from_cache = 0;
+    img.code.clear();
+    const std::vector<std::string> options = spec_options(include_dir);
+    uint64_t key[2];
+    std::string path;
+    const bool cached = cache_dir && *cache_dir && spec_cache_key(src, include_dir, options, key);
+    if (cached) {
+        path = spec_cache_path(cache_dir, key);
+        if (spec_cache_load(path, key, img)) {
+            if (from_cache) *from_cache = 1;
+            return HU_OK;
+        }
+        img.code.clear();
+    }
+    if (only_if_cached) return HU_OK;
+    int rc;
+    if ((rc = compile_specialised(src, options, img))) return rc;
+    if (cached) {
+        spec_cache_store(cache_dir, path, key, img);
+        spec_cache_prune(cache_dir);
+    }
+    return HU_OK;
+}
+
+int hu_tape_compile_cached(const float* tape, size_t n, const char* include_dir, const char* cache_dir, size_t* code_bytes,
+                           int* from_cache)
 {
     if (!tape || !include_dir) return fail(HU_ERR_BAD_ARG, "NULL argument");
     sdf::DecodedTape d;
@@ -876,57 +1076,51 @@ int hu_tape_compile_check(const float* tape, size_t n, const char* include_dir, 
     hu_tape_s t;  // host fields only
     t.n_slots = d.n_slots;
     t.recs_host = d.recs;
-    hiprtcProgram prog;
+    SpecImage img;
     int rc;
-    if ((rc = compile_specialised(generate_source(&t), include_dir, &prog))) return rc;
-    size_t size = 0;
-    (void)hiprtcGetCodeSize(prog, &size);
-    if (code_bytes) *code_bytes = size;
-    for (const char* name : kSpecKernelNames) {
-        const char* lowered = nullptr;
-        if (hiprtcGetLoweredName(prog, name, &lowered) != HIPRTC_SUCCESS || !lowered) {
-            (void)hiprtcDestroyProgram(&prog);
-            return fail(HU_ERR_UNSUPPORTED, std::string("kernel missing from the specialised module: ") + name);
-        }
-    }
-    (void)hiprtcDestroyProgram(&prog);
+    if ((rc = specialised_image(generate_source(&t), include_dir, cache_dir, false, img, from_cache))) return rc;
+    if (code_bytes) *code_bytes = img.code.size();
     return HU_OK;
 }
 
-int hu_tape_specialize(hu_tape t, const char* include_dir)
+int hu_tape_compile_check(const float* tape, size_t n, const char* include_dir, size_t* code_bytes)
 {
+    return hu_tape_compile_cached(tape, n, include_dir, nullptr, code_bytes, nullptr);
+}
+
+int hu_tape_specialize_cached(hu_tape t, const char* include_dir, const char* cache_dir, int only_if_cached, int* from_cache)
+{
+    if (from_cache) *from_cache = 0;
     if (!t || !include_dir) return fail(HU_ERR_BAD_ARG, "NULL argument");
     if (t->spec) return HU_OK;
-    hiprtcProgram prog;
-    int crc;
-    if ((crc = compile_specialised(generate_source(t), include_dir, &prog))) return crc;
-    const char* const* names = kSpecKernelNames;
-    size_t size = 0;
-    (void)hiprtcGetCodeSize(prog, &size);
-    std::vector<char> code(size);
-    (void)hiprtcGetCode(prog, code.data());
-    SpecKernels* k = new SpecKernels();
-    hipError_t e = hipModuleLoadData(&k->module, code.data());
-    hipFunction_t* slots[kSpecKernelCount] = {&k->dense[0], &k->dense[1], &k->blocks[0], &k->blocks[1],
-                                              &k->classify[0][0], &k->classify[0][1], &k->classify[1][0], &k->classify[1][1],
-                                              &k->ray_caster, &k->bitmap};
-    for (int i = 0; i < kSpecKernelCount && e == hipSuccess; ++i) {
-        const char* lowered = nullptr;
-        if (hiprtcGetLoweredName(prog, names[i], &lowered) != HIPRTC_SUCCESS || !lowered) {
-            e = hipErrorNotFound;
-            break;
+    const std::string src = generate_source(t);
+    int cached = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        SpecImage img;
+        int crc;
+        // second attempt: the cached image did not load (e.g. written by an incompatible runtime): build it
+        if ((crc = specialised_image(src, include_dir, attempt ? nullptr : cache_dir, only_if_cached != 0, img, &cached))) return crc;
+        if (img.code.empty()) return HU_OK;  // only_if_cached and not there: still interpreted
+        SpecKernels* k = new SpecKernels();
+        hipError_t e = hipModuleLoadData(&k->module, img.code.data());
+        hipFunction_t* slots[kSpecKernelCount] = {&k->dense[0], &k->dense[1], &k->blocks[0], &k->blocks[1],
+                                                  &k->classify[0][0], &k->classify[0][1], &k->classify[1][0], &k->classify[1][1],
+                                                  &k->ray_caster, &k->bitmap};
+        for (int i = 0; i < kSpecKernelCount && e == hipSuccess; ++i)
+            e = hipModuleGetFunction(slots[i], k->module, img.lowered[i].c_str());
+        if (e == hipSuccess) {
+            t->spec = k;
+            if (from_cache) *from_cache = cached;
+            return HU_OK;
         }
-        e = hipModuleGetFunction(slots[i], k->module, lowered);
-    }
-    (void)hiprtcDestroyProgram(&prog);
-    if (e != hipSuccess) {
         if (k->module) (void)hipModuleUnload(k->module);
         delete k;
-        return fail(HU_ERR_HIP, std::string("loading the specialised module: ") + hipGetErrorString(e));
+        if (!cached || only_if_cached) return fail(HU_ERR_HIP, std::string("loading the specialised module: ") + hipGetErrorString(e));
     }
-    t->spec = k;
-    return HU_OK;
+    return fail(HU_ERR_HIP, "loading the specialised module failed");
 }
+
+int hu_tape_specialize(hu_tape t, const char* include_dir) { return hu_tape_specialize_cached(t, include_dir, nullptr, 0, nullptr); }
 
 static int launch_process_polygon(bool batch, PolygonArgs& a, uint32_t n_blocks, void* stream)
 {

@@ -59,8 +59,10 @@ PROTOTYPES = {
     "hu_mesh_stl": [_vp, _vp, _c.c_uint64, _vp, _vp],
     "hu_sort_blocks": [_vp, _u32, _vp, _sz, _c.POINTER(_sz), _vp],
     "hu_tape_specialize": [_vp, _c.c_char_p],
+    "hu_tape_specialize_cached": [_vp, _c.c_char_p, _c.c_char_p, _i, _c.POINTER(_i)],
     "hu_tape_specialized": [_vp, _c.POINTER(_i)],
     "hu_tape_compile_check": [_f4, _sz, _c.c_char_p, _c.POINTER(_sz)],
+    "hu_tape_compile_cached": [_f4, _sz, _c.c_char_p, _c.c_char_p, _c.POINTER(_sz), _c.POINTER(_i)],
     "hu_selftest_math": [_c.POINTER(_c.c_uint64)],
     "hu_tape_source": [_f4, _sz, _c.c_char_p, _sz, _c.POINTER(_sz)],
 }

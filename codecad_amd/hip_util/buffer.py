@@ -201,11 +201,31 @@ class BufferList:
         self.release()
 
 
+def cache_dir():
+    """Directory of the on-disk cache of per-tape code objects (hu_tape_specialize_cached), or None:
+    CODECAD_AMD_CACHE=<dir> selects it, "" or "0" disables it; default $XDG_CACHE_HOME/codecad_amd or
+    ~/.cache/codecad_amd.  Created here if possible (the library only creates the last level)."""
+    v = os.environ.get("CODECAD_AMD_CACHE")
+    if v is not None:
+        if v in ("", "0"):
+            return None
+        path = v
+    else:
+        base = os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache")
+        path = os.path.join(base, "codecad_amd")
+    try:
+        os.makedirs(path, exist_ok=True)
+    except OSError:
+        pass    # best effort: the library ignores a directory it cannot use
+    return path
+
+
 class Tape:
     """A decoded instruction tape resident in HBM (replaces the reference's program buffer,
     nodes/program.py:79-84).  Accepted as the `scene` argument of every kernel."""
 
-    def __init__(self, tape):
+    def __init__(self, tape, policy=None):
+        """policy: "auto" / "0" / "1" for this tape, overriding CODECAD_AMD_SPECIALIZE (see below)."""
         m = _instance
         self.manager = m
         t = numpy.ascontiguousarray(tape, dtype=numpy.float32)
@@ -221,11 +241,15 @@ class Tape:
         # CODECAD_AMD_SPECIALIZE: "1" = compile per-tape kernels at upload, "0" = never on its own,
         # otherwise (default "auto") = when the interpreter has spent on this tape about what the
         # compilation costs (note_samples): a tape evaluated a few times never pays for hipRTC, a tape
-        # evaluated for seconds runs 2-3x faster from then on.  Results are the same bytes either way.
-        self._policy = os.environ.get("CODECAD_AMD_SPECIALIZE", "auto")
+        # evaluated for seconds runs 2-3x faster from then on -- and a program found in the on-disk cache
+        # (cache_dir) is taken at upload.  Results are the same bytes either way.
+        self._policy = policy if policy is not None else os.environ.get("CODECAD_AMD_SPECIALIZE", "auto")
         self._work = 0.0
+        self.from_cache = False
         if self._policy == "1":
             self.specialize()
+        elif self._policy == "auto":
+            self._specialize(only_if_cached=True)   # a program compiled before costs milliseconds: take it now
 
     # measured on MI355X: the interpreter retires ~2.5e12 (tape instruction x sample) per second whatever the
     # tape (sponge(4): 85 x 29e9; planetary: 467 x 6.2e9); hipRTC takes ~0.3 s + 4.5 ms per instruction
@@ -247,11 +271,21 @@ class Tape:
         """Compile straight-line kernels for this tape with hipRTC (seconds, once); afterwards
         every launch with this tape uses them.  Same results as the interpreter.  Raises
         RuntimeError (with the compiler log) if hipRTC cannot build it."""
-        if not self.specialized:
-            from . import builder
-            check(self.manager.lib.hu_tape_specialize(self.device_ptr, builder.CSRC.encode()), "hu_tape_specialize")
-            self.specialized = True
+        self._specialize(only_if_cached=False)
         return self
+
+    def _specialize(self, only_if_cached):
+        if self.specialized:
+            return
+        from . import builder
+        directory = cache_dir()
+        hit, flag = ctypes.c_int(0), ctypes.c_int(0)
+        check(self.manager.lib.hu_tape_specialize_cached(self.device_ptr, builder.CSRC.encode(),
+                                                         directory.encode() if directory else None,
+                                                         1 if only_if_cached else 0, ctypes.byref(hit)), "hu_tape_specialize_cached")
+        check(self.manager.lib.hu_tape_specialized(self.device_ptr, ctypes.byref(flag)), "hu_tape_specialized")
+        self.specialized = bool(flag.value)
+        self.from_cache = bool(hit.value)
 
     @property
     def alive(self):

@@ -222,6 +222,15 @@ int hu_sort_blocks(int32_t* blocks_dev, uint32_t n_blocks, void* scratch_dev, si
  * the specialised kernels; results are identical to the interpreter's.  Costs one compilation
  * (seconds); returns HU_ERR_UNSUPPORTED with the compiler log if hipRTC cannot build it. */
 int hu_tape_specialize(hu_tape t, const char* include_dir);
+/* The same with an on-disk cache of the compiled code objects: `cache_dir` (NULL or "" = no cache) holds one
+ * file per (generated source, op library headers, compiler options, hipRTC/HIP version); a hit loads in
+ * milliseconds instead of compiling for seconds -- the counterpart of pyopencl's program cache behind the
+ * reference's `Program(...).build()` (cl_util/opencl_manager.py:116-141).  The directory is created if its
+ * parent exists; unreadable, truncated or stale files are ignored and rebuilt; an unwritable directory is not
+ * an error.  only_if_cached != 0: load when cached, otherwise leave the tape interpreted and return HU_OK.
+ * `*from_cache` (may be NULL) <- 1 if the kernels came from the cache. */
+int hu_tape_specialize_cached(hu_tape t, const char* include_dir, const char* cache_dir,
+                              int only_if_cached, int* from_cache);
 int hu_tape_specialized(hu_tape t, int* out_flag);
 /* The HIP source hu_tape_specialize would compile for this tape (host only, no device needed):
  * `*needed` receives its size including the terminator; it is copied when `capacity` suffices. */
@@ -230,6 +239,10 @@ int hu_tape_source(const float* tape, size_t n_floats, char* buf, size_t capacit
  * op library headers in `include_dir` build under hipRTC and that all ten kernels are present.
  * `*code_bytes` (may be NULL) receives the code object size. */
 int hu_tape_compile_check(const float* tape, size_t n_floats, const char* include_dir, size_t* code_bytes);
+/* The same through the cache of hu_tape_specialize_cached (host only): a miss compiles and stores, a hit
+ * only reads.  `*from_cache` (may be NULL) <- 1 on a hit. */
+int hu_tape_compile_cached(const float* tape, size_t n_floats, const char* include_dir,
+                           const char* cache_dir, size_t* code_bytes, int* from_cache);
 
 /* Device self-test of the arithmetic contract: the kernels compute sqrt(x) and 1/sqrt(x) with a
  * short hardware-seeded sequence instead of the compiler's IEEE expansion (csrc/interp.hpp

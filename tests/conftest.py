@@ -9,6 +9,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+# The on-disk cache of per-tape code objects is off for the tests: a tape uploaded with the default policy must
+# be INTERPRETED until a test specialises it, whatever an earlier test (or run) compiled.  The cache's own tests
+# point CODECAD_AMD_CACHE at a temporary directory.
+os.environ.setdefault("CODECAD_AMD_CACHE", "0")
 
 
 def pytest_configure(config):

@@ -120,3 +120,53 @@ def test_tiered_specialisation_policy(hip, monkeypatch):
     hip.k.grid_eval((24, 24, 24), None, never, c, np.float32(1 / 24), out).wait()
     assert not never.specialized
     out.release()
+
+
+@pytest.mark.gpu
+def test_specialised_code_cache(hip, monkeypatch, tmp_path):
+    """CODECAD_AMD_CACHE: the first specialisation compiles and stores, the next tape with the same program
+    loads the stored code object (no hipRTC), under the default policy already at upload; results are the
+    same bytes as the interpreter's; a damaged file is rebuilt; policy "0" never looks at the cache."""
+    import os
+    import time
+    import numpy as np
+    from codecad_amd import hip_util, examples, nodes, grid_eval
+    monkeypatch.setenv("CODECAD_AMD_CACHE", str(tmp_path / "cache"))
+    tape = nodes.make_program(examples.sponge(2))
+    c = np.zeros(4, np.float32)
+    c[:3] = -0.5
+    out = hip_util.Buffer(grid_eval.FLOAT4, (24, 24, 24))
+
+    def run(t):
+        hip.k.grid_eval((24, 24, 24), None, t, c, np.float32(1 / 24), out).wait()
+        return out.read().view(np.uint32).copy()
+
+    first = hip_util.Tape(tape)
+    assert not first.specialized                    # nothing cached yet: interpreted
+    interpreted = run(first)
+    t0 = time.perf_counter()
+    first.specialize()
+    cold = time.perf_counter() - t0
+    files = os.listdir(tmp_path / "cache")
+    assert first.specialized and not first.from_cache and len(files) == 1
+    assert np.array_equal(run(first), interpreted)
+
+    t0 = time.perf_counter()
+    second = hip_util.Tape(tape)                    # default policy: taken from the cache at upload
+    warm = time.perf_counter() - t0
+    assert second.specialized and second.from_cache and warm < cold / 5
+    assert np.array_equal(run(second), interpreted)
+
+    never = hip_util.Tape(tape, policy="0")
+    assert not never.specialized and np.array_equal(run(never), interpreted)
+
+    path = tmp_path / "cache" / files[0]
+    blob = path.read_bytes()
+    path.write_bytes(blob[:len(blob) // 2])
+    third = hip_util.Tape(tape)
+    assert not third.specialized                    # the damaged file is ignored: interpreted until compiled
+    third.specialize()
+    assert third.specialized and not third.from_cache and len(path.read_bytes()) == len(blob)
+    assert np.array_equal(run(third), interpreted)
+    assert hip_util.Tape(tape).from_cache
+    out.release()

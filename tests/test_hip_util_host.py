@@ -152,6 +152,70 @@ def test_specialised_source_builds_under_hiprtc_without_a_device():
     assert b"malformed" in lib.hu_last_error()
 
 
+def test_specialised_code_cache_on_disk(tmp_path):
+    """hu_tape_compile_cached (host only): a miss compiles and stores one file, a hit only reads it and gives
+    the same code; truncated / bit-flipped / foreign files are ignored, rebuilt and replaced; another tape or other
+    compiler options get another file; an unusable directory is not an error."""
+    import ctypes
+    import os
+    import time
+    import codecad_amd as cc
+    from codecad_amd.hip_util import _lib
+    lib = _lib.load()
+    include_dir = os.path.join(os.path.dirname(cc.__file__), "csrc").encode()
+    cache = tmp_path / "cache"
+    t, p = _tape_ptr(cc.nodes.make_program(cc.shapes.sphere(2) - cc.shapes.box(1)))
+
+    def compile_(tape_ptr, tape, directory):
+        size, hit = ctypes.c_size_t(0), ctypes.c_int(-1)
+        t0 = time.perf_counter()
+        rc = lib.hu_tape_compile_cached(tape_ptr, tape.size, include_dir, None if directory is None else str(directory).encode(),
+                                        ctypes.byref(size), ctypes.byref(hit))
+        assert rc == 0, lib.hu_last_error().decode()
+        return size.value, hit.value, time.perf_counter() - t0
+
+    size0, hit, cold = compile_(p, t, cache)
+    files = sorted(os.listdir(cache))
+    assert hit == 0 and size0 > 10000 and len(files) == 1 and files[0].endswith(".huspec")
+    size1, hit, warm = compile_(p, t, cache)
+    assert hit == 1 and size1 == size0 and warm < cold / 5 and sorted(os.listdir(cache)) == files
+    path = cache / files[0]
+    good = path.read_bytes()
+    assert len(good) > size0
+    for bad in (good[:len(good) // 2], good[:-1], good + b"x", b"", b"HUSPEC1\0" + bytes(100),
+                good[:200] + bytes([good[200] ^ 1]) + good[201:],            # a lowered name / header byte
+                good[:-5000] + bytes([good[-5000] ^ 0x40]) + good[-4999:]):  # a byte of the code object
+        path.write_bytes(bad)
+        size, hit, _ = compile_(p, t, cache)
+        assert hit == 0 and size == size0
+        good = path.read_bytes()       # rebuilt and stored again (hipRTC's code objects carry a build id: not the same bytes)
+        assert len(good) > size0 and compile_(p, t, cache)[1] == 1
+    # another program -> another file; the first one still hits
+    t2, p2 = _tape_ptr(cc.nodes.make_program(cc.shapes.sphere(3) - cc.shapes.box(1)))
+    assert compile_(p2, t2, cache)[1] == 0 and len(os.listdir(cache)) == 2
+    assert compile_(p, t, cache)[1] == 1
+    # other compiler options -> another key
+    os.environ["HU_RTC_FLAGS"] = "-DHU_CACHE_TEST=1"
+    try:
+        assert compile_(p, t, cache)[1] == 0 and len(os.listdir(cache)) == 3
+    finally:
+        del os.environ["HU_RTC_FLAGS"]
+    # no cache / a directory that cannot be created: compiles, no error, nothing stored
+    assert compile_(p, t, None)[1] == 0
+    assert compile_(p, t, tmp_path / "missing" / "parent")[1] == 0 and not (tmp_path / "missing").exists()
+    assert not [f for f in os.listdir(cache) if ".tmp" in f]
+    # the cache is bounded: past 1024 entries the oldest go, the newest stay
+    for i in range(1030):
+        dummy = cache / ("%032x.huspec" % i)
+        dummy.write_bytes(b"old")
+        os.utime(dummy, (1000 + i, 1000 + i))
+    t3, p3 = _tape_ptr(cc.nodes.make_program(cc.shapes.sphere(4) - cc.shapes.box(1)))
+    assert compile_(p3, t3, cache)[1] == 0
+    left = set(os.listdir(cache))
+    assert len(left) == 768 and "%032x.huspec" % 0 not in left and "%032x.huspec" % 1029 in left
+    assert compile_(p3, t3, cache)[1] == 1 and compile_(p, t, cache)[1] == 1
+
+
 def test_block_pool_recycles_per_stream_and_respects_its_limit():
     from codecad_amd.hip_util.manager import _BlockPool
     live, counter = set(), [0]
