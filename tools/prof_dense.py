@@ -4,6 +4,8 @@ import ctypes
 import os
 import sys
 
+os.environ.setdefault("CODECAD_AMD_CACHE", "0")   # measurements and soaks choose their evaluator themselves
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 import codecad_amd as cc  # noqa: E402
