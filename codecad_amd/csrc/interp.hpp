@@ -228,14 +228,33 @@ __device__ __forceinline__ void quat_xform(float qx, float qy, float qz, float q
     oz = fma_(pz, K, tz + tz);
 }
 
-// Last step of the axis-rotation forms of transformation_to: p*k + 2t + offset, with k = w*w - q*q
-// (p[7]).  A quarter turn has k == 0 exactly; the product term is then an exact zero for finite p.
-template <class T> __device__ __forceinline__ V4<T> to_axis_finish(const V4<T>& in, T tx, T ty, T tz, const float* p)
+// Rotation about a coordinate axis as the 2x2 rotation-and-scale it is (constants A, B, C folded by the
+// decoder, tape.hpp axis_constants): `along` is the coordinate on the axis, (u, v) the other two in cyclic
+// order; returns the transformed (along, u, v) plus offsets.  A quarter turn has B == 0 exactly.
+template <class T>
+__device__ __forceinline__ void axis_rotate(const float* p, T along, T u, T v, float oa, float ou, float ov, T& ra, T& ru, T& rv)
 {
-    if (p[7] == 0.0f)  // wave-uniform: a tape constant
-        return v4<T>((tx + tx) + p[4], (ty + ty) + p[5], (tz + tz) + p[6], bc<T>(0.0f));
-    const T K = bc<T>(p[7]);
-    return v4<T>(fma_(in.x, K, tx + tx) + p[4], fma_(in.y, K, ty + ty) + p[5], fma_(in.z, K, tz + tz) + p[6], bc<T>(0.0f));
+    const T A = bc<T>(p[0]), B = bc<T>(p[1]), C = bc<T>(p[2]);
+    ra = fma_(along, A, bc<T>(oa));
+    ru = fma_(-v, C, bc<T>(ou));
+    rv = fma_(u, C, bc<T>(ov));
+    if (p[1] != 0.0f) {  // wave-uniform: a tape constant
+        ru = fma_(u, B, ru);
+        rv = fma_(v, B, rv);
+    }
+}
+// The same for directions (transformation_from: no offsets, constants over |Q|^2): plain products, so a
+// component keeps the sign its source had and a constant that is exactly 1 costs nothing in per-tape code.
+template <class T> __device__ __forceinline__ void axis_rotate_dir(const float* p, T along, T u, T v, T& ra, T& ru, T& rv)
+{
+    const T B = bc<T>(p[1]);
+    ra = along * p[0];
+    ru = (-v) * p[2];
+    rv = u * p[2];
+    if (p[1] != 0.0f) {
+        ru = fma_(u, B, ru);
+        rv = fma_(v, B, rv);
+    }
 }
 
 // reference shapes/simple2d.cl:1-4 (slab_x/slab_y of common.cl:33-39 inlined).  Equal to
@@ -682,25 +701,26 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const floa
         break;
     }
     case OPX_POINT: last = v4<T>(px, py, pz, bc<T>(0.0f)); break;
-    case OPX_TO_SCALE:  // p[7] = w*w; every cross/dot term is an exact zero
-        last = v4<T>(last.x * p[7] + p[4], last.y * p[7] + p[5], last.z * p[7] + p[6], bc<T>(0.0f));
+    case OPX_TO_SCALE:  // p[0] = w*w
+        last = v4<T>(fma_(last.x, bc<T>(p[0]), bc<T>(p[4])), fma_(last.y, bc<T>(p[0]), bc<T>(p[5])),
+                     fma_(last.z, bc<T>(p[0]), bc<T>(p[6])), bc<T>(0.0f));
         break;
     case OPX_TO_AXIS_X: {
-        const float q = p[0], qw = p[3];
-        const T d = last.x * q, cy = -(last.z * q), cz = last.y * q;
-        last = to_axis_finish<T>(last, d * q, cy * qw, cz * qw, p);
+        T x, y, z;
+        axis_rotate<T>(p, last.x, last.y, last.z, p[4], p[5], p[6], x, y, z);
+        last = v4<T>(x, y, z, bc<T>(0.0f));
         break;
     }
     case OPX_TO_AXIS_Y: {
-        const float q = p[1], qw = p[3];
-        const T d = last.y * q, cx = last.z * q, cz = -(last.x * q);
-        last = to_axis_finish<T>(last, cx * qw, d * q, cz * qw, p);
+        T x, y, z;
+        axis_rotate<T>(p, last.y, last.z, last.x, p[5], p[6], p[4], y, z, x);
+        last = v4<T>(x, y, z, bc<T>(0.0f));
         break;
     }
     case OPX_TO_AXIS_Z: {
-        const float q = p[2], qw = p[3];
-        const T d = last.z * q, cx = -(last.y * q), cy = last.x * q;
-        last = to_axis_finish<T>(last, cx * qw, cy * qw, d * q, p);
+        T x, y, z;
+        axis_rotate<T>(p, last.z, last.x, last.y, p[6], p[4], p[5], z, x, y);
+        last = v4<T>(x, y, z, bc<T>(0.0f));
         break;
     }
     case OP_TRANSFORMATION_FROM: {
@@ -713,40 +733,31 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const floa
         last = v4<T>(ox * p[6], oy * p[6], oz * p[6], last.w * p[5]);
         break;
     }
-    // transformation_from with an axis-aligned quaternion (decoder special cases, tape.hpp).
-    // Obtained from quat_xform by deleting every product with an exactly-zero quaternion
-    // component: a deleted term is +-0, adding it changes no non-zero value, and an fma with a
-    // +-0 addend rounds like the bare product.  Equal to the general op under == (a zero
-    // component may differ in sign; directions never reach copysign/atan2/division).
+    // transformation_from with an axis-aligned quaternion (decoder special cases, tape.hpp): the same 2x2
+    // forms with the constants divided by |Q|^2, so unit directions stay unit; p[5] = |Q|^2 scales the distance.
     case OPX_FROM_SCALE:
         if (DISTANCE_ONLY) { last.w = last.w * p[5]; break; }
-        last = v4<T>((last.x * p[4]) * p[6], (last.y * p[4]) * p[6], (last.z * p[4]) * p[6], last.w * p[5]);
+        last = v4<T>(last.x * p[0], last.y * p[0], last.z * p[0], last.w * p[5]);
         break;
     case OPX_FROM_AXIS_X: {
         if (DISTANCE_ONLY) { last.w = last.w * p[5]; break; }
-        const float q = p[0], qw = p[3];
-        T d = last.x * q, cy = -(last.z * q), cz = last.y * q;
-        T tx = d * q, ty = cy * qw, tz = cz * qw;
-        last = v4<T>(fma_(last.x, bc<T>(p[4]), tx + tx) * p[6], fma_(last.y, bc<T>(p[4]), ty + ty) * p[6],
-                     fma_(last.z, bc<T>(p[4]), tz + tz) * p[6], last.w * p[5]);
+        T x, y, z;
+        axis_rotate_dir<T>(p, last.x, last.y, last.z, x, y, z);
+        last = v4<T>(x, y, z, last.w * p[5]);
         break;
     }
     case OPX_FROM_AXIS_Y: {
         if (DISTANCE_ONLY) { last.w = last.w * p[5]; break; }
-        const float q = p[1], qw = p[3];
-        T d = last.y * q, cx = last.z * q, cz = -(last.x * q);
-        T tx = cx * qw, ty = d * q, tz = cz * qw;
-        last = v4<T>(fma_(last.x, bc<T>(p[4]), tx + tx) * p[6], fma_(last.y, bc<T>(p[4]), ty + ty) * p[6],
-                     fma_(last.z, bc<T>(p[4]), tz + tz) * p[6], last.w * p[5]);
+        T x, y, z;
+        axis_rotate_dir<T>(p, last.y, last.z, last.x, y, z, x);
+        last = v4<T>(x, y, z, last.w * p[5]);
         break;
     }
     case OPX_FROM_AXIS_Z: {
         if (DISTANCE_ONLY) { last.w = last.w * p[5]; break; }
-        const float q = p[2], qw = p[3];
-        T d = last.z * q, cx = -(last.y * q), cy = last.x * q;
-        T tx = cx * qw, ty = cy * qw, tz = d * q;
-        last = v4<T>(fma_(last.x, bc<T>(p[4]), tx + tx) * p[6], fma_(last.y, bc<T>(p[4]), ty + ty) * p[6],
-                     fma_(last.z, bc<T>(p[4]), tz + tz) * p[6], last.w * p[5]);
+        T x, y, z;
+        axis_rotate_dir<T>(p, last.z, last.x, last.y, z, x, y);
+        last = v4<T>(x, y, z, last.w * p[5]);
         break;
     }
     case OP_MIRROR: last.x = -last.x; break;

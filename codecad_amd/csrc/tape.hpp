@@ -151,6 +151,18 @@ inline bool allocate_slots(DecodedTape& d, std::string& err)
 
 // quaternion helpers used for the folded constants; same op order as the kernels/oracle
 inline float q_k(const float* q) { return fma_(q[3], q[3], -fma_(q[2], q[2], fma_(q[1], q[1], q[0] * q[0]))); }
+// Rotation about one coordinate axis (quaternion with a single non-zero vector component `q`, scalar
+// part `w`, not normalised: |Q|^2 is the transform's scale), written as the 2x2 rotation-and-scale it is:
+//   along the axis  A = w^2 + q^2,   in the plane  B = w^2 - q^2 (0 for a quarter turn),  C = 2 q w.
+// Folded in double (every product is exact there) and rounded once; `div` = 1 for transformation_to,
+// |Q|^2 for transformation_from (which returns unit directions).  The oracle folds the same way.
+inline void axis_constants(float q, float w, double div, float& A, float& B, float& C)
+{
+    const double qq = (double)q * (double)q, ww = (double)w * (double)w;
+    A = (float)((ww + qq) / div);
+    B = (float)((ww - qq) / div);
+    C = (float)((2.0 * ((double)q * (double)w)) / div);
+}
 inline float q_scale(const float* q) { return fma_(q[3], q[3], fma_(q[2], q[2], fma_(q[1], q[1], q[0] * q[0]))); }
 
 // Fold _load into the record that follows it and _store into the record before it (tape_format.hpp
@@ -252,6 +264,8 @@ inline std::string decode_tape(const float* tape, size_t n, DecodedTape& out)
                         out.recs.push_back(point);
                     }
                     r.hdr = special | (reg << 8);
+                    const float q = special == OPX_TO_AXIS_X ? p[0] : special == OPX_TO_AXIS_Y ? p[1] : special == OPX_TO_AXIS_Z ? p[2] : 0.0f;
+                    axis_constants(q, p[3], 1.0, r.p[0], r.p[1], r.p[2]);   // p[0..2] = A, B, C (p[3], p[7] unused)
                 }
                 break;
             }
@@ -271,6 +285,10 @@ inline std::string decode_tape(const float* tape, size_t n, DecodedTape& out)
                 else if (zx && zz) special = OPX_FROM_AXIS_Y;
                 else if (zx && zy) special = OPX_FROM_AXIS_Z;
                 r.hdr = special | (reg << 8);
+                if (special != op) {
+                    const float q = special == OPX_FROM_AXIS_X ? p[0] : special == OPX_FROM_AXIS_Y ? p[1] : special == OPX_FROM_AXIS_Z ? p[2] : 0.0f;
+                    axis_constants(q, p[3], (double)scale, r.p[0], r.p[1], r.p[2]);   // p[0..2] = A, B, C over |Q|^2; p[5] = scale
+                }
                 break;
             }
             case OP_REPETITION:

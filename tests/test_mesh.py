@@ -66,7 +66,7 @@ def oracle_mesh(shape, grid_size):
         v *= step
         v += np.array([corner.x, corner.y, corner.z])
         out.append((int_corner, v, t))
-    return out, (sy - 1) * boxes[0][1]
+    return out, ((sy - 1) * boxes[0][1] if boxes else 0.0)   # a shape without surface has no leaf blocks
 
 
 def concatenate(blocks):
