@@ -140,8 +140,8 @@ template <class T> __device__ __forceinline__ T dot3(T ax, T ay, T az, T bx, T b
 // the hardware seeds gives the SAME bits:
 //     y = v_rsq(x); s0 = x*y; s = fma(fma(-s0, s0, x), y/2, s0)          == sqrtf(x)
 //     r0 = v_rcp(s);          r = fma(fma(-s, r0, 1), r0, r0)            == 1.0f / s
-// (Seeding the reciprocal with y instead of v_rcp(s) would save a quarter-rate instruction, but is wrong
-// for 200 of the 2^32 inputs.)  Not an approximation argument: tests/test_gpu_math.py runs hu_selftest_math, which compares
+// (Seeding the reciprocal with y instead of v_rcp(s) would save a quarter-rate instruction, but one Newton
+// step from y is wrong for 200 of the 2^32 inputs, and two steps are still wrong for some and no faster.)  Not an approximation argument: tests/test_gpu_math.py runs hu_selftest_math, which compares
 // these functions with the IEEE expansions on ALL 2^32 inputs on the device.  Outside that range
 // (zeros, denormals, infinities, NaN, huge values) a wave-uniform branch takes the IEEE path.
 #ifndef SDF_FAST_CR_MATH
