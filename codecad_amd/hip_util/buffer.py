@@ -212,6 +212,8 @@ def cache_dir():
         path = v
     else:
         base = os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache")
+        if not os.path.isabs(base):
+            return None     # no home directory to put it in
         path = os.path.join(base, "codecad_amd")
     try:
         os.makedirs(path, exist_ok=True)

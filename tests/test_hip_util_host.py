@@ -302,3 +302,18 @@ def test_tape_decoder_survives_mutated_tapes():
             refused += 1
             assert b"malformed" in lib.hu_last_error()
     assert ok > 50 and refused > 500, (ok, refused)
+
+
+def test_cache_dir_resolution(monkeypatch, tmp_path):
+    from codecad_amd.hip_util import buffer
+    monkeypatch.setenv("CODECAD_AMD_CACHE", "0")
+    assert buffer.cache_dir() is None
+    monkeypatch.setenv("CODECAD_AMD_CACHE", "")
+    assert buffer.cache_dir() is None
+    monkeypatch.setenv("CODECAD_AMD_CACHE", str(tmp_path / "a" / "b"))
+    assert buffer.cache_dir() == str(tmp_path / "a" / "b") and (tmp_path / "a" / "b").is_dir()
+    monkeypatch.delenv("CODECAD_AMD_CACHE")
+    monkeypatch.setenv("XDG_CACHE_HOME", str(tmp_path / "xdg"))
+    assert buffer.cache_dir() == str(tmp_path / "xdg" / "codecad_amd") and (tmp_path / "xdg" / "codecad_amd").is_dir()
+    monkeypatch.setenv("XDG_CACHE_HOME", "relative/dir")
+    assert buffer.cache_dir() is None
