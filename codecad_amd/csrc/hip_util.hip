@@ -1040,7 +1040,7 @@ static int compile_specialised(const std::string& src, const std::vector<std::st
 // The image of `src`: from the cache when it is there, else built (and stored).  With only_if_cached a miss
 // leaves img.code empty and is not an error.
 static int specialised_image(const std::string& src, const char* include_dir, const char* cache_dir, bool only_if_cached,
-                             SpecImage& img, int* from_cache)
+                             SpecImage& img, int* from_cache, bool replace_cached = false)
 {
     if (from_cache) *from_cache = 0;
     img.code.clear();
@@ -1050,7 +1050,7 @@ static int specialised_image(const std::string& src, const char* include_dir, co
     const bool cached = cache_dir && *cache_dir && spec_cache_key(src, include_dir, options, key);
     if (cached) {
         path = spec_cache_path(cache_dir, key);
-        if (spec_cache_load(path, key, img)) {
+        if (!replace_cached && spec_cache_load(path, key, img)) {
             if (from_cache) *from_cache = 1;
             return HU_OK;
         }
@@ -1098,8 +1098,8 @@ int hu_tape_specialize_cached(hu_tape t, const char* include_dir, const char* ca
     for (int attempt = 0; attempt < 2; ++attempt) {
         SpecImage img;
         int crc;
-        // second attempt: the cached image did not load (e.g. written by an incompatible runtime): build it
-        if ((crc = specialised_image(src, include_dir, attempt ? nullptr : cache_dir, only_if_cached != 0, img, &cached))) return crc;
+        // second attempt: the cached image did not load (e.g. written by an incompatible runtime): build and replace it
+        if ((crc = specialised_image(src, include_dir, cache_dir, only_if_cached != 0, img, &cached, attempt != 0))) return crc;
         if (img.code.empty()) return HU_OK;  // only_if_cached and not there: still interpreted
         SpecKernels* k = new SpecKernels();
         hipError_t e = hipModuleLoadData(&k->module, img.code.data());
@@ -1115,7 +1115,9 @@ int hu_tape_specialize_cached(hu_tape t, const char* include_dir, const char* ca
         }
         if (k->module) (void)hipModuleUnload(k->module);
         delete k;
-        if (!cached || only_if_cached) return fail(HU_ERR_HIP, std::string("loading the specialised module: ") + hipGetErrorString(e));
+        (void)hipGetLastError();  // the failed load must not surface at the next launch's error check
+        if (cached && only_if_cached) return HU_OK;  // an unusable cached image is not the caller's problem: still interpreted
+        if (!cached) return fail(HU_ERR_HIP, std::string("loading the specialised module: ") + hipGetErrorString(e));
     }
     return fail(HU_ERR_HIP, "loading the specialised module failed");
 }

@@ -169,4 +169,22 @@ def test_specialised_code_cache(hip, monkeypatch, tmp_path):
     assert third.specialized and not third.from_cache and len(path.read_bytes()) == len(blob)
     assert np.array_equal(run(third), interpreted)
     assert hip_util.Tape(tape).from_cache
+
+    # a file that passes the container's checks but holds no loadable code object (e.g. written by another
+    # runtime): at upload it is skipped silently, an explicit specialize() rebuilds and replaces it
+    blob = bytearray(path.read_bytes())
+    elf_header_wrecked = bytearray(blob)
+    start = bytes(blob).find(b"\x7fELF")
+    assert start > 0
+    elf_header_wrecked[start:start + 64] = bytes(64)
+    h = 0xcbf29ce484222325
+    for byte in elf_header_wrecked[:-8]:
+        h = ((h ^ byte) * 0x100000001b3) & 0xffffffffffffffff
+    elf_header_wrecked[-8:] = h.to_bytes(8, "little")
+    path.write_bytes(bytes(elf_header_wrecked))
+    quiet = hip_util.Tape(tape)
+    assert not quiet.specialized and np.array_equal(run(quiet), interpreted)
+    quiet.specialize()
+    assert quiet.specialized and not quiet.from_cache and np.array_equal(run(quiet), interpreted)
+    assert hip_util.Tape(tape).from_cache
     out.release()
