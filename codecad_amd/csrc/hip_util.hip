@@ -44,8 +44,10 @@ int fail(int code, const std::string& msg)
 #define HU_HIP(expr)                                                                         \
     do {                                                                                     \
         hipError_t e_ = (expr);                                                              \
-        if (e_ != hipSuccess)                                                                \
+        if (e_ != hipSuccess) {                                                              \
+            (void)hipGetLastError(); /* reported through the return code: do not leave it sticky for the next launch check */ \
             return fail(HU_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+        }                                                                                    \
     } while (0)
 
 // ------------------------------------------------------------------------------------------

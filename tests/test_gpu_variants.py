@@ -188,3 +188,21 @@ def test_specialised_code_cache(hip, monkeypatch, tmp_path):
     assert quiet.specialized and not quiet.from_cache and np.array_equal(run(quiet), interpreted)
     assert hip_util.Tape(tape).from_cache
     out.release()
+
+
+@pytest.mark.gpu
+def test_a_reported_hip_error_does_not_resurface(hip):
+    """A HIP failure handed back through the return code (here an impossible allocation, which the block pools
+    answer by trimming and retrying) must not stay behind as the runtime's sticky last error: the next launch
+    checks hipGetLastError() and would report it as its own."""
+    import ctypes
+    import numpy as np
+    from codecad_amd import hip_util, examples, nodes, grid_eval
+    p = ctypes.c_void_p()
+    assert hip.lib.hu_malloc(ctypes.byref(p), 1 << 50) != 0
+    assert b"hipMalloc" in hip.lib.hu_last_error()
+    t = hip_util.Tape(nodes.make_program(examples.sponge(1)))
+    out = hip_util.Buffer(grid_eval.FLOAT4, (8, 8, 8))
+    c = np.zeros(4, np.float32)
+    hip.k.grid_eval((8, 8, 8), None, t, c, np.float32(0.1), out).wait()      # raises if the old error resurfaces
+    out.release()
