@@ -302,7 +302,11 @@ const char* const kSpecKernelNames[kSpecKernelCount] = {
 }  // namespace
 
 // for the other translation units of the library (sort.hip)
-int hu_fail_external(int code, const char* message) { return fail(code, message); }
+int hu_fail_external(int code, const char* message)
+{
+    if (code == HU_ERR_HIP) (void)hipGetLastError();  // reported through the return code, not left sticky
+    return fail(code, message);
+}
 
 extern "C" {
 
