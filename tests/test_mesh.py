@@ -317,3 +317,13 @@ def test_stl_records_errors(hip):
     assert len(stl_renderer.stl_records(np.zeros((3, 3)), np.zeros((0, 3), np.uint32))) == 0
     with pytest.raises(ValueError):
         stl_renderer.stl_records(np.zeros((3, 3)), np.array([[0, 1, 3]], np.uint32))
+    from codecad_amd import hip_util
+    v = hip_util.Buffer(np.float64, (3, 3))
+    t = hip_util.Buffer(np.uint32, (1, 3))
+    rec = hip_util.Buffer(np.uint8, (2, 50))
+    assert hip.lib.hu_mesh_stl(v.device_ptr, t.device_ptr, 1, rec.device_ptr + 2, None) != 0     # records must be 16-byte aligned
+    assert b"aligned" in hip.lib.hu_last_error()
+    assert hip.lib.hu_mesh_stl(None, t.device_ptr, 1, rec.device_ptr, None) != 0
+    assert hip.lib.hu_mesh_stl(None, None, 0, None, None) == 0                                    # nothing to do
+    for b in (v, t, rec):
+        b.release()
