@@ -50,6 +50,18 @@ def main():
                     help="auto = per-tape hipRTC specialisation when it builds, else the tape interpreter")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Called directly with --gpus N (the driver launches torch.distributed.run itself): start the ranks as a
+        # child job -- nothing has touched the GPU yet -- and pass its exit code on.
+        import socket
+        import subprocess
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
     import numpy as np
     import torch
     import codecad_amd as cc
