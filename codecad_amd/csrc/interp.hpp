@@ -39,6 +39,18 @@ __device__ __forceinline__ f2 sqrt_(f2 x) { return __builtin_elementwise_sqrt(x)
 __device__ __forceinline__ f2 abs_(f2 x) { return __builtin_elementwise_abs(x); }
 __device__ __forceinline__ f2 copysign_(f2 m, f2 s) { return __builtin_elementwise_copysign(m, s); }
 __device__ __forceinline__ float rint_(float x) { return __builtin_rintf(x); }
+// The hardware's v_min_f32 / v_max_f32 (ISA pseudocode: a NaN operand yields the other one, -0 orders below
+// +0): one full-rate instruction where `a < b ? a : b` is a compare and a select.  The canonical distance of
+// union / intersection / subtraction and of the nearer-slab case; the oracle restates it in
+// plain C.  Inline asm, not fminf/fmaxf: llvm.minnum leaves the sign of a zero result open and, in IEEE mode,
+// brings canonicalising instructions with it.
+__device__ __forceinline__ float min_(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float max_(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// max(a, -b): the negation rides in the instruction's source modifier
+__device__ __forceinline__ float max_neg_(float a, float b) { float r; asm("v_max_f32 %0, %1, -%2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ f2 max_neg_(f2 a, f2 b) { f2 r; r.x = max_neg_(a.x, b.x); r.y = max_neg_(a.y, b.y); return r; }
+__device__ __forceinline__ f2 min_(f2 a, f2 b) { f2 r; r.x = min_(a.x, b.x); r.y = min_(a.y, b.y); return r; }
+__device__ __forceinline__ f2 max_(f2 a, f2 b) { f2 r; r.x = max_(a.x, b.x); r.y = max_(a.y, b.y); return r; }
 __device__ __forceinline__ f2 rint_(f2 x) { return __builtin_elementwise_rint(x); }
 // Per-voxel predicates: the lane's own flag(s) PLUS the wavefront mask of each flag, built up
 // alongside (`w` = ballot of `v`).  Every flag starts as a float compare, whose result IS its
@@ -271,7 +283,7 @@ template <class T> __device__ __forceinline__ V4<T> rectangle_op(float hw, float
     auto xs = gt(wx, wy);
     // the nearer slab everywhere; the corner region (outside both slabs) is patched in only when some
     // lane of the wavefront is in it, so the common case pays three selects per voxel, not six
-    V4<T> r = v4<T>(sel(xs, sx, zero), sel(xs, zero, sy), zero, sel(xs, wx, wy));
+    V4<T> r = v4<T>(sel(xs, sx, zero), sel(xs, zero, sy), zero, max_(wx, wy));
     if (any_lane(corner)) {
         T dist, inv;
         sqrt_inv_cr(fma_(wy, wy, wx * wx), corner, dist, inv);
@@ -290,7 +302,7 @@ template <class T> __device__ __forceinline__ T perp_w(T a, T b)
     auto corner = gt(a, 0.0f) & gt(b, 0.0f);
     T dist = a;
     if (any_lane(corner)) dist = sqrt_cr(fma_(b, b, a * a), corner);
-    return sel(corner, dist, sel(gt(a, b), a, b));
+    return sel(corner, dist, max_(a, b));
 }
 
 // reference shapes/simple3d.cl:18-21 = perpendicular_intersection(slab_z(h, coords), in)
@@ -301,7 +313,7 @@ template <class T> __device__ __forceinline__ V4<T> extrusion_op(float hh, V4<T>
     T wz = abs_(coords.z) - hh;
     auto corner = gt(wz, 0.0f) & gt(in.w, 0.0f);
     auto cap = gt(wz, in.w);
-    V4<T> r = v4<T>(sel(cap, zero, in.x), sel(cap, zero, in.y), sel(cap, sz, in.z), sel(cap, wz, in.w));
+    V4<T> r = v4<T>(sel(cap, zero, in.x), sel(cap, zero, in.y), sel(cap, sz, in.z), max_(wz, in.w));
     if (any_lane(corner)) {
         T dist, inv;
         sqrt_inv_cr(fma_(in.w, in.w, wz * wz), corner, dist, inv);
@@ -334,7 +346,8 @@ template <class T> __device__ __forceinline__ V4<T> rounded_union(float r, V4<T>
 {
     if (r >= 0.0f)  // wave-uniform: r is a tape constant
         return per_voxel(a, b, [r](float4 x, float4 y) { return rounded_blend(r, x, y); });
-    return sel4(lt(a.w, b.w), a, b);
+    const auto first = lt(a.w, b.w);   // the direction of the nearer one; the distance is the hardware minimum
+    return v4<T>(sel(first, a.x, b.x), sel(first, a.y, b.y), sel(first, a.z, b.z), min_(a.w, b.w));
 }
 
 // reference shapes/simple2d.cl:6-14
@@ -813,15 +826,15 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const floa
         break;
     }
     case OP_UNION:
-        if (DISTANCE_ONLY) { T b = regs.load_res(reg); last.w = sel(lt(last.w, b), last.w, b); }
+        if (DISTANCE_ONLY) last.w = min_(last.w, regs.load_res(reg));
         else last = rounded_union(p[0], last, regs.load(reg));
         break;
     case OP_INTERSECTION:
-        if (DISTANCE_ONLY) { T a = -last.w, b = -regs.load_res(reg); last.w = -sel(lt(a, b), a, b); }
+        if (DISTANCE_ONLY) last.w = max_(last.w, regs.load_res(reg));         // == -min(-a, -b), zeros and NaNs included
         else last = neg(rounded_union(p[0], neg(last), neg(regs.load(reg))));
         break;
     case OP_SUBTRACTION:
-        if (DISTANCE_ONLY) { T a = -last.w, b = regs.load_res(reg); last.w = -sel(lt(a, b), a, b); }
+        if (DISTANCE_ONLY) last.w = max_neg_(last.w, regs.load_res(reg));     // == -min(-a, b)
         else last = neg(rounded_union(p[0], neg(last), regs.load(reg)));
         break;
     default: return true;  // unreachable: tapes are validated at upload

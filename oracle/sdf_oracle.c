@@ -59,7 +59,27 @@ static inline float quaternion_scale(f4 q)
     return fmaf(q.w, q.w, fmaf(q.z, q.z, fmaf(q.y, q.y, q.x * q.x)));
 }
 
-/* shapes/common.cl:15-31 perpendicular_intersection */
+/* gfx9 v_min_f32 / v_max_f32 as the ISA documents them: a NaN operand yields the other operand, -0 orders below
+ * +0.  The canonical distance of union / intersection / subtraction and of the nearer-slab case (DESIGN.md
+ * section 3): the kernels compute it with that one instruction.  It differs from `a < b ? a : b` only for NaN
+ * operands and for zeros of opposite sign. */
+static inline float hw_min(float a, float b)
+{
+    if (a != a) return b;
+    if (b != b) return a;
+    if (a == b) return signbit(a) ? a : b;
+    return a < b ? a : b;
+}
+static inline float hw_max(float a, float b)
+{
+    if (a != a) return b;
+    if (b != b) return a;
+    if (a == b) return signbit(a) ? b : a;
+    return a > b ? a : b;
+}
+
+/* shapes/common.cl:15-31 perpendicular_intersection (outside the corner: the direction of the nearer slab, the
+ * distance as the hardware maximum) */
 static inline f4 perpendicular_intersection(f4 a, f4 b)
 {
     if (a.w > 0.0f && b.w > 0.0f) {
@@ -68,10 +88,10 @@ static inline f4 perpendicular_intersection(f4 a, f4 b)
         float m1 = a.w * inv;
         float m2 = b.w * inv;
         return mk4(fmaf(b.x, m2, a.x * m1), fmaf(b.y, m2, a.y * m1), fmaf(b.z, m2, a.z * m1), dist);
-    } else if (a.w > b.w) {
-        return a;
     } else {
-        return b;
+        f4 r = (a.w > b.w) ? a : b;
+        r.w = hw_max(a.w, b.w);
+        return r;
     }
 }
 
@@ -94,7 +114,10 @@ static inline f4 rounded_union(float r, f4 a, f4 b)
             return mk4(0, 0, 0, d);
         }
     }
-    return (a.w < b.w) ? a : b;
+    if (r >= 0.0f) return (a.w < b.w) ? a : b;
+    f4 nearer = (a.w < b.w) ? a : b;   /* plain union: the direction of the nearer one, the distance as the hardware minimum */
+    nearer.w = hw_min(a.w, b.w);
+    return nearer;
 }
 
 /* shapes/common.cl:66-76 */

@@ -206,3 +206,48 @@ def test_a_reported_hip_error_does_not_resurface(hip):
     c = np.zeros(4, np.float32)
     hip.k.grid_eval((8, 8, 8), None, t, c, np.float32(0.1), out).wait()      # raises if the old error resurfaces
     out.release()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("specialise", [False, True])
+def test_union_distances_at_signed_zeros_and_nans(hip, specialise):
+    """The distance of a union / intersection / subtraction is the hardware's v_min_f32 / v_max_f32, which the
+    oracle restates: where the two operands are zeros of opposite sign (samples exactly on both surfaces) and
+    where one of them is NaN (a NaN sample coordinate that only one operand reads), kernels and oracle must still
+    agree bit for bit, in the full program (float4) and in the distance-only one (float)."""
+    import numpy as np
+    import oracle
+    from conftest import same_bits
+    from codecad_amd import hip_util, nodes, grid_eval
+    from codecad_amd.shapes import half_space, sphere, box
+    solid, plane = box(4), half_space().translated(0, 2, 0)     # on the face y = 2: distances +0 and -0
+    far = sphere(1).translated(50, 0, 0)
+    cases = {"union": solid + plane, "intersection": solid & plane, "subtraction": solid - plane,
+             "subtraction_swapped": plane - solid, "nested": (plane + far) - (solid & box(6))}
+    n = 9
+    step = np.float32(0.5)
+    for label, shape in cases.items():
+        tape = nodes.make_program(shape)
+        t = hip_util.Tape(tape, policy="0")
+        if specialise:
+            t.specialize()
+        for corner in ([-2.0, -2.0, -2.0], [float("nan"), -2.0, -2.0], [-2.0, -2.0, float("nan")]):
+            c4 = np.zeros(4, np.float32)
+            c4[:3] = corner
+            full = hip_util.Buffer(grid_eval.FLOAT4, (n, n, n))
+            hip.k.grid_eval((n, n, n), None, t, c4, step, full).wait()
+            got = full.read().view(np.float32).reshape(n, n, n, 4)
+            want = oracle.grid_eval(tape, np.array(corner, np.float32), step, (n, n, n))
+            assert same_bits(got, want), (label, corner, "float4")
+            scalar = hip_util.Buffer(np.float32, (n, n, n))
+            hip.k.grid_eval_pymcubes((n, n, n), None, t, c4, step, scalar).wait()
+            want_s = oracle.grid_eval_pymcubes(tape, np.array(corner, np.float32), step, (n, n, n))
+            assert same_bits(scalar.read().reshape(-1), np.asarray(want_s).reshape(-1)), (label, corner, "float")
+            full.release()
+            scalar.release()
+        if label == "union":   # the case this test is about really occurs: +0 and -0 meet on the face
+            w = oracle.grid_eval(tape, np.array([-2.0, -2.0, -2.0], np.float32), step, (n, n, n))[2:7, 8, 2:7, 3]
+            a = oracle.grid_eval(nodes.make_program(solid), np.array([-2.0, -2.0, -2.0], np.float32), step, (n, n, n))[2:7, 8, 2:7, 3]
+            b = oracle.grid_eval(nodes.make_program(plane), np.array([-2.0, -2.0, -2.0], np.float32), step, (n, n, n))[2:7, 8, 2:7, 3]
+            assert np.all(a == 0) and not np.any(np.signbit(a)) and np.all(b == 0) and np.all(np.signbit(b))
+            assert np.all(w == 0) and np.all(np.signbit(w))          # the minimum of +0 and -0 is -0
