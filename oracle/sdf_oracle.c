@@ -65,17 +65,19 @@ static inline float quaternion_scale(f4 q)
  * operands and for zeros of opposite sign. */
 static inline float hw_min(float a, float b)
 {
-    if (a != a) return b;
+    if (a < b) return a;
+    if (b < a) return b;
+    if (a != a) return b;              /* unordered: the operand that is not NaN */
     if (b != b) return a;
-    if (a == b) return signbit(a) ? a : b;
-    return a < b ? a : b;
+    return signbit(a) ? a : b;         /* equal: -0 before +0 */
 }
 static inline float hw_max(float a, float b)
 {
+    if (a > b) return a;
+    if (b > a) return b;
     if (a != a) return b;
     if (b != b) return a;
-    if (a == b) return signbit(a) ? b : a;
-    return a > b ? a : b;
+    return signbit(a) ? b : a;
 }
 
 /* shapes/common.cl:15-31 perpendicular_intersection (outside the corner: the direction of the nearer slab, the
