@@ -39,6 +39,11 @@ __device__ __forceinline__ f2 sqrt_(f2 x) { return __builtin_elementwise_sqrt(x)
 __device__ __forceinline__ f2 abs_(f2 x) { return __builtin_elementwise_abs(x); }
 __device__ __forceinline__ f2 copysign_(f2 m, f2 s) { return __builtin_elementwise_copysign(m, s); }
 __device__ __forceinline__ float rint_(float x) { return __builtin_rintf(x); }
+// |x| - h per voxel: the absolute value rides in the subtraction's source modifier (one instruction per voxel),
+// where the packed form needs a v_and per voxel in front of the packed subtraction
+// (inline asm: written as fabsf(x) - h the compiler re-packs the two voxels and puts the v_and back)
+__device__ __forceinline__ float abs_minus(float x, float h) { float r; asm("v_sub_f32 %0, |%1|, %2" : "=v"(r) : "v"(x), "s"(h)); return r; }
+__device__ __forceinline__ f2 abs_minus(f2 x, float h) { f2 r; r.x = abs_minus(x.x, h); r.y = abs_minus(x.y, h); return r; }
 // The hardware's v_min_f32 / v_max_f32 (ISA pseudocode: a NaN operand yields the other one, -0 orders below
 // +0): one full-rate instruction where `a < b ? a : b` is a compare and a select.  The canonical distance of
 // union / intersection / subtraction and of the nearer-slab case; the oracle restates it in
@@ -278,7 +283,7 @@ template <class T> __device__ __forceinline__ V4<T> rectangle_op(float hw, float
 {
     const T one = bc<T>(1.0f), zero = bc<T>(0.0f);
     T sx = copysign_(one, c.x), sy = copysign_(one, c.y);
-    T wx = abs_(c.x) - hw, wy = abs_(c.y) - hh;
+    T wx = abs_minus(c.x, hw), wy = abs_minus(c.y, hh);
     auto corner = gt(wx, 0.0f) & gt(wy, 0.0f);
     auto xs = gt(wx, wy);
     // the nearer slab everywhere; the corner region (outside both slabs) is patched in only when some
@@ -310,7 +315,7 @@ template <class T> __device__ __forceinline__ V4<T> extrusion_op(float hh, V4<T>
 {
     const T zero = bc<T>(0.0f);
     T sz = copysign_(bc<T>(1.0f), coords.z);
-    T wz = abs_(coords.z) - hh;
+    T wz = abs_minus(coords.z, hh);
     auto corner = gt(wz, 0.0f) & gt(in.w, 0.0f);
     auto cap = gt(wz, in.w);
     V4<T> r = v4<T>(sel(cap, zero, in.x), sel(cap, zero, in.y), sel(cap, sz, in.z), max_(wz, in.w));
@@ -670,7 +675,7 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const floa
         else last = regs.load(reg);
         break;
     case OP_RECTANGLE:
-        if (DISTANCE_ONLY) last.w = perp_w<T>(abs_(last.x) - p[0], abs_(last.y) - p[1]);
+        if (DISTANCE_ONLY) last.w = perp_w<T>(abs_minus(last.x, p[0]), abs_minus(last.y, p[1]));
         else last = rectangle_op(p[0], p[1], last);
         break;
     case OP_CIRCLE:
@@ -807,7 +812,7 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const floa
         break;
     }
     case OP_EXTRUSION:
-        if (DISTANCE_ONLY) last.w = perp_w<T>(abs_(regs.load_z(reg)) - p[0], last.w);
+        if (DISTANCE_ONLY) last.w = perp_w<T>(abs_minus(regs.load_z(reg), p[0]), last.w);
         else last = extrusion_op(p[0], last, regs.load(reg));
         break;
     case OP_REVOLUTION_FROM:
