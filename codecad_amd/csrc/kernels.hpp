@@ -140,10 +140,17 @@ __device__ __forceinline__ void wg_compact_slots(const bool (&flag)[N], uint32_t
     for (int i = 1; i < N; ++i) slot[i] = slot[i - 1] + (flag[i - 1] ? 1u : 0u);
 }
 
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+// Sum over the 64 lanes of a wavefront; the total arrives in lane 63 (other lanes hold partial sums).
+// Data-parallel-primitive adds (row shifts inside the rows of 16, then the two row broadcasts): six VALU
+// instructions per value, where a __shfl_xor butterfly is six ds_bpermute round trips through the LDS crossbar.
+__device__ __forceinline__ uint32_t wave_sum_to_last_lane(uint32_t v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8: lane 15 of a row = its total
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
     return v;
 }
 
@@ -285,17 +292,18 @@ __global__ void __launch_bounds__(256) k_classify(const E ev, const ClassifyArgs
             uint32_t v[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int i = 0; i < N; ++i) {
+                // cell indices are below 256 (the launchers check): 24-bit multiplies, which are full rate
                 const uint32_t m = inside[i] ? 1u : 0u;
                 const uint32_t x = c.x[i], y = c.y[i], z = c.z[i];
-                const uint32_t xm = x * m, ym = y * m, zm = z * m;
-                v[0] += xm * x; v[1] += xm * y; v[2] += xm * z; v[3] += xm;
-                v[4] += ym * y; v[5] += ym * z; v[6] += ym;
-                v[7] += zm * z; v[8] += zm; v[9] += m;
+                const uint32_t xm = inside[i] ? x : 0u, ym = inside[i] ? y : 0u, zm = inside[i] ? z : 0u;
+                v[0] += __umul24(xm, x); v[1] += __umul24(xm, y); v[2] += __umul24(xm, z); v[3] += xm;
+                v[4] += __umul24(ym, y); v[5] += __umul24(ym, z); v[6] += ym;
+                v[7] += __umul24(zm, z); v[8] += zm; v[9] += m;
             }
 #pragma unroll
             for (int i = 0; i < 10; ++i) {
-                const uint32_t sum = wave_sum(v[i]);
-                if ((threadIdx.x & 63u) == 0 && sum) atomicAdd(&scratch[8 + i], sum);
+                const uint32_t sum = wave_sum_to_last_lane(v[i]);
+                if ((threadIdx.x & 63u) == 63u && sum) atomicAdd(&scratch[8 + i], sum);
             }
         }
     } else {
