@@ -54,21 +54,26 @@ int fail(int code, const std::string& msg)
 // mass_properties: per-parent index sums -> the ten integrals of this level, on the device.
 // The reference does this on the host, block by block, in Python doubles with Kahan sums
 // (mass_properties.py:119-148).  Same per-block formulas in fp64 (no contraction), summed
-// deterministically: thread t Kahan-accumulates parents t, t+1024, ... and the 1024 partial
-// sums are combined by a fixed tree, so the result does not depend on launch timing.
-// One workgroup: a level has at most a few 100k parents, i.e. microseconds of work.
-// out[10] order: 1, x, y, z, xx, yy, zz, xy, xz, yz.
+// deterministically: workgroup g takes the g-th contiguous slice of the parents, thread t of it
+// Kahan-accumulates the slice's parents t, t+1024, ... and the 1024 partial sums are combined by a
+// fixed tree into row g of the output; the caller adds the rows in order.  Nothing depends on launch
+// timing.  (One workgroup for a whole level -- the first version -- took 172 us for the 167 k leaf
+// parents of sponge(4) at 1/512, 15 % of the whole mass_properties call.)
+// out[g][10] order: 1, x, y, z, xx, yy, zz, xy, xz, yz.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024)
-k_mass_integrals(const double4* __restrict__ parents, const uint32_t* __restrict__ sums, uint32_t n, double s,
-                 double* __restrict__ out)
+k_mass_integrals(const double4* __restrict__ parents, const uint32_t* __restrict__ sums, uint32_t n, uint32_t per_row,
+                 double s, double* __restrict__ out)
 {
+    const uint64_t first = (uint64_t)blockIdx.x * per_row;              // rows past the last parent get an empty slice
+    const uint32_t begin = first < n ? (uint32_t)first : n;
+    const uint32_t end = (n - begin < per_row) ? n : begin + per_row;
     __shared__ double part[10][1024];
     double acc[10], comp[10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) acc[k] = comp[k] = 0.0;
     const double s2 = s * s, s3 = s * s2, h = s / 2, twelfth = s2 / 12;
-    for (uint32_t p = threadIdx.x; p < n; p += 1024) {
+    for (uint32_t p = begin + threadIdx.x; p < end; p += 1024) {
         const double4 c = parents[p];
         const uint32_t* u = sums + (size_t)p * 10;
         const double sxx = u[0], sxy = u[1], sxz = u[2], sx = u[3], syy = u[4], syz = u[5], sy = u[6], szz = u[7],
@@ -102,7 +107,7 @@ k_mass_integrals(const double4* __restrict__ parents, const uint32_t* __restrict
         }
         __syncthreads();
     }
-    if (threadIdx.x < 10) out[threadIdx.x] = part[threadIdx.x][0];
+    if (threadIdx.x < 10) out[(size_t)blockIdx.x * 10 + threadIdx.x] = part[threadIdx.x][0];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -760,11 +765,13 @@ int hu_mass_properties_level(hu_tape t, const double* parents_dev, uint32_t n_pa
 }
 
 int hu_mass_integrals(const double* parents_dev, const uint32_t* sums_dev, uint32_t n_parents, double s,
-                      double* out10_dev, void* stream)
+                      double* out_dev, uint32_t rows, void* stream)
 {
-    if (!out10_dev || ((!parents_dev || !sums_dev) && n_parents)) return fail(HU_ERR_BAD_ARG, "NULL argument");
-    hipLaunchKernelGGL(k_mass_integrals, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const double4*)parents_dev,
-                       sums_dev, n_parents, s, out10_dev);
+    if (!out_dev || ((!parents_dev || !sums_dev) && n_parents)) return fail(HU_ERR_BAD_ARG, "NULL argument");
+    if (rows == 0 || rows > 65535u) return fail(HU_ERR_BAD_ARG, "rows must be in 1..65535");
+    const uint32_t per_row = (n_parents + rows - 1) / rows;   // rows past the end get an empty slice and write zeros
+    hipLaunchKernelGGL(k_mass_integrals, dim3(rows), dim3(1024), 0, (hipStream_t)stream, (const double4*)parents_dev,
+                       sums_dev, n_parents, per_row, s, out_dev);
     HU_HIP(hipGetLastError());
     return HU_OK;
 }

@@ -211,7 +211,7 @@ def mass_properties(shape, resolution, grid_size=None):
     import math
     import numpy
     from . import nodes, subdivision
-    from .mass_properties import finish, _KEYS   # (the package attribute of that name is the function)
+    from .mass_properties import finish, integral_rows, _KEYS   # (the package attribute of that name is the function)
     from .hip_util import manager as hip_manager, check
 
     if grid_size is None:
@@ -250,8 +250,11 @@ def mass_properties(shape, resolution, grid_size=None):
             if leaf or count <= capacity:
                 break
             capacity = count
-        check(lib.hu_mass_integrals(parents.data_ptr(), sums.data_ptr(), n, float(s), partial.data_ptr(), stream),
+        rows = integral_rows(n)
+        pieces = torch.empty((rows, 10), dtype=torch.float64, device=device)
+        check(lib.hu_mass_integrals(parents.data_ptr(), sums.data_ptr(), n, float(s), pieces.data_ptr(), rows, stream),
               "hu_mass_integrals")
+        partial = pieces.sum(dim=0)     # a fixed reduction over <= 64 rows
         return children[:0 if leaf else count], partial
 
     top = torch.tensor([[box.a.x, box.a.y, box.a.z, 0.0]], dtype=torch.float64, device=device)

@@ -107,14 +107,21 @@ def level_integrals(tape, parents, n_parents, s, dims, leaf, queue, counter):
             break
         children.release()
         capacity = count
-    # the ten integrals of this level, reduced on the device: 80 bytes come back
-    out = hip_util.Buffer(numpy.float64, 10, queue=queue)
-    check(lib.hu_mass_integrals(parents.device_ptr, sums.device_ptr, n_parents, float(s), out.device_ptr,
+    # the ten integrals of this level, reduced on the device, one row per slice of ~2048 parents: at most
+    # 5 KB come back, and the rows are added here in order (deterministic whatever the launch did)
+    rows = integral_rows(n_parents)
+    out = hip_util.Buffer(numpy.float64, (rows, 10), queue=queue)
+    check(lib.hu_mass_integrals(parents.device_ptr, sums.device_ptr, n_parents, float(s), out.device_ptr, rows,
                                 queue.handle), "hu_mass_integrals")
-    values = out.read().tolist()
+    values = [math.fsum(column) for column in out.read().T.tolist()]
     sums.release()
     out.release()
     return dict(zip(_KEYS, values)), children, (0 if leaf else count)
+
+
+def integral_rows(n_parents):
+    """Rows (workgroups) hu_mass_integrals is asked for: one per ~2048 parents, at most 64."""
+    return max(1, min(64, (int(n_parents) + 2047) // 2048))
 
 
 def mass_properties(shape, resolution, grid_size=None):

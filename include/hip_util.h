@@ -134,9 +134,12 @@ int hu_mass_properties_level(hu_tape t, const double* parents_dev, uint32_t n_pa
 
 /* The ten integrals (1, x, y, z, xx, yy, zz, xy, xz, yz over the inside cells) of one level from
  * the per-parent index sums, with the per-block formulas of mass_properties.py:119-148 in fp64,
- * summed deterministically on the device.  out10_dev: double[10]. */
+ * summed deterministically on the device: out_dev: double[rows][10], row g = the integrals of the g-th
+ * of `rows` contiguous slices of the parents (Kahan per thread, fixed tree per workgroup); the caller adds
+ * the rows in order.  rows = 1 gives the level's integrals directly; more rows spread a long level over
+ * the chip (1 row per ~2048 parents is plenty). */
 int hu_mass_integrals(const double* parents_dev, const uint32_t* sums_dev, uint32_t n_parents, double s,
-                      double* out10_dev, void* stream);
+                      double* out_dev, uint32_t rows, void* stream);
 
 /* ---- renderers on the same evaluate() -------------------- */
 /* rendering/ray_caster.cl:146-159, launched by rendering/ray_caster.py:93-110 with global size

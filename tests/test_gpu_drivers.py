@@ -286,17 +286,22 @@ def test_device_integrals_match_host_formulas(hip):
         want = integrals_host(sums, corners[:, :3], s)
         pb = hip_util.Buffer(np.float64, (n, 4))
         sb = hip_util.Buffer(np.uint32, (n, 10))
-        ob = hip_util.Buffer(np.float64, 10)
         pb.enqueue_write(corners)
         sb.enqueue_write(sums)
-        results = []
-        for _ in range(2):
-            check(hip.lib.hu_mass_integrals(pb.device_ptr, sb.device_ptr, n, s, ob.device_ptr, hip.queue.handle), "integrals")
-            results.append(ob.read().copy())
-        assert np.array_equal(results[0], results[1])
         scale = max(abs(want[k]) for k in _KEYS) + 1e-300
-        for k, v in zip(_KEYS, results[0]):
-            assert v == pytest.approx(want[k], rel=1e-12, abs=1e-13 * scale * n)
+        for rows in (1, 3, 64, 1000):          # one workgroup, ragged slices, more rows than slices hold parents
+            ob = hip_util.Buffer(np.float64, (rows, 10))
+            results = []
+            for _ in range(2):
+                ob.enqueue_fill(0xff)           # every row must be written, also the empty ones
+                check(hip.lib.hu_mass_integrals(pb.device_ptr, sb.device_ptr, n, s, ob.device_ptr, rows, hip.queue.handle),
+                      "integrals")
+                results.append(ob.read().copy())
+            assert np.array_equal(results[0], results[1])
+            for k, v in zip(_KEYS, results[0].sum(axis=0)):
+                assert v == pytest.approx(want[k], rel=1e-12, abs=1e-13 * scale * n)
+            ob.release()
+        assert hip.lib.hu_mass_integrals(pb.device_ptr, sb.device_ptr, n, s, pb.device_ptr, 0, hip.queue.handle) != 0
 
 
 def _wide_tape(k):
