@@ -238,7 +238,7 @@ def mass_properties(shape, resolution, grid_size=None):
         cells = dims[0] * dims[1] * dims[2]
         thr = 0.0 if leaf else s * math.sqrt(3) / 2
         d = (ctypes.c_uint32 * 3)(*dims)
-        capacity = 0 if leaf else min(n * cells, max(1 << 14, 4 * n * int(round(cells ** (2.0 / 3.0)))))
+        capacity = 0 if leaf else subdivision.child_capacity(n, cells)
         while True:
             children = torch.empty((max(capacity, 1), 4), dtype=torch.float64, device=device)
             sums = torch.zeros((n, 10), dtype=torch.int32, device=device)

@@ -92,7 +92,7 @@ def level_integrals(tape, parents, n_parents, s, dims, leaf, queue, counter):
     thr = 0.0 if leaf else s * math.sqrt(3) / 2  # reference mass_properties.py:87-90
     d = (ctypes.c_uint32 * 3)(int(dims[0]), int(dims[1]), int(dims[2]))
     sums = hip_util.Buffer(numpy.uint32, (n_parents, 10), queue=queue)
-    capacity = 0 if leaf else min(n_parents * cells, max(1 << 14, 4 * n_parents * int(round(cells ** (2.0 / 3.0)))))
+    capacity = 0 if leaf else subdivision.child_capacity(n_parents, cells)
     while True:
         children = hip_util.Buffer(numpy.float64, (max(capacity, 1), 4), queue=queue)
         sums.enqueue_fill(0)

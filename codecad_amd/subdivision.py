@@ -104,6 +104,16 @@ class LeafBlocks:
         return numpy.ascontiguousarray(a[order])
 
 
+def child_capacity(n_parents, cells):
+    """First size of a level's child list (the launch is repeated with the exact count if it is short): every
+    cell when that is at most 2^21 rows -- a level of a fractal keeps most of its cells, and a repeat costs more
+    than the memory --, else the surface estimate: it crosses O(cells^(2/3)) cells of a block, x4 headroom."""
+    upper = int(n_parents) * int(cells)
+    if upper <= 1 << 21:
+        return upper
+    return min(upper, max(1 << 21, 4 * int(n_parents) * int(round(cells ** (2.0 / 3.0)))))
+
+
 def _level_launch(tape, parents, n_parents, int_step, dims, dimension, resolution, origin, counter, queue,
                   capacity_hint=None):
     """Run one level, growing the child list until everything fits.  Returns (children, count)."""
@@ -114,10 +124,7 @@ def _level_launch(tape, parents, n_parents, int_step, dims, dimension, resolutio
     d = (ctypes.c_uint32 * 3)(int(dims[0]), int(dims[1]), int(dims[2]))
     o = (ctypes.c_double * 3)(origin.x, origin.y, origin.z)
     upper = n_parents * cells
-    if capacity_hint is None:
-        # the surface crosses O(cells^(2/3)) cells of a block; x4 headroom, retried if short
-        capacity_hint = max(1 << 14, 4 * n_parents * int(round(cells ** (2.0 / 3.0))))
-    capacity = min(upper, capacity_hint)
+    capacity = child_capacity(n_parents, cells) if capacity_hint is None else min(upper, capacity_hint)
     while True:
         children = hip_util.Buffer(numpy.int32, (max(capacity, 1), 4), queue=queue)
         counter.enqueue_fill(0)
