@@ -93,6 +93,10 @@ def level_integrals(tape, parents, n_parents, s, dims, leaf, queue, counter):
     d = (ctypes.c_uint32 * 3)(int(dims[0]), int(dims[1]), int(dims[2]))
     sums = hip_util.Buffer(numpy.uint32, (n_parents, 10), queue=queue)
     capacity = 0 if leaf else subdivision.child_capacity(n_parents, cells)
+    # the ten integrals of this level are reduced on the device, one row per slice of ~2048 parents: at most
+    # 5 KB come back, and the rows are added here in order (deterministic whatever the launch did)
+    rows = integral_rows(n_parents)
+    out = hip_util.Buffer(numpy.float64, (rows, 10), queue=queue)
     while True:
         children = hip_util.Buffer(numpy.float64, (max(capacity, 1), 4), queue=queue)
         sums.enqueue_fill(0)
@@ -102,17 +106,14 @@ def level_integrals(tape, parents, n_parents, s, dims, leaf, queue, counter):
                                            numpy.float32(s), numpy.float32(thr), sums.device_ptr,
                                            counter.device_ptr, children.device_ptr, capacity, queue.handle),
               "hu_mass_properties_level")
+        # enqueued before the host waits for the counter: the reduction runs during that round trip
+        check(lib.hu_mass_integrals(parents.device_ptr, sums.device_ptr, n_parents, float(s), out.device_ptr, rows,
+                                    queue.handle), "hu_mass_integrals")
         count = int(counter.read()[0])
         if count <= capacity or leaf:
             break
         children.release()
         capacity = count
-    # the ten integrals of this level, reduced on the device, one row per slice of ~2048 parents: at most
-    # 5 KB come back, and the rows are added here in order (deterministic whatever the launch did)
-    rows = integral_rows(n_parents)
-    out = hip_util.Buffer(numpy.float64, (rows, 10), queue=queue)
-    check(lib.hu_mass_integrals(parents.device_ptr, sums.device_ptr, n_parents, float(s), out.device_ptr, rows,
-                                queue.handle), "hu_mass_integrals")
     values = [math.fsum(column) for column in out.read().T.tolist()]
     sums.release()
     out.release()
