@@ -315,11 +315,20 @@ __global__ void __launch_bounds__(256) k_classify(const E ev, const ClassifyArgs
         }
     }
 
+    // With a zero threshold (the leaf level of mass_properties) no sample can be ambiguous: nothing to compact,
+    // one barrier (for the moment sums below) instead of the compaction's two.  Kernel-uniform.
+    const bool nothing_ambiguous = MASS && a.thr == 0.0f;
     uint32_t slot[N];
-    wg_compact_slots<N>(ambiguous, a.counter, scratch, slot);  // has __syncthreads
+    if (nothing_ambiguous) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) slot[i] = 0u;
+        __syncthreads();
+    } else {
+        wg_compact_slots<N>(ambiguous, a.counter, scratch, slot);  // has __syncthreads
+    }
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        if (!(ambiguous[i] && slot[i] < a.capacity)) continue;
+        if (nothing_ambiguous || !(ambiguous[i] && slot[i] < a.capacity)) continue;
         const uint32_t x = c.x[i], y = c.y[i], z = c.z[i];
         if (!BATCH) {
             static_cast<uchar4*>(a.list)[slot[i]] = make_uchar4((unsigned char)x, (unsigned char)y, (unsigned char)z, 0);
