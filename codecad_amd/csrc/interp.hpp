@@ -720,6 +720,16 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const floa
         break;
     }
     case OPX_POINT: last = v4<T>(px, py, pz, bc<T>(0.0f)); break;
+    // a general quaternion as its matrix (tape_format.hpp): x' is parked in w, then y', z' and the assembly
+    case OPX_TO_ROW_X:
+        last.w = fma_(last.x, bc<T>(p[0]), fma_(last.y, bc<T>(p[1]), fma_(last.z, bc<T>(p[2]), bc<T>(p[3]))));
+        break;
+    case OPX_TO_ROWS_YZ: {
+        const T y = fma_(last.x, bc<T>(p[0]), fma_(last.y, bc<T>(p[1]), fma_(last.z, bc<T>(p[2]), bc<T>(p[3]))));
+        const T z = fma_(last.x, bc<T>(p[4]), fma_(last.y, bc<T>(p[5]), fma_(last.z, bc<T>(p[6]), bc<T>(p[7]))));
+        last = v4<T>(last.w, y, z, bc<T>(0.0f));
+        break;
+    }
     case OPX_TO_SCALE:  // p[0] = w*w
         last = v4<T>(fma_(last.x, bc<T>(p[0]), bc<T>(p[4])), fma_(last.y, bc<T>(p[0]), bc<T>(p[5])),
                      fma_(last.z, bc<T>(p[0]), bc<T>(p[6])), bc<T>(0.0f));
@@ -750,6 +760,23 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const floa
         T ox, oy, oz;
         quat_xform<T>(p[0], p[1], p[2], p[3], p[4], last.x, last.y, last.z, ox, oy, oz);
         last = v4<T>(ox * p[6], oy * p[6], oz * p[6], last.w * p[5]);
+        break;
+    }
+    case OPX_INIT_ROW_X:
+        last.w = fma_(px, bc<T>(p[0]), fma_(py, bc<T>(p[1]), fma_(pz, bc<T>(p[2]), bc<T>(p[3]))));
+        break;
+    case OPX_INIT_ROWS_YZ: {
+        const T y = fma_(px, bc<T>(p[0]), fma_(py, bc<T>(p[1]), fma_(pz, bc<T>(p[2]), bc<T>(p[3]))));
+        const T z = fma_(px, bc<T>(p[4]), fma_(py, bc<T>(p[5]), fma_(pz, bc<T>(p[6]), bc<T>(p[7]))));
+        last = v4<T>(last.w, y, z, bc<T>(0.0f));
+        break;
+    }
+    case OPX_FROM_MATRIX: {  // general quaternion: matrix over |Q|^2 (unit directions stay unit), p[9] = |Q|^2
+        if (DISTANCE_ONLY) { last.w = last.w * p[9]; break; }
+        const T x = fma_(last.x, bc<T>(p[0]), fma_(last.y, bc<T>(p[1]), last.z * p[2]));
+        const T y = fma_(last.x, bc<T>(p[3]), fma_(last.y, bc<T>(p[4]), last.z * p[5]));
+        const T z = fma_(last.x, bc<T>(p[6]), fma_(last.y, bc<T>(p[7]), last.z * p[8]));
+        last = v4<T>(x, y, z, last.w * p[9]);
         break;
     }
     // transformation_from with an axis-aligned quaternion (decoder special cases, tape.hpp): the same 2x2

@@ -65,6 +65,7 @@ inline bool produces_point(uint32_t op)
     case OP_INITIAL_TRANSFORMATION_TO: case OP_TRANSFORMATION_TO: case OP_SYMMETRICAL_TO: case OP_REPETITION:
     case OP_CIRCULAR_REPETITION_TO: case OP_REVOLUTION_TO: case OP_TWIST_REVOLUTION_TO:
     case OPX_POINT: case OPX_TO_SCALE: case OPX_TO_AXIS_X: case OPX_TO_AXIS_Y: case OPX_TO_AXIS_Z:
+    case OPX_TO_ROW_X: case OPX_TO_ROWS_YZ: case OPX_INIT_ROW_X: case OPX_INIT_ROWS_YZ:
         return true;
     default: return false;
     }
@@ -162,6 +163,21 @@ inline void axis_constants(float q, float w, double div, float& A, float& B, flo
     A = (float)((ww + qq) / div);
     B = (float)((ww - qq) / div);
     C = (float)((2.0 * ((double)q * (double)w)) / div);
+}
+// A general quaternion Q = (x, y, z, w), not normalised (|Q|^2 is the transform's scale), as its matrix
+//   R = (w^2 - |v|^2) I + 2 v v^T + 2 w [v]x,      m[3*row + column],
+// folded in double in exactly this order and rounded once; `div` as in axis_constants.  The oracle folds
+// the same way (sdf_oracle.c matrix_constants).
+inline void matrix_constants(const float* q, double div, float m[9])
+{
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    const double xx = x * x, yy = y * y, zz = z * z, ww = w * w;
+    const double xy = x * y, xz = x * z, yz = y * z, wx = w * x, wy = w * y, wz = w * z;
+    const double k = ww - ((xx + yy) + zz);
+    const double e[9] = {k + 2.0 * xx,     2.0 * (xy - wz),  2.0 * (xz + wy),
+                         2.0 * (xy + wz),  k + 2.0 * yy,     2.0 * (yz - wx),
+                         2.0 * (xz - wy),  2.0 * (yz + wx),  k + 2.0 * zz};
+    for (int i = 0; i < 9; ++i) m[i] = (float)(e[i] / div);
 }
 inline float q_scale(const float* q) { return fma_(q[3], q[3], fma_(q[2], q[2], fma_(q[1], q[1], q[0] * q[0]))); }
 
@@ -266,6 +282,21 @@ inline std::string decode_tape(const float* tape, size_t n, DecodedTape& out)
                     r.hdr = special | (reg << 8);
                     const float q = special == OPX_TO_AXIS_X ? p[0] : special == OPX_TO_AXIS_Y ? p[1] : special == OPX_TO_AXIS_Z ? p[2] : 0.0f;
                     axis_constants(q, p[3], 1.0, r.p[0], r.p[1], r.p[2]);   // p[0..2] = A, B, C (p[3], p[7] unused)
+                } else if (SDF_TO_SPECIAL) {
+                    // general quaternion: two records (tape_format.hpp OPX_TO_ROW_X / OPX_TO_ROWS_YZ)
+                    float m[9];
+                    matrix_constants(p, 1.0, m);
+                    const float ox = r.p[4], oy = r.p[5], oz = r.p[6];
+                    const bool initial = op == OP_INITIAL_TRANSFORMATION_TO;
+                    Rec first;
+                    std::memset(&first, 0, sizeof(first));
+                    first.hdr = (initial ? OPX_INIT_ROW_X : OPX_TO_ROW_X) | (reg << 8);
+                    first.p[0] = m[0]; first.p[1] = m[1]; first.p[2] = m[2]; first.p[3] = ox;
+                    out.recs.push_back(first);
+                    std::memset(&r, 0, sizeof(r));
+                    r.hdr = (initial ? OPX_INIT_ROWS_YZ : OPX_TO_ROWS_YZ) | (reg << 8);
+                    r.p[0] = m[3]; r.p[1] = m[4]; r.p[2] = m[5]; r.p[3] = oy;
+                    r.p[4] = m[6]; r.p[5] = m[7]; r.p[6] = m[8]; r.p[7] = oz;
                 }
                 break;
             }
@@ -288,6 +319,13 @@ inline std::string decode_tape(const float* tape, size_t n, DecodedTape& out)
                 if (special != op) {
                     const float q = special == OPX_FROM_AXIS_X ? p[0] : special == OPX_FROM_AXIS_Y ? p[1] : special == OPX_FROM_AXIS_Z ? p[2] : 0.0f;
                     axis_constants(q, p[3], (double)scale, r.p[0], r.p[1], r.p[2]);   // p[0..2] = A, B, C over |Q|^2; p[5] = scale
+                } else if (SDF_FROM_SPECIAL) {
+                    float m[9];
+                    matrix_constants(p, (double)scale, m);
+                    std::memset(&r, 0, sizeof(r));
+                    r.hdr = OPX_FROM_MATRIX | (reg << 8);
+                    for (int i = 0; i < 9; ++i) r.p[i] = m[i];
+                    r.p[9] = scale;
                 }
                 break;
             }

@@ -28,7 +28,14 @@ enum Op : uint32_t {
     // the dropped terms are exact zeros for every finite point (DESIGN.md "Canonical arithmetic":
     // this reduction is part of the arithmetic contract; the oracle applies it too).  OPX_POINT
     // loads the sample point, so that initial_transformation_to can use the same reduced forms.
-    OPX_POINT = 33, OPX_TO_SCALE = 34, OPX_TO_AXIS_X = 35, OPX_TO_AXIS_Y = 36, OPX_TO_AXIS_Z = 37
+    OPX_POINT = 33, OPX_TO_SCALE = 34, OPX_TO_AXIS_X = 35, OPX_TO_AXIS_Y = 36, OPX_TO_AXIS_Z = 37,
+    // A general quaternion as the 3x3 rotation-and-scale matrix it is (tape.hpp matrix_constants).  A record has
+    // ten free parameters and transformation_to needs twelve (nine entries, three offsets), so it becomes two
+    // records: the first parks the new x in the w component of `last` (a point has no use for w) and leaves
+    // x, y, z alone, the second computes y and z from them and assembles (x', y', z', 0).  transformation_from
+    // (nine entries over |Q|^2 and the distance scale) fits one record.
+    // The OPX_INIT_* pair is the same for initial_transformation_to: it reads the sample point itself.
+    OPX_TO_ROW_X = 38, OPX_TO_ROWS_YZ = 39, OPX_FROM_MATRIX = 40, OPX_INIT_ROW_X = 41, OPX_INIT_ROWS_YZ = 42
 };
 
 

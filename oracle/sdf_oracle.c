@@ -164,6 +164,21 @@ static inline void axis_rotate_dir(float A, float B, float C, float along, float
     }
 }
 
+/* A general quaternion Q = (x, y, z, w), not normalised, as its matrix R = (w^2 - |v|^2) I + 2 v v^T + 2 w [v]x,
+ * m[3*row + column], folded in double in exactly this order and rounded once (the kernels' decoder:
+ * codecad_amd/csrc/tape.hpp matrix_constants). */
+static inline void matrix_constants(f4 q, double div, float m[9])
+{
+    const double x = q.x, y = q.y, z = q.z, w = q.w;
+    const double xx = x * x, yy = y * y, zz = z * z, ww = w * w;
+    const double xy = x * y, xz = x * z, yz = y * z, wx = w * x, wy = w * y, wz = w * z;
+    const double k = ww - ((xx + yy) + zz);
+    const double e[9] = {k + 2.0 * xx,     2.0 * (xy - wz),  2.0 * (xz + wy),
+                         2.0 * (xy + wz),  k + 2.0 * yy,     2.0 * (yz - wx),
+                         2.0 * (xz - wy),  2.0 * (yz + wx),  k + 2.0 * zz};
+    for (int i = 0; i < 9; ++i) m[i] = (float)(e[i] / div);
+}
+
 /* shapes/common.cl:78-98 (initial_)transformation_to_op.
  * Canonical arithmetic: a zero offset component counts as +0, so a transformed
  * coordinate is never -0 (the reference builds with -cl-no-signed-zeros and cannot tell); and when the
@@ -176,9 +191,12 @@ static inline f4 transformation_to_op(const float *p, f4 point)
     const float ox = p[4] + 0.0f, oy = p[5] + 0.0f, oz = p[6] + 0.0f;
     const int zx = p[0] == 0.0f, zy = p[1] == 0.0f, zz = p[2] == 0.0f;
     f4 q = mk4(p[0], p[1], p[2], p[3]);
-    if (!(zx + zy + zz >= 2)) {
-        f4 t = quaternion_transform(q, point);
-        return mk4(t.x + ox, t.y + oy, t.z + oz, 0.0f);
+    if (!(zx + zy + zz >= 2)) {   /* general: the matrix, one fma chain per row */
+        float m[9];
+        matrix_constants(q, 1.0, m);
+        return mk4(fmaf(point.x, m[0], fmaf(point.y, m[1], fmaf(point.z, m[2], ox))),
+                   fmaf(point.x, m[3], fmaf(point.y, m[4], fmaf(point.z, m[5], oy))),
+                   fmaf(point.x, m[6], fmaf(point.y, m[7], fmaf(point.z, m[8], oz))), 0.0f);
     }
     float A, B, C, x, y, z;
     if (zx && zy && zz) {
@@ -208,10 +226,12 @@ static inline f4 transformation_from_op(const float *p, f4 in)
     f4 q = mk4(p[0], p[1], p[2], p[3]);
     float scale = quaternion_scale(q);
     const int zx = p[0] == 0.0f, zy = p[1] == 0.0f, zz = p[2] == 0.0f;
-    if (!(zx + zy + zz >= 2)) {
-        float inv = 1.0f / scale;
-        f4 t = quaternion_transform(q, in);
-        return mk4(t.x * inv, t.y * inv, t.z * inv, in.w * scale);
+    if (!(zx + zy + zz >= 2)) {   /* general: the matrix over |Q|^2 */
+        float m[9];
+        matrix_constants(q, (double)scale, m);
+        return mk4(fmaf(in.x, m[0], fmaf(in.y, m[1], in.z * m[2])),
+                   fmaf(in.x, m[3], fmaf(in.y, m[4], in.z * m[5])),
+                   fmaf(in.x, m[6], fmaf(in.y, m[7], in.z * m[8])), in.w * scale);
     }
     float A, B, C, x, y, z;
     if (zx && zy && zz) {
