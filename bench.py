@@ -269,7 +269,9 @@ def main():
                          "valu_flop_per_voxel": flop,
                          "valu_achieved_tflops": round(dense_voxels * flop / (dense_avg_ms * 1e-3) / 1e12, 2),
                          "valu_peak_tflops": FP32_PEAK_TFLOPS,
-                         "valu_frac": round(dense_voxels * flop / (dense_avg_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)},
+                         "valu_frac": round(dense_voxels * flop / (dense_avg_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
+                         # issue-slot utilisation of the vector ALUs from the committed rocprofv3 counters (like `traffic`)
+                         "valu_busy_measured": measured_valu_busy(n, evaluator)},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(tape.host_tape, n)
@@ -286,6 +288,22 @@ _FLOP = {0: 0, 1: 0, 2: 0, 3: 14, 4: 9, 5: 90, 6: 0, 7: 12, 8: 1, 9: 4, 10: 120,
          26: 2, 27: 6, 28: 4}
 _PARAMS = {0: 0, 1: 0, 2: 0, 3: 2, 4: 1, 5: 2, 7: 1, 8: 0, 9: 0, 10: 2, 11: 7, 12: 7, 13: 4, 14: 0, 15: 0,
            16: 1, 17: 1, 18: 3, 19: 1, 20: 1, 21: 2, 22: 1, 23: 0, 24: 3, 25: 0, 26: 1, 27: 1, 28: 1}
+
+
+def measured_valu_busy(n, evaluator="specialised"):
+    """Fraction of the VALU issue slots the dense kernel used, from the same committed PMC passes:
+    SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs); None without a matching profile."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*summary.json"))):
+        try:
+            d = json.load(open(f))
+            c = d["dense_kernel_counters_per_launch"]
+            if d.get("grid_edge", 512) == n and d.get("evaluator", "interpreter") == evaluator:
+                best = round(c["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (c["GRBM_GUI_ACTIVE"] / 8), 3)
+        except (ValueError, KeyError, ZeroDivisionError):
+            continue
+    return best
 
 
 def measured_traffic(n, evaluator="specialised"):
