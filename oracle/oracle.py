@@ -11,10 +11,13 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+_LITERAL_PATH = os.path.join(_HERE, "_build", "libliteral.so")
+_LITERAL64_PATH = os.path.join(_HERE, "_build", "libliteral64.so")
 _lib = None
+_literal = {}
 
 __all__ = ["build", "lib", "evaluate_points", "grid_eval", "grid_eval_pymcubes", "ray_caster", "bitmap", "process_polygon", "marching_cubes", "stl_records", "STL_RECORD",
-           "subdivision_step", "mass_properties", "det_math"]
+           "subdivision_step", "mass_properties", "det_math", "evaluate_points_literal", "grid_distance_literal"]
 
 _f32p = ctypes.POINTER(ctypes.c_float)
 _u32p = ctypes.POINTER(ctypes.c_uint32)
@@ -23,9 +26,10 @@ _u8p = ctypes.POINTER(ctypes.c_uint8)
 
 def build(force=False):
     """Compile the oracle with gcc (a few seconds).  Building the checker is not using it."""
-    src = [os.path.join(_HERE, f) for f in ("sdf_oracle.c", "det_math.h", "mc_table.h", "Makefile")]
-    if (not force and os.path.exists(_LIB_PATH)
-            and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in src)):
+    src = [os.path.join(_HERE, f) for f in ("sdf_oracle.c", "sdf_literal.c", "det_math.h", "mc_table.h", "Makefile")]
+    libs = (_LIB_PATH, _LITERAL_PATH, _LITERAL64_PATH)
+    if (not force and all(os.path.exists(b) for b in libs)
+            and all(min(os.path.getmtime(b) for b in libs) >= os.path.getmtime(s) for s in src)):
         return _LIB_PATH
     subprocess.run(["make", "-C", _HERE, "-B"], check=True, capture_output=True)
     return _LIB_PATH
@@ -41,6 +45,19 @@ def lib():
                      "oracle_subdivision_step", "oracle_mass_properties", "oracle_det_math"):
             getattr(_lib, name).restype = ctypes.c_int
     return _lib
+
+
+def literal_lib(double=False):
+    """The frozen formula-for-formula restatement (sdf_literal.c), its own library; double=True: the same
+    formulas evaluated in binary64."""
+    if double not in _literal:
+        path = _LITERAL64_PATH if double else _LITERAL_PATH
+        if not os.path.exists(path):
+            build()
+        _literal[double] = ctypes.CDLL(path)
+        for name in ("oracle_evaluate_points_literal", "oracle_grid_distance_literal"):
+            getattr(_literal[double], name).restype = ctypes.c_int
+    return _literal[double]
 
 
 def _tape(tape):
@@ -74,6 +91,28 @@ def evaluate_points(tape, points):
     _check(lib().oracle_evaluate_points(tp, tn, pts.ctypes.data_as(_f32p),
                                         ctypes.c_int(pts.shape[0]),
                                         out.ctypes.data_as(_f32p)), "evaluate_points")
+    return out
+
+
+def evaluate_points_literal(tape, points, double=False):
+    """evaluate() at each row of `points` with the reference's formulas verbatim (sdf_literal.c) -> (n,4)
+    float32, or float64 with double=True (the same formulas and binary32 constants evaluated in binary64)."""
+    t, tp, tn = _tape(tape)
+    pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
+    out = np.empty((pts.shape[0], 4), dtype=np.float64 if double else np.float32)
+    _check(literal_lib(double).oracle_evaluate_points_literal(tp, tn, pts.ctypes.data_as(_f32p), ctypes.c_int(pts.shape[0]),
+                                                              ctypes.c_void_p(out.ctypes.data)), "evaluate_points_literal")
+    return out
+
+
+def grid_distance_literal(tape, corner, step, dims, double=False):
+    """Distances of the reference's formulas at the kernels' sample points (corner + step * gid) -> dims."""
+    t, tp, tn = _tape(tape)
+    c, d = _corner(corner), _dims(dims)
+    out = np.empty(tuple(int(x) for x in d), dtype=np.float64 if double else np.float32)
+    _check(literal_lib(double).oracle_grid_distance_literal(tp, tn, c.ctypes.data_as(_f32p), ctypes.c_float(step),
+                                                            d.ctypes.data_as(_u32p), ctypes.c_void_p(out.ctypes.data)),
+           "grid_distance_literal")
     return out
 
 

@@ -1,0 +1,448 @@
+/* oracle/sdf_literal.c -- TEST INFRASTRUCTURE ONLY.  FROZEN: this file does not follow the kernels.
+ *
+ * The reference's op library and evaluate() restated FORMULA FOR FORMULA: every expression keeps the
+ * reference's operators, operand order and association (C and OpenCL C agree on both), evaluated in
+ * strict IEEE-754 binary32 -- no contraction (-ffp-contract=off), no reciprocal substitution, no fused
+ * multiply-add, a real divide wherever the reference divides, libm (correctly rounded or <= 1 ulp:
+ * hypotf, remainderf, atan2f, sinf, cosf, tanf, acosf, fmodf) wherever it calls an OpenCL builtin.
+ * OpenCL vector expressions are written out per component; dot() and length() sum left to right.
+ * All literals are binary32: the reference builds with -cl-single-precision-constant
+ * (cl_util/opencl_manager.py:12-18), which also makes M_PI a float.
+ *
+ * Purpose ("oracle moves with the kernel"): oracle/sdf_oracle.c restates the CANONICAL
+ * arithmetic the kernels use (folded rotation forms, reciprocal multiplies, fma where the kernels fuse,
+ * hardware min/max, polynomial elementary functions) and changes together with them, so "HIP == oracle
+ * bit for bit" cannot show a drift away from the reference's formulas.  This file can: it is the fixed
+ * point.  tests/test_literal_oracle.py evaluates both on the golden tapes and on random trees and bounds
+ * the difference by the north star's 1e-5.  Rule: an arithmetic change lands in the
+ * kernels and in sdf_oracle.c -- never here.  Edit this file only to correct a misreading of the
+ * reference, and say so in the commit.
+ *
+ * Each function cites the reference lines it follows (paths relative to /root/reference/codecad/).
+ */
+#include <float.h>
+#include <math.h>
+#include <tgmath.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#define LIT_REGISTERS 512 /* nodes/__init__.py:6 EVAL_REGISTER_COUNT */
+
+/* `real` is float: the reference's arithmetic.  Built a second time with -DLIT_DOUBLE (libliteral64.so) the SAME
+ * formulas with the SAME binary32 constants are evaluated in binary64 -- the value the reference's formulas
+ * would have without rounding noise.  Where the binary32 and binary64 evaluations of the reference's own
+ * formulas disagree by more than the tolerance, the formula is ill-conditioned at that point (e.g. a rounded
+ * blend of nearly parallel surfaces divides by 1 - cos^2 ~ 1e-7) and no arithmetic can be held to 1e-5 there;
+ * the test skips such points and bounds how many there are.  The math calls are <tgmath.h> generics: sqrt on a
+ * float is sqrtf. */
+#ifdef LIT_DOUBLE
+typedef double real;
+#else
+typedef float real;
+#endif
+
+static const real LIT_PI = 3.14159265358979323846f;     /* M_PI under -cl-single-precision-constant, M_PI_F */
+static const real LIT_PI_2 = 1.57079632679489661923f;   /* M_PI_2_F */
+#define LIT_2PI (2 * LIT_PI)                             /* cl_util/util.h:4 */
+
+typedef struct { real x, y, z; } l3;
+typedef struct { real x, y, z, w; } l4;
+
+static l3 v3(real x, real y, real z) { l3 r = {x, y, z}; return r; }
+static l4 v4(real x, real y, real z, real w) { l4 r = {x, y, z, w}; return r; }
+static l3 xyz(l4 a) { return v3(a.x, a.y, a.z); }
+static l4 neg(l4 a) { return v4(-a.x, -a.y, -a.z, -a.w); }
+static l3 add3(l3 a, l3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static l3 mul3(l3 a, real k) { return v3(a.x * k, a.y * k, a.z * k); }
+static l3 div3(l3 a, real k) { return v3(a.x / k, a.y / k, a.z / k); }
+static real dot3(l3 a, l3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static real dot2(real ax, real ay, real bx, real by) { return ax * bx + ay * by; }
+static l3 cross3(l3 a, l3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+static real length2(real x, real y) { return sqrt(x * x + y * y); }
+static real length3(l3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+static real sign1(real s) { return s > 0 ? 1.0f : (s < 0 ? -1.0f : 0.0f); }
+
+/* shapes/common.cl:1-6 */
+static l3 quaternion_transform(l4 q, l3 p)
+{
+    l3 v = xyz(q);
+    l3 a = mul3(add3(mul3(v, dot3(v, p)), mul3(cross3(v, p), q.w)), 2);
+    l3 b = mul3(p, q.w * q.w - dot3(v, v));
+    return add3(a, b);
+}
+
+/* shapes/common.cl:8-11 */
+static real quaternion_scale(l4 q) { return q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w; }
+
+/* shapes/common.cl:15-31 */
+static l4 perpendicular_intersection(l4 i1, l4 i2)
+{
+    if (i1.w > 0 && i2.w > 0) {
+        real dist = hypot(i1.w, i2.w);
+        real m1 = i1.w / dist;
+        real m2 = i2.w / dist;
+        return v4(i1.x * m1 + i2.x * m2, i1.y * m1 + i2.y * m2, i1.z * m1 + i2.z * m2, dist);
+    } else if (i1.w > i2.w)
+        return i1;
+    else
+        return i2;
+}
+
+/* shapes/common.cl:33-43 */
+static l4 slab_x(real h, l4 p) { return v4(copysign(1.0f, p.x), 0, 0, fabs(p.x) - h); }
+static l4 slab_y(real h, l4 p) { return v4(0, copysign(1.0f, p.y), 0, fabs(p.y) - h); }
+static l4 slab_z(real h, l4 p) { return v4(0, 0, copysign(1.0f, p.z), fabs(p.z) - h); }
+
+/* shapes/common.cl:45-64 */
+static l4 rounded_union(real r, l4 o1, l4 o2)
+{
+    if (r >= 0) {
+        real cos_alpha = dot3(xyz(o1), xyz(o2));
+        real x1 = r - o1.w;
+        real x2 = r - o2.w;
+        if (cos_alpha * x1 < x2 && cos_alpha * x2 < x1) {
+            real d = r - sqrt((x1 * x1 + x2 * x2 - 2 * cos_alpha * x1 * x2) / (1 - cos_alpha * cos_alpha));
+            return v4(0, 0, 0, d);
+        }
+    }
+    if (o1.w < o2.w)
+        return o1;
+    else
+        return o2;
+}
+
+/* shapes/common.cl:66-76 */
+static l4 union_op(real r, l4 a, l4 b) { return rounded_union(r, a, b); }
+static l4 intersection_op(real r, l4 a, l4 b) { return neg(rounded_union(r, neg(a), neg(b))); }
+static l4 subtraction_op(real r, l4 a, l4 b) { return neg(rounded_union(r, neg(a), b)); }
+
+/* shapes/common.cl:78-98 (both forms) */
+static l4 transformation_to_op(const real *p, l3 point)
+{
+    l4 q = v4(p[0], p[1], p[2], p[3]);
+    l3 t = add3(quaternion_transform(q, point), v3(p[4], p[5], p[6]));
+    return v4(t.x, t.y, t.z, 0.0f); /* as_float4 of a float3: the reference leaves w undefined; nothing reads it */
+}
+
+/* shapes/common.cl:100-110 */
+static l4 transformation_from_op(const real *p, l4 in)
+{
+    l4 q = v4(p[0], p[1], p[2], p[3]);
+    real scale = quaternion_scale(q);
+    l3 d = div3(quaternion_transform(q, xyz(in)), scale);
+    return v4(d.x, d.y, d.z, in.w * scale);
+}
+
+/* shapes/common.cl:112-131 */
+static l4 mirror_op(l4 in) { return v4(-in.x, in.y, in.z, in.w); }
+static l4 symmetrical_to_op(l4 p) { return v4(fabs(p.x), p.y, p.z, p.w); }
+static l4 symmetrical_from_op(l4 in, l4 point) { return v4(point.x < 0 ? -in.x : in.x, in.y, in.z, in.w); }
+static l4 offset_op(real d, l4 in) { return v4(in.x, in.y, in.z, in.w - d); }
+static l4 shell_op(real h, l4 in) { return offset_op(h, (in.w >= 0) ? in : neg(in)); }
+
+/* shapes/simple2d.cl:1-4 */
+static l4 rectangle_op(real hw, real hh, l4 c) { return perpendicular_intersection(slab_x(hw, c), slab_y(hh, c)); }
+
+/* shapes/simple2d.cl:6-14 */
+static l4 circle_op(real r, l4 c)
+{
+    real fx = c.x, fy = c.y;
+    real a = length2(fx, fy);
+    if (a == 0) { fx = 1; fy = 0; }
+    else { fx /= a; fy /= a; }
+    return v4(fx, fy, 0, a - r);
+}
+
+/* shapes/simple2d.cl:16-46 */
+static l4 regular_polygon2d_op(real pi_over_n, real r, l4 c)
+{
+    real len = hypot(c.x, c.y);
+    real alpha = atan2(c.y, c.x) + 2 * LIT_PI + pi_over_n;
+    int side = (int)floor(alpha / (2 * pi_over_n));
+    real mod_alpha = alpha - side * 2 * pi_over_n - pi_over_n;
+    real co = cos(mod_alpha), s = sin(mod_alpha);
+    if (fabs(s * len) > r * sin(pi_over_n)) {
+        real a2 = side * 2 * pi_over_n + sign1(s) * pi_over_n;
+        real nx = cos(a2) * r, ny = sin(a2) * r;
+        real dx = c.x - nx, dy = c.y - ny;
+        real dist = length2(dx, dy);
+        if (dist > 0)
+            return v4(dx / dist, dy / dist, 0, dist);
+    }
+    real a3 = side * 2 * pi_over_n;
+    return v4(cos(a3), sin(a3), 0, len * co - r * cos(pi_over_n));
+}
+
+/* shapes/polygons2d.cl:1-74; *pp points at [n, x0, y0, ...] and is advanced past it */
+static l4 polygon2d_op(const real **pp, l4 coords)
+{
+    uint32_t n = (uint32_t)**pp;
+    ++*pp;
+    const real *pts = *pp;
+    real qx = coords.x, qy = coords.y;
+    real nnx = 0, nny = 0;
+    real nearest_d2 = INFINITY;
+    int nearest_is_vertex = 0;
+    real outside = 1;
+    real cx = pts[2 * (n - 1)], cy = pts[2 * (n - 1) + 1];
+    for (uint32_t i = 0; i < n; ++i) {
+        real px = cx, py = cy;
+        cx = pts[2 * i];
+        cy = pts[2 * i + 1];
+        real dx = cx - px, dy = cy - py;
+        real tqx = qx - px, tqy = qy - py;
+        real snx = -dy, sny = dx;
+        if (((py < coords.y) != (cy < coords.y)) && (dy * dot2(snx, sny, tqx, tqy) > 0))
+            outside = -outside;
+        real t = dot2(dx, dy, tqx, tqy) / dot2(dx, dy, dx, dy);
+        if (t > 1)
+            continue;
+        real cnx, cny, cd2;
+        int cvert;
+        if (t >= 0) {
+            real tcx = tqx - t * dx, tcy = tqy - t * dy;
+            cd2 = dot2(tcx, tcy, tcx, tcy);
+            cnx = snx; cny = sny;
+            cvert = 0;
+        } else {
+            cnx = qx - px; cny = qy - py;
+            cd2 = dot2(cnx, cny, cnx, cny);
+            cvert = cd2 > FLT_EPSILON;
+            if (!cvert) { cnx = snx; cny = sny; }
+        }
+        if (cd2 < nearest_d2) {
+            nearest_d2 = cd2; nnx = cnx; nny = cny; nearest_is_vertex = cvert;
+        }
+    }
+    real distance = outside * sqrt(nearest_d2);
+    real ox, oy;
+    if (nearest_is_vertex) { ox = nnx / distance; oy = nny / distance; }
+    else { real l = length2(nnx, nny); ox = nnx / l; oy = nny / l; }   /* normalize() */
+    *pp += 2 * n;
+    return v4(ox, oy, 0, distance);
+}
+
+/* shapes/simple3d.cl:1-12 */
+static l4 sphere_op(real r, l4 c)
+{
+    real a = length3(xyz(c));
+    real dist = a - r;
+    if (a == 0)
+        return v4(1, 0, 0, dist);
+    return v4(c.x / a, c.y / a, c.z / a, dist);
+}
+
+/* shapes/simple3d.cl:14-16 */
+static l4 half_space_op(l4 c) { return v4(0, -1, 0, -c.y); }
+
+/* shapes/simple3d.cl:18-21 */
+static l4 extrusion_op(real hh, l4 in, l4 coords) { return perpendicular_intersection(slab_z(hh, coords), in); }
+
+/* shapes/simple3d.cl:23-26 */
+static l4 revolution_to_op(l4 c) { return v4(hypot(c.x, c.z), c.y, 0, 0); }
+
+/* shapes/simple3d.cl:28-39 */
+static l4 revolution_from_op(l4 flat, l4 coords)
+{
+    real len = hypot(coords.x, coords.z);
+    real m;
+    if (len == 0) { coords.x = 1; m = flat.x; }
+    else m = flat.x / len;
+    return v4(coords.x * m, flat.y, coords.z * m, flat.w);
+}
+
+/* cl_util/util.cl:1-15 rotated2d(point, angle) */
+static void rotated2d(real px, real py, real angle, real *ox, real *oy)
+{
+    real c = cos(angle), s = sin(angle);
+    *ox = c * px - s * py;
+    *oy = s * px + c * py;
+}
+
+/* shapes/simple3d.cl:42-51 */
+static l4 twist_revolution_to_op(real r, real twist, l4 c)
+{
+    real alpha = fmod(atan2(c.z, c.x) + LIT_PI, LIT_2PI);
+    real beta = twist * alpha / LIT_2PI;
+    real axis = length2(c.x, c.z);
+    real ox, oy;
+    rotated2d(axis - r, c.y, -beta, &ox, &oy);
+    return v4(ox, oy, 0, 0);
+}
+
+/* shapes/simple3d.cl:53-97 */
+static l4 twist_revolution_from_op(real minor_r, real r, real twist, l4 res, l4 c)
+{
+    real axis = length2(c.x, c.z);
+    real ipx = axis - r, ipy = c.y;
+    real center = length2(ipx, ipy);
+    real wrapper = center - minor_r;
+    real padding = 0.05f * r;
+    real bound, dx, dy;
+    if (axis == 0)
+        return v4(1, 0, 0, r - minor_r);
+    else if (wrapper > padding) {
+        bound = wrapper;
+        dx = ipx / center; dy = ipy / center;
+    } else {
+        real alpha = fmod(atan2(c.z, c.x) + LIT_PI, LIT_2PI);
+        real beta = twist * alpha / LIT_2PI;
+        real lip = (r - minor_r) * 2 * sin(fmin(LIT_PI, LIT_PI_2 * LIT_PI_2 / fabs(twist))) / minor_r;
+        bound = res.w * fmin(1.0f, lip);
+        rotated2d(res.x, res.y, beta, &dx, &dy);
+    }
+    real m = dx / axis;
+    return v4(c.x * m, dy, c.z * m, bound);
+}
+
+/* shapes/unsafe.cl:1-6 */
+static l4 repetition_op(real ox, real oy, real oz, l4 c)
+{
+    return v4(remainder(c.x, ox), remainder(c.y, oy), remainder(c.z, oz), 0);
+}
+
+/* shapes/unsafe.cl:8-15 */
+static l4 circular_repetition_to_op(real pi_over_n, l4 c)
+{
+    real len = length2(c.x, c.y);
+    real alpha = atan2(c.y, c.x) + 2 * LIT_PI + pi_over_n;
+    int side = (int)floor(alpha / (2 * pi_over_n));
+    real mod_alpha = alpha - side * 2 * pi_over_n - pi_over_n;
+    return v4(len * cos(mod_alpha), len * sin(mod_alpha), c.z, 0);   /* len * sincos2(): (cos, sin) */
+}
+
+/* shapes/unsafe.cl:17-23 */
+static l4 circular_repetition_from_op(real pi_over_n, l4 dist, l4 c)
+{
+    real alpha = atan2(c.y, c.x) + 2 * LIT_PI + pi_over_n;
+    int side = (int)floor(alpha / (2 * pi_over_n));
+    real ox, oy;
+    rotated2d(dist.x, dist.y, side * 2 * pi_over_n, &ox, &oy);
+    return v4(ox, oy, dist.z, dist.w);
+}
+
+/* shapes/gears.cl:1-42 */
+static l4 involute_gear_op(real tooth_count, real pressure_angle, l4 c)
+{
+    real base_radius = cos(pressure_angle);
+    real tooth_angle = LIT_PI / tooth_count;
+    real half_tooth_base = tooth_angle / 2 + tan(pressure_angle) - pressure_angle;
+    real len = hypot(c.x, c.y);
+    real alpha = atan2(c.y, c.x);
+    real wrapped = fmod(alpha + 2 * LIT_PI, 2 * tooth_angle);
+    real involute_alpha = half_tooth_base - fabs(wrapped - tooth_angle);
+    if (len < base_radius) {
+        real nx = c.y / len, ny = -c.x / len;
+        if (wrapped > tooth_angle) { nx = -nx; ny = -ny; }
+        real angular = fabs(wrapped - tooth_angle) - half_tooth_base;
+        return v4(nx, ny, 0, angular * len);
+    } else {
+        real phi = involute_alpha + acos(base_radius / len);
+        real normal_angle;
+        if (wrapped < tooth_angle)
+            normal_angle = LIT_PI - phi - (alpha - involute_alpha);
+        else
+            normal_angle = phi - (alpha - involute_alpha);
+        real nx = sin(normal_angle), ny = cos(normal_angle);   /* normal.x = sincos(angle, &normal.y) */
+        real distance = sqrt(len * len - base_radius * base_radius) - base_radius * phi;
+        return v4(nx, ny, 0, distance);
+    }
+}
+
+/* The interpreter generated by nodes/codegen.py:5-63 with the handlers of :91-134; opcodes from the table
+ * of nodes/node.py:12-56 in declaration order.  0 on success, < 0 on a malformed tape. */
+static int evaluate_literal(const real *program, const real *end, l3 point, l4 *result)
+{
+    l4 registers[LIT_REGISTERS];
+    l4 last = v4(0, 0, 0, 0);
+    while (program < end) {
+        uint32_t instruction = (uint32_t)(*program++);
+        uint32_t opcode = instruction / LIT_REGISTERS;
+        uint32_t reg = instruction % LIT_REGISTERS;
+        const real *p = program;
+        switch (opcode) {
+        case 0: *result = last; return 0;
+        case 1: registers[reg] = last; break;
+        case 2: last = registers[reg]; break;
+        case 3: last = rectangle_op(p[0], p[1], last); program += 2; break;
+        case 4: last = circle_op(p[0], last); program += 1; break;
+        case 5: last = regular_polygon2d_op(p[0], p[1], last); program += 2; break;
+        case 6: last = polygon2d_op(&program, last); break;
+        case 7: last = sphere_op(p[0], last); program += 1; break;
+        case 8: last = half_space_op(last); break;
+        case 9: last = revolution_to_op(last); break;
+        case 10: last = twist_revolution_to_op(p[0], p[1], last); program += 2; break;
+        case 11: last = transformation_to_op(p, point); program += 7; break;
+        case 12: last = transformation_to_op(p, xyz(last)); program += 7; break;
+        case 13: last = transformation_from_op(p, last); program += 4; break;
+        case 14: last = mirror_op(last); break;
+        case 15: last = symmetrical_to_op(last); break;
+        case 16: last = offset_op(p[0], last); program += 1; break;
+        case 17: last = shell_op(p[0], last); program += 1; break;
+        case 18: last = repetition_op(p[0], p[1], p[2], last); program += 3; break;
+        case 19: last = circular_repetition_to_op(p[0], last); program += 1; break;
+        case 20: last = circular_repetition_from_op(p[0], last, registers[reg]); program += 1; break;
+        case 21: last = involute_gear_op(p[0], p[1], last); program += 2; break;
+        case 22: last = extrusion_op(p[0], last, registers[reg]); program += 1; break;
+        case 23: last = revolution_from_op(last, registers[reg]); break;
+        case 24: last = twist_revolution_from_op(p[0], p[1], p[2], last, registers[reg]); program += 3; break;
+        case 25: last = symmetrical_from_op(last, registers[reg]); break;
+        case 26: last = union_op(p[0], last, registers[reg]); program += 1; break;
+        case 27: last = intersection_op(p[0], last, registers[reg]); program += 1; break;
+        case 28: last = subtraction_op(p[0], last, registers[reg]); program += 1; break;
+        default: return -1;
+        }
+    }
+    return -2;
+}
+
+/* The exported entry points take the tape and the points as binary32 (what they are) and return `real`
+ * (float from libliteral.so, double from libliteral64.so). */
+static real *widen(const float *a, int n)
+{
+    real *r = (real *)malloc(sizeof(real) * (size_t)(n > 0 ? n : 1));
+    if (r) for (int i = 0; i < n; ++i) r[i] = a[i];
+    return r;
+}
+
+/* evaluate() at n points (x, y, z triples) -> n (x, y, z, w) */
+int oracle_evaluate_points_literal(const float *tape, int n_tape, const float *pts, int n, real *out)
+{
+    int err = 0;
+    real *t = widen(tape, n_tape);
+    if (!t) return -3;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        l4 r = v4(0, 0, 0, 0);
+        int rc = evaluate_literal(t, t + n_tape, v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]), &r);
+        if (rc) err = rc;
+        out[4 * i] = r.x; out[4 * i + 1] = r.y; out[4 * i + 2] = r.z; out[4 * i + 3] = r.w;
+    }
+    free(t);
+    return err;
+}
+
+/* The sample points of grid_eval.cl:31 / subdivision.cl:22 / mass_properties.cl:25-27 (corner + step * gid,
+ * multiply then add, in binary32: the point is the kernels' input) over a (sx, sy, sz) launch -> .w only,
+ * index z + sz*(y + sy*x). */
+int oracle_grid_distance_literal(const float *tape, int n_tape, const float *corner, float step, const uint32_t *dims,
+                                 real *out)
+{
+    int err = 0;
+    const uint32_t sx = dims[0], sy = dims[1], sz = dims[2];
+    real *t = widen(tape, n_tape);
+    if (!t) return -3;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (uint32_t x = 0; x < sx; ++x)
+        for (uint32_t y = 0; y < sy; ++y)
+            for (uint32_t z = 0; z < sz; ++z) {
+                l4 r = v4(0, 0, 0, 0);
+                const float px = corner[0] + step * (float)x, py = corner[1] + step * (float)y, pz = corner[2] + step * (float)z;
+                int rc = evaluate_literal(t, t + n_tape, v3(px, py, pz), &r);
+                if (rc) err = rc;
+                out[(size_t)z + (size_t)sz * ((size_t)y + (size_t)sy * x)] = r.w;
+            }
+    free(t);
+    return err;
+}
