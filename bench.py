@@ -1,28 +1,34 @@
 #!/usr/bin/env python3
-"""bench.py -- SDF Mvoxels/s (grid_eval + subdivision) on the 512^3 Menger sponge.
+"""bench.py -- SDF Mvoxels/s (grid_eval + subdivision) on the 512^3 Menger sponge, 1..N GPUs.
 
-One "step" is one pass of the hot path over one batch of synthetic input (no RNG: the only
-input is the CSG tree), per GPU:
+One "step" is one pass of the hot path over ONE object (no RNG: the only input is the CSG tree):
   A. dense grid_eval (float4) of sponge(4) on the 512^3 cell-centred grid          [k_grid_eval<0>]
   B. adaptive subdivision of sponge(4) at resolution 1/512, grid 16, overlapping
      leaf samples: levels [(240,3^3),(15,16^3),(1,16^3)], survivors compacted by the
      wavefront ballot scan                                                      [k_classify<0,1>]
   C. grid_eval of ALL surviving 16^3 leaf blocks in one launch (float, PyMCubes layout,
      what the reference's mesh pipeline does block by block)                [k_grid_eval_blocks<1>]
-`value` counts SDF samples actually evaluated (A + B + C) per second over all ranks; nothing
-is cached between steps and the output buffers are rewritten every step.  B is latency (tiny
-kernels, counter reads, all-gathers), so it runs on a second HIP stream concurrently with A; C
-waits for both.
+`value` counts SDF samples actually evaluated (A + B + C) per second over all ranks; nothing is cached
+between steps and the output buffers are rewritten every step.  B is latency (tiny kernels, all-gathers),
+so it runs on a second HIP stream concurrently with A; C waits for both.  Nothing in a step waits for
+the host: list lengths stay on the device (codecad_amd.dist.LevelPipeline) and are validated after the
+timed region.
 
-N > 1 (torchrun, one rank per GPU, RCCL): weak scaling -- the job is N sponges; the dense
-grid is x-slab sharded (rank r owns object r's 512^3 slab, no collective); the subdivision
-hierarchy of all N objects is ONE global parent list per level, cut into balanced slices,
-with a variable-length RCCL all-gather of the survivors between levels (codecad_amd/dist.py).
+N > 1 (torchrun, one rank per GPU, RCCL): STRONG scaling -- the same one object.  The 512^3 grid is cut
+into x-slabs (rank r evaluates dist.x_slab(512, r, N) through hu_grid_eval_slab, no collective); the ONE
+hierarchy is walked level by level, every rank classifying its balanced slice of the level's parents, with
+one fixed-size RCCL all-gather of the survivors per level; the leaf blocks are balanced over the ranks.
+`--weak` keeps round 1's mode (N objects, one per GPU) as a secondary measurement.
+`--config c5` is BASELINE config 5: sponge(5) at 1/2048 (2048^3 effective), grid 16: subdivision + grid_eval
+of its 1.34 M leaf blocks (5.5 G samples) -- the multi-GPU workload that is not launch-latency-sized.
 
-The JSON line also carries `roofline` for the dominant kernel (k_grid_eval<0>, measured with
-HIP events on its own stream) and `cpu_baseline` (the CPU oracle on a bounded sample).
+The JSON line carries `roofline` for the dominant kernel (timed with HIP events on its own stream),
+`roofline_hbm` (the HBM-bound regime: the same dense kernel on tapes whose arithmetic fits under the store
+stream) and, at N = 1, `cpu_baseline` (the CPU oracle on a bounded sample).
 """
 import argparse
+import ctypes
+import hashlib
 import json
 import math
 import os
@@ -33,10 +39,29 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 N = 512
-SPONGE_DEPTH = 4
 SUBDIV_GRID = 16
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3   # vector FP32, FMA-counted
+SIMDS = 1024               # 256 CUs x 4 SIMDs
+CLOCK_HZ = 2.4e9           # peak engine clock
+VALU_ISSUE_PEAK = SIMDS * CLOCK_HZ / 4 / 1e9   # a wave64 VALU instruction occupies its SIMD16 for 4 cycles: G wavefront-instructions / s
+
+CONFIGS = {
+    # name: (sponge depth, effective grid edge, dense leg?)
+    "c3": (4, 512, True),
+    "c5": (5, 2048, False),
+}
+
+
+def csrc_hash():
+    """Identifies the device code a profile was taken on (profiles/*summary.json carry the same field)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "codecad_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hpp", ".hip")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -44,8 +69,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c3")
+    ap.add_argument("--weak", action="store_true", help="N objects (one per GPU) instead of one object over N GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--n", type=int, default=N, help="grid edge (default 512)")
+    ap.add_argument("--no-hbm-leg", action="store_true")
+    ap.add_argument("--n", type=int, default=None, help="grid edge (default: the config's)")
     ap.add_argument("--evaluator", choices=["auto", "specialised", "interpreter"], default="auto",
                     help="auto = per-tape hipRTC specialisation when it builds, else the tape interpreter")
     args = ap.parse_args()
@@ -67,7 +95,6 @@ def main():
     import codecad_amd as cc
     from codecad_amd import hip_util, dist
     from codecad_amd.hip_util import check
-    import ctypes
 
     rank, world = dist.init()
     local = dist.local_device()
@@ -76,144 +103,152 @@ def main():
     m = hip_util.manager
     lib = m.lib
     dev = torch.device("cuda", local)
-    n = args.n
+    depth, n_default, dense_leg = CONFIGS[args.config]
+    n = args.n or n_default
+    weak = args.weak and world > 1
+    fptr = ctypes.POINTER(ctypes.c_float)
 
-    shape = cc.examples.sponge(SPONGE_DEPTH)
-    tape = cc.nodes.make_program_buffer(shape)
-    interp_tape = hip_util.Tape(tape.host_tape, policy="0")   # the same program, always interpreted (reported beside the headline)
+    shape = cc.examples.sponge(depth)
+    host_tape = cc.nodes.make_program(shape)
+    interp_tape = hip_util.Tape(host_tape, policy="0")   # the same program, always interpreted (reported beside the headline)
     tape = interp_tape
     evaluator = "interpreter"
     if args.evaluator != "interpreter":
         try:
-            tape = hip_util.Tape(tape.host_tape, policy="0").specialize()   # ~1 s of hipRTC (ms from the disk cache), outside the timed region
+            tape = hip_util.Tape(host_tape, policy="0").specialize()   # ~1 s of hipRTC (ms from the disk cache), outside the timed region
             evaluator = "specialised"
         except RuntimeError as e:
             if args.evaluator == "specialised":
                 raise
             print("bench: hipRTC specialisation unavailable, using the interpreter: %s" % str(e)[:300], file=sys.stderr)
-    # Everything is enqueued on torch's current stream: the survivor lists travel through
-    # torch.distributed (RCCL orders its collectives against that stream), so one stream gives
-    # the kernel -> all-gather -> kernel dependencies without extra synchronisation.
-    queue = m.wrap_stream(torch.cuda.current_stream().cuda_stream)
-    stream = queue.handle
-    # The subdivision (B) is a chain of tiny kernels, 4-byte counter reads and (N > 1) all-gathers: latency,
-    # not work.  It runs on a second, high-priority stream so that this latency hides behind the dense
-    # kernel (A) instead of following it; C waits for both.
+    # A and C are enqueued on torch's current stream.  The subdivision (B) is a chain of tiny kernels and
+    # (N > 1) all-gathers: latency, not work.  It runs on a second, high-priority stream -- made torch's current
+    # stream while it is enqueued, so that the collectives order against it -- and hides behind A; C waits for both.
     main_stream = torch.cuda.current_stream()
+    stream = main_stream.cuda_stream
     side_stream = torch.cuda.Stream(device=dev, priority=-1)
     side = side_stream.cuda_stream
 
-    # ---- A: dense grid ------------------------------------------------------------------
+    # ---- A: dense grid (this rank's x-slab of the ONE grid; --weak: a whole grid per rank) --------------
     step_f = np.float32(1.0 / n)
     corner = np.array([-0.5 + 0.5 / n] * 3 + [0.0], dtype=np.float32)
     dims = (ctypes.c_uint32 * 3)(n, n, n)
-    dense_out = torch.empty((n, n, n, 4), dtype=torch.float32, device=dev)
-    dense_voxels = n ** 3
+    x0, x1 = (0, n) if (weak or world == 1) else dist.x_slab(n, rank, world)
+    dense_voxels = (x1 - x0) * n * n if dense_leg else 0
+    dense_out = torch.empty((max(x1 - x0, 1), n, n, 4), dtype=torch.float32, device=dev) if dense_leg else None
 
-    # ---- B: subdivision hierarchy ---------------------------------------------------------
+    # ---- B: the hierarchy ---------------------------------------------------------------------------------
     resolution = 1.0 / n
     box = shape.bounding_box().expanded_additive(resolution / 2)
     levels = cc.subdivision.calculate_block_sizes(box, 3, resolution, SUBDIV_GRID, True)
     origin = (ctypes.c_double * 3)(box.a.x, box.a.y, box.a.z)
-    counter = torch.zeros(1, dtype=torch.int32, device=dev)
-    stats = {"samples": 0, "leaves": 0, "level_counts": None}
-    capacity = [1 << 16] * len(levels)
-
-    def classify(level, parents):
-        int_step, ldims = levels[level]
-        k = int(parents.shape[0])
-        cells = int(ldims[0]) * int(ldims[1]) * int(ldims[2])
-        stats["samples"] += k * cells
-        if k == 0:
-            return parents[:0]
-        d = (ctypes.c_uint32 * 3)(int(ldims[0]), int(ldims[1]), int(ldims[2]))
-        box_step = int_step * resolution
-        thr = box_step * math.sqrt(3) / 2
-        parents = parents.contiguous()
-        while True:
-            children = torch.empty((capacity[level], 4), dtype=torch.int32, device=dev)
-            check(lib.hu_memset(counter.data_ptr(), 0, 4, side), "memset")
-            check(lib.hu_subdivision_level(tape.device_ptr, parents.data_ptr(), k, int(int_step), d, 3,
-                                           resolution, origin, np.float32(box_step), np.float32(thr),
-                                           counter.data_ptr(), children.data_ptr(), capacity[level], side),
-                  "hu_subdivision_level")
-            count = int(counter.item())   # synchronises the side stream only
-            if count <= capacity[level]:
-                return children[:count]
-            capacity[level] = int(count * 1.25)
-
-    top = torch.zeros((world, 4), dtype=torch.int32, device=dev)
-    top[:, 3] = torch.arange(world, dtype=torch.int32, device=dev)   # one hierarchy per object
+    cells = [int(d[0]) * int(d[1]) * int(d[2]) for _, d in levels]
+    n_objects = world if weak else 1
+    top = torch.zeros((n_objects, 4), dtype=torch.int32, device=dev)
+    top[:, 3] = torch.arange(n_objects, dtype=torch.int32, device=dev)   # the object id rides in the 4th component
     leaf_int_step, leaf_dims = levels[-1]
-    leaf_cells = int(leaf_dims[0]) * int(leaf_dims[1]) * int(leaf_dims[2])
+    leaf_cells = cells[-1]
     ld = (ctypes.c_uint32 * 3)(int(leaf_dims[0]), int(leaf_dims[1]), int(leaf_dims[2]))
+
+    def build_pipeline(capacities):
+        with torch.cuda.stream(side_stream):
+            p = dist.subdivision_pipeline(tape, levels, resolution, (box.a.x, box.a.y, box.a.z), 3, capacities, dev, side, top)
+        side_stream.synchronize()
+        return p
+
+    # first capacities: every cell of a level while that is small, else a surface estimate; a traversal that
+    # overflows says what it needed (dist.Overflow) and the pipeline is rebuilt -- during warm-up only
+    capacities, parents_bound = [], n_objects
+    for c in cells[:-1]:
+        capacities.append(cc.subdivision.child_capacity(parents_bound, c))
+        parents_bound = capacities[-1]
+    pipe = build_pipeline(capacities)
     leaf_out = [None]
-    level_hints = []   # per-level survivor counts of the previous step: one collective per level (dist.allgather_rows)
 
     ev0, ev1, ev2, evb0, evb1, evc0 = (ctypes.c_void_p() for _ in range(6))
     for ev in (ev0, ev1, ev2, evb0, evb1, evc0):
         check(lib.hu_event_create(ctypes.byref(ev)), "event")
-    dense_ms, adaptive_ms = [], []
+    dense_ms, b_ms, c_ms = [], [], []
 
     def one_step(timed):
         # A
-        check(lib.hu_event_record(ev0, stream), "record")
-        check(lib.hu_grid_eval(tape.device_ptr, corner.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), step_f,
-                               dims, dense_out.data_ptr(), stream), "hu_grid_eval")
-        check(lib.hu_event_record(ev1, stream), "record")
-        # B, concurrently with A, on the side stream (torch ops and collectives follow the stream context)
-        stats["samples"] = 0
+        if dense_leg:
+            check(lib.hu_event_record(ev0, stream), "record")
+            check(lib.hu_grid_eval_slab(tape.device_ptr, corner.ctypes.data_as(fptr), step_f, dims, x0, x1 - x0, 0,
+                                        dense_out.data_ptr(), stream), "hu_grid_eval_slab")
+            check(lib.hu_event_record(ev1, stream), "record")
+        # B, concurrently with A, on the side stream
         with torch.cuda.stream(side_stream):
             check(lib.hu_event_record(evb0, side), "record")
-            leaves, counts = dist.run_levels(top, len(levels) - 1, classify, hints=level_hints)
-            # this rank's balanced share of the global leaf list
-            b, e = dist.balanced_slice(int(leaves.shape[0]), rank, world)
-            mine = leaves[b:e].contiguous()
+            mine = pipe.enqueue()                     # [header | this rank's share of the leaf blocks], all on the device
             check(lib.hu_event_record(evb1, side), "record")
-        stats["level_counts"] = counts
-        mine.record_stream(main_stream)       # allocated on the side stream, consumed on the main one
         main_stream.wait_stream(side_stream)
-        # C, after A and B
-        k = int(mine.shape[0])
-        stats["leaves"] = k
-        if leaf_out[0] is None or leaf_out[0].shape[0] < k:
-            leaf_out[0] = torch.empty((int(k * 1.1) + 1, leaf_cells), dtype=torch.float32, device=dev)
+        # C, after A and B: the launch is sized for the list's capacity, the length is read on the device
+        cap = int(mine.shape[0]) - 1
+        if leaf_out[0] is None or leaf_out[0].shape[0] < cap:
+            leaf_out[0] = torch.empty((cap, leaf_cells), dtype=torch.float32, device=dev)
         check(lib.hu_event_record(evc0, stream), "record")
-        check(lib.hu_grid_eval_blocks(tape.device_ptr, mine.data_ptr(), k, resolution, origin,
-                                      np.float32(leaf_int_step * resolution), ld, 1, leaf_out[0].data_ptr(), stream),
-              "hu_grid_eval_blocks")
+        check(lib.hu_grid_eval_blocks_indirect(tape.device_ptr, mine[1:].data_ptr(), mine.data_ptr(), cap, resolution, origin,
+                                               np.float32(leaf_int_step * resolution), ld, 1, leaf_out[0].data_ptr(), stream),
+              "hu_grid_eval_blocks_indirect")
         check(lib.hu_event_record(ev2, stream), "record")
+        side_stream.wait_stream(main_stream)          # the next step's B must not overwrite the list C is reading
         if timed:
             check(lib.hu_event_synchronize(ev2), "sync")
             ms = ctypes.c_float()
-            check(lib.hu_event_elapsed_ms(ev0, ev1, ctypes.byref(ms)), "elapsed")
-            dense_ms.append(ms.value)
+            if dense_leg:
+                check(lib.hu_event_elapsed_ms(ev0, ev1, ctypes.byref(ms)), "elapsed")
+                dense_ms.append(ms.value)
             check(lib.hu_event_elapsed_ms(evb0, evb1, ctypes.byref(ms)), "elapsed")
-            b_ms = ms.value                    # B: subdivision with its per-level counter reads (and all-gathers)
+            b_ms.append(ms.value)                  # B: the whole traversal on its stream (kernels + all-gathers)
             check(lib.hu_event_elapsed_ms(evc0, ev2, ctypes.byref(ms)), "elapsed")
-            adaptive_ms.append(b_ms + ms.value)   # + C: every sample of every leaf block
+            c_ms.append(ms.value)                  # C: every sample of every leaf block of this rank
+        return mine
 
     def barrier():
-        queue.synchronize()
+        main_stream.synchronize()
         side_stream.synchronize()
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        one_step(False)
-    # the interpreter on the same dense grid, timed the same way (reported, not part of `value`)
+    torch.cuda.synchronize()                       # setup (default-stream fills and copies) is complete before any stream runs
+    # warm-up: the first traversals also settle the list capacities at what the lists need + 12 % (a launch is
+    # sized for the capacity, and workgroups past the list's end cost their dispatch: 80 000 spare leaf blocks are 0.2 ms)
+    totals, settled, done = None, False, 0
+    for i in range(max(args.warmup, 1) + 4):
+        mine = one_step(False)
+        try:
+            totals = pipe.check()
+            tight = [int(v * 1.125) + 16 for v in pipe.needed]
+        except dist.Overflow as e:
+            totals, tight = None, [int(v * 1.125) + 16 for v in e.needed]
+        if totals is None or (not settled and any(c > t for c, t in zip(pipe.capacities, tight))):
+            barrier()
+            pipe = build_pipeline(tight)
+            leaf_out[0] = None
+            settled = totals is not None
+            totals = None
+            continue
+        done += 1
+        if done >= max(args.warmup, 1):
+            break
+    assert totals is not None, "list capacities did not settle"
+    my_leaves = int(mine[0, 0].item())
+
+    # the interpreter on the same dense launch, timed the same way (reported, not part of `value`)
     interp_ms = []
-    for i in range(3):
-        check(lib.hu_event_record(ev0, stream), "record")
-        check(lib.hu_grid_eval(interp_tape.device_ptr, corner.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), step_f,
-                               dims, dense_out.data_ptr(), stream), "hu_grid_eval")
-        check(lib.hu_event_record(ev1, stream), "record")
-        check(lib.hu_event_synchronize(ev1), "sync")
-        ms = ctypes.c_float()
-        check(lib.hu_event_elapsed_ms(ev0, ev1, ctypes.byref(ms)), "elapsed")
-        if i:
-            interp_ms.append(ms.value)
+    if dense_leg:
+        for i in range(3):
+            check(lib.hu_event_record(ev0, stream), "record")
+            check(lib.hu_grid_eval_slab(interp_tape.device_ptr, corner.ctypes.data_as(fptr), step_f, dims, x0, x1 - x0, 0,
+                                        dense_out.data_ptr(), stream), "hu_grid_eval_slab")
+            check(lib.hu_event_record(ev1, stream), "record")
+            check(lib.hu_event_synchronize(ev1), "sync")
+            ms = ctypes.c_float()
+            check(lib.hu_event_elapsed_ms(ev0, ev1, ctypes.byref(ms)), "elapsed")
+            if i:
+                interp_ms.append(ms.value)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -222,66 +257,150 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         elapsed = float(dist.allreduce_max(torch.tensor([elapsed], dtype=torch.float64, device=dev)).item())
+    # the timed traversals were not looked at while they ran: validate now (identical work every step)
+    assert pipe.check() == totals, "the timed steps did not reproduce the warm-up traversal"
 
-    per_rank_samples = dense_voxels + stats["samples"] + stats["leaves"] * leaf_cells
-    job_samples = float(dist.allreduce_sum(torch.tensor([per_rank_samples], dtype=torch.float64, device=dev)).item())
+    # samples of one step over ALL ranks: dense voxels + every classified cell + every leaf sample
+    parents_per_level = [n_objects] + totals[:-1]
+    subdivision_samples = sum(p * c for p, c in zip(parents_per_level, cells[:-1]))
+    leaf_samples = totals[-1] * leaf_cells
+    job_dense = (n ** 3 * n_objects) if dense_leg else 0
+    job_samples = job_dense + subdivision_samples + leaf_samples
     value = job_samples * args.steps / elapsed / 1e6
 
+    def avg(v):
+        return sum(v) / len(v) if v else 0.0
+
+    def allmax(x):
+        return float(dist.allreduce_max(torch.tensor([x], dtype=torch.float64, device=dev)).item()) if world > 1 else x
+
+    b_avg, c_avg, dense_avg_ms = allmax(avg(b_ms)), allmax(avg(c_ms)), avg(dense_ms)
+    hbm_leg = None
+    if rank == 0 and world == 1 and not args.no_hbm_leg:
+        hbm_leg = hbm_regime(lib, check, hip_util, cc, torch, np, dev, stream, n if dense_leg else 512, evaluator)
+
     if rank == 0:
-        flop = tape_flop(tape.host_tape)
-        dense_avg_ms = sum(dense_ms) / len(dense_ms)
-        alg_bytes = dense_voxels * 16.0
-        achieved = alg_bytes / (dense_avg_ms * 1e-3) / 1e9
+        flop = tape_flop(host_tape)
+        adaptive_ms = b_avg + c_avg
+        if dense_leg:
+            kernel = "k_grid_eval<%s, 0, 2>" % ("JitEval" if evaluator == "specialised" else "InterpEval<false>")
+            k_ms, k_voxels, k_bytes = dense_avg_ms, dense_voxels, dense_voxels * 16.0
+            k_note = "16 B stored per voxel (float4), reads ~ 0"
+        else:
+            kernel = "k_grid_eval_blocks<%s, 1, 2>" % ("JitEval" if evaluator == "specialised" else "InterpEval<true>")
+            k_ms, k_voxels, k_bytes = avg(c_ms), my_leaves * leaf_cells, my_leaves * (leaf_cells * 4.0 + 16.0)
+            k_note = "4 B stored per sample (float) + 16 B read per leaf block"
+        achieved = k_bytes / (k_ms * 1e-3) / 1e9
+        prof = profile_summary(n, evaluator, args.config)
+        roofline = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel_ms": round(k_ms, 4),
+                    "algorithmic_bytes": k_bytes, "algorithmic_bytes_note": k_note,
+                    "voxels_per_s": round(k_voxels / (k_ms * 1e-3), 0), "rank": 0}
+        if prof is not None:
+            # VALU issue: what actually binds this tape.  Instructions per wavefront come from the rocprofv3 PMC pass
+            # of THIS device code (the profile carries a hash of csrc/; a stale profile is ignored); the time is this run's.
+            waves = k_voxels / 128.0
+            issue_rate = prof["valu_insts_per_wave"] * waves / (k_ms * 1e-3) / 1e9
+            roofline.update({
+                "bound": "valu_issue", "achieved": round(issue_rate, 2), "peak": VALU_ISSUE_PEAK,
+                "unit": "G wavefront-instructions/s", "frac": round(issue_rate / VALU_ISSUE_PEAK, 4),
+                "traffic": prof.get("hbm_traffic_bytes_per_launch"),
+                "from_profile": {"file": prof["file"], "csrc_hash": prof["csrc_hash"],
+                                 "valu_insts_per_wave": prof["valu_insts_per_wave"],
+                                 "valu_issue_busy_in_profiled_run": prof.get("valu_issue_busy")},
+                "hbm": {"achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5)},
+                "note": "VALU-issue-bound: frac = VALU instructions issued per second / (1024 SIMDs x 2.4 GHz / 4 cycles per "
+                        "wave64 instruction); the HBM fraction of the same launch is in `hbm`"})
+        else:
+            roofline["note"] = ("no rocprofv3 counter profile of this device code (csrc hash %s) is committed: only the HBM "
+                                "fraction is reported; the sponge tapes are VALU-issue-bound (DESIGN.md section 5)" % csrc_hash())
+        roofline["algorithmic_flop_per_voxel_reference_formulas"] = flop
         line = {
-            "metric": "SDF Mvoxels/s (grid_eval+subdivision), 512^3 menger_sponge",
+            "metric": "SDF Mvoxels/s (grid_eval+subdivision), 512^3 menger_sponge" if args.config == "c3" else
+                      "SDF Mvoxels/s (subdivision + leaf-block grid_eval), 2048^3-effective menger_sponge depth 5",
             "value": round(value, 1), "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "menger_sponge depth=4, %d^3: dense float4 grid_eval + adaptive subdivision "
-                                   "(grid %d, overlap) + grid_eval of all leaf blocks; one object per GPU" % (n, SUBDIV_GRID),
+            "config": {"workload": ("menger_sponge depth=%d, %d^3%s: %sadaptive subdivision (grid %d, overlap) + grid_eval of all "
+                                    "leaf blocks; %s" % (depth, n, " effective" if not dense_leg else "",
+                                                         "dense float4 grid_eval + " if dense_leg else "", SUBDIV_GRID,
+                                                         "one object per GPU" if weak else "ONE object over all GPUs")),
+                       "baseline_config": args.config,
                        "evaluator": evaluator + (" (per-tape straight-line kernels compiled with hipRTC from the same "
                                                   "op library; bit-identical to the interpreter)" if evaluator == "specialised" else ""),
-                       "tape_floats": int(tape.host_tape.size), "tape_instructions": tape.n_instructions,
-                       "value_registers": tape.n_registers, "parallelism": "x-slab/object per rank, "
-                       "balanced parent slices + RCCL all-gather of survivors per level" if world > 1 else "single GPU"},
-            "samples_per_step_per_gpu": {"dense": dense_voxels, "subdivision": stats["samples"],
-                                         "leaf_blocks": stats["leaves"] * leaf_cells,
-                                         "survivors_per_level_global": stats["level_counts"]},
-            "interpreter_dense_kernel_ms": round(sum(interp_ms) / len(interp_ms), 4),
-            # adaptive runs report effective voxels/s (N^3 / time) beside evaluated samples/s
-            "adaptive": {"what": "B + C on this rank: subdivision to the leaf blocks (on its own stream, overlapping A), then every "
-                                 "sample of every leaf block; ms = B's stream time + C's kernel time",
-                         "ms": round(sum(adaptive_ms) / len(adaptive_ms), 4),
-                         "evaluated_samples": stats["samples"] + stats["leaves"] * leaf_cells,
-                         "evaluated_msamples_per_s": round((stats["samples"] + stats["leaves"] * leaf_cells)
-                                                           / (sum(adaptive_ms) / len(adaptive_ms)) / 1e3, 1),
-                         "effective_voxels": n ** 3,
-                         "effective_mvoxels_per_s": round(n ** 3 / (sum(adaptive_ms) / len(adaptive_ms)) / 1e3, 1)},
-            "roofline": {"bound": "hbm", "kernel": "k_grid_eval<%s, 0, 2>" % ("JitEval" if evaluator == "specialised" else "InterpEval<false>"),
-                         "achieved": round(achieved, 2),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": measured_traffic(n, evaluator), "kernel_ms": round(dense_avg_ms, 4),
-                         "voxels_per_s": round(dense_voxels / (dense_avg_ms * 1e-3), 0),
-                         "note": "this tape is FP32-VALU-bound, not HBM-bound: see valu_* fields; valu_flop_per_voxel is the "
-                                 "ALGORITHMIC count of the reference's formulas (SURVEY.md section 8(d) convention, FMA = 2), "
-                                 "not instructions executed: the kernel's reduced transformation forms execute fewer",
-                         "valu_flop_per_voxel": flop,
-                         "valu_achieved_tflops": round(dense_voxels * flop / (dense_avg_ms * 1e-3) / 1e12, 2),
-                         "valu_peak_tflops": FP32_PEAK_TFLOPS,
-                         "valu_frac": round(dense_voxels * flop / (dense_avg_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
-                         # issue-slot utilisation of the vector ALUs from the committed rocprofv3 counters (like `traffic`)
-                         "valu_busy_measured": measured_valu_busy(n, evaluator)},
+                       "tape_floats": int(host_tape.size), "tape_instructions": tape.n_instructions,
+                       "value_registers": tape.n_registers,
+                       "parallelism": ("x-slabs of the one grid, balanced parent slices + one fixed-size RCCL all-gather of the "
+                                       "survivors per level, leaf blocks balanced over ranks" if world > 1 and not weak else
+                                       "one object per rank; one global parent list per level, re-balanced" if weak else "single GPU")},
+            "samples_per_step": {"dense": job_dense, "subdivision": subdivision_samples, "leaf_blocks": leaf_samples,
+                                 "survivors_per_level_global": totals, "rank0_dense": dense_voxels,
+                                 "rank0_leaf_blocks": my_leaves},
+            "adaptive": {"what": "B + C, slowest rank: the whole traversal on its own stream (kernels + all-gathers, overlapping A), "
+                                 "then every sample of this rank's leaf blocks",
+                         "subdivision_ms": round(b_avg, 4), "leaf_blocks_ms": round(c_avg, 4), "ms": round(adaptive_ms, 4),
+                         "evaluated_samples": subdivision_samples + leaf_samples,
+                         "evaluated_msamples_per_s": round((subdivision_samples + leaf_samples) / adaptive_ms / 1e3, 1),
+                         "effective_voxels": n ** 3 * n_objects,
+                         "effective_mvoxels_per_s": round(n ** 3 * n_objects / adaptive_ms / 1e3, 1)},
+            "roofline": roofline,
         }
+        if interp_ms:
+            line["interpreter_dense_kernel_ms"] = round(avg(interp_ms), 4)
+        if hbm_leg is not None:
+            line["roofline_hbm"] = hbm_leg
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(tape.host_tape, n)
+            line["cpu_baseline"] = cpu_baseline(host_tape, n if dense_leg else 512)
         print(json.dumps(line))
     if world > 1:
         dist.barrier()
         torch.distributed.destroy_process_group()
 
 
-# FLOPs per instruction of the canonical arithmetic (DESIGN.md "Algorithmic FLOPs"): 1 per
+def hbm_regime(lib, check, hip_util, cc, torch, np, dev, stream, n, evaluator):
+    """The HBM-bound regime, measured in this run: the SAME dense kernels on tapes whose arithmetic fits under the
+    store stream (sphere: 3 instructions; sphere + box: 9; csg_example: 28), float4 (16 B/voxel) and float (4 B/voxel).
+    Each entry: algorithmic bytes / average kernel time (HIP events) against the 8 TB/s peak."""
+    out = []
+    fptr = ctypes.POINTER(ctypes.c_float)
+    e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+    check(lib.hu_event_create(ctypes.byref(e0)), "event")
+    check(lib.hu_event_create(ctypes.byref(e1)), "event")
+    buf = torch.empty((n, n, n, 4), dtype=torch.float32, device=dev)
+    dims = (ctypes.c_uint32 * 3)(n, n, n)
+    for name, shape in (("sphere", cc.shapes.sphere(130)), ("sphere_plus_box", cc.examples.sphere_plus_box()),
+                        ("csg_example", cc.examples.csg_example())):
+        host_tape = cc.nodes.make_program(shape)
+        t = hip_util.Tape(host_tape, policy="0")
+        if evaluator == "specialised":
+            t = t.specialize()
+        bb = shape.bounding_box()
+        extent = max(bb.b.x - bb.a.x, bb.b.y - bb.a.y, bb.b.z - bb.a.z)
+        step = np.float32(extent / n)
+        corner = np.array([bb.a.x + extent / n / 2, bb.a.y + extent / n / 2, bb.a.z + extent / n / 2, 0.0], dtype=np.float32)
+        for layout, bytes_per_voxel in ((0, 16), (1, 4)):
+            times = []
+            for i in range(7):
+                check(lib.hu_event_record(e0, stream), "record")
+                check(lib.hu_grid_eval_slab(t.device_ptr, corner.ctypes.data_as(fptr), step, dims, 0, n, layout, buf.data_ptr(), stream),
+                      "hu_grid_eval_slab")
+                check(lib.hu_event_record(e1, stream), "record")
+                check(lib.hu_event_synchronize(e1), "sync")
+                ms = ctypes.c_float()
+                check(lib.hu_event_elapsed_ms(e0, e1, ctypes.byref(ms)), "elapsed")
+                if i >= 2:
+                    times.append(ms.value)
+            k_ms = sum(times) / len(times)
+            gbs = n ** 3 * bytes_per_voxel / (k_ms * 1e-3) / 1e9
+            out.append({"tape": name, "tape_instructions": t.n_instructions,
+                        "kernel": "k_grid_eval<%s, %d, 2>" % ("JitEval" if evaluator == "specialised" else "InterpEval", layout),
+                        "bytes": n ** 3 * bytes_per_voxel, "ms": round(k_ms, 4), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "gvoxels_per_s": round(n ** 3 / k_ms / 1e6, 1)})
+    return out
+
+
+# FLOPs per instruction of the reference's formulas (SURVEY.md section 8(d) convention): 1 per
 # add/mul/compare-select/abs/copysign, 2 per fma, sqrt 1, divide 1, as executed on the common path.
 _FLOP = {0: 0, 1: 0, 2: 0, 3: 14, 4: 9, 5: 90, 6: 0, 7: 12, 8: 1, 9: 4, 10: 120, 11: 39, 12: 39, 13: 40,
          14: 1, 15: 1, 16: 1, 17: 3, 18: 15, 19: 90, 20: 90, 21: 160, 22: 14, 23: 8, 24: 120, 25: 2,
@@ -290,36 +409,27 @@ _PARAMS = {0: 0, 1: 0, 2: 0, 3: 2, 4: 1, 5: 2, 7: 1, 8: 0, 9: 0, 10: 2, 11: 7, 1
            16: 1, 17: 1, 18: 3, 19: 1, 20: 1, 21: 2, 22: 1, 23: 0, 24: 3, 25: 0, 26: 1, 27: 1, 28: 1}
 
 
-def measured_valu_busy(n, evaluator="specialised"):
-    """Fraction of the VALU issue slots the dense kernel used, from the same committed PMC passes:
-    SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs); None without a matching profile."""
+def profile_summary(n, evaluator, config):
+    """The committed rocprofv3 PMC summary (profiles/*summary.json, tools/collect_profiles.sh) of the dominant
+    kernel for this grid, evaluator and config -- only if it was taken on THIS device code (csrc hash); else None."""
     import glob
+    want = csrc_hash()
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*summary.json"))):
         try:
             d = json.load(open(f))
             c = d["dense_kernel_counters_per_launch"]
-            if d.get("grid_edge", 512) == n and d.get("evaluator", "interpreter") == evaluator:
-                best = round(c["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (c["GRBM_GUI_ACTIVE"] / 8), 3)
-        except (ValueError, KeyError, ZeroDivisionError):
+            if (d.get("csrc_hash") == want and d.get("grid_edge", 512) == n and d.get("evaluator", "interpreter") == evaluator
+                    and d.get("config", "c3") == config):
+                waves = c["SQ_WAVES"]
+                best = {"file": os.path.basename(f), "csrc_hash": want,
+                        "valu_insts_per_wave": round(c["SQ_INSTS_VALU"] / waves, 2),
+                        "hbm_traffic_bytes_per_launch": d.get("hbm_traffic_bytes_per_launch"),
+                        # share of the VALU issue slots used while the kernel ran: busy cycles of the vector ALUs over
+                        # the kernel's cycles (GRBM_GUI_ACTIVE counts per XCD; SQ_BUSY_CYCLES would count per SE)
+                        "valu_issue_busy": d.get("valu_issue_busy")}
+        except (ValueError, KeyError, ZeroDivisionError, TypeError):
             continue
-    return best
-
-
-def measured_traffic(n, evaluator="specialised"):
-    """HBM bytes per launch of the dense kernel from the committed rocprofv3 PMC passes
-    (profiles/*_summary.json, produced by tools/collect_profiles.sh for this same kernel and
-    grid); None when no profile of this grid size is present."""
-    import glob
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*summary.json"))):
-        try:
-            d = json.load(open(f))
-        except ValueError:
-            continue
-        if d.get("grid_edge", 512) == n and d.get("evaluator", "interpreter") == evaluator and \
-                "hbm_traffic_bytes_per_launch" in d:
-            best = d["hbm_traffic_bytes_per_launch"]
     return best
 
 
@@ -373,7 +483,7 @@ def cpu_baseline(tape, n):
     dt = time.perf_counter() - t0
     return {"value": round(planes * n * n / dt / 1e6, 2), "unit": "Mvoxels/s", "cores": cores, "kind": "port",
             "sample": "oracle grid_eval (C restatement, OpenMP over x) of the first %d of %d x-planes of the "
-                      "same %d^3 sponge(4) grid, %.1f s wall" % (planes, n, n, dt),
+                      "%d^3 grid of this tape, %.1f s wall" % (planes, n, n, dt),
             "single_thread_mvoxels_s": round(one / 1e6, 3)}
 
 

@@ -594,9 +594,10 @@ int hu_grid_eval_pymcubes(hu_tape t, const float corner[4], float step, const ui
     return hu_grid_eval_slab(t, corner, step, dims, 0, dims[0], 1, out_dev, stream);
 }
 
-int hu_grid_eval_blocks(hu_tape t, const int32_t* blocks_dev, uint32_t n_blocks, double resolution,
-                        const double origin[3], float step, const uint32_t dims[3], int layout,
-                        void* out_dev, void* stream)
+// n_dev == NULL: exactly n_blocks blocks; else the launch covers n_blocks and workgroups past *n_dev leave at once
+static int grid_eval_blocks_impl(hu_tape t, const int32_t* blocks_dev, uint32_t n_blocks, const uint32_t* n_dev, double resolution,
+                                 const double origin[3], float step, const uint32_t dims[3], int layout,
+                                 void* out_dev, void* stream)
 {
     if (!t || !origin || !out_dev || (!blocks_dev && n_blocks)) return fail(HU_ERR_BAD_ARG, "NULL argument");
     if (layout != 0 && layout != 1) return fail(HU_ERR_BAD_ARG, "layout must be 0 or 1");
@@ -614,7 +615,7 @@ int hu_grid_eval_blocks(hu_tape t, const int32_t* blocks_dev, uint32_t n_blocks,
         double res = resolution, ox = origin[0], oy = origin[1], oz = origin[2];
         uint32_t sx = dims[0];
         Dim sy = make_dim(dims[1]), sz = make_dim(dims[2]);
-        void* args[] = {&ev, &b, &chunks, &res, &ox, &oy, &oz, &step, &sx, &sy, &sz, &out_dev};
+        void* args[] = {&ev, &b, &n_dev, &chunks, &res, &ox, &oy, &oz, &step, &sx, &sy, &sz, &out_dev};
         HU_HIP(hipModuleLaunchKernel(t->spec->blocks[layout], chunks * n_blocks, 1, 1, kSpecBlock, 1, 1, 0, (hipStream_t)stream,
                                      args, nullptr));
         return HU_OK;
@@ -628,7 +629,7 @@ int hu_grid_eval_blocks(hu_tape t, const int32_t* blocks_dev, uint32_t n_blocks,
     const dim3 grid(chunks * n_blocks), block(ls.block);
 #define HU_LAUNCH_BLOCKS(L, D, NV)                                                                                 \
     hipLaunchKernelGGL((k_grid_eval_blocks<InterpEval<D>, L, NV>), grid, block, ls.lds, (hipStream_t)stream,           \
-                       (InterpEval<D>{ls.prog, t->extra_dev, ls.n4}), (const int4*)blocks_dev, chunks, resolution,        \
+                       (InterpEval<D>{ls.prog, t->extra_dev, ls.n4}), (const int4*)blocks_dev, n_dev, chunks, resolution, \
                        origin[0], origin[1], origin[2], step, dims[0], make_dim(dims[1]), make_dim(dims[2]), out_dev)
     const bool d_only = layout == 1 && distance_only(t);
     if (ls.voxels_per_lane == 2) {
@@ -643,6 +644,21 @@ int hu_grid_eval_blocks(hu_tape t, const int32_t* blocks_dev, uint32_t n_blocks,
 #undef HU_LAUNCH_BLOCKS
     HU_HIP(hipGetLastError());
     return HU_OK;
+}
+
+int hu_grid_eval_blocks(hu_tape t, const int32_t* blocks_dev, uint32_t n_blocks, double resolution,
+                        const double origin[3], float step, const uint32_t dims[3], int layout,
+                        void* out_dev, void* stream)
+{
+    return grid_eval_blocks_impl(t, blocks_dev, n_blocks, nullptr, resolution, origin, step, dims, layout, out_dev, stream);
+}
+
+int hu_grid_eval_blocks_indirect(hu_tape t, const int32_t* blocks_dev, const uint32_t* n_blocks_dev, uint32_t max_blocks,
+                                 double resolution, const double origin[3], float step, const uint32_t dims[3], int layout,
+                                 void* out_dev, void* stream)
+{
+    if (!n_blocks_dev) return fail(HU_ERR_BAD_ARG, "n_blocks_dev is NULL");
+    return grid_eval_blocks_impl(t, blocks_dev, max_blocks, n_blocks_dev, resolution, origin, step, dims, layout, out_dev, stream);
 }
 
 }  // extern "C"
@@ -746,6 +762,25 @@ int hu_subdivision_level(hu_tape t, const int32_t* parents_dev, uint32_t n_paren
     a.step = step; a.thr = threshold;
     a.counter = counter_dev; a.list = children_dev; a.capacity = capacity;
     return launch_classify<false, true>(t, a, n_parents, dims, stream);
+}
+
+int hu_subdivision_level_indirect(hu_tape t, const int32_t* parents_dev, const uint32_t* n_parents_dev, uint32_t max_parents,
+                                  int32_t int_step, const uint32_t dims[3], int dimension, double resolution,
+                                  const double origin[3], float step, float threshold, uint32_t* counter_dev,
+                                  int32_t* children_dev, uint32_t capacity, void* stream)
+{
+    if (!t || !origin || !counter_dev || !n_parents_dev || (!children_dev && capacity) || (!parents_dev && max_parents))
+        return fail(HU_ERR_BAD_ARG, "NULL argument");
+    if (dimension != 2 && dimension != 3) return fail(HU_ERR_BAD_ARG, "dimension must be 2 or 3");
+    ClassifyArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.parents = parents_dev;
+    a.n_parents_dev = n_parents_dev;
+    a.int_step = int_step; a.dimension = dimension;
+    a.res = resolution; a.ox = origin[0]; a.oy = origin[1]; a.oz = origin[2];
+    a.step = step; a.thr = threshold;
+    a.counter = counter_dev; a.list = children_dev; a.capacity = capacity;
+    return launch_classify<false, true>(t, a, max_parents, dims, stream);
 }
 
 int hu_mass_properties_level(hu_tape t, const double* parents_dev, uint32_t n_parents, double s,

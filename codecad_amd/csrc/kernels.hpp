@@ -185,14 +185,17 @@ k_grid_eval(const E ev, float cx, float cy, float cz, float step, uint32_t sx, D
 
 template <class E, int LAYOUT, int N>
 __global__ void __launch_bounds__(256)
-k_grid_eval_blocks(const E ev, const int4* __restrict__ blocks, uint32_t chunks, double res, double ox,
-                   double oy, double oz, float step, uint32_t sx, Dim dy, Dim dz,
+k_grid_eval_blocks(const E ev, const int4* __restrict__ blocks, const uint32_t* __restrict__ n_blocks_dev, uint32_t chunks,
+                   double res, double ox, double oy, double oz, float step, uint32_t sx, Dim dy, Dim dz,
                    void* __restrict__ out)
 {
     const uint32_t sy = dy.n, sz = dz.n;
     using T = typename Pack<N>::T;
     extern __shared__ float4 lds[];
     const uint32_t b = blockIdx.x / chunks, chunk = blockIdx.x - b * chunks;
+    // indirect form: the list length lives on the device (the launch is sized for its capacity), so a
+    // traversal needs no host round trip between its levels; workgroup-uniform exit
+    if (n_blocks_dev && b >= *n_blocks_dev) return;
     const uint32_t cells = sx * sy * sz;
     const int4 ic = blocks[b];
     // subdivision.py:100: pos = int_pos * resolution + origin (fp64), cast once (geometry.py:98-99)
@@ -219,6 +222,7 @@ k_grid_eval_blocks(const E ev, const int4* __restrict__ blocks, uint32_t chunks,
 // ------------------------------------------------------------------------------------------
 struct ClassifyArgs {
     const void* parents;   // BATCH: int4[] (subdivision) or double4[] (mass); else unused
+    const uint32_t* n_parents_dev;  // BATCH, optional: the number of parents, on the device (the launch is sized for the list's capacity)
     uint32_t chunks;       // workgroups per parent
     uint32_t sx, sy, sz;
     Dim dy, dz;            // sy, sz with their division constants
@@ -244,6 +248,7 @@ __global__ void __launch_bounds__(256) k_classify(const E ev, const ClassifyArgs
     const uint32_t b = BATCH ? blockIdx.x / a.chunks : 0u;
     const uint32_t chunk = BATCH ? blockIdx.x - b * a.chunks : blockIdx.x;
     const uint32_t cells = a.sx * a.sy * a.sz;
+    if (BATCH && a.n_parents_dev && b >= *a.n_parents_dev) return;   // workgroup-uniform, before any barrier
 
     float cx = a.cx, cy = a.cy, cz = a.cz;
     int4 ipar = make_int4(0, 0, 0, 0);

@@ -178,6 +178,153 @@ def run_levels(top_parents, n_levels, classify_level, hints=None):
     return parents, counts
 
 
+class Overflow(RuntimeError):
+    """A list of a LevelPipeline traversal was longer than its capacity (the result is incomplete)."""
+
+    def __init__(self, needed):
+        RuntimeError.__init__(self, "level capacities too small, needed per level: %s" % (needed,))
+        self.needed = needed    # per level: the largest per-rank survivor count (and share) seen
+
+
+def slice_rows_reference(gathered, rank, out, stats):
+    """What `hu_slice_rows` computes on the device, in torch ops (CPU tensors: the gloo tests and nothing else).
+    gathered: (world, piece_rows, k) integer tensor, row 0 of a piece = header (element 0 = rows that follow);
+    out: (capacity + 1, k) <- [header | this rank's balanced share of the concatenated rows]; stats: (2,)."""
+    world, piece_rows = int(gathered.shape[0]), int(gathered.shape[1])
+    counts = [int(c) for c in gathered[:, 0, 0].tolist()]
+    over = any(c > piece_rows - 1 for c in counts)
+    counts = [min(c, piece_rows - 1) for c in counts]
+    rows = torch.cat([gathered[r, 1:1 + c] for r, c in enumerate(counts)], dim=0)
+    begin, end = balanced_slice(int(rows.shape[0]), rank, world)
+    capacity = int(out.shape[0]) - 1
+    if end - begin > capacity:
+        over, end = True, begin + capacity
+    out[0] = 0
+    out[0, 0] = end - begin
+    out[1:1 + end - begin] = rows[begin:end]
+    stats[0] = int(rows.shape[0])
+    stats[1] = 1 if over else 0
+
+
+class LevelPipeline:
+    """Level-synchronous traversal in which NOTHING waits for the host between levels.
+
+    The reference reads a counter and a list back to the host after every block (subdivision.py:75-94); the
+    drivers of this package read one counter per level; on eight GPUs even that -- plus the host-side slicing of
+    the gathered lists -- is what a step consists of (a 512^3 level is ~10 us of kernel per rank).  Here every
+    list is a fixed-capacity device buffer [header row | rows...] whose header holds its length:
+
+      classify(level)  counts into the header of `send[level]`, appends to its rows   (hu_subdivision_level_indirect)
+      all-gather       of the whole fixed-size piece, one collective, no sizes on the host        (world > 1)
+      slice            the rank's balanced share of the concatenation -> `mine[level]`, again
+                       [header | rows], on the device                                             (hu_slice_rows)
+      next level       reads its parent count from that header; its launch is sized for the capacity.
+
+    The host enqueues the whole traversal (and whatever consumes the leaf list) and looks at the headers once,
+    afterwards (`check`): a list that outgrew its capacity raises Overflow with the sizes needed.  Capacities
+    are per level: survivors PER RANK, hence also an upper bound of a rank's share.
+
+    `classify(level, parents, n_parents, max_parents, out)`: parents = (max_parents, k) tensor of rows,
+    n_parents = the 1-element view of the header holding their count, out = the (capacity + 1, k) buffer to
+    count into / append to (header already zeroed).  For the HIP path see `subdivision_pipeline`."""
+
+    def __init__(self, top_rows, capacities, classify, slice_rows=None, device=None):
+        self.rank, self.world = rank_world()
+        self.classify = classify
+        self.slice_rows = slice_rows or slice_rows_reference
+        self.capacities = [int(c) for c in capacities]
+        device = device if device is not None else top_rows.device
+        k = int(top_rows.shape[1])
+        begin, end = balanced_slice(int(top_rows.shape[0]), self.rank, self.world)   # the top list is host knowledge
+        self.top = torch.zeros((max(end - begin, 1) + 1, k), dtype=top_rows.dtype, device=device)
+        self.top[0, 0] = end - begin
+        self.top[1:1 + end - begin] = top_rows[begin:end]
+        self.top_max = max(end - begin, 1)
+        self.send = [torch.zeros((c + 1, k), dtype=top_rows.dtype, device=device) for c in self.capacities]
+        self.gathered = self.mine = self.stats = None
+        if self.world > 1:
+            self.gathered = [torch.zeros((self.world, c + 1, k), dtype=top_rows.dtype, device=device) for c in self.capacities]
+            self.mine = [torch.zeros((c + 1, k), dtype=top_rows.dtype, device=device) for c in self.capacities]
+            self.stats = torch.zeros((len(self.capacities), 2), dtype=torch.int32, device=device)
+
+    def enqueue(self):
+        """Enqueue the whole traversal on the current stream.  Returns the buffer [header | rows] holding this
+        rank's share of the last level's survivors (world 1: all of them)."""
+        parents, max_parents = self.top, self.top_max
+        for level, capacity in enumerate(self.capacities):
+            out = self.send[level]
+            out[:1].zero_()
+            self.classify(level, parents[1:], parents[0, :1], max_parents, out)
+            if self.world == 1:
+                parents = out
+            else:
+                g = self.gathered[level]
+                if g.device.type != "cpu" and _host_staged():     # several ranks on one GPU through gloo: rehearsal only
+                    host = [torch.empty(out.shape, dtype=out.dtype) for _ in range(self.world)]
+                    dist.all_gather(host, out.cpu())
+                    g.copy_(torch.stack(host))
+                elif g.device.type == "cpu":
+                    dist.all_gather(list(g.unbind(0)), out)
+                else:
+                    dist.all_gather_into_tensor(g, out)
+                self.slice_rows(g, self.rank, self.mine[level], self.stats[level])
+                parents = self.mine[level]
+            max_parents = capacity
+        return parents
+
+    def check(self):
+        """Wait for the traversal and validate it.  Returns the global survivor count of every level; raises
+        Overflow (with the capacities that would have sufficed) if a list was truncated."""
+        if not self.send:
+            self.needed = []
+            return []
+        own = [int(b[0, 0].item()) for b in self.send]       # synchronises
+        if self.world == 1:
+            totals, needed = own, own
+        else:
+            st = self.stats.cpu().tolist()
+            totals = [int(row[0]) for row in st]
+            biggest = allreduce_max(torch.tensor(own, dtype=torch.int64, device=self.send[0].device)).tolist()
+            needed = [max(int(b), -(-t // self.world)) for b, t in zip(biggest, totals)]
+        self.needed = needed      # per level: the largest list any rank held (what the capacities must cover)
+        if any(n > c for n, c in zip(needed, self.capacities)):
+            raise Overflow(needed)
+        return totals
+
+
+def subdivision_pipeline(tape, levels, resolution, origin, dimension, capacities, device, stream, top_rows=None):
+    """A LevelPipeline over the HIP kernels: `levels` as calculate_block_sizes returns them (the leaf level,
+    the last one, is left to the consumer like in subdivision_device), `origin` the box corner.  The launches
+    go to `stream` (a raw hipStream_t; it must be the current torch stream when world > 1, the collectives
+    follow that)."""
+    import ctypes
+    import math
+    import numpy
+    from .hip_util import manager as hip_manager, check
+
+    lib = hip_manager.lib
+    o = (ctypes.c_double * 3)(*[float(v) for v in origin])
+
+    def classify(level, parents, n_parents, max_parents, out):
+        int_step, dims = levels[level]
+        d = (ctypes.c_uint32 * 3)(int(dims[0]), int(dims[1]), int(dims[2]))
+        box_step = int_step * resolution
+        thr = box_step * math.sqrt(dimension) / 2
+        check(lib.hu_subdivision_level_indirect(tape.device_ptr, parents.data_ptr(), n_parents.data_ptr(), int(max_parents),
+                                                int(int_step), d, dimension, float(resolution), o, numpy.float32(box_step),
+                                                numpy.float32(thr), out.data_ptr(), out[1:].data_ptr(), int(out.shape[0]) - 1,
+                                                stream), "hu_subdivision_level_indirect")
+
+    def slice_rows(gathered, rank, out, stats):
+        check(lib.hu_slice_rows(gathered.data_ptr(), int(gathered.shape[0]), int(gathered.shape[1]),
+                                int(gathered.shape[2]) * gathered.element_size(), rank, out.data_ptr(), int(out.shape[0]) - 1,
+                                stats.data_ptr(), stream), "hu_slice_rows")
+
+    if top_rows is None:
+        top_rows = torch.zeros((1, 4), dtype=torch.int32, device=device)
+    return LevelPipeline(top_rows, capacities, classify, slice_rows, device)
+
+
 def integrate_levels(top_parents, n_levels, level_fn):
     """Level-synchronous hierarchical integration (mass properties) over all ranks.
 
@@ -267,21 +414,17 @@ def subdivision(shape, resolution, overlap_edge_samples=True, grid_size=None):
     level's parent list is cut into balanced slices, `hu_subdivision_level` classifies and compacts the
     slice, the survivors are all-gathered.  Returns (leaves, info): `leaves` an (n, 4) int32 device tensor of
     integer leaf corners, identical (as a set; ordered by rank slice) on every rank, and `info` with
-    `dims`, `int_step`, `step`, `resolution`, `origin`, `level_counts` like LeafBlocks.  A consumer takes
-    `leaves[balanced_slice(n, rank, world)]` (e.g. hu_grid_eval_blocks: bench.py step C)."""
-    import ctypes
-    import math
-    import numpy
+    `dims`, `int_step`, `step`, `resolution`, `origin`, `level_counts` like LeafBlocks, plus `share`: this rank's
+    balanced share of the leaves (what a sharded consumer evaluates, e.g. hu_grid_eval_blocks: bench.py step C)."""
     from . import nodes
     from . import subdivision as sub
-    from .hip_util import manager as hip_manager, check
+    from .hip_util import manager as hip_manager
 
     if grid_size is None:
         grid_size = 128
     assert resolution > 0 and 1 < grid_size <= 256
     device = torch.device("cuda", local_device())
     hip_manager.use_device(device.index)
-    lib = hip_manager.lib
     stream = torch.cuda.current_stream(device).cuda_stream
     tape = nodes.make_program_buffer(shape)
     dimension = shape.dimension()
@@ -289,35 +432,24 @@ def subdivision(shape, resolution, overlap_edge_samples=True, grid_size=None):
     if dimension == 2:
         box = box.flattened()
     levels = sub.calculate_block_sizes(box, dimension, resolution, grid_size, overlap_edge_samples)
-    origin = (ctypes.c_double * 3)(box.a.x, box.a.y, box.a.z)
-    counter = torch.zeros(1, dtype=torch.int32, device=device)
-    capacity = {}
-
-    def classify(level, parents):
-        int_step, dims = levels[level]
-        k = int(parents.shape[0])
-        if k == 0:
-            return parents[:0]
-        parents = parents.contiguous()
-        d = (ctypes.c_uint32 * 3)(int(dims[0]), int(dims[1]), int(dims[2]))
-        box_step = int_step * resolution
-        thr = box_step * math.sqrt(dimension) / 2
-        cap = capacity.get(level, max(1 << 14, 8 * k))
-        while True:
-            children = torch.empty((cap, 4), dtype=torch.int32, device=device)
-            counter.zero_()
-            check(lib.hu_subdivision_level(tape.device_ptr, parents.data_ptr(), k, int(int_step), d, dimension,
-                                           resolution, origin, numpy.float32(box_step), numpy.float32(thr),
-                                           counter.data_ptr(), children.data_ptr(), cap, stream), "hu_subdivision_level")
-            count = int(counter.item())
-            if count <= cap:
-                capacity[level] = cap
-                return children[:count]
-            cap = int(count * 1.25)
-
-    top = torch.zeros((1, 4), dtype=torch.int32, device=device)
-    leaves, counts = run_levels(top, len(levels) - 1, classify)
+    # the whole traversal is enqueued without a host round trip (LevelPipeline); the list capacities start at the
+    # single-GPU driver's first guess and grow to what an overflowing traversal reports
+    cells = [int(d[0]) * int(d[1]) * int(d[2]) for _, d in levels]
+    capacities, bound = [], 1
+    for c in cells[:-1]:
+        capacities.append(sub.child_capacity(bound, c))
+        bound = capacities[-1]
+    while True:
+        pipe = subdivision_pipeline(tape, levels, resolution, (box.a.x, box.a.y, box.a.z), dimension, capacities, device, stream)
+        mine = pipe.enqueue()
+        try:
+            counts = pipe.check()
+            break
+        except Overflow as e:
+            capacities = [max(int(v * 1.125) + 16, c) for v, c in zip(e.needed, capacities)]
+    share = mine[1:1 + int(mine[0, 0])] if len(levels) > 1 else torch.zeros((1, 4), dtype=torch.int32, device=device)
+    leaves = allgather_rows(share) if len(levels) > 1 else share
     leaf_int_step, leaf_dims = levels[-1]
     info = {"tape": tape, "dims": leaf_dims, "int_step": leaf_int_step, "step": leaf_int_step * resolution,
-            "resolution": resolution, "origin": box.a, "level_counts": counts}
+            "resolution": resolution, "origin": box.a, "level_counts": counts, "share": share}
     return leaves, info

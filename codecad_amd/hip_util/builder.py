@@ -11,15 +11,20 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.normpath(os.path.join(HERE, "..", "csrc"))
 INCLUDE = os.path.normpath(os.path.join(HERE, "..", "..", "include"))
 LIB_PATH = os.path.join(HERE, "libhip_util.so")
-SOURCES = ["hip_util.hip", "sort.hip"]
+SOURCES = ["hip_util.hip", "sort.hip", "exchange.hip"]
 HEADERS = ["interp.hpp", "kernels.hpp", "mesh_kernels.hpp", "mc_table.hpp", "tape.hpp", "tape_format.hpp", "sdf_math.hpp"]
 
 # Strict IEEE arithmetic is part of the contract (DESIGN.md "Canonical arithmetic"):
 # no contraction, no fast-math, correctly rounded sqrt/divide.
 HIPCC_FLAGS = [
-    "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
+    "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC",
     "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
     "-Wall", "-Wno-unused-function",
+]
+# Only for the translation unit that holds the tape interpreter (hip_util.hip).  NOT harmless elsewhere: with
+# -structurizecfg-skip-uniform-regions a divergent loop with a second, uniform exit got its exit-dependent value
+# from a scalar branch (csrc/exchange.hip tells the story), so every other source is compiled without these.
+INTERPRETER_FLAGS = [
     # The tape dispatch loop is wave-uniform control flow (scalar branches).  By default the
     # AMDGPU backend still runs StructurizeCFG over it and turns the opcode switch into a
     # chain of flag-guarded blocks (~37 SALU + phi copies per tape instruction, measured
@@ -65,13 +70,30 @@ def _compile(LIB_PATH, extra_flags, verbose):
     if hipcc is None:
         raise RuntimeError("hipcc not found: cannot build libhip_util.so (set HIPCC or install ROCm)")
     tmp = LIB_PATH + ".tmp.%d" % os.getpid()
-    cmd = ([hipcc] + HIPCC_FLAGS + extra_flags + ["-I", INCLUDE, "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
-           + ["-lhiprtc"])
-    proc = subprocess.run(cmd, capture_output=True, text=True)
-    if proc.returncode != 0:
+    objects, procs = [], []
+    for s in SOURCES:      # one object per source, each with its own flags, compiled side by side
+        obj = "%s.%s.o" % (tmp, s)
+        flags = HIPCC_FLAGS + (INTERPRETER_FLAGS if s == "hip_util.hip" else []) + extra_flags
+        cmd = [hipcc] + flags + ["-I", INCLUDE, "-c", "-o", obj, os.path.join(CSRC, s)]
+        objects.append(obj)
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+    errors = []
+    for cmd, proc in procs:
+        _, err = proc.communicate()
+        if proc.returncode != 0:
+            errors.append("hipcc failed:\n" + " ".join(cmd) + "\n" + err[-4000:])
+    if not errors:
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objects + ["-lhiprtc"]
+        proc = subprocess.run(cmd, capture_output=True, text=True)
+        if proc.returncode != 0:
+            errors.append("hipcc link failed:\n" + " ".join(cmd) + "\n" + proc.stderr[-4000:])
+    for obj in objects:
+        if os.path.exists(obj):
+            os.unlink(obj)
+    if errors:
         if os.path.exists(tmp):
             os.unlink(tmp)
-        raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + proc.stderr[-4000:])
+        raise RuntimeError("\n".join(errors))
     os.replace(tmp, LIB_PATH)
     if verbose:
         print("built", LIB_PATH)

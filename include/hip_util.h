@@ -122,6 +122,29 @@ int hu_subdivision_level(hu_tape t, const int32_t* parents_dev, uint32_t n_paren
                          uint32_t* counter_dev, int32_t* children_dev, uint32_t capacity,
                          void* stream);
 
+/* The same with the list lengths ON THE DEVICE, so that a whole traversal can be enqueued without a host
+ * round trip between its levels: the launch covers max_parents (the list's capacity) and workgroups past
+ * *n_parents_dev leave at once.  Typical chaining: counter_dev = word 0 of a [header row | rows...] buffer and
+ * children_dev = its row 1, which makes the buffer the next level's (parents_dev = row 1, n_parents_dev = word
+ * 0) and, on several GPUs, the fixed-size piece of the all-gather (hu_slice_rows).  The caller checks
+ * counter <= capacity once, at the end of the traversal. */
+int hu_subdivision_level_indirect(hu_tape t, const int32_t* parents_dev, const uint32_t* n_parents_dev,
+                                  uint32_t max_parents, int32_t int_step, const uint32_t dims[3],
+                                  int dimension, double resolution, const double origin[3], float step,
+                                  float threshold, uint32_t* counter_dev, int32_t* children_dev,
+                                  uint32_t capacity, void* stream);
+int hu_grid_eval_blocks_indirect(hu_tape t, const int32_t* blocks_dev, const uint32_t* n_blocks_dev,
+                                 uint32_t max_blocks, double resolution, const double origin[3], float step,
+                                 const uint32_t dims[3], int layout, void* out_dev, void* stream);
+/* Multi-GPU level exchange (the reference has one device and no counterpart).  After
+ * an all-gather of fixed-size pieces gathered_dev holds world x piece_rows rows of row_bytes (16 or 32) each;
+ * row 0 of a piece is its header (word 0 = number of rows that follow).  Writes this rank's balanced share of
+ * the concatenated rows -- begin = rank*base + min(rank, extra), base/extra = divmod(total, world) -- to
+ * out_dev as [header | rows] (out_capacity rows after the header).  stats_dev: uint32[2] <- {rows over all
+ * ranks, 1 if a piece or the share was truncated}.  Asynchronous, no host involvement. */
+int hu_slice_rows(const void* gathered_dev, uint32_t world, uint32_t piece_rows, uint32_t row_bytes,
+                  uint32_t rank, void* out_dev, uint32_t out_capacity, uint32_t* stats_dev, void* stream);
+
 /* One level of mass_properties() for ALL parents (mass_properties.py:69-157).
  * parents_dev: double[4]*n_parents box corners; sample corner = corner + s/2 (fp64), cast
  * once.  sums_dev: uint32[10]*n_parents (caller zeroes), same order as hu_mass_properties.

@@ -46,6 +46,40 @@ def _traverse(tape, levels, resolution, origin, n_objects, hints=None):
     return dist.run_levels(top, len(levels) - 1, classify, hints=hints)
 
 
+def _pipeline(tape, levels, resolution, origin, n_objects, capacities):
+    """The traversal through dist.LevelPipeline (lists with their lengths in header rows, one fixed-size
+    all-gather per level, the balanced share taken without the host looking at any count), classification by
+    the CPU oracle.  -> (this rank's share of the leaves, global survivors per level)"""
+    import math
+    import oracle
+    from codecad_amd import dist
+
+    def classify(level, parents, n_parents, max_parents, out):
+        int_step, dims = levels[level]
+        k = min(int(n_parents.item()), max_parents)   # an overflowed list holds `capacity` rows: the launch covers no more
+        rows = []
+        for ix, iy, iz, obj in parents[:k].tolist():
+            half = int_step / 2
+            corner = [(ix + half) * resolution + origin[0], (iy + half) * resolution + origin[1],
+                      (iz + half) * resolution + origin[2]]
+            step = int_step * resolution
+            n, cells = oracle.subdivision_step(tape, np.array(corner).astype(np.float32), np.float32(step),
+                                               np.float32(step * math.sqrt(3) / 2), dims)
+            rows += [[ix + i * int_step, iy + j * int_step, iz + k_ * int_step, obj] for i, j, k_, _ in cells.tolist()]
+        capacity = out.shape[0] - 1
+        out[0, 0] = len(rows)                       # like the kernel: the counter counts everything ...
+        rows = rows[:capacity]                      # ... and only what fits is stored
+        if rows:
+            out[1:1 + len(rows)] = torch.tensor(rows, dtype=torch.int32)
+
+    top = torch.zeros((n_objects, 4), dtype=torch.int32)
+    top[:, 3] = torch.arange(n_objects, dtype=torch.int32)
+    pipe = dist.LevelPipeline(top, capacities, classify)
+    mine = pipe.enqueue()
+    totals = pipe.check()
+    return mine[1:1 + int(mine[0, 0])], totals
+
+
 def _integrate(tape, box_a, levels):
     """Sharded mass-properties integration with the oracle's kernel as the per-level worker."""
     import math
@@ -127,6 +161,21 @@ def _worker(rank, world, port, queue):
     assert torch.equal(first[0], leaves) and torch.equal(again[0], leaves) and again[1] == counts
     total = dist.allreduce_sum(torch.tensor([leaves.shape[0]], dtype=torch.int64))
     assert int(total.item()) == world * leaves.shape[0]
+    # ONE object over both ranks (strong scaling, what bench.py --gpus N runs) through the device-side protocol:
+    # the shares tile the single-rank leaf list, the per-level totals are the single-rank counts
+    one, one_counts = _traverse(tape, levels, res, origin, n_objects=1)
+    share, totals = _pipeline(tape, levels, res, origin, 1, [max(one_counts) + 3] * len(one_counts))
+    assert totals == one_counts
+    b, e = dist.balanced_slice(one.shape[0], rank, world)
+    assert e - b == share.shape[0]
+    shares = dist.allgather_rows(share)
+    assert sorted(map(tuple, shares.tolist())) == sorted(map(tuple, one.tolist()))
+    # a list that outgrows its capacity is reported with the sizes that would have sufficed -- on every rank
+    try:
+        _pipeline(tape, levels, res, origin, 1, [2] * len(one_counts))
+        raise AssertionError("overflow went unnoticed")
+    except dist.Overflow as err:
+        assert err.needed[0] > 2
     mtape, box_a, mlevels = _setup_mass()
     integrals = _integrate(mtape, box_a, mlevels)
     if rank == 0:
@@ -162,6 +211,50 @@ def test_two_rank_traversal_equals_single_rank():
     single = _integrate(mtape, box_a, mlevels).tolist()
     assert np.allclose(got_integrals, single, rtol=1e-13, atol=1e-15)   # first moments are 0 up to rounding noise
     assert got_integrals[0] == pytest.approx((20 / 27) ** 2, rel=1e-12)   # the sponge's exact volume at this resolution
+
+
+def test_pipeline_single_rank_and_slice_rule():
+    """World 1: the pipeline is the plain traversal.  And the share rule of slice_rows_reference (= hu_slice_rows)
+    is dist.balanced_slice on the concatenation, with truncated pieces and shares flagged."""
+    from codecad_amd import dist
+    tape, levels, res, origin = _setup()
+    leaves, counts = _traverse(tape, levels, res, origin, n_objects=1)
+    share, totals = _pipeline(tape, levels, res, origin, 1, [c + 1 for c in counts])
+    assert totals == counts and sorted(map(tuple, share.tolist())) == sorted(map(tuple, leaves.tolist()))
+    with pytest.raises(dist.Overflow) as info:
+        _pipeline(tape, levels, res, origin, 1, [counts[0] - 1] + [c + 1 for c in counts[1:]])
+    assert info.value.needed[0] == counts[0]
+
+    rng = np.random.default_rng(3)
+    for world in (1, 2, 3, 8):
+        piece_rows = 7
+        counts = rng.integers(0, piece_rows, world).tolist()
+        gathered = torch.zeros((world, piece_rows, 4), dtype=torch.int32)
+        rows = []
+        for r, c in enumerate(counts):
+            gathered[r, 0, 0] = c
+            gathered[r, 1:1 + c] = torch.arange(c * 4, dtype=torch.int32).reshape(c, 4) + 1000 * r
+            gathered[r, 1 + c:] = -1     # stale rows behind the count must not leak
+            rows += gathered[r, 1:1 + c].tolist()
+        got = []
+        for rank in range(world):
+            out = torch.full((piece_rows, 4), -7, dtype=torch.int32)
+            stats = torch.zeros(2, dtype=torch.int32)
+            dist.slice_rows_reference(gathered, rank, out, stats)
+            b, e = dist.balanced_slice(len(rows), rank, world)
+            assert int(out[0, 0]) == e - b and stats.tolist() == [len(rows), 0]
+            got += out[1:1 + e - b].tolist()
+        assert got == rows
+    # a piece whose header claims more rows than it holds, and a share larger than the output
+    gathered = torch.zeros((2, 3, 4), dtype=torch.int32)
+    gathered[:, 0, 0] = torch.tensor([5, 2])
+    out, stats = torch.zeros((3, 4), dtype=torch.int32), torch.zeros(2, dtype=torch.int32)
+    dist.slice_rows_reference(gathered, 0, out, stats)
+    assert stats.tolist() == [4, 1] and int(out[0, 0]) == 2
+    gathered[:, 0, 0] = torch.tensor([2, 2])
+    out = torch.zeros((2, 4), dtype=torch.int32)
+    dist.slice_rows_reference(gathered, 1, out, stats)
+    assert stats.tolist() == [4, 1] and int(out[0, 0]) == 1
 
 
 def test_single_process_helpers():

@@ -443,3 +443,91 @@ def test_config_c5_sponge5_at_2048_single_gpu_form(hip):
     # every leaf corner sits on the lattice of its level (15 cells apart: blocks share their edge samples)
     assert np.all(got % 15 == 0)
     leaves.blocks.release()
+
+
+def test_slice_rows_kernel_equals_the_reference_rule(hip):
+    """hu_slice_rows (the device side of the multi-GPU level exchange) == dist.slice_rows_reference, for 16- and
+    32-byte rows, ragged pieces, overflowing pieces and shares."""
+    import torch
+    from codecad_amd import dist
+    from codecad_amd.hip_util import check
+    lib = hip.lib
+    rng = np.random.default_rng(11)
+    dev = torch.device("cuda", 0)
+    for world, piece_rows, k, dtype, cap in ((1, 9, 4, torch.int32, 8), (2, 700, 4, torch.int32, 699), (3, 5, 4, torch.int32, 3),
+                                             (8, 300, 4, torch.int32, 299), (5, 40, 4, torch.float64, 39), (2, 6, 4, torch.int32, 1)):
+        counts = rng.integers(0, piece_rows + 3, world)     # some headers claim more than a piece holds
+        g = torch.zeros((world, piece_rows, k), dtype=dtype)
+        for r in range(world):
+            body = torch.from_numpy(rng.integers(-1000, 1000, (piece_rows - 1, k))).to(dtype)
+            g[r, 1:] = body
+            if dtype == torch.float64:
+                g[r, 0].view(torch.int32)[0] = int(counts[r])
+            else:
+                g[r, 0, 0] = int(counts[r])
+        for rank in range(world):
+            want, wstats = torch.zeros((cap + 1, k), dtype=dtype), torch.zeros(2, dtype=torch.int32)
+            gi = g if dtype != torch.float64 else g
+            if dtype == torch.float64:
+                # the reference rule reads the count as the tensor's element 0: give it the int view's value
+                gref = g.clone()
+                gref[:, 0, 0] = torch.tensor([float(c) for c in counts], dtype=torch.float64)
+                dist.slice_rows_reference(gref, rank, want, wstats)
+            else:
+                dist.slice_rows_reference(gi, rank, want, wstats)
+            gd = g.to(dev)
+            out = torch.full((cap + 1, k), 77, dtype=dtype, device=dev)
+            stats = torch.zeros(2, dtype=torch.int32, device=dev)
+            check(lib.hu_slice_rows(gd.data_ptr(), world, piece_rows, k * g.element_size(), rank, out.data_ptr(), cap,
+                                    stats.data_ptr(), None), "hu_slice_rows")
+            torch.cuda.synchronize()
+            n = int(want[0, 0]) if dtype != torch.float64 else int(want[0, 0].item())
+            got_n = int(out[0].cpu().view(torch.int32)[0])
+            assert got_n == n and stats.cpu().tolist() == wstats.tolist()
+            assert torch.equal(out[1:1 + n].cpu(), want[1:1 + n])
+
+
+@pytest.mark.parametrize("name, resolution, grid", [("sponge3", 1 / 243, 9), ("sponge4", 1 / 512, 16), ("csg_example", 1.0, 8)])
+def test_pipeline_without_host_round_trips_equals_the_level_driver(hip, name, resolution, grid):
+    """dist.LevelPipeline over hu_subdivision_level_indirect (list lengths read on the device, launches sized for
+    the capacities) gives the leaf set of subdivision_device; the leaf blocks evaluated through
+    hu_grid_eval_blocks_indirect equal the direct launch; a capacity that is too small is reported."""
+    import torch
+    import codecad_amd as cc
+    from codecad_amd import dist, hip_util
+    from codecad_amd.hip_util import check
+    shape = _tape_shape(name)
+    single = cc.subdivision.subdivision_device(shape, resolution, True, grid)
+    want = sorted(map(tuple, single.int_corners().tolist()))
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    box = shape.bounding_box().expanded_additive(resolution / 2)
+    levels = cc.subdivision.calculate_block_sizes(box, 3, resolution, grid, True)
+    tape = cc.nodes.make_program_buffer(shape)
+    counts = list(single.level_counts)
+    pipe = dist.subdivision_pipeline(tape, levels, resolution, tuple(box.a), 3, [c + 5 for c in counts], dev, stream)
+    for _ in range(2):     # a pipeline is reusable: headers are reset on every traversal
+        mine = pipe.enqueue()
+        assert pipe.check() == counts
+        n = int(mine[0, 0])
+        assert sorted(map(tuple, mine[1:1 + n, :3].cpu().tolist())) == want
+    # the consumer, launched for the capacity with the length read on the device
+    dims = tuple(int(d) for d in levels[-1][1])
+    cells = dims[0] * dims[1] * dims[2]
+    cap = int(mine.shape[0]) - 1
+    out = torch.full((cap, cells), float("nan"), dtype=torch.float32, device=dev)
+    ref = torch.empty((n, cells), dtype=torch.float32, device=dev)
+    o = (ctypes.c_double * 3)(*tuple(box.a))
+    d = (ctypes.c_uint32 * 3)(*dims)
+    step = np.float32(levels[-1][0] * resolution)
+    check(hip.lib.hu_grid_eval_blocks_indirect(tape.device_ptr, mine[1:].data_ptr(), mine.data_ptr(), cap, resolution, o, step, d, 1,
+                                               out.data_ptr(), stream), "indirect")
+    check(hip.lib.hu_grid_eval_blocks(tape.device_ptr, mine[1:].data_ptr(), n, resolution, o, step, d, 1, ref.data_ptr(), stream), "direct")
+    torch.cuda.synchronize()
+    assert same_bits(out[:n].cpu().numpy(), ref.cpu().numpy())
+    assert bool(torch.isnan(out[n:]).all())      # nothing past the list's length was touched
+    small = dist.subdivision_pipeline(tape, levels, resolution, tuple(box.a), 3, [max(c // 2, 1) for c in counts], dev, stream)
+    small.enqueue()
+    with pytest.raises(dist.Overflow) as info:
+        small.check()
+    assert info.value.needed[0] == counts[0]

@@ -17,7 +17,7 @@ shutil.copy(stats, os.path.join(dst, prefix + "_bench_kernel_stats.csv"))
 line = [l for l in open(os.path.join(src, "bench_under_rocprof.log")) if l.startswith('{"metric"')][-1]
 open(os.path.join(dst, prefix + "_bench_line_under_rocprof.json"), "w").write(line)
 summary = json.load(open(os.path.join(src, "summary.json")))
-summary.update({"grid_edge": 512, "round": 1, "evaluator": evaluator, "note": note,
+summary.update({"grid_edge": 512, "round": int(prefix[1:3]) if prefix[1:3].isdigit() else 2, "config": "c3", "evaluator": evaluator, "note": note,
                 "command": "tools/collect_profiles.sh: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 "
                            "--no-cpu-baseline ; PMC passes: rocprofv3 --pmc <counters> --kernel-trace -- python3 tools/prof_dense.py 512 3 "
                            "(CODECAD_AMD_SPECIALIZE=%s)" % ("1" if evaluator == "specialised" else "0")})

@@ -34,4 +34,15 @@ if "WRITE_SIZE" in c and "FETCH_SIZE" in c:
 if "SQ_WAVES" in c:
     w = c["SQ_WAVES"]
     out["per_wave"] = {k: v / w for k, v in c.items() if k.startswith("SQ_")}
+    dense = [k for k in out["kernel_stats"] if re.search(r"k_grid_eval<JitEval, 0, \d>|k_grid_eval<InterpEval<false>, 0, \d>", k["name"])]
+    if dense and "SQ_INSTS_VALU" in c:
+        # Share of the chip's VALU issue slots the kernel used: a wave64 VALU instruction occupies its SIMD16 for 4
+        # cycles; 1024 SIMDs; 2.4 GHz peak clock; the kernel's average duration from the --stats pass.  (Round 1
+        # divided SQ_ACTIVE_INST_VALU by GRBM_GUI_ACTIVE / 8 and got 1.025: that counter adds up per-wave
+        # execution windows, which overlap in the pipeline, so it is not a utilisation.)
+        avg_s = max(dense, key=lambda k: k["calls"])["avg_ns"] * 1e-9
+        out["valu_issue_busy"] = c["SQ_INSTS_VALU"] * 4 / (1024 * 2.4e9 * avg_s)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+out["csrc_hash"] = bench.csrc_hash()   # the device code these counters describe (bench.py ignores a profile of other code)
 print(json.dumps(out, indent=1))
