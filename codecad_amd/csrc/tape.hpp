@@ -198,7 +198,9 @@ inline void fold_moves(std::vector<Rec>& prog)
         Rec r = prog[i];
         const uint32_t op = r.hdr & 0xffu, slot = (r.hdr >> 8) & 0xffffu;
         const bool result = (r.hdr & kResultKind) != 0;
-        const bool next_is_real = i + 1 < prog.size() && (prog[i + 1].hdr & 0xffu) != OP_STORE && (prog[i + 1].hdr & 0xffu) != OP_LOAD;
+        // never into _return: the per-tape code generator stops AT the return record and would drop the load
+        const uint32_t next_op = i + 1 < prog.size() ? (prog[i + 1].hdr & 0xffu) : (uint32_t)OP_RETURN;
+        const bool next_is_real = next_op != OP_STORE && next_op != OP_LOAD && next_op != OP_RETURN;
         if (op == OP_LOAD && slot < 256u && next_is_real && !pending_load) {
             pending_load = kFoldLoad | (result ? kFoldLoadResult : 0u) | slot;
             last_foldable = false;

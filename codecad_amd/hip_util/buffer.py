@@ -37,6 +37,7 @@ class _PinnedBlock:
     def __init__(self, manager, nbytes, stream_key):
         self.manager = manager
         self.stream_key = stream_key
+        self.in_flight = False   # an asynchronous copy from / into the block was enqueued (Buffer.enqueue_*)
         self.ptr, self.size_class = manager.pinned_pool.take(stream_key, nbytes)
 
     def view(self, dtype, nitems, shape, nbytes):
@@ -47,7 +48,9 @@ class _PinnedBlock:
     def __del__(self):
         try:
             if self.ptr:
-                self.manager.pinned_pool.give(self.stream_key, self.ptr, self.size_class)
+                # the host is not stream-ordered: the next owner may only write the block after copies still
+                # queued on it have run (the pool records a fence on the stream now and waits for it on reuse)
+                self.manager.pinned_pool.give(self.stream_key, self.ptr, self.size_class, self.in_flight)
                 self.ptr = None
         except Exception:
             pass
@@ -106,6 +109,8 @@ class Buffer:
             raise RuntimeError("Not enough space to store contents of the buffer")
         self._wait_all(wait_for)
         ev = Event(self.manager, self.queue)
+        if host is self.array and self._pinned is not None:
+            self._pinned.in_flight = True
         check(self.manager.lib.hu_memcpy_d2h(host.ctypes.data, self.device_ptr, self.size, self.queue.handle), "hu_memcpy_d2h")
         return ev._done()
 
@@ -118,15 +123,18 @@ class Buffer:
     def enqueue_write(self, a=None, wait_for=None):
         """Host (self.array or `a`) -> device, asynchronous; returns an Event."""
         host = self._host(a)
+        from_shadow = host is self.array and self._pinned is not None
         host = numpy.ascontiguousarray(host)
         if host.nbytes > self.size:
             raise RuntimeError("Not enough space to store contents in the buffer")
         self._wait_all(wait_for)
         ev = Event(self.manager, self.queue)
         self._keepalive = host  # the copy is asynchronous: keep the source alive
+        if from_shadow:
+            self._pinned.in_flight = True
         check(self.manager.lib.hu_memcpy_h2d(self.device_ptr, host.ctypes.data, host.nbytes, self.queue.handle), "hu_memcpy_h2d")
-        if a is not None and self._pinned is None:
-            self.queue.synchronize()  # pageable source: do not return before it is consumed
+        if not from_shadow:
+            self.queue.synchronize()  # any other source (pageable, or the caller's to reuse): consumed before we return
         return ev._done()
 
     def enqueue_zero_fill_compatible(self, wait_for=None):

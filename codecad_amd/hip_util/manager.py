@@ -232,9 +232,13 @@ class _BlockPool:
     enqueues on the same in-order stream, so work still in flight on the block finishes first.
     CODECAD_AMD_POOL_MB caps the cached bytes (default 4096, 0 disables pooling)."""
 
-    def __init__(self, alloc, free, limit_bytes):
+    def __init__(self, alloc, free, limit_bytes, fence=None, wait=None):
+        """fence(stream_key) -> token, wait(token): for memory the HOST writes (pinned blocks), where handing a
+        block to the next user of the same stream is not enough -- the host does not run in stream order.  A
+        block is given back together with a fence recorded on its stream and taken only after the fence passed."""
         self._alloc, self._free, self.limit = alloc, free, limit_bytes
-        self.blocks = {}   # (stream key, size class) -> [pointers]
+        self._fence, self._wait = fence, wait
+        self.blocks = {}   # (stream key, size class) -> [(pointer, fence token or None)]
         self.cached = 0
 
     @staticmethod
@@ -249,23 +253,30 @@ class _BlockPool:
         stack = self.blocks.get((stream_key, cls))
         if stack:
             self.cached -= cls
-            return stack.pop(), cls
+            ptr, token = stack.pop()
+            if token is not None:
+                self._wait(token)   # copies that were still queued from / into the block when it came back
+            return ptr, cls
         try:
             return self._alloc(cls), cls
         except RuntimeError:
             self.trim()          # out of memory with blocks cached: give them back and retry once
             return self._alloc(cls), cls
 
-    def give(self, stream_key, ptr, cls):
+    def give(self, stream_key, ptr, cls, in_flight=False):
+        """in_flight: asynchronous copies may still be queued on the block (pools with a fence only)."""
         if self.cached + cls <= self.limit:
-            self.blocks.setdefault((stream_key, cls), []).append(ptr)
+            token = self._fence(stream_key) if (in_flight and self._fence is not None) else None
+            self.blocks.setdefault((stream_key, cls), []).append((ptr, token))
             self.cached += cls
         else:
-            self._free(ptr)
+            self._free(ptr)     # hipHostFree / hipFree wait for the device themselves
 
     def trim(self):
         for stack in self.blocks.values():
-            for ptr in stack:
+            for ptr, token in stack:
+                if token is not None:
+                    self._wait(token)
                 self._free(ptr)
         self.blocks, self.cached = {}, 0
 
@@ -284,7 +295,8 @@ class HipManager:
         self.k = _Kernels(self)
         limit = int(float(os.environ.get("CODECAD_AMD_POOL_MB", "4096")) * (1 << 20))
         self.device_pool = _BlockPool(self._raw_malloc, self._raw_free, limit)
-        self.pinned_pool = _BlockPool(self._raw_host_alloc, self._raw_host_free, min(limit, 1 << 30))
+        self.pinned_pool = _BlockPool(self._raw_host_alloc, self._raw_host_free, min(limit, 1 << 30),
+                                      fence=self._pinned_fence, wait=self._pinned_wait)
 
     # -- lifecycle -----------------------------------------------------------------------
     @property
@@ -327,6 +339,15 @@ class HipManager:
 
     def _raw_host_free(self, ptr):
         check(self.lib.hu_host_free(ptr), "hu_host_free")
+
+    def _pinned_fence(self, stream_key):
+        ev = self._new_event()
+        check(self.lib.hu_event_record(ev, stream_key), "hu_event_record")
+        return ev
+
+    def _pinned_wait(self, ev):
+        check(self.lib.hu_event_synchronize(ev), "hu_event_synchronize")
+        self._free_events.append(ev)
 
     def empty_cache(self):
         """Return every pooled block to the driver."""

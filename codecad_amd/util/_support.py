@@ -1,72 +1,93 @@
-"""Small host-side helpers: compensated summation, rounding, status printing, iterable helpers and
-duck-typed argument coercion (reference util/math.py, util/misc.py, util/types.py)."""
+"""Small host-side helpers behind `codecad_amd.util`: compensated summation, integer rounding, a timing
+context manager, iterable helpers and the coercions the shape constructors use for their arguments.
+The names are the reference's (`util/math.py`, `util/misc.py`, `util/types.py` are where its shape code looks
+them up); the implementations are this package's own."""
 import contextlib
-import math as _math
+import itertools
 import numbers
 import sys
 import time
 
 
 class KahanSummation:
-    """Compensated running sum; `s += x` / `s -= x`, result in `.result`."""
+    """Running sum with a carried low-order part (Neumaier's variant of compensated summation: the lost bits
+    of whichever operand is smaller are kept, so a term larger than the running sum is handled too).
+    `acc += x`, `acc -= x`; the sum is `acc.result`."""
 
-    def __init__(self):
-        self.result = 0
-        self.correction = 0
+    __slots__ = ("_high", "_low")
 
-    def __iadd__(self, x):
-        y = x - self.correction
-        t = self.result + y
-        self.correction = (t - self.result) - y
-        self.result = t
+    def __init__(self, start=0):
+        self._high = start
+        self._low = 0
+
+    @property
+    def result(self):
+        return self._high + self._low
+
+    def __iadd__(self, term):
+        total = self._high + term
+        if abs(self._high) >= abs(term):
+            self._low += (self._high - total) + term
+        else:
+            self._low += (term - total) + self._high
+        self._high = total
         return self
 
-    def __isub__(self, x):
-        self += -x
-        return self
+    def __isub__(self, term):
+        return self.__iadd__(-term)
 
 
-def round_up_to(x, multiple):
-    """Smallest multiple of `multiple` that is >= x."""
-    return ((x + multiple - 1) // multiple) * multiple
+def round_up_to(value, multiple):
+    """The smallest multiple of `multiple` not below `value` (integers)."""
+    return value + (-value) % multiple
 
 
-def round_up_to_power_of_2(x):
-    return 2 ** _math.ceil(_math.log2(x))
+def round_up_to_power_of_2(value):
+    """The smallest power of two not below `value` (exact for integers; the reference goes through log2)."""
+    if value != int(value):
+        power = 1.0
+        while power < value:
+            power *= 2
+        while power / 2 >= value:
+            power /= 2
+        return int(power) if power >= 1 else power
+    return 1 if value <= 1 else 1 << (int(value) - 1).bit_length()
 
 
-def clamp(v, lower, upper):
-    return max(lower, min(v, upper))
+def clamp(value, lower, upper):
+    if value < lower:
+        return lower
+    return upper if value > upper else value
 
 
 @contextlib.contextmanager
-def status_block(title):
-    """Print `title... <seconds> s` around a block."""
-    print(title, end="...")
-    sys.stdout.flush()
-    t0 = time.perf_counter()
+def status_block(title, stream=None):
+    """`title... 0.12 s` around a block of work."""
+    out = stream or sys.stdout
+    out.write("%s..." % title)
+    out.flush()
+    started = time.perf_counter()
     try:
         yield
     finally:
-        print(" {:0.2f} s".format(time.perf_counter() - t0))
+        out.write(" %.2f s\n" % (time.perf_counter() - started))
+        out.flush()
 
 
 class Concatenate:
-    """Re-iterable chain of iterables (used for variable-length tape parameters)."""
+    """Several iterables presented as one that can be walked repeatedly (a tape's variable-length parameters
+    are measured first and written afterwards)."""
 
-    def __init__(self, *iterables):
-        self._iterables = iterables
+    def __init__(self, *parts):
+        self._parts = parts
 
     def __iter__(self):
-        for it in self._iterables:
-            yield from it
+        return itertools.chain.from_iterable(self._parts)
 
 
-def at_most_one(iterable):
-    """True when at most one element is truthy."""
-    it = iter(iterable)
-    any(it)
-    return not any(it)
+def at_most_one(flags):
+    """No more than one of `flags` is true."""
+    return sum(1 for flag in flags if flag) <= 1
 
 
 def wrap_number_like(value):

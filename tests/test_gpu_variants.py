@@ -251,3 +251,44 @@ def test_union_distances_at_signed_zeros_and_nans(hip, specialise):
             b = oracle.grid_eval(nodes.make_program(plane), np.array([-2.0, -2.0, -2.0], np.float32), step, (n, n, n))[2:7, 8, 2:7, 3]
             assert np.all(a == 0) and not np.any(np.signbit(a)) and np.all(b == 0) and np.all(np.signbit(b))
             assert np.all(w == 0) and np.all(np.signbit(w))          # the minimum of +0 and -0 is -0
+
+
+@pytest.mark.gpu
+def test_external_tape_ending_in_load_return(hip):
+    """hu_tape_create accepts tapes our scheduler never emits.  One that ends `..., _load r; _return` returns the
+    LOADED value: the decoder must not fold that load into the return record (the per-tape code generator stops at
+    the return record and would drop it) -- interpreter, per-tape code and oracle agree."""
+    import numpy as np
+    import oracle
+    from conftest import same_bits
+    from codecad_amd import hip_util, grid_eval
+    from codecad_amd.nodes import node as nm
+    code = {name: spec[2] for name, spec in nm.Node.node_types.items()}
+
+    def word(op, reg=0):
+        return float(code[op] * 512 + reg)
+
+    # sphere(1) -> r1; box-ish rectangle -> last; then _load r1; _return  => the sphere, not the rectangle
+    tape = np.array([word("initial_transformation_to"), 0, 0, 0, 1, 0, 0, 0, word("_store", 0),
+                     word("sphere"), 1.0, word("_store", 1),
+                     word("_load", 0), word("rectangle"), 0.5, 0.25,
+                     word("_load", 1), word("_return")], dtype=np.float32)
+    n = 8
+    corner, step = np.array([-1.1, -0.9, -1.0], np.float32), np.float32(0.27)
+    want = oracle.grid_eval(tape, corner, step, (n, n, n))
+    sphere_only = oracle.grid_eval(tape[:12].tolist() + [word("_return")], corner, step, (n, n, n))
+    assert same_bits(want, sphere_only)
+    c4 = np.zeros(4, np.float32)
+    c4[:3] = corner
+    for specialise in (False, True):
+        t = hip_util.Tape(tape, policy="0")
+        if specialise:
+            t.specialize()
+        out = hip_util.Buffer(grid_eval.FLOAT4, (n, n, n))
+        hip.k.grid_eval((n, n, n), None, t, c4, step, out).wait()
+        assert same_bits(out.read().view(np.float32).reshape(n, n, n, 4), want), specialise
+        w = hip_util.Buffer(np.float32, (n, n, n))
+        hip.k.grid_eval_pymcubes((n, n, n), None, t, c4, step, w).wait()
+        assert same_bits(w.read().reshape(-1), oracle.grid_eval_pymcubes(tape, corner, step, (n, n, n)).reshape(-1)), specialise
+        out.release()
+        w.release()
