@@ -360,8 +360,9 @@ def main():
 
 def hbm_regime(lib, check, hip_util, cc, torch, np, dev, stream, n, evaluator):
     """The HBM-bound regime, measured in this run: the SAME dense kernels on tapes whose arithmetic fits under the
-    store stream (sphere: 3 instructions; sphere + box: 9; csg_example: 28), float4 (16 B/voxel) and float (4 B/voxel).
-    Each entry: algorithmic bytes / average kernel time (HIP events) against the 8 TB/s peak."""
+    store stream (sphere: 3 instructions; sphere + box: 9; csg_example: 28), float4 (16 B/voxel) and float (4 B/voxel),
+    with the tape interpreter and with per-tape code.  Each entry: algorithmic bytes / average kernel time (HIP
+    events around ten back-to-back launches, after three warm ones) against the 8 TB/s peak."""
     out = []
     fptr = ctypes.POINTER(ctypes.c_float)
     e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
@@ -369,34 +370,37 @@ def hbm_regime(lib, check, hip_util, cc, torch, np, dev, stream, n, evaluator):
     check(lib.hu_event_create(ctypes.byref(e1)), "event")
     buf = torch.empty((n, n, n, 4), dtype=torch.float32, device=dev)
     dims = (ctypes.c_uint32 * 3)(n, n, n)
+    reps = 10
     for name, shape in (("sphere", cc.shapes.sphere(130)), ("sphere_plus_box", cc.examples.sphere_plus_box()),
                         ("csg_example", cc.examples.csg_example())):
         host_tape = cc.nodes.make_program(shape)
-        t = hip_util.Tape(host_tape, policy="0")
-        if evaluator == "specialised":
-            t = t.specialize()
         bb = shape.bounding_box()
         extent = max(bb.b.x - bb.a.x, bb.b.y - bb.a.y, bb.b.z - bb.a.z)
         step = np.float32(extent / n)
         corner = np.array([bb.a.x + extent / n / 2, bb.a.y + extent / n / 2, bb.a.z + extent / n / 2, 0.0], dtype=np.float32)
-        for layout, bytes_per_voxel in ((0, 16), (1, 4)):
-            times = []
-            for i in range(7):
+        for mode in (["interpreter", "specialised"] if evaluator == "specialised" else ["interpreter"]):
+            t = hip_util.Tape(host_tape, policy="0")
+            if mode == "specialised":
+                t = t.specialize()
+            for layout, bytes_per_voxel in ((0, 16), (1, 4)):
+                def launch():
+                    check(lib.hu_grid_eval_slab(t.device_ptr, corner.ctypes.data_as(fptr), step, dims, 0, n, layout, buf.data_ptr(),
+                                                stream), "hu_grid_eval_slab")
+                for _ in range(3):
+                    launch()
                 check(lib.hu_event_record(e0, stream), "record")
-                check(lib.hu_grid_eval_slab(t.device_ptr, corner.ctypes.data_as(fptr), step, dims, 0, n, layout, buf.data_ptr(), stream),
-                      "hu_grid_eval_slab")
+                for _ in range(reps):
+                    launch()
                 check(lib.hu_event_record(e1, stream), "record")
                 check(lib.hu_event_synchronize(e1), "sync")
                 ms = ctypes.c_float()
                 check(lib.hu_event_elapsed_ms(e0, e1, ctypes.byref(ms)), "elapsed")
-                if i >= 2:
-                    times.append(ms.value)
-            k_ms = sum(times) / len(times)
-            gbs = n ** 3 * bytes_per_voxel / (k_ms * 1e-3) / 1e9
-            out.append({"tape": name, "tape_instructions": t.n_instructions,
-                        "kernel": "k_grid_eval<%s, %d, 2>" % ("JitEval" if evaluator == "specialised" else "InterpEval", layout),
-                        "bytes": n ** 3 * bytes_per_voxel, "ms": round(k_ms, 4), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "gvoxels_per_s": round(n ** 3 / k_ms / 1e6, 1)})
+                k_ms = ms.value / reps
+                gbs = n ** 3 * bytes_per_voxel / (k_ms * 1e-3) / 1e9
+                kernel = "k_grid_eval<%s, %d, 2>" % ("JitEval" if mode == "specialised" else "InterpEval<%s>" % ("true" if layout else "false"), layout)
+                out.append({"tape": name, "tape_instructions": t.n_instructions, "evaluator": mode, "kernel": kernel,
+                            "bytes": n ** 3 * bytes_per_voxel, "ms": round(k_ms, 4), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "gvoxels_per_s": round(n ** 3 / k_ms / 1e6, 1)})
     return out
 
 

@@ -27,6 +27,7 @@
 #include "kernels.hpp"
 #include "mesh_kernels.hpp"
 #include "tape.hpp"
+#include "specialise.hpp"
 
 using sdf::Rec;
 using namespace sdfk;
@@ -136,7 +137,7 @@ struct hu_tape_s {
     int n_slots = 0;             // float4 slots of the full program after renaming
     int n_point_slots = 0, n_result_slots = 0;  // distance-only program
     int flags = 0;
-    std::vector<Rec> recs_host;  // full program, kept for hu_tape_specialize
+    sdf::SpecProgram program;    // both programs on the host, kept for hu_tape_specialize (specialise.hpp)
     struct SpecKernels* spec = nullptr;
 };
 
@@ -231,6 +232,14 @@ int ensure_attrs()
     return HU_OK;
 }
 
+// Dense launches over compact 4 x 4 x 8 bricks per wavefront (kernels.hpp k_grid_eval) when the slab's extents
+// allow it without ragged bricks; the same number of workgroups either way.  HU_BRICKS=0: always runs along z.
+uint32_t brick_tiles(uint32_t nx, uint32_t sy, uint32_t sz)
+{
+    static const bool off = [] { const char* e = getenv("HU_BRICKS"); return e && e[0] == '0'; }();
+    return (!off && nx % 4u == 0u && sy % 4u == 0u && sz % 32u == 0u) ? 1u : 0u;
+}
+
 int check_dims(const uint32_t dims[3], uint64_t& cells)
 {
     if (!dims) return fail(HU_ERR_BAD_ARG, "dims is NULL");
@@ -260,6 +269,7 @@ struct SpecKernels {
     hipFunction_t blocks[2] = {nullptr, nullptr};
     hipFunction_t classify[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [MASS][BATCH]
     hipFunction_t ray_caster = nullptr, bitmap = nullptr;
+    bool deferred = false;   // the module was generated with deferred directions (specialise.hpp): dense launches use bricks
 };
 
 namespace {
@@ -267,31 +277,25 @@ namespace {
 constexpr int kSpecVoxelsPerLane = 2;
 constexpr uint32_t kSpecBlock = 256;
 
-std::string generate_source(const hu_tape_s* t)
+// HU_DEFER_DIRECTIONS=0 keeps the plain straight-line form of every tape (measurements, bisecting)
+bool defer_directions()
 {
-    std::ostringstream o;
-    o << "#include \"kernels.hpp\"\nnamespace sdfk {\n"
-      << "template <class T> __device__ __forceinline__ sdf::V4<T> tape_eval(T px, T py, T pz, const float* __restrict__ extra)\n{\n"
-      << "    using namespace sdf;\n    RegsV<T, " << t->n_slots << "> regs;\n"
-      << "    V4<T> last = v4<T>(bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f));\n";
-    char buf[32];
-    for (const Rec& r : t->recs_host) {
-        if ((r.hdr & 0xffu) == sdf::OP_RETURN) break;
-        std::snprintf(buf, sizeof buf, "0x%08xu", r.hdr);
-        o << "    { const Rec r = {" << buf << ", {";
-        for (int i = 0; i < SDF_REC_DWORDS - 1; ++i) {
-            uint32_t bits;
-            std::memcpy(&bits, &r.p[i], 4);
-            std::snprintf(buf, sizeof buf, "0x%08xu", bits);
-            o << (i ? ", " : "") << "__builtin_bit_cast(float, " << buf << ")";
-        }
-        o << "}}; exec_one<T, false, decltype(regs), " << (r.hdr & 0xffu) << ">(r, last, extra, px, py, pz, regs); }\n";
-    }
-    o << "    return last;\n}\n"
-      << "struct JitEval {\n    const float* extra;\n"
-      << "    template <class T> __device__ __forceinline__ sdf::V4<T> operator()(T px, T py, T pz, void*) const\n"
-      << "    { return tape_eval<T>(px, py, pz, extra); }\n};\n}  // namespace sdfk\n";
-    return o.str();
+    static const bool off = [] { const char* e = getenv("HU_DEFER_DIRECTIONS"); return e && e[0] == '0'; }();
+    return !off;
+}
+
+std::string generate_source(const hu_tape_s* t, bool* deferred = nullptr)
+{
+    return sdf::specialised_source(t->program, defer_directions(), deferred);
+}
+
+void keep_programs(hu_tape_s* t, const sdf::DecodedTape& d)
+{
+    t->program.full = d.recs;
+    t->program.dist = d.recs_do;
+    t->program.n_slots = d.n_slots;
+    t->program.n_point_slots = d.n_point_slots;
+    t->program.n_result_slots = d.n_result_slots;
 }
 
 struct SpecEval { const float* extra; };  // same layout as the generated sdfk::JitEval
@@ -478,7 +482,7 @@ int hu_tape_create(const float* tape, size_t n, hu_tape* out)
     t->n_point_slots = d.n_point_slots;
     t->n_result_slots = d.n_result_slots;
     t->flags = d.direction_feeds_distance ? 1 : 0;
-    t->recs_host = d.recs;
+    keep_programs(t, d);
     hipError_t e = hipMalloc((void**)&t->recs_dev, d.recs.size() * sizeof(Rec));
     if (e == hipSuccess && !d.recs_do.empty()) {
         e = hipMalloc((void**)&t->recs_do_dev, d.recs_do.size() * sizeof(Rec));
@@ -542,7 +546,11 @@ int hu_grid_eval_slab(hu_tape t, const float corner[4], float step, const uint32
             const uint32_t nx = (x_count - done < max_x) ? (x_count - done) : max_x;
             uint32_t n_cells = (uint32_t)(nx * plane), xs = x0 + done;
             void* o = (layout == 0) ? (void*)(static_cast<float4*>(out_dev) + (size_t)done * plane) : out_dev;
-            void* args[] = {&ev, &cx, &cy, &cz, &step, &sx, &sy, &sz, &xs, &n_cells, &o};
+            // bricks pay where a wavefront's work depends on how many primitives win in it (deferred directions);
+            // a tape that is bound by its store stream keeps the runs along z (2 KiB contiguous per wavefront:
+            // sphere, 512^3 float4: 0.34 ms in runs, 0.42 ms in bricks)
+            uint32_t tiles = t->spec->deferred ? brick_tiles(nx, dims[1], dims[2]) : 0u;
+            void* args[] = {&ev, &cx, &cy, &cz, &step, &sx, &sy, &sz, &xs, &n_cells, &tiles, &o};
             const uint32_t per_block = kSpecBlock * kSpecVoxelsPerLane;
             HU_HIP(hipModuleLaunchKernel(t->spec->dense[layout], (n_cells + per_block - 1) / per_block, 1, 1, kSpecBlock, 1, 1,
                                          0, (hipStream_t)stream, args, nullptr));
@@ -564,7 +572,8 @@ int hu_grid_eval_slab(hu_tape t, const float corner[4], float step, const uint32
 #define HU_LAUNCH_DENSE(L, D, NV)                                                                                  \
     hipLaunchKernelGGL((k_grid_eval<InterpEval<D>, L, NV>), dim3(blocks), dim3(ls.block), ls.lds, (hipStream_t)stream, \
                        (InterpEval<D>{ls.prog, t->extra_dev, ls.n4}), corner[0], corner[1], corner[2], step, dims[0],  \
-                       make_dim(dims[1]), make_dim(dims[2]), x0 + done, n_cells, o)
+                       make_dim(dims[1]), make_dim(dims[2]), x0 + done, n_cells,                                       \
+                       0u /* the interpreter evaluates every primitive anyway: runs along z */, o)
         const bool d_only = layout == 1 && distance_only(t);
         if (ls.voxels_per_lane == 2) {
             if (layout == 0) HU_LAUNCH_DENSE(0, false, 2);
@@ -1123,7 +1132,7 @@ int hu_tape_compile_cached(const float* tape, size_t n, const char* include_dir,
     if (!err.empty()) return fail(HU_ERR_BAD_TAPE, "malformed tape: " + err);
     hu_tape_s t;  // host fields only
     t.n_slots = d.n_slots;
-    t.recs_host = d.recs;
+    keep_programs(&t, d);
     SpecImage img;
     int rc;
     if ((rc = specialised_image(generate_source(&t), include_dir, cache_dir, false, img, from_cache))) return rc;
@@ -1141,7 +1150,8 @@ int hu_tape_specialize_cached(hu_tape t, const char* include_dir, const char* ca
     if (from_cache) *from_cache = 0;
     if (!t || !include_dir) return fail(HU_ERR_BAD_ARG, "NULL argument");
     if (t->spec) return HU_OK;
-    const std::string src = generate_source(t);
+    bool deferred = false;
+    const std::string src = generate_source(t, &deferred);
     int cached = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         SpecImage img;
@@ -1157,6 +1167,7 @@ int hu_tape_specialize_cached(hu_tape t, const char* include_dir, const char* ca
         for (int i = 0; i < kSpecKernelCount && e == hipSuccess; ++i)
             e = hipModuleGetFunction(slots[i], k->module, img.lowered[i].c_str());
         if (e == hipSuccess) {
+            k->deferred = deferred;
             t->spec = k;
             if (from_cache) *from_cache = cached;
             return HU_OK;
@@ -1359,7 +1370,7 @@ int hu_tape_source(const float* tape, size_t n, char* buf, size_t capacity, size
     if (!err.empty()) return fail(HU_ERR_BAD_TAPE, "malformed tape: " + err);
     hu_tape_s t;  // host fields only: nothing touches a device
     t.n_slots = d.n_slots;
-    t.recs_host = d.recs;
+    keep_programs(&t, d);
     const std::string src = generate_source(&t);
     *needed = src.size() + 1;
     if (capacity >= src.size() + 1) std::memcpy(buf, src.c_str(), src.size() + 1);

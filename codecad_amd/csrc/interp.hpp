@@ -71,6 +71,9 @@ __device__ __forceinline__ m1 operator&(m1 a, m1 b) { return m1{a.v && b.v, a.w 
 __device__ __forceinline__ m1 operator|(m1 a, m1 b) { return m1{a.v || b.v, a.w | b.w}; }
 __device__ __forceinline__ m2 operator&(m2 a, m2 b) { return m2{a.x && b.x, a.y && b.y, a.wx & b.wx, a.wy & b.wy}; }
 __device__ __forceinline__ m2 operator|(m2 a, m2 b) { return m2{a.x || b.x, a.y || b.y, a.wx | b.wx, a.wy | b.wy}; }
+// complement, and the masks of "all lanes" -- for the path masks of deferred directions (hip_util.hip generate_source)
+__device__ __forceinline__ m1 operator~(m1 a) { return m1{!a.v, ~a.w}; }
+__device__ __forceinline__ m2 operator~(m2 a) { return m2{!a.x, !a.y, ~a.wx, ~a.wy}; }
 __device__ __forceinline__ m1 gt(float a, float b) { return mk(a > b); }
 __device__ __forceinline__ m1 lt(float a, float b) { return mk(a < b); }
 __device__ __forceinline__ m1 ge(float a, float b) { return mk(a >= b); }
@@ -630,6 +633,35 @@ template <class T, int SLOTS> struct RegsV {
     __device__ __forceinline__ T load_res(uint32_t r) const { return v[r].w; }
     __device__ __forceinline__ void store_res(uint32_t r, T w) { v[r].w = w; }
 };
+
+// Register file of specialised DISTANCE-ONLY code: the distance-only program numbers its point slots and its
+// result slots separately (tape.hpp allocate_slots), so they are two arrays here; both dissolve into VGPRs.
+template <class T, int POINTS, int RESULTS> struct RegsDO {
+    V4<T> pt[POINTS > 0 ? POINTS : 1];
+    T res[RESULTS > 0 ? RESULTS : 1];
+    __device__ __forceinline__ V4<T> load(uint32_t r) const { return pt[r]; }
+    __device__ __forceinline__ void store(uint32_t r, const V4<T>& x) { pt[r] = x; }
+    __device__ __forceinline__ T load_x(uint32_t r) const { return pt[r].x; }
+    __device__ __forceinline__ T load_z(uint32_t r) const { return pt[r].z; }
+    __device__ __forceinline__ T load_res(uint32_t r) const { return res[r]; }
+    __device__ __forceinline__ void store_res(uint32_t r, T w) { res[r] = w; }
+};
+// One operand, whatever slot the record names: the second phase of deferred directions re-executes single
+// records along the path of the winning primitive and hands each its register operand here.
+template <class T> struct RegsOne {
+    V4<T> v;
+    __device__ __forceinline__ V4<T> load(uint32_t) const { return v; }
+    __device__ __forceinline__ void store(uint32_t, const V4<T>&) {}
+    __device__ __forceinline__ T load_x(uint32_t) const { return v.x; }
+    __device__ __forceinline__ T load_z(uint32_t) const { return v.z; }
+    __device__ __forceinline__ T load_res(uint32_t) const { return v.w; }
+    __device__ __forceinline__ void store_res(uint32_t, T) {}
+};
+// An opaque copy: the compiler must not recognise values derived from it as the ones it already has.  The
+// second phase recomputes a primitive's local coordinates from the sample point; without this, value numbering
+// would instead keep EVERY primitive's coordinates of the first phase alive across it (sponge(4): 78 registers).
+__device__ __forceinline__ float opaque(float x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ f2 opaque(f2 x) { asm volatile("" : "+v"(x)); return x; }
 
 // ---------------------------------------------------------------------------------------
 // The interpreter.  `prog` and `extra` are wave-uniform.

@@ -36,6 +36,9 @@ template <bool DO> struct InterpEval {
         sdf::Regs<T> regs(lds, threadIdx.x, blockDim.x, n4);
         return sdf::run_tape<T, DO>(prog, extra, px, py, pz, regs);
     }
+    // the distance alone (kernels that never look at the direction ask for this: per-tape code answers it
+    // without its direction phase)
+    template <class T> __device__ __forceinline__ T dist(T px, T py, T pz, void* lds) const { return (*this)(px, py, pz, lds).w; }
 };
 
 // ------------------------------------------------------------------------------------------
@@ -66,34 +69,66 @@ __device__ __forceinline__ uint32_t div(uint32_t x, Dim d)
     return d.n == 1u ? x : q;  // kernel-uniform select
 }
 
+// Grid stores.  Non-temporal stores (-DSDF_NT_STORES=1) were measured and are OFF: a 512^3 float4 grid of a
+// store-bound tape takes 1.03 ms with `global_store_dwordx4 ... nt` (2.1 TB/s) against 0.40 ms with plain stores.
+#ifndef SDF_NT_STORES
+#define SDF_NT_STORES 0
+#endif
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_voxel(float4* p, float4 v)
+{
+#if SDF_NT_STORES
+    f4v t;
+    t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<f4v*>(p));
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void store_voxel(float* p, float v)
+{
+#if SDF_NT_STORES
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 // N = voxels per lane (1: T = float, 2: T = packed float2, see interp.hpp)
 template <int N> struct Pack { using T = float; };
 template <> struct Pack<2> { using T = sdf::f2; };
 __device__ __forceinline__ float pack(const float (&v)[1]) { return v[0]; }
 __device__ __forceinline__ sdf::f2 pack(const float (&v)[2]) { return sdf::make_f2(v[0], v[1]); }
 
-// The N consecutive cells (z fastest) a lane owns, starting at linear index lin0 of a grid
-// with `n_cells` cells: coordinates by one divide for the first cell and carries for the rest.
+// The N cells a lane owns of a grid with `n_cells` cells (z fastest): linear indices lin0, lin0 + stride, ...
+// stride 1 (neighbours along z; the classification kernels): coordinates by one divide for the first cell and
+// carries for the rest.  stride 64 (the grid kernels): CONSECUTIVE LANES own consecutive cells, so every store
+// instruction of a wavefront writes one contiguous run (64 x 16 B = eight full 128-byte lines for a float4 grid)
+// instead of every other 16 bytes of a run twice as long; each cell gets its own divide (5 instructions).
 template <int N> struct Cells {
     uint32_t x[N], y[N], z[N];
     bool active[N];
-    __device__ __forceinline__ Cells(uint32_t lin0, uint32_t n_cells, Dim dy, Dim dz)
+    __device__ __forceinline__ Cells(uint32_t lin0, uint32_t n_cells, Dim dy, Dim dz, uint32_t stride = 1u)
     {
         const uint32_t sy = dy.n, sz = dz.n;
-        active[0] = lin0 < n_cells;
-        const uint32_t l = active[0] ? lin0 : 0u;  // idle tail lanes follow the (uniform) tape harmlessly
-        const uint32_t t = div(l, dz);
-        z[0] = l - t * sz;
-        x[0] = div(t, dy);
-        y[0] = t - x[0] * sy;
 #pragma unroll
-        for (int i = 1; i < N; ++i) {
-            active[i] = active[0] && (lin0 + i < n_cells);
-            const bool wrap_z = z[i - 1] + 1u == sz;
-            const bool wrap_y = wrap_z && (y[i - 1] + 1u == sy);
-            z[i] = wrap_z ? 0u : z[i - 1] + 1u;
-            y[i] = wrap_y ? 0u : (wrap_z ? y[i - 1] + 1u : y[i - 1]);
-            x[i] = wrap_y ? x[i - 1] + 1u : x[i - 1];
+        for (int i = 0; i < N; ++i) {
+            if (i == 0 || stride != 1u) {
+                const uint32_t lin = lin0 + (uint32_t)i * stride;
+                active[i] = lin < n_cells;
+                const uint32_t l = active[i] ? lin : 0u;  // idle tail lanes follow the (uniform) tape harmlessly
+                const uint32_t t = div(l, dz);
+                z[i] = l - t * sz;
+                x[i] = div(t, dy);
+                y[i] = t - x[i] * sy;
+            } else {
+                active[i] = active[0] && (lin0 + i < n_cells);
+                const bool wrap_z = z[i - 1] + 1u == sz;
+                const bool wrap_y = wrap_z && (y[i - 1] + 1u == sy);
+                z[i] = wrap_z ? 0u : z[i - 1] + 1u;
+                y[i] = wrap_y ? 0u : (wrap_z ? y[i - 1] + 1u : y[i - 1]);
+                x[i] = wrap_y ? x[i - 1] + 1u : x[i - 1];
+            }
         }
     }
     __device__ __forceinline__ typename Pack<N>::T position(float corner, float step, const uint32_t (&c)[N], uint32_t c0 = 0) const
@@ -104,6 +139,12 @@ template <int N> struct Cells {
         return pack(v);
     }
 };
+// linear index of a lane's first grid cell and the stride to its next one: a wavefront owns 64 * N consecutive cells
+template <int N> __device__ __forceinline__ uint32_t first_cell(uint32_t block)
+{
+    return (block * blockDim.x + (threadIdx.x & ~63u)) * N + (threadIdx.x & 63u);
+}
+constexpr uint32_t kLaneStride = 64u;
 
 // Workgroup-aggregated stream compaction of N flags per lane: 64-lane ballots + popcount
 // prefixes inside each wavefront, wave totals combined through LDS, ONE global atomic per
@@ -157,28 +198,67 @@ __device__ __forceinline__ uint32_t wave_sum_to_last_lane(uint32_t v)
 // ------------------------------------------------------------------------------------------
 // dense grid evaluation
 // ------------------------------------------------------------------------------------------
+// `tiles` != 0 (the launcher sets it when the slab's extents allow: sx % 4 == 0, sy % 4 == 0, sz % 32 == 0, two voxels
+// per lane): a wavefront covers a compact 4 x 4 x 8 brick of voxels (a lane: two voxels two x planes apart) and a workgroup
+// four bricks along z, instead of a run of 128 (512) cells along z.  What that buys: values that are uniform over a
+// wavefront stay uniform far more often -- which primitive of a CSG tree is nearest (sponge(4) at 512^3: 1.8
+// distinct winners per brick against 3.1 per run; per-tape code computes the direction once per DISTINCT winner,
+// hip_util.hip generate_source), and whether any lane is in the corner region of a rectangle.  Stores: a
+// workgroup writes 512 contiguous bytes per (x, y) row of its bricks.
 template <class E, int LAYOUT, int N>
 __global__ void __launch_bounds__(256) SDF_KERNEL_ATTRS
 k_grid_eval(const E ev, float cx, float cy, float cz, float step, uint32_t sx, Dim dy, Dim dz, uint32_t x0,
-            uint32_t n_cells, void* __restrict__ out)
+            uint32_t n_cells, uint32_t tiles, void* __restrict__ out)
 {
     const uint32_t sy = dy.n, sz = dz.n;
     using T = typename Pack<N>::T;
     extern __shared__ float4 lds[];
-    const uint32_t lin0 = (blockIdx.x * blockDim.x + threadIdx.x) * N;
-    const Cells<N> c(lin0, n_cells, dy, dz);
-    const sdf::V4<T> r = ev(c.position(cx, step, c.x, x0), c.position(cy, step, c.y), c.position(cz, step, c.z), lds);
+    if (N == 2 && tiles) {
+        // blockIdx.x -> (bx, by, bz), bz fastest; tiles = bricks-of-32 along z, dz/dy constants divide by tz and ty
+        const uint32_t tz = sz >> 5, ty = sy >> 2;
+        const uint32_t bz = blockIdx.x % tz, t = blockIdx.x / tz, by = t % ty, bx = t / ty;
+        // lane -> (z: 8, y: 4, x: 2), its two voxels two x planes apart: a store instruction writes 128 contiguous
+        // bytes (eight float4 along z) per (x, y) row of the brick
+        const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+        const uint32_t x = bx * 4u + (lane >> 5), y = by * 4u + ((lane >> 3) & 3u);
+        const uint32_t z = bz * 32u + wave * 8u + (lane & 7u);
+        float xs[N];
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-        if (!c.active[i]) continue;
+        for (int i = 0; i < N; ++i) xs[i] = sample(cx, step, x0 + x + 2u * i);
+        const T px = pack(xs), py = (T)(sample(cy, step, y)), pz = (T)(sample(cz, step, z));
         if (LAYOUT == 0) {
-            // INDEX3 = z + sz*(y + sy*x) (cl_util/indexing.h:4): inside a slab this is the linear
-            // cell index; 64 lanes store 1 KiB (N = 2: 2 KiB) contiguous.
-            static_cast<float4*>(out)[lin0 + i] = sdf::voxel(r, i);
+            const sdf::V4<T> r = ev(px, py, pz, lds);
+            float4* o = static_cast<float4*>(out) + ((size_t)z + (size_t)sz * ((size_t)y + (size_t)sy * x));
+#pragma unroll
+            for (int i = 0; i < N; ++i) store_voxel(o + (size_t)i * 2u * sy * sz, sdf::voxel(r, i));
         } else {
+            const T w = ev.dist(px, py, pz, lds);
+            float* o = static_cast<float*>(out) + ((size_t)z + ((size_t)(x0 + x) + (size_t)(sy - 1u - y) * sx) * sz);
+#pragma unroll
+            for (int i = 0; i < N; ++i) store_voxel(o + (size_t)i * 2u * sz, sdf::get(w, i));
+        }
+        return;
+    }
+    const uint32_t lin0 = first_cell<N>(blockIdx.x);
+    const Cells<N> c(lin0, n_cells, dy, dz, kLaneStride);
+    const T px = c.position(cx, step, c.x, x0), py = c.position(cy, step, c.y), pz = c.position(cz, step, c.z);
+    if (LAYOUT == 0) {
+        const sdf::V4<T> r = ev(px, py, pz, lds);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            if (!c.active[i]) continue;
+            // INDEX3 = z + sz*(y + sy*x) (cl_util/indexing.h:4): inside a slab this is the linear
+            // cell index; each store instruction of a wavefront writes 1 KiB contiguous.
+            store_voxel(static_cast<float4*>(out) + lin0 + (uint32_t)i * kLaneStride, sdf::voxel(r, i));
+        }
+    } else {
+        const T w = ev.dist(px, py, pz, lds);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            if (!c.active[i]) continue;
             // grid_eval.cl:18: z + (x + (sy-1-y)*sx)*sz; z-fastest so a wave stores contiguous runs
             const size_t idx = (size_t)c.z[i] + ((size_t)(x0 + c.x[i]) + (size_t)(sy - 1u - c.y[i]) * sx) * sz;
-            static_cast<float*>(out)[idx] = sdf::get(r.w, i);
+            store_voxel(static_cast<float*>(out) + idx, sdf::get(w, i));
         }
     }
 }
@@ -202,18 +282,21 @@ k_grid_eval_blocks(const E ev, const int4* __restrict__ blocks, const uint32_t* 
     const float cx = (float)((double)ic.x * res + ox);
     const float cy = (float)((double)ic.y * res + oy);
     const float cz = (float)((double)ic.z * res + oz);
-    const uint32_t lin0 = (chunk * blockDim.x + threadIdx.x) * N;
-    const Cells<N> c(lin0, cells, dy, dz);
-    const sdf::V4<T> r = ev(c.position(cx, step, c.x), c.position(cy, step, c.y), c.position(cz, step, c.z), lds);
+    const uint32_t lin0 = first_cell<N>(chunk);
+    const Cells<N> c(lin0, cells, dy, dz, kLaneStride);
+    const T px = c.position(cx, step, c.x), py = c.position(cy, step, c.y), pz = c.position(cz, step, c.z);
     const size_t base = (size_t)b * cells;
+    if (LAYOUT == 0) {
+        const sdf::V4<T> r = ev(px, py, pz, lds);
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-        if (!c.active[i]) continue;
-        if (LAYOUT == 0)
-            static_cast<float4*>(out)[base + lin0 + i] = sdf::voxel(r, i);
-        else
-            static_cast<float*>(out)[base + (size_t)c.z[i] + ((size_t)c.x[i] + (size_t)(sy - 1u - c.y[i]) * sx) * sz] =
-                sdf::get(r.w, i);
+        for (int i = 0; i < N; ++i)
+            if (c.active[i]) store_voxel(static_cast<float4*>(out) + base + lin0 + (uint32_t)i * kLaneStride, sdf::voxel(r, i));
+    } else {
+        const T w = ev.dist(px, py, pz, lds);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            if (c.active[i])
+                store_voxel(static_cast<float*>(out) + base + (size_t)c.z[i] + ((size_t)c.x[i] + (size_t)(sy - 1u - c.y[i]) * sx) * sz, sdf::get(w, i));
     }
 }
 
@@ -276,7 +359,7 @@ __global__ void __launch_bounds__(256) k_classify(const E ev, const ClassifyArgs
 
     const uint32_t lin0 = (chunk * blockDim.x + threadIdx.x) * N;
     const Cells<N> c(lin0, cells, a.dy, a.dz);
-    const T w = ev(c.position(cx, a.step, c.x), c.position(cy, a.step, c.y), c.position(cz, a.step, c.z), lds).w;
+    const T w = ev.dist(c.position(cx, a.step, c.x), c.position(cy, a.step, c.y), c.position(cz, a.step, c.z), lds);
 
     bool ambiguous[N];
     if (MASS) {
@@ -608,7 +691,7 @@ k_bitmap(const E ev, float ox, float oy, float oz, float step_size, uint32_t w, 
     const uint32_t lin = blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = lin < w * h;
     const uint32_t x = active ? lin / h : 0u, y = active ? lin % h : 0u;
-    const float v = ev(ox + step_size * (float)x, oy + step_size * (float)(h - y - 1u), oz + step_size * 0.0f, lds).w;
+    const float v = ev.dist(ox + step_size * (float)x, oy + step_size * (float)(h - y - 1u), oz + step_size * 0.0f, lds);
     if (!active) return;
     const float t = (v < 0.0f) ? 0.0f : 1.0f;  // step(0, v)
     store_rgb(out + (size_t)lin * 3, mk3(mixf(125.0f, 230.0f, t), mixf(179.0f, 230.0f, t), mixf(0.0f, 241.0f, t)));

@@ -37,7 +37,7 @@ def main():
         tape = np.array({s["name"]: s for s in shapes}[name]["tape_u32"], dtype=np.uint32).view(np.float32)
     out = "/tmp/spec_isa"
     os.makedirs(out, exist_ok=True)
-    src = source_of(tape) + "\ntemplate __global__ void sdfk::k_grid_eval<sdfk::JitEval, %d, 2>(const sdfk::JitEval, float, float, float, float, uint32_t, sdfk::Dim, sdfk::Dim, uint32_t, uint32_t, void*);\n" % layout
+    src = source_of(tape) + "\ntemplate __global__ void sdfk::k_grid_eval<sdfk::JitEval, %d, 2>(const sdfk::JitEval, float, float, float, float, uint32_t, sdfk::Dim, sdfk::Dim, uint32_t, uint32_t, uint32_t, void*);\n" % layout
     open(out + "/spec.hip", "w").write(src)
     extra = [a for a in sys.argv[3:]]
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I", ROOT + "/codecad_amd/csrc",
