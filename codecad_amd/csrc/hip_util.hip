@@ -165,7 +165,11 @@ int launch_shape(const hu_tape_s* t, LaunchShape& ls, bool distance_only_kernel,
     static const int forced = [] { const char* e = getenv("HU_VOXELS_PER_LANE"); return e ? atoi(e) : 0; }();
     const size_t lane_bytes = distance_only_kernel ? (size_t)t->n_point_slots * 16 + (size_t)t->n_result_slots * 4
                                                    : (size_t)t->n_slots * 16;
-    const int by_rule = (forced == 1 || forced == 2) ? forced : ((lane_bytes * 2 * 256 <= 48 * 1024) ? 2 : 1);
+    // (with fused leaf records the scalar work per voxel fell and latency -- waves per SIMD -- took over for the full
+    // program: sponge(4), 6 float4 slots: 3.17 ms with one voxel per lane (24 KiB per workgroup, 6 workgroups per
+    // CU) against 3.74 ms with two (48 KiB, 3); csg_example, 3 slots: 0.96 against 1.06 ms the other way round)
+    const size_t two_voxel_limit = distance_only_kernel ? 48 * 1024 : 32 * 1024;
+    const int by_rule = (forced == 1 || forced == 2) ? forced : ((lane_bytes * 2 * 256 <= two_voxel_limit) ? 2 : 1);
     const int wanted = by_rule < max_voxels_per_lane ? by_rule : max_voxels_per_lane;
     const Rec* prog = distance_only_kernel ? t->recs_do_dev : t->recs_dev;
     ls.prog = prog;
@@ -483,13 +487,14 @@ int hu_tape_create(const float* tape, size_t n, hu_tape* out)
     t->n_result_slots = d.n_result_slots;
     t->flags = d.direction_feeds_distance ? 1 : 0;
     keep_programs(t, d);
-    hipError_t e = hipMalloc((void**)&t->recs_dev, d.recs.size() * sizeof(Rec));
-    if (e == hipSuccess && !d.recs_do.empty()) {
-        e = hipMalloc((void**)&t->recs_do_dev, d.recs_do.size() * sizeof(Rec));
-        if (e == hipSuccess) e = hipMemcpy(t->recs_do_dev, d.recs_do.data(), d.recs_do.size() * sizeof(Rec), hipMemcpyHostToDevice);
+    // the device holds the interpreter's (fused) programs; per-tape code is generated from the unfused ones
+    hipError_t e = hipMalloc((void**)&t->recs_dev, d.fused.size() * sizeof(Rec));
+    if (e == hipSuccess && !d.fused_do.empty()) {
+        e = hipMalloc((void**)&t->recs_do_dev, d.fused_do.size() * sizeof(Rec));
+        if (e == hipSuccess) e = hipMemcpy(t->recs_do_dev, d.fused_do.data(), d.fused_do.size() * sizeof(Rec), hipMemcpyHostToDevice);
     }
     if (e == hipSuccess) e = hipMalloc((void**)&t->extra_dev, d.extra.size() * sizeof(float));
-    if (e == hipSuccess) e = hipMemcpy(t->recs_dev, d.recs.data(), d.recs.size() * sizeof(Rec), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(t->recs_dev, d.fused.data(), d.fused.size() * sizeof(Rec), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(t->extra_dev, d.extra.data(), d.extra.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         (void)hipFree(t->recs_dev);
@@ -1374,6 +1379,51 @@ int hu_tape_source(const float* tape, size_t n, char* buf, size_t capacity, size
     const std::string src = generate_source(&t);
     *needed = src.size() + 1;
     if (capacity >= src.size() + 1) std::memcpy(buf, src.c_str(), src.size() + 1);
+    return HU_OK;
+}
+
+int hu_tape_listing(const float* tape, size_t n, int which, char* buf, size_t capacity, size_t* needed)
+{
+    if (!tape || !needed || (!buf && capacity)) return fail(HU_ERR_BAD_ARG, "NULL argument");
+    if (which < 0 || which > 3) return fail(HU_ERR_BAD_ARG, "which must be 0..3");
+    sdf::DecodedTape d;
+    const std::string err = sdf::decode_tape(tape, n, d);
+    if (!err.empty()) return fail(HU_ERR_BAD_TAPE, "malformed tape: " + err);
+    const std::vector<Rec>& prog = which == 0 ? d.recs : which == 1 ? d.recs_do : which == 2 ? d.fused : d.fused_do;
+    static const char* const internal[] = {"FROM_SCALE", "FROM_X", "FROM_Y", "FROM_Z", "POINT", "TO_SCALE", "TO_X", "TO_Y", "TO_Z",
+                                           "TO_ROW_X", "TO_ROWS_YZ", "FROM_MATRIX", "INIT_ROW_X", "INIT_ROWS_YZ", "LEAF"};
+    static const char* const kinds[] = {"-", "scale", "x", "y", "z"};
+    static const char* const prims[] = {"rectangle", "circle", "sphere", "half_space"};
+    static const char* const combs[] = {"", "union", "intersection", "subtraction"};
+    std::ostringstream o;
+    for (const Rec& r : prog) {
+        const uint32_t op = r.hdr & 0xffu, slot = (r.hdr >> 8) & 0xffffu;
+        uint32_t fold;
+        std::memcpy(&fold, &r.p[sdf::kFoldParam], 4);
+        if (fold & sdf::kFoldLoad) o << "[load " << (fold & 0xffu) << ((fold & sdf::kFoldLoadResult) ? "r" : "") << "] ";
+        o << (op < sdf::OP_COUNT ? sdf::op_info(op).name : internal[op - sdf::OP_COUNT]);
+        if (op == sdf::OPX_LEAF) {
+            uint32_t c;
+            std::memcpy(&c, &r.p[sdf::kLeafControl], 4);
+            o << "(" << ((c & sdf::kLeafSample) ? "sample " : "") << "to:" << kinds[(c >> sdf::kLeafToShift) & 7u]
+              << ((c & sdf::kLeafMidStore) ? " store-point:" + std::to_string(slot) : std::string()) << " "
+              << prims[(c >> sdf::kLeafPrimShift) & 7u] << ((c & sdf::kLeafExtrusion) ? " extrusion" : "")
+              << " from:" << kinds[(c >> sdf::kLeafFromShift) & 7u];
+            for (int k = 0; k < 2; ++k) {
+                const uint32_t cb = c >> (k == 0 ? sdf::kLeafComb1Shift : sdf::kLeafComb2Shift);
+                if (cb & 3u) o << " " << combs[cb & 3u] << ":" << ((cb >> 2) & 0xffu);
+            }
+            o << ")";
+        } else if (sdf::rec_arity(op) == 2 || op == sdf::OP_STORE || op == sdf::OP_LOAD) {
+            o << " " << slot << ((r.hdr & sdf::kResultKind) ? "r" : "");
+        }
+        if (fold & sdf::kFoldStore) o << " [store " << ((fold >> 16) & 0xffu) << ((fold & sdf::kFoldStoreResult) ? "r" : "") << "]";
+        o << "\n";
+        if (op == sdf::OP_RETURN) break;
+    }
+    const std::string text = o.str();
+    *needed = text.size() + 1;
+    if (capacity >= text.size() + 1) std::memcpy(buf, text.c_str(), text.size() + 1);
     return HU_OK;
 }
 

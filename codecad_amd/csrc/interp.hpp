@@ -677,6 +677,9 @@ __device__ __forceinline__ f2 opaque(f2 x) { asm volatile("" : "+v"(x)); return 
 #endif
 constexpr int kFetchGroup = SDF_FETCH_GROUP;  // tape.hpp pads the program with kTapePadding _return records
 
+template <class T, bool DISTANCE_ONLY, class R>
+__device__ __forceinline__ void exec_leaf(const Rec& cur, V4<T>& last, T px, T py, T pz, R& regs);   // below
+
 // STATIC_OP >= 0 (per-tape code, where the generator knows each record's opcode): the switch below is on a
 // compile-time constant, so the front end emits only that case.  Leaving it to the optimiser to discover
 // that a literal record selects one case of 38 made hipRTC spend 94 % of its time in the inliner and in
@@ -696,6 +699,14 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const floa
         if (DISTANCE_ONLY && (fold & kFoldLoadResult)) last.w = regs.load_res(fold & 0xffu);
         else last = regs.load(fold & 0xffu);
     }
+#ifndef SDF_LEAF_FIRST
+#define SDF_LEAF_FIRST 1
+#endif
+    // the interpreter's programs are mostly fused leaves (tape.hpp fuse_leaves): one test instead of the walk down
+    // the compare tree
+    if (SDF_LEAF_FIRST && !kStaticOp && op == OPX_LEAF) {
+        exec_leaf<T, DISTANCE_ONLY, R>(cur, last, px, py, pz, regs);
+    } else
     switch (op) {
     case OP_RETURN: return true;
     case OP_STORE:
@@ -901,6 +912,7 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const floa
         if (DISTANCE_ONLY) last.w = max_neg_(last.w, regs.load_res(reg));     // == -min(-a, b)
         else last = neg(rounded_union(p[0], neg(last), regs.load(reg)));
         break;
+    case OPX_LEAF: exec_leaf<T, DISTANCE_ONLY, R>(cur, last, px, py, pz, regs); break;
     default: return true;  // unreachable: tapes are validated at upload
     }
     if (fold & kFoldStore) {
@@ -908,6 +920,95 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const floa
         else regs.store((fold >> 16) & 0xffu, last);
     }
     return false;
+}
+
+// OPX_LEAF (tape_format.hpp, tape.hpp fuse_leaves): the parts of a transformed primitive back to back, each exactly
+// the code of its single record above; which parts are present is wave-uniform (bits of the control word).
+template <class T, bool DISTANCE_ONLY, class R>
+__device__ __forceinline__ void exec_leaf(const Rec& cur, V4<T>& last, T px, T py, T pz, R& regs)
+{
+    const float* p = cur.p;
+    const uint32_t c = __float_as_uint(p[kLeafControl]);
+    const T zero = bc<T>(0.0f);
+    V4<T> q = last;
+    if (c & kLeafSample) q = v4<T>(px, py, pz, zero);
+    const uint32_t to = (c >> kLeafToShift) & 7u;
+    const float* t = p + kLeafTo;
+    if (to == 1u) {
+        q = v4<T>(fma_(q.x, bc<T>(t[0]), bc<T>(t[3])), fma_(q.y, bc<T>(t[0]), bc<T>(t[4])), fma_(q.z, bc<T>(t[0]), bc<T>(t[5])), zero);
+    } else if (to == 2u) {
+        T x, y, z;
+        axis_rotate<T>(t, q.x, q.y, q.z, t[3], t[4], t[5], x, y, z);
+        q = v4<T>(x, y, z, zero);
+    } else if (to == 3u) {
+        T x, y, z;
+        axis_rotate<T>(t, q.y, q.z, q.x, t[4], t[5], t[3], y, z, x);
+        q = v4<T>(x, y, z, zero);
+    } else if (to == 4u) {
+        T x, y, z;
+        axis_rotate<T>(t, q.z, q.x, q.y, t[5], t[3], t[4], z, x, y);
+        q = v4<T>(x, y, z, zero);
+    }
+    if (c & kLeafMidStore) regs.store((cur.hdr >> 8) & 0xffu, q);
+    // the primitive
+    const uint32_t prim = (c >> kLeafPrimShift) & 7u;
+    V4<T> r = q;
+    if (prim == LEAF_RECTANGLE) {
+        if (DISTANCE_ONLY) r.w = perp_w<T>(abs_minus(q.x, p[kLeafPrim]), abs_minus(q.y, p[kLeafPrim + 1]));
+        else r = rectangle_op(p[kLeafPrim], p[kLeafPrim + 1], q);
+    } else if (prim == LEAF_CIRCLE) {
+        if (DISTANCE_ONLY) r.w = len2(q.x, q.y) - p[kLeafPrim];
+        else r = circle_op(p[kLeafPrim], q);
+    } else if (prim == LEAF_SPHERE) {
+        if (DISTANCE_ONLY) r.w = len3(q.x, q.y, q.z) - p[kLeafPrim];
+        else r = sphere_op(p[kLeafPrim], q);
+    } else {
+        if (DISTANCE_ONLY) r.w = -q.y;
+        else r = v4<T>(zero, bc<T>(-1.0f), zero, -q.y);
+    }
+    if (c & kLeafExtrusion) {
+        if (DISTANCE_ONLY) r.w = perp_w<T>(abs_minus(q.z, p[kLeafExtrude]), r.w);
+        else r = extrusion_op(p[kLeafExtrude], r, q);
+    }
+    const uint32_t from = (c >> kLeafFromShift) & 7u;
+    if (from != 0u) {
+        const float* f = p + kLeafFrom;
+        if (DISTANCE_ONLY) {
+            r.w = r.w * p[kLeafScale];
+        } else if (from == 1u) {
+            r = v4<T>(r.x * f[0], r.y * f[0], r.z * f[0], r.w * p[kLeafScale]);
+        } else if (from == 2u) {
+            T x, y, z;
+            axis_rotate_dir<T>(f, r.x, r.y, r.z, x, y, z);
+            r = v4<T>(x, y, z, r.w * p[kLeafScale]);
+        } else if (from == 3u) {
+            T x, y, z;
+            axis_rotate_dir<T>(f, r.y, r.z, r.x, y, z, x);
+            r = v4<T>(x, y, z, r.w * p[kLeafScale]);
+        } else {
+            T x, y, z;
+            axis_rotate_dir<T>(f, r.z, r.x, r.y, z, x, y);
+            r = v4<T>(x, y, z, r.w * p[kLeafScale]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const uint32_t cb = c >> (k == 0 ? kLeafComb1Shift : kLeafComb2Shift);
+        const uint32_t kind = cb & 3u, slot = (cb >> 2) & 0xffu;
+        if (kind == 0u) continue;
+        if (DISTANCE_ONLY) {
+            const T b = regs.load_res(slot);
+            if (kind == 1u) r.w = min_(r.w, b);
+            else if (kind == 2u) r.w = max_(r.w, b);
+            else r.w = max_neg_(r.w, b);
+        } else {
+            const V4<T> b = regs.load(slot);
+            if (kind == 1u) r = rounded_union(-1.0f, r, b);
+            else if (kind == 2u) r = neg(rounded_union(-1.0f, neg(r), neg(b)));
+            else r = neg(rounded_union(-1.0f, neg(r), b));
+        }
+    }
+    last = r;
 }
 
 template <class T, bool DISTANCE_ONLY, class R>

@@ -28,6 +28,7 @@ using sdf::Rec;
 
 // Evaluate through the interpreter.  `prog` is the full or the distance-only program (DO).
 template <bool DO> struct InterpEval {
+    static constexpr bool kBricks = false;   // every primitive is evaluated anyway: runs along z (k_grid_eval)
     const Rec* prog;
     const float* extra;
     uint32_t n4;  // float4 slots of the LDS register file (scalar slots follow them)
@@ -213,7 +214,7 @@ k_grid_eval(const E ev, float cx, float cy, float cz, float step, uint32_t sx, D
     const uint32_t sy = dy.n, sz = dz.n;
     using T = typename Pack<N>::T;
     extern __shared__ float4 lds[];
-    if (N == 2 && tiles) {
+    if (E::kBricks && N == 2 && tiles) {
         // blockIdx.x -> (bx, by, bz), bz fastest; tiles = bricks-of-32 along z, dz/dy constants divide by tz and ty
         const uint32_t tz = sz >> 5, ty = sy >> 2;
         const uint32_t bz = blockIdx.x % tz, t = blockIdx.x / tz, by = t % ty, bx = t / ty;

@@ -335,7 +335,7 @@ inline std::string specialised_source(const SpecProgram& p, bool allow_deferred,
     if (ok) o << d.str();
     else emit_plain(o, p);
     if (deferred) *deferred = ok;
-    o << "struct JitEval {\n    const float* extra;\n"
+    o << "struct JitEval {\n    static constexpr bool kBricks = " << (ok ? "true" : "false") << ";\n    const float* extra;\n"
       << "    template <class T> __device__ __forceinline__ sdf::V4<T> operator()(T px, T py, T pz, void*) const\n"
       << "    { return tape_eval<T>(px, py, pz, extra); }\n"
       << "    template <class T> __device__ __forceinline__ T dist(T px, T py, T pz, void*) const\n"

@@ -49,6 +49,8 @@ inline float bits_f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 struct DecodedTape {
     std::vector<Rec> recs;        // full program: every slot is a float4 (direction + distance / point)
     std::vector<Rec> recs_do;     // distance-only program: point slots (float4) and result slots (float)
+    std::vector<Rec> fused;       // the interpreter's form of `recs`: transformed primitives as single records (fuse_leaves)
+    std::vector<Rec> fused_do;    // ... and of `recs_do`
     std::vector<float> extra;     // polygon2d vertex data
     int n_instructions = 0;       // instructions of the TAPE (the decoder may add internal records)
     int n_regs = 0;               // highest register index of the TAPE + 1 (what the reference allocates)
@@ -221,6 +223,171 @@ inline void fold_moves(std::vector<Rec>& prog)
     prog.swap(out);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Superinstructions for the interpreter (tape_format.hpp OPX_LEAF).  The interpreter is bound by its SCALAR work:
+// fetch, decode, a compare tree and ~10 branches per record (rocprofv3: 1136 scalar instructions and 599 branches
+// per wavefront for sponge(4)'s 56 records, the one scalar unit of a CU saturated before its four vector units).
+// CAD tapes are made of one pattern -- a primitive under a transformation, combined into an accumulator -- and
+// the decoder recognises it: [point] to primitive [extrusion] [from] [select] [select] becomes ONE record whose
+// parts run back to back, chosen by a few uniform bit tests.  Only what is provably the same computation is fused:
+// the parts must be adjacent, `last` must flow straight through them (a folded load only on the first, a folded
+// store only on the last; the store of the transformed point that an extrusion reads back is kept, or dropped when
+// nothing else reads it), selects must be plain (r < 0).  Per-tape code is generated from the unfused records.
+// ---------------------------------------------------------------------------------------------------------------
+#ifndef SDF_FUSE_LEAVES
+#define SDF_FUSE_LEAVES 1
+#endif
+namespace fuse_detail {
+inline uint32_t& fold_word(Rec& r) { return reinterpret_cast<uint32_t&>(r.p[kFoldParam]); }
+inline uint32_t fold_word(const Rec& r) { uint32_t f; std::memcpy(&f, &r.p[kFoldParam], 4); return f; }
+inline uint32_t op_of(const Rec& r) { return r.hdr & 0xffu; }
+inline uint32_t slot_of(const Rec& r) { return (r.hdr >> 8) & 0xffffu; }
+inline int to_kind(uint32_t op) { return op == OPX_TO_SCALE ? 1 : op == OPX_TO_AXIS_X ? 2 : op == OPX_TO_AXIS_Y ? 3 : op == OPX_TO_AXIS_Z ? 4 : 0; }
+inline int from_kind(uint32_t op) { return op == OPX_FROM_SCALE ? 1 : op == OPX_FROM_AXIS_X ? 2 : op == OPX_FROM_AXIS_Y ? 3 : op == OPX_FROM_AXIS_Z ? 4 : 0; }
+inline int prim_kind(uint32_t op) { return op == OP_RECTANGLE ? LEAF_RECTANGLE : op == OP_CIRCLE ? LEAF_CIRCLE : op == OP_SPHERE ? LEAF_SPHERE : op == OP_HALF_SPACE ? LEAF_HALF_SPACE : -1; }
+inline int select_kind(const Rec& r)
+{
+    const uint32_t op = op_of(r);
+    if (!(r.p[0] < 0.0f)) return 0;   // rounded (or NaN): not fused
+    return op == OP_UNION ? 1 : op == OP_INTERSECTION ? 2 : op == OP_SUBTRACTION ? 3 : 0;
+}
+// Is POINT slot `slot` read after record `from` before it is written again?  (typed: in the distance-only program
+// point slots and result slots are numbered separately)
+inline bool point_slot_read_later(const std::vector<Rec>& prog, size_t from, uint32_t slot, bool typed)
+{
+    for (size_t i = from; i < prog.size(); ++i) {
+        const Rec& r = prog[i];
+        const uint32_t op = op_of(r), f = fold_word(r);
+        const bool is_result_access = typed && (r.hdr & kResultKind);
+        if ((f & kFoldLoad) && (f & 0xffu) == slot && !(typed && (f & kFoldLoadResult))) return true;
+        if (op == OP_LOAD && slot_of(r) == slot && !is_result_access) return true;
+        if (rec_arity(op) == 2 && slot_of(r) == slot && reads_point_operand(op)) return true;
+        if (op == OP_STORE && slot_of(r) == slot && !is_result_access) return false;
+        if ((f & kFoldStore) && ((f >> 16) & 0xffu) == slot && !(typed && (f & kFoldStoreResult))) return false;
+        if (op == OP_RETURN) return false;
+    }
+    return false;
+}
+}  // namespace fuse_detail
+
+inline void fuse_leaves(const std::vector<Rec>& prog, bool typed, std::vector<Rec>& out)
+{
+    using namespace fuse_detail;
+    out.clear();
+    if (!SDF_FUSE_LEAVES || SDF_REC_DWORDS < 16) { out = prog; return; }
+    const size_t n = prog.size();
+    size_t i = 0;
+    while (i < n) {
+        // ---- try to match a leaf starting at record i
+        size_t j = i;
+        Rec leaf;
+        std::memset(&leaf, 0, sizeof(leaf));
+        uint32_t control = 0, fold = 0, mid_slot = 0;
+        bool ok = true, closed = false;      // closed: a folded store ended the match
+        int parts = 0;
+        bool have_mid_store = false;
+        int64_t point_slot = -1;             // the slot the point in `last` was loaded from (for a following extrusion)
+        auto take_fold = [&](const Rec& r, bool first) {
+            const uint32_t f = fold_word(r);
+            if ((f & kFoldLoad) && !first) return false;
+            if (first) fold |= f & (kFoldLoad | kFoldLoadResult | 0xffu);
+            return true;
+        };
+        // [sample point]
+        if (op_of(prog[j]) == OPX_POINT && !(fold_word(prog[j]) & kFoldStore) && j + 1 < n && to_kind(op_of(prog[j + 1])) &&
+            !(fold_word(prog[j + 1]) & kFoldLoad)) {
+            control |= kLeafSample;
+            ++j;
+            ++parts;
+        }
+        // [to]
+        if (j < n && to_kind(op_of(prog[j]))) {
+            const Rec& r = prog[j];
+            if (!take_fold(r, j == i)) ok = false;
+            else {
+                control |= (uint32_t)to_kind(op_of(r)) << kLeafToShift;
+                leaf.p[kLeafTo + 0] = r.p[0]; leaf.p[kLeafTo + 1] = r.p[1]; leaf.p[kLeafTo + 2] = r.p[2];
+                leaf.p[kLeafTo + 3] = r.p[4]; leaf.p[kLeafTo + 4] = r.p[5]; leaf.p[kLeafTo + 5] = r.p[6];
+                const uint32_t f = fold_word(r);
+                if (f & kFoldStore) {
+                    if (typed && (f & kFoldStoreResult)) ok = false;
+                    have_mid_store = true;
+                    mid_slot = (f >> 16) & 0xffu;
+                }
+                ++j;
+                ++parts;
+            }
+        } else if (j == i && j < n) {
+            const uint32_t f = fold_word(prog[j]);
+            if ((f & kFoldLoad) && !(typed && (f & kFoldLoadResult))) point_slot = f & 0xffu;
+        }
+        // primitive (required)
+        if (ok && j < n && prim_kind(op_of(prog[j])) >= 0) {
+            const Rec& r = prog[j];
+            if (!take_fold(r, j == i)) ok = false;
+            else {
+                control |= (uint32_t)prim_kind(op_of(r)) << kLeafPrimShift;
+                leaf.p[kLeafPrim] = r.p[0];
+                leaf.p[kLeafPrim + 1] = r.p[1];
+                if (fold_word(r) & kFoldStore) { fold |= fold_word(r) & (kFoldStore | kFoldStoreResult | 0xff0000u); closed = true; }
+                ++j;
+                ++parts;
+            }
+        } else ok = false;
+        // [extrusion]: its point operand must be the point this leaf computed (or was handed)
+        if (ok && !closed && j < n && op_of(prog[j]) == OP_EXTRUSION && !(fold_word(prog[j]) & kFoldLoad)) {
+            const Rec& r = prog[j];
+            const bool same_point = (have_mid_store && slot_of(r) == mid_slot) ||
+                                    (!have_mid_store && !(control & (7u << kLeafToShift)) && !(control & kLeafSample) &&
+                                     point_slot >= 0 && slot_of(r) == (uint32_t)point_slot);
+            if (same_point) {
+                control |= kLeafExtrusion;
+                leaf.p[kLeafExtrude] = r.p[0];
+                if (fold_word(r) & kFoldStore) { fold |= fold_word(r) & (kFoldStore | kFoldStoreResult | 0xff0000u); closed = true; }
+                ++j;
+                ++parts;
+            }
+        }
+        // [from]
+        if (ok && !closed && j < n && from_kind(op_of(prog[j])) && !(fold_word(prog[j]) & kFoldLoad)) {
+            const Rec& r = prog[j];
+            control |= (uint32_t)from_kind(op_of(r)) << kLeafFromShift;
+            leaf.p[kLeafFrom + 0] = r.p[0]; leaf.p[kLeafFrom + 1] = r.p[1]; leaf.p[kLeafFrom + 2] = r.p[2];
+            leaf.p[kLeafScale] = r.p[5];
+            if (fold_word(r) & kFoldStore) { fold |= fold_word(r) & (kFoldStore | kFoldStoreResult | 0xff0000u); closed = true; }
+            ++j;
+            ++parts;
+        }
+        // [select] [select]
+        for (int k = 0; k < 2 && ok && !closed && j < n; ++k) {
+            const Rec& r = prog[j];
+            const int kind = select_kind(r);
+            if (!kind || (fold_word(r) & kFoldLoad) || slot_of(r) >= 256u) break;
+            control |= ((uint32_t)kind | (slot_of(r) << 2)) << (k == 0 ? kLeafComb1Shift : kLeafComb2Shift);
+            if (fold_word(r) & kFoldStore) { fold |= fold_word(r) & (kFoldStore | kFoldStoreResult | 0xff0000u); closed = true; }
+            ++j;
+            ++parts;
+        }
+        // The folded store of the transformed point: dropped when nothing reads the slot afterwards (the fused
+        // extrusion has the point in registers), which includes the leaf's own final store overwriting it.
+        if (ok && have_mid_store) {
+            const bool own_store_overwrites = (fold & kFoldStore) && ((fold >> 16) & 0xffu) == mid_slot &&
+                                              !(typed && (fold & kFoldStoreResult));
+            if (!own_store_overwrites && point_slot_read_later(prog, j, mid_slot, typed)) control |= kLeafMidStore;
+        }
+        if (ok && parts >= 2) {
+            leaf.hdr = OPX_LEAF | (mid_slot << 8);
+            fold_word(leaf) = fold;
+            std::memcpy(&leaf.p[kLeafControl], &control, 4);
+            out.push_back(leaf);
+            i = j;
+        } else {
+            out.push_back(prog[i]);
+            ++i;
+        }
+    }
+}
+
 // Validate + decode.  Returns "" on success, otherwise the reason the tape is malformed.
 inline std::string decode_tape(const float* tape, size_t n, DecodedTape& out)
 {
@@ -379,12 +546,15 @@ inline std::string decode_tape(const float* tape, size_t n, DecodedTape& out)
     }
     fold_moves(out.recs);
     if (!out.recs_do.empty()) fold_moves(out.recs_do);
+    fuse_leaves(out.recs, false, out.fused);
+    if (!out.recs_do.empty()) fuse_leaves(out.recs_do, true, out.fused_do);
     // Zero (= _return) records of padding: the interpreter fetches records in groups.
     Rec pad;
     std::memset(&pad, 0, sizeof(pad));
     for (int i = 0; i < kTapePadding; ++i) {
         out.recs.push_back(pad);
-        if (!out.recs_do.empty()) out.recs_do.push_back(pad);
+        out.fused.push_back(pad);
+        if (!out.recs_do.empty()) { out.recs_do.push_back(pad); out.fused_do.push_back(pad); }
     }
     return "";
 }

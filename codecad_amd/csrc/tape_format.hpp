@@ -35,8 +35,30 @@ enum Op : uint32_t {
     // x, y, z alone, the second computes y and z from them and assembles (x', y', z', 0).  transformation_from
     // (nine entries over |Q|^2 and the distance scale) fits one record.
     // The OPX_INIT_* pair is the same for initial_transformation_to: it reads the sample point itself.
-    OPX_TO_ROW_X = 38, OPX_TO_ROWS_YZ = 39, OPX_FROM_MATRIX = 40, OPX_INIT_ROW_X = 41, OPX_INIT_ROWS_YZ = 42
+    OPX_TO_ROW_X = 38, OPX_TO_ROWS_YZ = 39, OPX_FROM_MATRIX = 40, OPX_INIT_ROW_X = 41, OPX_INIT_ROWS_YZ = 42,
+    // A transformed primitive combined into an accumulator -- the unit CAD tapes are made of -- as ONE record of the
+    // interpreter's programs (tape.hpp fuse_leaves; per-tape code is generated from the unfused records):
+    //   [sample point | last | slot] -> to (scale / axis rotation) -> rectangle | circle | sphere | half_space
+    //   -> extrusion -> from (scale / axis rotation) -> up to two of union | intersection | subtraction -> [store]
+    // every part optional except the primitive.  The SAME operations in the same order as the single records (the
+    // results are identical); what goes is the dispatch between them: sponge(4) 56 -> 26 records.
+    OPX_LEAF = 43
 };
+
+// OPX_LEAF parameter layout (16-dword records) and its control word p[kLeafControl]
+constexpr int kLeafTo = 0;        // p[0..2] = A, B, C of the to-part, p[3..5] = its offsets
+constexpr int kLeafPrim = 6;      // p[6], p[7]: the primitive's parameters
+constexpr int kLeafExtrude = 8;   // p[8]: half height
+constexpr int kLeafScale = 9;     // p[9]: the from-part's distance scale, p[11..13] = its A, B, C   (p[10] is the fold word)
+constexpr int kLeafFrom = 11;
+constexpr int kLeafControl = 14;
+constexpr uint32_t kLeafSample = 1u;                 // the point is the sample point (OPX_POINT fused)
+constexpr uint32_t kLeafToShift = 1, kLeafPrimShift = 4, kLeafFromShift = 8;   // 3 bits each: 0 none, 1 scale, 2/3/4 axis x/y/z
+constexpr uint32_t kLeafExtrusion = 1u << 7;
+constexpr uint32_t kLeafComb1Shift = 11, kLeafComb2Shift = 21;   // 2 bits kind (1 union, 2 intersection, 3 subtraction) + 8 bits slot
+constexpr uint32_t kLeafMidStore = 1u << 31;         // the transformed point is also stored, to the slot in hdr
+enum LeafPrim : uint32_t { LEAF_RECTANGLE = 0, LEAF_CIRCLE = 1, LEAF_SPHERE = 2, LEAF_HALF_SPACE = 3 };
+
 
 
 constexpr int kRefRegisterCount = 512;  // reference nodes/__init__.py:6
@@ -45,7 +67,7 @@ constexpr int kTapePadding = 8;         // >= interp.hpp kFetchGroup
 
 
 
-// One decoded instruction: 12 dwords.  hdr = opcode | (slot << 8) | kResultKind?.
+// One decoded instruction: 16 dwords.  hdr = opcode | (slot << 8) | kResultKind?.
 // `slot` is NOT the tape's register number: registers are renamed at decode time
 // (allocate_slots below) to the smallest set of LDS slots that liveness allows.
 constexpr uint32_t kResultKind = 0x80000000u;  // distance-only program: the slot holds a bare distance
@@ -56,7 +78,7 @@ constexpr int kFoldParam = 10;   // p[10]: no op uses it (records have 11 parame
 constexpr uint32_t kFoldLoad = 0x100u, kFoldLoadResult = 0x200u;          // bits 0-7: slot
 constexpr uint32_t kFoldStore = 0x1000000u, kFoldStoreResult = 0x2000000u;  // bits 16-23: slot
 #ifndef SDF_REC_DWORDS
-#define SDF_REC_DWORDS 12
+#define SDF_REC_DWORDS 16     // 64-byte records: one s_load_dwordx16 each, and room for a fused leaf (OPX_LEAF)
 #endif
 struct alignas(SDF_REC_DWORDS == 16 ? 64 : 16) Rec {
     uint32_t hdr;

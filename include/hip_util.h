@@ -261,6 +261,10 @@ int hu_tape_specialized(hu_tape t, int* out_flag);
 /* The HIP source hu_tape_specialize would compile for this tape (host only, no device needed):
  * `*needed` receives its size including the terminator; it is copied when `capacity` suffices. */
 int hu_tape_source(const float* tape, size_t n_floats, char* buf, size_t capacity, size_t* needed);
+/* A readable listing of a tape's decoded programs, one record per line (host only, no device needed): which = 0 the
+ * full program, 1 the distance-only program (empty for tapes with a rounded blend), 2 / 3 the same as the
+ * interpreter runs them, transformed primitives fused into single records.  Same calling convention. */
+int hu_tape_listing(const float* tape, size_t n_floats, int which, char* buf, size_t capacity, size_t* needed);
 /* Compile that source with hipRTC without loading it (host only, no device needed): checks that the
  * op library headers in `include_dir` build under hipRTC and that all ten kernels are present.
  * `*code_bytes` (may be NULL) receives the code object size. */

@@ -141,11 +141,25 @@ def test_specialised_source_builds_under_hiprtc_without_a_device():
     buf = ctypes.create_string_buffer(needed.value)
     assert lib.hu_tape_source(p, t.size, buf, needed.value, ctypes.byref(needed)) == 0
     src = buf.value.decode()
-    assert 0 < src.count("exec_one<T, false, decltype(regs), ") <= 52 and "struct JitEval" in src  # the decoder may fold records
+    # sponge(2): the deferred-directions form (specialise.hpp): the distance-only program, then one block per
+    # (primitive, path to the root) -- 6 bars + the box
+    assert "struct JitEval" in src and "tape_dist" in src and "deferred directions: 7 " in src
+    assert 0 < src.count("exec_one<T, true, decltype(regs), ") <= 2 * 52      # the decoder may fold records
+    assert src.count("// the primitive of record") == 7
     size = ctypes.c_size_t(0)
     rc = lib.hu_tape_compile_check(p, t.size, include_dir, ctypes.byref(size))
     assert rc == 0, lib.hu_last_error().decode()
     assert size.value > 10000
+    # a tape with a rounded blend keeps the plain straight-line form (its distance depends on directions)
+    blend = cc.nodes.make_program(cc.shapes.union([cc.shapes.sphere(2), cc.shapes.box(1).translated_x(1)], r=0.3))
+    tb, pb_ = _tape_ptr(blend)
+    assert lib.hu_tape_source(pb_, tb.size, None, 0, ctypes.byref(needed)) == 0
+    buf = ctypes.create_string_buffer(needed.value)
+    assert lib.hu_tape_source(pb_, tb.size, buf, needed.value, ctypes.byref(needed)) == 0
+    plain = buf.value.decode()
+    assert "deferred directions" not in plain and plain.count("exec_one<T, false, decltype(regs), ") > 0
+    rc = lib.hu_tape_compile_check(pb_, tb.size, include_dir, ctypes.byref(size))
+    assert rc == 0, lib.hu_last_error().decode()
     # a malformed tape is rejected before any compilation
     bad, pb = _tape_ptr([99 * 512.0])
     assert lib.hu_tape_compile_check(pb, bad.size, include_dir, None) != 0
@@ -317,3 +331,34 @@ def test_cache_dir_resolution(monkeypatch, tmp_path):
     assert buffer.cache_dir() == str(tmp_path / "xdg" / "codecad_amd") and (tmp_path / "xdg" / "codecad_amd").is_dir()
     monkeypatch.setenv("XDG_CACHE_HOME", "relative/dir")
     assert buffer.cache_dir() is None
+
+
+def _listing(tape, which):
+    import ctypes
+    from codecad_amd.hip_util import _lib
+    lib = _lib.load()
+    t, p = _tape_ptr(tape)
+    needed = ctypes.c_size_t(0)
+    assert lib.hu_tape_listing(p, t.size, which, None, 0, ctypes.byref(needed)) == 0, lib.hu_last_error()
+    buf = ctypes.create_string_buffer(needed.value)
+    assert lib.hu_tape_listing(p, t.size, which, buf, needed.value, ctypes.byref(needed)) == 0
+    return buf.value.decode().splitlines()
+
+
+def test_leaf_fusion_of_the_interpreter_programs():
+    """The interpreter's programs fuse `to -> primitive -> extrusion -> from -> select` runs into single records
+    (tape.hpp fuse_leaves): sponge(4) 56 -> 26 dispatches, csg_example 20 -> 5; the unfused programs (what per-tape
+    code is generated from) are untouched; a store of the transformed point survives only where it is still read."""
+    import codecad_amd as cc
+    sponge = cc.nodes.make_program(cc.examples.sponge(4))
+    assert len(_listing(sponge, 0)) == 57 and len(_listing(sponge, 2)) == 27      # incl. _return
+    assert len(_listing(sponge, 1)) == 57 and len(_listing(sponge, 3)) == 27
+    assert sum(line.count("LEAF(") for line in _listing(sponge, 2)) == 13
+    csg = _listing(cc.nodes.make_program(cc.examples.csg_example()), 2)
+    assert len(csg) == 6 and all("LEAF(" in line for line in csg[:5])
+    assert "LEAF(sample to:y circle extrusion from:y) [store 0]" == csg[0]          # the point's store is gone ...
+    assert "store-point:2" in csg[2] and csg[3].startswith("[load 2]")              # ... and kept where a later record loads it
+    # a rounded blend is never fused into a leaf (its operands' directions matter), plain selects are
+    blend = _listing(cc.nodes.make_program(cc.shapes.union([cc.shapes.sphere(2), cc.shapes.box(1).translated_x(1)], r=0.3)), 2)
+    assert any(line.startswith("union") or " union" in line and "LEAF" not in line for line in blend)
+    assert _listing(cc.nodes.make_program(cc.shapes.union([cc.shapes.sphere(2), cc.shapes.box(1).translated_x(1)], r=0.3)), 1) == []

@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 rm -rf "$OUT" && mkdir -p "$OUT"
 EVAL=auto; [ "$CODECAD_AMD_SPECIALIZE" = "0" ] && EVAL=interpreter
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_stats" -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --evaluator $EVAL > "$OUT/bench_under_rocprof.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_stats" -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-hbm-leg --evaluator $EVAL > "$OUT/bench_under_rocprof.log" 2>&1
 echo "bench_stats rc=$?"
 pass() { # name counters...
   local name=$1; shift

@@ -19,7 +19,7 @@ open(os.path.join(dst, prefix + "_bench_line_under_rocprof.json"), "w").write(li
 summary = json.load(open(os.path.join(src, "summary.json")))
 summary.update({"grid_edge": 512, "round": int(prefix[1:3]) if prefix[1:3].isdigit() else 2, "config": "c3", "evaluator": evaluator, "note": note,
                 "command": "tools/collect_profiles.sh: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 "
-                           "--no-cpu-baseline ; PMC passes: rocprofv3 --pmc <counters> --kernel-trace -- python3 tools/prof_dense.py 512 3 "
+                           "--no-cpu-baseline --no-hbm-leg ; PMC passes: rocprofv3 --pmc <counters> --kernel-trace -- python3 tools/prof_dense.py 512 3 "
                            "(CODECAD_AMD_SPECIALIZE=%s)" % ("1" if evaluator == "specialised" else "0")})
 json.dump(summary, open(os.path.join(dst, prefix + "_summary.json"), "w"), indent=1)
 print("published", prefix, "dense kernel avg %.3f ms" % (summary["kernel_stats"][0]["avg_ns"] / 1e6))
