@@ -165,12 +165,17 @@ def main():
     pipe = build_pipeline(capacities)
     leaf_out = [None]
 
-    ev0, ev1, ev2, evb0, evb1, evc0 = (ctypes.c_void_p() for _ in range(6))
-    for ev in (ev0, ev1, ev2, evb0, evb1, evc0):
-        check(lib.hu_event_create(ctypes.byref(ev)), "event")
-    dense_ms, b_ms, c_ms = [], [], []
+    # one set of events per step: nothing in a step waits for the host, the elapsed times are read after the timed region
+    def new_events():
+        evs = [ctypes.c_void_p() for _ in range(6)]
+        for ev in evs:
+            check(lib.hu_event_create(ctypes.byref(ev)), "event")
+        return evs
+    warm_events = new_events()
+    step_events = [new_events() for _ in range(args.steps)]
 
-    def one_step(timed):
+    def one_step(evs):
+        ev0, ev1, ev2, evb0, evb1, evc0 = evs
         # A
         if dense_leg:
             check(lib.hu_event_record(ev0, stream), "record")
@@ -193,17 +198,12 @@ def main():
               "hu_grid_eval_blocks_indirect")
         check(lib.hu_event_record(ev2, stream), "record")
         side_stream.wait_stream(main_stream)          # the next step's B must not overwrite the list C is reading
-        if timed:
-            check(lib.hu_event_synchronize(ev2), "sync")
-            ms = ctypes.c_float()
-            if dense_leg:
-                check(lib.hu_event_elapsed_ms(ev0, ev1, ctypes.byref(ms)), "elapsed")
-                dense_ms.append(ms.value)
-            check(lib.hu_event_elapsed_ms(evb0, evb1, ctypes.byref(ms)), "elapsed")
-            b_ms.append(ms.value)                  # B: the whole traversal on its stream (kernels + all-gathers)
-            check(lib.hu_event_elapsed_ms(evc0, ev2, ctypes.byref(ms)), "elapsed")
-            c_ms.append(ms.value)                  # C: every sample of every leaf block of this rank
         return mine
+
+    def elapsed(a, b):
+        ms = ctypes.c_float()
+        check(lib.hu_event_elapsed_ms(a, b, ctypes.byref(ms)), "elapsed")
+        return ms.value
 
     def barrier():
         main_stream.synchronize()
@@ -217,7 +217,7 @@ def main():
     # sized for the capacity, and workgroups past the list's end cost their dispatch: 80 000 spare leaf blocks are 0.2 ms)
     totals, settled, done = None, False, 0
     for i in range(max(args.warmup, 1) + 4):
-        mine = one_step(False)
+        mine = one_step(warm_events)
         try:
             totals = pipe.check()
             tight = [int(v * 1.125) + 16 for v in pipe.needed]
@@ -239,24 +239,26 @@ def main():
     # the interpreter on the same dense launch, timed the same way (reported, not part of `value`)
     interp_ms = []
     if dense_leg:
+        ev0, ev1 = warm_events[0], warm_events[1]
         for i in range(3):
             check(lib.hu_event_record(ev0, stream), "record")
             check(lib.hu_grid_eval_slab(interp_tape.device_ptr, corner.ctypes.data_as(fptr), step_f, dims, x0, x1 - x0, 0,
                                         dense_out.data_ptr(), stream), "hu_grid_eval_slab")
             check(lib.hu_event_record(ev1, stream), "record")
             check(lib.hu_event_synchronize(ev1), "sync")
-            ms = ctypes.c_float()
-            check(lib.hu_event_elapsed_ms(ev0, ev1, ctypes.byref(ms)), "elapsed")
             if i:
-                interp_ms.append(ms.value)
+                interp_ms.append(elapsed(ev0, ev1))
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step(True)
+    for evs in step_events:
+        one_step(evs)
     barrier()
-    elapsed = time.perf_counter() - t0
+    wall = time.perf_counter() - t0
     if world > 1:
-        elapsed = float(dist.allreduce_max(torch.tensor([elapsed], dtype=torch.float64, device=dev)).item())
+        wall = float(dist.allreduce_max(torch.tensor([wall], dtype=torch.float64, device=dev)).item())
+    dense_ms = [elapsed(e[0], e[1]) for e in step_events] if dense_leg else []
+    b_ms = [elapsed(e[3], e[4]) for e in step_events]   # B: the whole traversal on its stream (kernels + all-gathers)
+    c_ms = [elapsed(e[5], e[2]) for e in step_events]   # C: every sample of every leaf block of this rank
     # the timed traversals were not looked at while they ran: validate now (identical work every step)
     assert pipe.check() == totals, "the timed steps did not reproduce the warm-up traversal"
 
@@ -266,7 +268,7 @@ def main():
     leaf_samples = totals[-1] * leaf_cells
     job_dense = (n ** 3 * n_objects) if dense_leg else 0
     job_samples = job_dense + subdivision_samples + leaf_samples
-    value = job_samples * args.steps / elapsed / 1e6
+    value = job_samples * args.steps / wall / 1e6
 
     def avg(v):
         return sum(v) / len(v) if v else 0.0
@@ -319,7 +321,7 @@ def main():
             "metric": "SDF Mvoxels/s (grid_eval+subdivision), 512^3 menger_sponge" if args.config == "c3" else
                       "SDF Mvoxels/s (subdivision + leaf-block grid_eval), 2048^3-effective menger_sponge depth 5",
             "value": round(value, 1), "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": ("menger_sponge depth=%d, %d^3%s: %sadaptive subdivision (grid %d, overlap) + grid_eval of all "

@@ -244,6 +244,15 @@ uint32_t brick_tiles(uint32_t nx, uint32_t sy, uint32_t sz)
     return (!off && nx % 4u == 0u && sy % 4u == 0u && sz % 32u == 0u) ? 1u : 0u;
 }
 
+// How many units (blocks / parents) of `chunks` workgroups of `threads` lanes go into one launch: a grid may
+// have at most 2^31 - 1 workgroups and 2^32 - 1 work-items; longer lists are launched in pieces.
+uint32_t units_per_launch(uint32_t chunks, uint32_t threads)
+{
+    const uint64_t by_items = 0xffffffffull / threads / chunks, by_groups = 0x7fffffffull / chunks;
+    const uint64_t n = by_items < by_groups ? by_items : by_groups;
+    return n < 1 ? 1u : (uint32_t)n;
+}
+
 int check_dims(const uint32_t dims[3], uint64_t& cells)
 {
     if (!dims) return fail(HU_ERR_BAD_ARG, "dims is NULL");
@@ -623,15 +632,19 @@ static int grid_eval_blocks_impl(hu_tape t, const int32_t* blocks_dev, uint32_t 
     if (t->spec) {
         const uint32_t per_block = kSpecBlock * kSpecVoxelsPerLane;
         uint32_t chunks = (uint32_t)((cells + per_block - 1) / per_block);
-        if ((uint64_t)chunks * n_blocks > 0x7fffffffull) return fail(HU_ERR_BAD_ARG, "too many workgroups in one launch");
         SpecEval ev{t->extra_dev};
         const int4* b = (const int4*)blocks_dev;
         double res = resolution, ox = origin[0], oy = origin[1], oz = origin[2];
         uint32_t sx = dims[0];
         Dim sy = make_dim(dims[1]), sz = make_dim(dims[2]);
-        void* args[] = {&ev, &b, &n_dev, &chunks, &res, &ox, &oy, &oz, &step, &sx, &sy, &sz, &out_dev};
-        HU_HIP(hipModuleLaunchKernel(t->spec->blocks[layout], chunks * n_blocks, 1, 1, kSpecBlock, 1, 1, 0, (hipStream_t)stream,
-                                     args, nullptr));
+        const uint32_t piece = units_per_launch(chunks, kSpecBlock);
+        for (uint32_t b0 = 0; b0 < n_blocks; b0 += piece) {
+            uint32_t first = b0;
+            const uint32_t count = n_blocks - b0 < piece ? n_blocks - b0 : piece;
+            void* args[] = {&ev, &b, &n_dev, &first, &chunks, &res, &ox, &oy, &oz, &step, &sx, &sy, &sz, &out_dev};
+            HU_HIP(hipModuleLaunchKernel(t->spec->blocks[layout], chunks * count, 1, 1, kSpecBlock, 1, 1, 0, (hipStream_t)stream,
+                                         args, nullptr));
+        }
         return HU_OK;
     }
     LaunchShape ls;
@@ -639,21 +652,24 @@ static int grid_eval_blocks_impl(hu_tape t, const int32_t* blocks_dev, uint32_t 
     if ((rc = ensure_attrs())) return rc;
     const uint32_t per_block = ls.block * ls.voxels_per_lane;
     const uint32_t chunks = (uint32_t)((cells + per_block - 1) / per_block);
-    if ((uint64_t)chunks * n_blocks > 0x7fffffffull) return fail(HU_ERR_BAD_ARG, "too many workgroups in one launch");
-    const dim3 grid(chunks * n_blocks), block(ls.block);
+    const dim3 block(ls.block);
+    const uint32_t piece = units_per_launch(chunks, ls.block);
 #define HU_LAUNCH_BLOCKS(L, D, NV)                                                                                 \
     hipLaunchKernelGGL((k_grid_eval_blocks<InterpEval<D>, L, NV>), grid, block, ls.lds, (hipStream_t)stream,           \
-                       (InterpEval<D>{ls.prog, t->extra_dev, ls.n4}), (const int4*)blocks_dev, n_dev, chunks, resolution, \
+                       (InterpEval<D>{ls.prog, t->extra_dev, ls.n4}), (const int4*)blocks_dev, n_dev, b0, chunks, resolution, \
                        origin[0], origin[1], origin[2], step, dims[0], make_dim(dims[1]), make_dim(dims[2]), out_dev)
     const bool d_only = layout == 1 && distance_only(t);
-    if (ls.voxels_per_lane == 2) {
-        if (layout == 0) HU_LAUNCH_BLOCKS(0, false, 2);
-        else if (d_only) HU_LAUNCH_BLOCKS(1, true, 2);
-        else HU_LAUNCH_BLOCKS(1, false, 2);
-    } else {
-        if (layout == 0) HU_LAUNCH_BLOCKS(0, false, 1);
-        else if (d_only) HU_LAUNCH_BLOCKS(1, true, 1);
-        else HU_LAUNCH_BLOCKS(1, false, 1);
+    for (uint32_t b0 = 0; b0 < n_blocks; b0 += piece) {
+        const dim3 grid(chunks * (n_blocks - b0 < piece ? n_blocks - b0 : piece));
+        if (ls.voxels_per_lane == 2) {
+            if (layout == 0) HU_LAUNCH_BLOCKS(0, false, 2);
+            else if (d_only) HU_LAUNCH_BLOCKS(1, true, 2);
+            else HU_LAUNCH_BLOCKS(1, false, 2);
+        } else {
+            if (layout == 0) HU_LAUNCH_BLOCKS(0, false, 1);
+            else if (d_only) HU_LAUNCH_BLOCKS(1, true, 1);
+            else HU_LAUNCH_BLOCKS(1, false, 1);
+        }
     }
 #undef HU_LAUNCH_BLOCKS
     HU_HIP(hipGetLastError());
@@ -695,11 +711,15 @@ int launch_classify(hu_tape t, ClassifyArgs& a, uint32_t n_parents, const uint32
         a.dy = make_dim(dims[1]); a.dz = make_dim(dims[2]);
         a.chunks = (uint32_t)((cells + per_block - 1) / per_block);
         a.scratch_offset = 0;
-        if ((uint64_t)a.chunks * n_parents > 0x7fffffffull) return fail(HU_ERR_BAD_ARG, "too many workgroups in one launch");
         SpecEval ev{t->extra_dev};
-        void* args[] = {&ev, &a};
-        HU_HIP(hipModuleLaunchKernel(t->spec->classify[MASS ? 1 : 0][BATCH ? 1 : 0], a.chunks * n_parents, 1, 1, kSpecBlock, 1, 1,
-                                     (unsigned)kScratchBytes, (hipStream_t)stream, args, nullptr));
+        const uint32_t piece = units_per_launch(a.chunks, kSpecBlock);
+        for (uint32_t p0 = 0; p0 < n_parents; p0 += piece) {
+            a.parent_base = p0;
+            void* args[] = {&ev, &a};
+            HU_HIP(hipModuleLaunchKernel(t->spec->classify[MASS ? 1 : 0][BATCH ? 1 : 0],
+                                         a.chunks * (n_parents - p0 < piece ? n_parents - p0 : piece), 1, 1, kSpecBlock, 1, 1,
+                                         (unsigned)kScratchBytes, (hipStream_t)stream, args, nullptr));
+        }
         return HU_OK;
     }
     LaunchShape ls;
@@ -713,18 +733,22 @@ int launch_classify(hu_tape t, ClassifyArgs& a, uint32_t n_parents, const uint32
     const uint32_t per_block = ls.block * ls.voxels_per_lane;
     a.chunks = (uint32_t)((cells + per_block - 1) / per_block);
     a.scratch_offset = (uint32_t)ls.regfile_bytes;
-    if ((uint64_t)a.chunks * n_parents > 0x7fffffffull) return fail(HU_ERR_BAD_ARG, "too many workgroups in one launch");
-    const dim3 grid(a.chunks * n_parents), block(ls.block);
+    const dim3 block(ls.block);
     const bool d_only = distance_only(t);
+    const uint32_t piece = units_per_launch(a.chunks, ls.block);
 #define HU_LAUNCH_CLASSIFY(D, NV)                                                                                \
     hipLaunchKernelGGL((k_classify<InterpEval<D>, MASS, BATCH, NV>), grid, block, ls.lds, (hipStream_t)stream,     \
                        (InterpEval<D>{ls.prog, t->extra_dev, ls.n4}), a)
-    if (ls.voxels_per_lane == 2) {
-        if (d_only) HU_LAUNCH_CLASSIFY(true, 2);
-        else HU_LAUNCH_CLASSIFY(false, 2);
-    } else {
-        if (d_only) HU_LAUNCH_CLASSIFY(true, 1);
-        else HU_LAUNCH_CLASSIFY(false, 1);
+    for (uint32_t p0 = 0; p0 < n_parents; p0 += piece) {
+        a.parent_base = p0;
+        const dim3 grid(a.chunks * (n_parents - p0 < piece ? n_parents - p0 : piece));
+        if (ls.voxels_per_lane == 2) {
+            if (d_only) HU_LAUNCH_CLASSIFY(true, 2);
+            else HU_LAUNCH_CLASSIFY(false, 2);
+        } else {
+            if (d_only) HU_LAUNCH_CLASSIFY(true, 1);
+            else HU_LAUNCH_CLASSIFY(false, 1);
+        }
     }
 #undef HU_LAUNCH_CLASSIFY
     HU_HIP(hipGetLastError());

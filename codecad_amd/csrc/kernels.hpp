@@ -266,14 +266,15 @@ k_grid_eval(const E ev, float cx, float cy, float cz, float step, uint32_t sx, D
 
 template <class E, int LAYOUT, int N>
 __global__ void __launch_bounds__(256)
-k_grid_eval_blocks(const E ev, const int4* __restrict__ blocks, const uint32_t* __restrict__ n_blocks_dev, uint32_t chunks,
-                   double res, double ox, double oy, double oz, float step, uint32_t sx, Dim dy, Dim dz,
+k_grid_eval_blocks(const E ev, const int4* __restrict__ blocks, const uint32_t* __restrict__ n_blocks_dev, uint32_t b0,
+                   uint32_t chunks, double res, double ox, double oy, double oz, float step, uint32_t sx, Dim dy, Dim dz,
                    void* __restrict__ out)
 {
     const uint32_t sy = dy.n, sz = dz.n;
     using T = typename Pack<N>::T;
     extern __shared__ float4 lds[];
-    const uint32_t b = blockIdx.x / chunks, chunk = blockIdx.x - b * chunks;
+    // b0: the first block of this launch (a list too long for one grid is launched in pieces)
+    const uint32_t chunk = blockIdx.x % chunks, b = b0 + blockIdx.x / chunks;
     // indirect form: the list length lives on the device (the launch is sized for its capacity), so a
     // traversal needs no host round trip between its levels; workgroup-uniform exit
     if (n_blocks_dev && b >= *n_blocks_dev) return;
@@ -306,6 +307,7 @@ k_grid_eval_blocks(const E ev, const int4* __restrict__ blocks, const uint32_t* 
 // ------------------------------------------------------------------------------------------
 struct ClassifyArgs {
     const void* parents;   // BATCH: int4[] (subdivision) or double4[] (mass); else unused
+    uint32_t parent_base;           // BATCH: the first parent of this launch (a level too long for one grid is launched in pieces)
     const uint32_t* n_parents_dev;  // BATCH, optional: the number of parents, on the device (the launch is sized for the list's capacity)
     uint32_t chunks;       // workgroups per parent
     uint32_t sx, sy, sz;
@@ -329,8 +331,8 @@ __global__ void __launch_bounds__(256) k_classify(const E ev, const ClassifyArgs
     using T = typename Pack<N>::T;
     extern __shared__ float4 lds[];
     uint32_t* scratch = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(lds) + a.scratch_offset);  // [0..4] compaction, [8..17] sums
-    const uint32_t b = BATCH ? blockIdx.x / a.chunks : 0u;
-    const uint32_t chunk = BATCH ? blockIdx.x - b * a.chunks : blockIdx.x;
+    const uint32_t b = BATCH ? a.parent_base + blockIdx.x / a.chunks : 0u;
+    const uint32_t chunk = BATCH ? blockIdx.x % a.chunks : blockIdx.x;
     const uint32_t cells = a.sx * a.sy * a.sz;
     if (BATCH && a.n_parents_dev && b >= *a.n_parents_dev) return;   // workgroup-uniform, before any barrier
 

@@ -531,3 +531,32 @@ def test_pipeline_without_host_round_trips_equals_the_level_driver(hip, name, re
     with pytest.raises(dist.Overflow) as info:
         small.check()
     assert info.value.needed[0] == counts[0]
+
+
+def test_lists_longer_than_one_grid_are_launched_in_pieces(hip):
+    """A launch may have at most 2^32 - 1 work-items: 17 M blocks of 2^3 samples (one workgroup each) exceed that,
+    as does a capacity-sized launch over a short list.  Blocks beyond the first piece equal the oracle."""
+    import torch
+    from codecad_amd import hip_util
+    from codecad_amd.hip_util import check
+    ref = GOLDEN["sphere_plus_box"]
+    tape = hip_util.Tape(ref["tape"], policy="0")
+    n_blocks = (1 << 24) + 12345
+    rng = np.random.default_rng(21)
+    rows = torch.from_numpy(rng.integers(-60, 60, (n_blocks, 4)).astype(np.int32)).cuda()
+    count = torch.tensor([n_blocks], dtype=torch.int32, device="cuda")
+    out = torch.zeros((n_blocks, 8), dtype=torch.float32, device="cuda")
+    dims = (ctypes.c_uint32 * 3)(2, 2, 2)
+    origin = (ctypes.c_double * 3)(0.25, -0.5, 0.125)
+    step = np.float32(0.75)
+    for specialise in (False, True):
+        if specialise:
+            tape.specialize()
+        out.zero_()
+        check(hip.lib.hu_grid_eval_blocks_indirect(tape.device_ptr, rows.data_ptr(), count.data_ptr(), n_blocks + 1000, 1.0, origin, step,
+                                                   dims, 1, out.data_ptr(), None), "indirect")
+        torch.cuda.synchronize()
+        for b in (0, 5, (1 << 24) - 1, 1 << 24, n_blocks - 1):
+            corner = rows[b, :3].cpu().numpy().astype(np.float64) * 1.0 + np.array([0.25, -0.5, 0.125])
+            want = oracle.grid_eval_pymcubes(ref["tape"], corner.astype(np.float32), step, (2, 2, 2))
+            assert same_bits(out[b].cpu().numpy(), np.asarray(want).reshape(-1)), (specialise, b)
