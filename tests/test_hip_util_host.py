@@ -362,3 +362,34 @@ def test_leaf_fusion_of_the_interpreter_programs():
     blend = _listing(cc.nodes.make_program(cc.shapes.union([cc.shapes.sphere(2), cc.shapes.box(1).translated_x(1)], r=0.3)), 2)
     assert any(line.startswith("union") or " union" in line and "LEAF" not in line for line in blend)
     assert _listing(cc.nodes.make_program(cc.shapes.union([cc.shapes.sphere(2), cc.shapes.box(1).translated_x(1)], r=0.3)), 1) == []
+
+
+def test_interpreter_kernels_keep_their_program_in_scalar_registers(tmp_path):
+    """Compile the library's device code to assembly (hipcc cross-compiles here, ~1 min) and look at every interpreter
+    kernel: no scratch, and no vector-memory loads in the dense grid kernels (their only loads are the program's records,
+    which belong in s_load).  Round 2 found this silently broken: two instantiations of the interpreter in one kernel
+    made the compiler keep the record group in scratch and fetch it with global_load."""
+    import re
+    import subprocess
+    from codecad_amd.hip_util import builder
+    hipcc = builder.find_hipcc()
+    if hipcc is None:
+        pytest.skip("no hipcc in this environment")
+    out = tmp_path / "hu.s"
+    flags = [f for f in builder.HIPCC_FLAGS if f not in ("-fPIC",)] + builder.INTERPRETER_FLAGS
+    subprocess.run([hipcc] + flags + ["-I", builder.INCLUDE, "--cuda-device-only", "-S", "-o", str(out),
+                                      os.path.join(builder.CSRC, "hip_util.hip")], check=True, capture_output=True)
+    text = out.read_text()
+    seen = 0
+    for chunk in re.split(r"\n(?=_Z\w+:\s+; @)", text):
+        m = re.match(r"(_Z\w+):", chunk)
+        if not m or "InterpEval" not in m.group(1):
+            continue
+        seen += 1
+        scratch = re.search(r"; ScratchSize: (\d+)", chunk)
+        assert scratch and int(scratch.group(1)) == 0, m.group(1)
+        body = chunk.split(".section")[0]
+        if "k_grid_eval" in m.group(1) and "blocks" not in m.group(1):
+            assert not re.search(r"\tglobal_load|\tscratch_", body), m.group(1)
+            assert re.search(r"\ts_load_dwordx(8|16)", body), m.group(1)
+    assert seen >= 20
