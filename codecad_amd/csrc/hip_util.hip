@@ -1431,12 +1431,13 @@ int hu_tape_listing(const float* tape, size_t n, int which, char* buf, size_t ca
             std::memcpy(&c, &r.p[sdf::kLeafControl], 4);
             o << "(" << ((c & sdf::kLeafSample) ? "sample " : "") << "to:" << kinds[(c >> sdf::kLeafToShift) & 7u]
               << ((c & sdf::kLeafMidStore) ? " store-point:" + std::to_string(slot) : std::string()) << " "
-              << prims[(c >> sdf::kLeafPrimShift) & 7u] << ((c & sdf::kLeafExtrusion) ? " extrusion" : "")
-              << " from:" << kinds[(c >> sdf::kLeafFromShift) & 7u];
+              << prims[(c >> sdf::kLeafPrimShift) & 3u] << ((c & sdf::kLeafExtrusion) ? " extrusion" : "");
+            if (!(c & sdf::kLeafFromLast)) o << " from:" << kinds[(c >> sdf::kLeafFromShift) & 7u];
             for (int k = 0; k < 2; ++k) {
                 const uint32_t cb = c >> (k == 0 ? sdf::kLeafComb1Shift : sdf::kLeafComb2Shift);
                 if (cb & 3u) o << " " << combs[cb & 3u] << ":" << ((cb >> 2) & 0xffu);
             }
+            if (c & sdf::kLeafFromLast) o << " then-from:scale";
             o << ")";
         } else if (sdf::rec_arity(op) == 2 || op == sdf::OP_STORE || op == sdf::OP_LOAD) {
             o << " " << slot << ((r.hdr & sdf::kResultKind) ? "r" : "");

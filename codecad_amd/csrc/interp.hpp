@@ -951,7 +951,7 @@ __device__ __forceinline__ void exec_leaf(const Rec& cur, V4<T>& last, T px, T p
     }
     if (c & kLeafMidStore) regs.store((cur.hdr >> 8) & 0xffu, q);
     // the primitive
-    const uint32_t prim = (c >> kLeafPrimShift) & 7u;
+    const uint32_t prim = (c >> kLeafPrimShift) & 3u;
     V4<T> r = q;
     if (prim == LEAF_RECTANGLE) {
         if (DISTANCE_ONLY) r.w = perp_w<T>(abs_minus(q.x, p[kLeafPrim]), abs_minus(q.y, p[kLeafPrim + 1]));
@@ -971,8 +971,8 @@ __device__ __forceinline__ void exec_leaf(const Rec& cur, V4<T>& last, T px, T p
         else r = extrusion_op(p[kLeafExtrude], r, q);
     }
     const uint32_t from = (c >> kLeafFromShift) & 7u;
-    if (from != 0u) {
-        const float* f = p + kLeafFrom;
+    const float* f = p + kLeafFrom;
+    if (from != 0u && !(c & kLeafFromLast)) {
         if (DISTANCE_ONLY) {
             r.w = r.w * p[kLeafScale];
         } else if (from == 1u) {
@@ -1007,6 +1007,10 @@ __device__ __forceinline__ void exec_leaf(const Rec& cur, V4<T>& last, T px, T p
             else if (kind == 2u) r = neg(rounded_union(-1.0f, neg(r), neg(b)));
             else r = neg(rounded_union(-1.0f, neg(r), b));
         }
+    }
+    if (c & kLeafFromLast) {   // a scaling applied to the combined value (OPX_FROM_SCALE after the selects)
+        if (DISTANCE_ONLY) r.w = r.w * p[kLeafScale];
+        else r = v4<T>(r.x * f[0], r.y * f[0], r.z * f[0], r.w * p[kLeafScale]);
     }
     last = r;
 }

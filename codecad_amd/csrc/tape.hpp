@@ -368,6 +368,20 @@ inline void fuse_leaves(const std::vector<Rec>& prog, bool typed, std::vector<Re
             ++j;
             ++parts;
         }
+        // [from: a scaling of the combined value] -- `to prim select select from_scale`, the tail of a repeated cross
+#ifndef SDF_LEAF_FROM_LAST
+#define SDF_LEAF_FROM_LAST 1
+#endif
+        if (SDF_LEAF_FROM_LAST && ok && !closed && j < n && !(control & (7u << kLeafFromShift)) && (control & (3u << kLeafComb1Shift)) &&
+            op_of(prog[j]) == OPX_FROM_SCALE && !(fold_word(prog[j]) & kFoldLoad)) {
+            const Rec& r = prog[j];
+            control |= (1u << kLeafFromShift) | kLeafFromLast;
+            leaf.p[kLeafFrom + 0] = r.p[0]; leaf.p[kLeafFrom + 1] = r.p[1]; leaf.p[kLeafFrom + 2] = r.p[2];
+            leaf.p[kLeafScale] = r.p[5];
+            if (fold_word(r) & kFoldStore) { fold |= fold_word(r) & (kFoldStore | kFoldStoreResult | 0xff0000u); closed = true; }
+            ++j;
+            ++parts;
+        }
         // The folded store of the transformed point: dropped when nothing reads the slot afterwards (the fused
         // extrusion has the point in registers), which includes the leaf's own final store overwriting it.
         if (ok && have_mid_store) {

@@ -53,10 +53,11 @@ constexpr int kLeafScale = 9;     // p[9]: the from-part's distance scale, p[11.
 constexpr int kLeafFrom = 11;
 constexpr int kLeafControl = 14;
 constexpr uint32_t kLeafSample = 1u;                 // the point is the sample point (OPX_POINT fused)
-constexpr uint32_t kLeafToShift = 1, kLeafPrimShift = 4, kLeafFromShift = 8;   // 3 bits each: 0 none, 1 scale, 2/3/4 axis x/y/z
+constexpr uint32_t kLeafToShift = 1, kLeafPrimShift = 4, kLeafFromShift = 8;   // to / from: 3 bits, 0 none, 1 scale, 2/3/4 axis x/y/z; primitive: 2 bits
 constexpr uint32_t kLeafExtrusion = 1u << 7;
 constexpr uint32_t kLeafComb1Shift = 11, kLeafComb2Shift = 21;   // 2 bits kind (1 union, 2 intersection, 3 subtraction) + 8 bits slot
 constexpr uint32_t kLeafMidStore = 1u << 31;         // the transformed point is also stored, to the slot in hdr
+constexpr uint32_t kLeafFromLast = 1u << 6;          // the from-part (a scaling) runs AFTER the selects: to prim select select from
 enum LeafPrim : uint32_t { LEAF_RECTANGLE = 0, LEAF_CIRCLE = 1, LEAF_SPHERE = 2, LEAF_HALF_SPACE = 3 };
 
 
