@@ -140,6 +140,38 @@ def _level_launch(tape, parents, n_parents, int_step, dims, dimension, resolutio
         capacity = count
 
 
+def _traverse_device_counted(tape, levels, dimension, resolution, origin, capacities, queue):
+    """All classification levels enqueued back to back, no host round trip between them: every list is a
+    `[header row | rows...]` buffer whose header word 0 is its length; a level counts into the header of its child
+    list and the next launch -- sized for the capacity -- reads its parent count from there
+    (`hu_subdivision_level_indirect`).  Returns (buffers, counts) after ONE synchronisation; counts above the
+    capacities mean "repeat with larger lists"."""
+    lib = hip_manager.lib
+    o = (ctypes.c_double * 3)(origin.x, origin.y, origin.z)
+    top = hip_util.Buffer(numpy.int32, (2, 4), queue=queue)
+    top.enqueue_write(numpy.array([[1, 0, 0, 0], [0, 0, 0, 0]], dtype=numpy.int32))
+    buffers, parents, max_parents = [], top, 1
+    for (int_step, dims), capacity in zip(levels[:-1], capacities):
+        children = hip_util.Buffer(numpy.int32, (capacity + 1, 4), queue=queue)
+        check(lib.hu_memset(children.device_ptr, 0, 16, queue.handle), "hu_memset")
+        box_step = int_step * resolution
+        thr = box_step * math.sqrt(dimension) / 2  # reference subdivision.py:67
+        d = (ctypes.c_uint32 * 3)(int(dims[0]), int(dims[1]), int(dims[2]))
+        check(lib.hu_subdivision_level_indirect(tape.device_ptr, parents.device_ptr + 16, parents.device_ptr, max_parents,
+                                                int(int_step), d, dimension, float(resolution), o, numpy.float32(box_step),
+                                                numpy.float32(thr), children.device_ptr, children.device_ptr + 16, capacity,
+                                                queue.handle), "hu_subdivision_level_indirect")
+        buffers.append(children)
+        parents, max_parents = children, capacity
+    # the headers: small asynchronous reads, one wait
+    heads = [numpy.zeros(4, dtype=numpy.int32) for _ in buffers]
+    for b, h in zip(buffers, heads):
+        check(lib.hu_memcpy_d2h(h.ctypes.data, b.device_ptr, 16, queue.handle), "hu_memcpy_d2h")
+    queue.synchronize()
+    top.release()
+    return buffers, [int(h[0]) for h in heads]
+
+
 def subdivision_device(shape, resolution, overlap_edge_samples=True, grid_size=None, queue=None):
     """Level-synchronous subdivision that leaves the leaf list on the GPU -> LeafBlocks."""
     if grid_size is None:
@@ -154,23 +186,43 @@ def subdivision_device(shape, resolution, overlap_edge_samples=True, grid_size=N
     if dimension == 2:
         box = box.flattened()
     levels = calculate_block_sizes(box, dimension, resolution, grid_size, overlap_edge_samples)
-
-    parents = hip_util.Buffer(numpy.int32, (1, 4), queue=queue)
-    parents.enqueue_write(numpy.zeros((1, 4), dtype=numpy.int32))
-    count, level_counts, samples = 1, [], 0
-    counter = hip_util.Buffer(numpy.uint32, 1, queue=queue)
-    for int_step, dims in levels[:-1]:  # the leaf level is left to the consumer (reference :96-111)
-        samples += count * int(dims[0]) * int(dims[1]) * int(dims[2])
-        children, count = _level_launch(tape, parents, count, int_step, dims, dimension, resolution, box.a,
-                                        counter, queue)
-        parents.release()
-        parents = children
-        level_counts.append(count)
-        if count == 0:
-            break
-    counter.release()
     leaf_int_step, leaf_dims = levels[-1]
-    return LeafBlocks(tape, parents, count, leaf_dims, leaf_int_step * resolution, leaf_int_step, resolution,
+    cells = [int(d[0]) * int(d[1]) * int(d[2]) for _, d in levels]
+    if len(levels) == 1:
+        parents = hip_util.Buffer(numpy.int32, (1, 4), queue=queue)
+        parents.enqueue_write(numpy.zeros((1, 4), dtype=numpy.int32))
+        return LeafBlocks(tape, parents, 1, leaf_dims, leaf_int_step * resolution, leaf_int_step, resolution, box.a, [], 0)
+
+    # first sizes as before (every cell while that is small, else the surface estimate); the whole traversal is
+    # repeated with the sizes it reported when a list was too short (fractal shapes keep most cells: rare)
+    capacities, bound = [], 1
+    for c in cells[:-1]:
+        capacities.append(child_capacity(bound, c))
+        bound = capacities[-1]
+    while True:
+        buffers, counts = _traverse_device_counted(tape, levels, dimension, resolution, box.a, capacities, queue)
+        if all(n <= c for n, c in zip(counts, capacities)):
+            break
+        for b in buffers:
+            b.release()
+        capacities = [max(c, int(n * 1.125) + 16) for n, c in zip(counts, capacities)]
+    level_counts, samples, parents_n = [], 0, 1
+    for n, c in zip(counts, cells[:-1]):
+        samples += parents_n * c
+        tape.note_samples(parents_n * c)
+        level_counts.append(n)
+        parents_n = n
+        if n == 0:
+            break
+    count = level_counts[-1]
+    # consumers take a plain row list: the leaf rows without their header row
+    leaves = hip_util.Buffer(numpy.int32, (max(count, 1), 4), queue=queue)
+    if count:
+        check(hip_manager.lib.hu_memcpy_d2d(leaves.device_ptr, buffers[len(level_counts) - 1].device_ptr + 16, count * 16, queue.handle),
+              "hu_memcpy_d2d")
+    for b in buffers:
+        b.release()      # stream-ordered: the pool hands the block to the next user of this queue
+    return LeafBlocks(tape, leaves, count, leaf_dims, leaf_int_step * resolution, leaf_int_step, resolution,
                       box.a, level_counts, samples)
 
 
