@@ -252,6 +252,7 @@ def main():
     t0 = time.perf_counter()
     for evs in step_events:
         one_step(evs)
+    enqueue_s = time.perf_counter() - t0            # host time to enqueue the steps (they run behind it)
     barrier()
     wall = time.perf_counter() - t0
     if world > 1:
@@ -322,6 +323,7 @@ def main():
                       "SDF Mvoxels/s (subdivision + leaf-block grid_eval), 2048^3-effective menger_sponge depth 5",
             "value": round(value, 1), "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 3),
+            "host_enqueue_ms_per_step": round(enqueue_s / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": ("menger_sponge depth=%d, %d^3%s: %sadaptive subdivision (grid %d, overlap) + grid_eval of all "
