@@ -364,7 +364,7 @@ def main():
 
 def hbm_regime(lib, check, hip_util, cc, torch, np, dev, stream, n, evaluator):
     """The HBM-bound regime, measured in this run: the SAME dense kernels on tapes whose arithmetic fits under the
-    store stream (sphere: 3 instructions; sphere + box: 9; csg_example: 28), float4 (16 B/voxel) and float (4 B/voxel),
+    store stream (box: 5 instructions; sphere: 3; sphere + box: 9; csg_example: 28), float4 (16 B/voxel) and float (4 B/voxel),
     with the tape interpreter and with per-tape code.  Each entry: algorithmic bytes / average kernel time (HIP
     events around ten back-to-back launches, after three warm ones) against the 8 TB/s peak."""
     out = []
@@ -375,7 +375,7 @@ def hbm_regime(lib, check, hip_util, cc, torch, np, dev, stream, n, evaluator):
     buf = torch.empty((n, n, n, 4), dtype=torch.float32, device=dev)
     dims = (ctypes.c_uint32 * 3)(n, n, n)
     reps = 10
-    for name, shape in (("sphere", cc.shapes.sphere(130)), ("sphere_plus_box", cc.examples.sphere_plus_box()),
+    for name, shape in (("box", cc.shapes.box(100)), ("sphere", cc.shapes.sphere(130)), ("sphere_plus_box", cc.examples.sphere_plus_box()),
                         ("csg_example", cc.examples.csg_example())):
         host_tape = cc.nodes.make_program(shape)
         bb = shape.bounding_box()

@@ -282,7 +282,11 @@ template <class T> __device__ __forceinline__ void axis_rotate_dir(const float* 
 // perpendicular_intersection(slab_x, slab_y) (common.cl:15-31) under ==: the zero components
 // only drop exact zeros.  Written with selects, not branches: a divergent branch inside the
 // dispatch loop makes the compiler structurize the WHOLE loop (~4x instruction bloat).
-template <class T> __device__ __forceinline__ V4<T> rectangle_op(float hw, float hh, V4<T> c)
+// `wanted` (here and in extrusion_op / circle_op / sphere_op): the lanes whose result will be used.  The second phase
+// of deferred directions evaluates a primitive for the lanes where it won; a corner block or an IEEE fallback that only
+// other lanes would need is skipped (their values are discarded anyway).  Everywhere else: all lanes.
+template <class T, class M = typename mask_of<T>::type>
+__device__ __forceinline__ V4<T> rectangle_op(float hw, float hh, V4<T> c, M wanted = mask_of<T>::all())
 {
     const T one = bc<T>(1.0f), zero = bc<T>(0.0f);
     T sx = copysign_(one, c.x), sy = copysign_(one, c.y);
@@ -292,9 +296,9 @@ template <class T> __device__ __forceinline__ V4<T> rectangle_op(float hw, float
     // the nearer slab everywhere; the corner region (outside both slabs) is patched in only when some
     // lane of the wavefront is in it, so the common case pays three selects per voxel, not six
     V4<T> r = v4<T>(sel(xs, sx, zero), sel(xs, zero, sy), zero, max_(wx, wy));
-    if (any_lane(corner)) {
+    if (any_lane(corner & wanted)) {
         T dist, inv;
-        sqrt_inv_cr(fma_(wy, wy, wx * wx), corner, dist, inv);
+        sqrt_inv_cr(fma_(wy, wy, wx * wx), corner & wanted, dist, inv);
         r.x = sel(corner, sx * (wx * inv), r.x);
         r.y = sel(corner, sy * (wy * inv), r.y);
         r.w = sel(corner, dist, r.w);
@@ -314,7 +318,8 @@ template <class T> __device__ __forceinline__ T perp_w(T a, T b)
 }
 
 // reference shapes/simple3d.cl:18-21 = perpendicular_intersection(slab_z(h, coords), in)
-template <class T> __device__ __forceinline__ V4<T> extrusion_op(float hh, V4<T> in, V4<T> coords)
+template <class T, class M = typename mask_of<T>::type>
+__device__ __forceinline__ V4<T> extrusion_op(float hh, V4<T> in, V4<T> coords, M wanted = mask_of<T>::all())
 {
     const T zero = bc<T>(0.0f);
     T sz = copysign_(bc<T>(1.0f), coords.z);
@@ -322,9 +327,9 @@ template <class T> __device__ __forceinline__ V4<T> extrusion_op(float hh, V4<T>
     auto corner = gt(wz, 0.0f) & gt(in.w, 0.0f);
     auto cap = gt(wz, in.w);
     V4<T> r = v4<T>(sel(cap, zero, in.x), sel(cap, zero, in.y), sel(cap, sz, in.z), max_(wz, in.w));
-    if (any_lane(corner)) {
+    if (any_lane(corner & wanted)) {
         T dist, inv;
-        sqrt_inv_cr(fma_(in.w, in.w, wz * wz), corner, dist, inv);
+        sqrt_inv_cr(fma_(in.w, in.w, wz * wz), corner & wanted, dist, inv);
         T m1 = wz * inv, m2 = in.w * inv;
         // + 0: the slab's direction has x = y = +0, and (+0)*m1 added to a product that is -0 gives +0
         // (perpendicular_intersection, common.cl:15-31, adds both terms); zero signs are observable
@@ -359,19 +364,21 @@ template <class T> __device__ __forceinline__ V4<T> rounded_union(float r, V4<T>
 }
 
 // reference shapes/simple2d.cl:6-14
-template <class T> __device__ __forceinline__ V4<T> circle_op(float r, V4<T> c)
+template <class T, class M = typename mask_of<T>::type>
+__device__ __forceinline__ V4<T> circle_op(float r, V4<T> c, M wanted = mask_of<T>::all())
 {
     T a, inv;
-    sqrt_inv_cr(fma_(c.y, c.y, c.x * c.x), mask_of<T>::all(), a, inv);
+    sqrt_inv_cr(fma_(c.y, c.y, c.x * c.x), wanted, a, inv);
     auto zero = eq(a, 0.0f);
     return v4<T>(sel(zero, bc<T>(1.0f), c.x * inv), sel(zero, bc<T>(0.0f), c.y * inv), bc<T>(0.0f), a - r);
 }
 
 // reference shapes/simple3d.cl:1-12
-template <class T> __device__ __forceinline__ V4<T> sphere_op(float r, V4<T> c)
+template <class T, class M = typename mask_of<T>::type>
+__device__ __forceinline__ V4<T> sphere_op(float r, V4<T> c, M wanted = mask_of<T>::all())
 {
     T a, inv;
-    sqrt_inv_cr(fma_(c.z, c.z, fma_(c.y, c.y, c.x * c.x)), mask_of<T>::all(), a, inv);
+    sqrt_inv_cr(fma_(c.z, c.z, fma_(c.y, c.y, c.x * c.x)), wanted, a, inv);
     auto zero = eq(a, 0.0f);
     return v4<T>(sel(zero, bc<T>(1.0f), c.x * inv), sel(zero, bc<T>(0.0f), c.y * inv), sel(zero, bc<T>(0.0f), c.z * inv),
                  a - r);
@@ -594,6 +601,7 @@ template <> struct Regs<float> {
     float* res;    // this lane's slot of scalar register 0
     uint32_t stride;
     static constexpr uint32_t kLaneBytes = 4;
+    static __device__ __forceinline__ m1 wanted() { return mask_of<float>::all(); }
     __device__ __forceinline__ Regs(void* lds, uint32_t lane, uint32_t lanes, uint32_t n4)
         : base((float4*)lds + lane), res((float*)((float4*)lds + n4 * lanes) + lane), stride(lanes) {}
     __device__ __forceinline__ V4<float> load(uint32_t r) const { float4 v = base[r * stride]; return v4<float>(v.x, v.y, v.z, v.w); }
@@ -608,6 +616,7 @@ template <> struct Regs<f2> {
     f2* res;
     uint32_t stride;
     static constexpr uint32_t kLaneBytes = 8;
+    static __device__ __forceinline__ m2 wanted() { return mask_of<f2>::all(); }
     __device__ __forceinline__ Regs(void* lds, uint32_t lane, uint32_t lanes, uint32_t n4)
         : base((f2*)lds + lane), res((f2*)lds + n4 * 4u * lanes + lane), stride(lanes) {}
     __device__ __forceinline__ f2* slot(uint32_t r, uint32_t c) const { return base + (r * 4u + c) * stride; }
@@ -626,6 +635,7 @@ template <> struct Regs<f2> {
 // once exec_one is inlined with a literal record, so the array dissolves into VGPRs.
 template <class T, int SLOTS> struct RegsV {
     V4<T> v[SLOTS > 0 ? SLOTS : 1];
+    static __device__ __forceinline__ typename mask_of<T>::type wanted() { return mask_of<T>::all(); }
     __device__ __forceinline__ V4<T> load(uint32_t r) const { return v[r]; }
     __device__ __forceinline__ void store(uint32_t r, const V4<T>& x) { v[r] = x; }
     __device__ __forceinline__ T load_x(uint32_t r) const { return v[r].x; }
@@ -637,6 +647,7 @@ template <class T, int SLOTS> struct RegsV {
 // Register file of specialised DISTANCE-ONLY code: the distance-only program numbers its point slots and its
 // result slots separately (tape.hpp allocate_slots), so they are two arrays here; both dissolve into VGPRs.
 template <class T, int POINTS, int RESULTS> struct RegsDO {
+    static __device__ __forceinline__ typename mask_of<T>::type wanted() { return mask_of<T>::all(); }
     V4<T> pt[POINTS > 0 ? POINTS : 1];
     T res[RESULTS > 0 ? RESULTS : 1];
     __device__ __forceinline__ V4<T> load(uint32_t r) const { return pt[r]; }
@@ -650,6 +661,8 @@ template <class T, int POINTS, int RESULTS> struct RegsDO {
 // records along the path of the winning primitive and hands each its register operand here.
 template <class T> struct RegsOne {
     V4<T> v;
+    typename mask_of<T>::type act = mask_of<T>::all();   // the lanes the path being re-executed won
+    __device__ __forceinline__ typename mask_of<T>::type wanted() const { return act; }
     __device__ __forceinline__ V4<T> load(uint32_t) const { return v; }
     __device__ __forceinline__ void store(uint32_t, const V4<T>&) {}
     __device__ __forceinline__ T load_x(uint32_t) const { return v.x; }
@@ -719,11 +732,11 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const floa
         break;
     case OP_RECTANGLE:
         if (DISTANCE_ONLY) last.w = perp_w<T>(abs_minus(last.x, p[0]), abs_minus(last.y, p[1]));
-        else last = rectangle_op(p[0], p[1], last);
+        else last = rectangle_op(p[0], p[1], last, regs.wanted());
         break;
     case OP_CIRCLE:
         if (DISTANCE_ONLY) last.w = len2(last.x, last.y) - p[0];
-        else last = circle_op(p[0], last);
+        else last = circle_op(p[0], last, regs.wanted());
         break;
     case OP_REGULAR_POLYGON2D: {
         const float a = p[0], b = p[1], c = p[2], d = p[3], e = p[4];
@@ -738,7 +751,7 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const floa
     }
     case OP_SPHERE:
         if (DISTANCE_ONLY) last.w = len3(last.x, last.y, last.z) - p[0];
-        else last = sphere_op(p[0], last);
+        else last = sphere_op(p[0], last, regs.wanted());
         break;
     case OP_HALF_SPACE:
         if (DISTANCE_ONLY) last.w = -last.y;
@@ -883,7 +896,7 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const floa
     }
     case OP_EXTRUSION:
         if (DISTANCE_ONLY) last.w = perp_w<T>(abs_minus(regs.load_z(reg), p[0]), last.w);
-        else last = extrusion_op(p[0], last, regs.load(reg));
+        else last = extrusion_op(p[0], last, regs.load(reg), regs.wanted());
         break;
     case OP_REVOLUTION_FROM:
         if (!DISTANCE_ONLY) last = per_voxel(last, regs.load(reg), [](float4 l, float4 r) { return revolution_from_op(l, r); });

@@ -25,6 +25,7 @@
 #pragma once
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <sstream>
 #include <string>
@@ -213,7 +214,7 @@ inline void emit_plain(std::ostringstream& o, const SpecProgram& p)
 }
 
 // true: the deferred form was emitted; false: nothing was written (use emit_plain)
-inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t max_paths = 40)
+inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t max_paths = 40, bool save_points = false)
 {
     using namespace spec_detail;
     if (p.dist.empty() || p.dist.size() != p.full.size()) return false;
@@ -231,6 +232,15 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
         for (const Step& s : path.up)
             if (s.node >= 0 && reads_input_distance(nodes[s.node].op)) keep_w[nodes[s.node].rec] = 1;
     }
+    // save_points: keep each primitive's local coordinates from phase 1 instead of recomputing them in phase 2
+    // (registers against instructions: measured per tape family)
+    std::vector<char> keep_pt(p.full.size(), 0);
+    if (save_points)
+        for (const Path& path : paths) {
+            keep_pt[nodes[nodes[path.leaf].a].rec] = 1;
+            for (const Step& s : path.up)
+                if (s.node >= 0 && nodes[s.node].role == WITH_POINT) keep_pt[nodes[nodes[s.node].b].rec] = 1;
+        }
     std::ostringstream body;
     body << "    using namespace sdf;\n    using M = typename mask_of<T>::type;\n"
          << "    RegsDO<T, " << p.n_point_slots << ", " << p.n_result_slots << "> regs;\n"
@@ -253,6 +263,7 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
         }
         body << "    { const Rec r = " << rec_literal(r, true, r.hdr) << "; exec_one<T, true, decltype(regs), " << op
              << ">(r, last, extra, px, py, pz, regs); }\n";
+        if (keep_pt[i]) body << "    const V4<T> pt" << i << " = last;\n";
         if (fold & kFoldStore) {
             if (fold & kFoldStoreResult) body << "    regs.store_res(" << ((fold >> 16) & 0xffu) << ", last.w);\n";
             else body << "    regs.store(" << ((fold >> 16) & 0xffu) << ", last);\n";
@@ -282,11 +293,12 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
         if (path.choices.empty()) o << "mask_of<T>::all()";
         for (size_t k = 0; k < path.choices.size(); ++k)
             o << (k ? " & " : "") << (path.choices[k].second ? "c" : "~c") << path.choices[k].first;
-        o << ";\n        if (wave_any(m)) {\n";
+        o << ";\n        if (wave_any(m)) {\n#ifndef SDF_PHASE2_ALL_LANES\n            one.act = m;\n#endif\n";
         // the local coordinates of a point node: its chain of point ops from the sample point, emitted once per block
         std::vector<int> var(nodes.size(), -1);
         int next_var = 0;
         auto emit_point = [&](int node) -> std::string {
+            if (keep_pt[nodes[node].rec]) return "pt" + std::to_string(nodes[node].rec);
             std::vector<int> chain;
             for (int at = node; at >= 0 && var[at] < 0; at = nodes[at].a) chain.push_back(at);
             for (auto it = chain.rbegin(); it != chain.rend(); ++it) {
@@ -331,7 +343,8 @@ inline std::string specialised_source(const SpecProgram& p, bool allow_deferred,
     std::ostringstream o;
     o << "#include \"kernels.hpp\"\nnamespace sdfk {\nusing sdf::Rec;\n";
     std::ostringstream d;
-    const bool ok = allow_deferred && emit_deferred(d, p);
+    static const bool save_points = [] { const char* e = getenv("HU_PHASE2_SAVE_POINTS"); return e && e[0] == '1'; }();
+    const bool ok = allow_deferred && emit_deferred(d, p, 40, save_points);
     if (ok) o << d.str();
     else emit_plain(o, p);
     if (deferred) *deferred = ok;

@@ -39,7 +39,7 @@ def test_bench_line(hip, evaluator):
     assert r["achieved"] == pytest.approx(128 ** 3 * 16 / (r["kernel_ms"] * 1e-3) / 1e9, rel=1e-2)
     for leg in line["roofline_hbm"]:
         assert leg["frac"] == pytest.approx(leg["achieved"] / 8000.0, rel=1e-2) and leg["bytes"] in (128 ** 3 * 16, 128 ** 3 * 4)
-    assert {leg["tape"] for leg in line["roofline_hbm"]} == {"sphere", "sphere_plus_box", "csg_example"}
+    assert {leg["tape"] for leg in line["roofline_hbm"]} == {"box", "sphere", "sphere_plus_box", "csg_example"}
     c = line["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mvoxels/s" and c["sample"]
     # whole-job throughput = samples of one step / time of one step
