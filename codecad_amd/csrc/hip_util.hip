@@ -283,6 +283,7 @@ struct SpecKernels {
     hipFunction_t classify[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [MASS][BATCH]
     hipFunction_t ray_caster = nullptr, bitmap = nullptr;
     bool deferred = false;   // the module was generated with deferred directions (specialise.hpp): dense launches use bricks
+    bool culling = false;    // ... and with per-brick culling: a wavefront takes several bricks
 };
 
 namespace {
@@ -297,9 +298,9 @@ bool defer_directions()
     return !off;
 }
 
-std::string generate_source(const hu_tape_s* t, bool* deferred = nullptr)
+std::string generate_source(const hu_tape_s* t, bool* deferred = nullptr, bool* culling = nullptr)
 {
-    return sdf::specialised_source(t->program, defer_directions(), deferred);
+    return sdf::specialised_source(t->program, defer_directions(), deferred, culling);
 }
 
 void keep_programs(hu_tape_s* t, const sdf::DecodedTape& d)
@@ -564,9 +565,20 @@ int hu_grid_eval_slab(hu_tape t, const float corner[4], float step, const uint32
             // a tape that is bound by its store stream keeps the runs along z (2 KiB contiguous per wavefront:
             // sphere, 512^3 float4: 0.34 ms in runs, 0.42 ms in bricks)
             uint32_t tiles = t->spec->deferred ? brick_tiles(nx, dims[1], dims[2]) : 0u;
-            void* args[] = {&ev, &cx, &cy, &cz, &step, &sx, &sy, &sz, &xs, &n_cells, &tiles, &o};
             const uint32_t per_block = kSpecBlock * kSpecVoxelsPerLane;
-            HU_HIP(hipModuleLaunchKernel(t->spec->dense[layout], (n_cells + per_block - 1) / per_block, 1, 1, kSpecBlock, 1, 1,
+            uint32_t grid = (n_cells + per_block - 1) / per_block;
+            if (tiles) {
+                // a wavefront takes G bricks in a row along z: up to 16, with culling up to 64 (one centre evaluation per
+                // lane) -- while the launch still has a few thousand wavefronts
+                const uint32_t nbz = dims[2] / 8u;   // a multiple of four (sz % 32 == 0)
+                const uint64_t bricks = (uint64_t)(nx / 4u) * (dims[1] / 4u) * nbz;
+                tiles = 4u;
+                for (uint32_t g = t->spec->culling ? 64u : 16u; g > 4u; g >>= 1)
+                    if (nbz % g == 0u && bricks / g >= 8192u) { tiles = g; break; }
+                grid = (uint32_t)((bricks / tiles + 3u) / 4u);
+            }
+            void* args[] = {&ev, &cx, &cy, &cz, &step, &sx, &sy, &sz, &xs, &n_cells, &tiles, &o};
+            HU_HIP(hipModuleLaunchKernel(t->spec->dense[layout], grid, 1, 1, kSpecBlock, 1, 1,
                                          0, (hipStream_t)stream, args, nullptr));
             done += nx;
         }
@@ -1179,8 +1191,8 @@ int hu_tape_specialize_cached(hu_tape t, const char* include_dir, const char* ca
     if (from_cache) *from_cache = 0;
     if (!t || !include_dir) return fail(HU_ERR_BAD_ARG, "NULL argument");
     if (t->spec) return HU_OK;
-    bool deferred = false;
-    const std::string src = generate_source(t, &deferred);
+    bool deferred = false, culling = false;
+    const std::string src = generate_source(t, &deferred, &culling);
     int cached = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         SpecImage img;
@@ -1197,6 +1209,7 @@ int hu_tape_specialize_cached(hu_tape t, const char* include_dir, const char* ca
             e = hipModuleGetFunction(slots[i], k->module, img.lowered[i].c_str());
         if (e == hipSuccess) {
             k->deferred = deferred;
+            k->culling = culling;
             t->spec = k;
             if (from_cache) *from_cache = cached;
             return HU_OK;

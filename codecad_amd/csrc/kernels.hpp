@@ -29,6 +29,7 @@ using sdf::Rec;
 // Evaluate through the interpreter.  `prog` is the full or the distance-only program (DO).
 template <bool DO> struct InterpEval {
     static constexpr bool kBricks = false;   // every primitive is evaluated anyway: runs along z (k_grid_eval)
+    static constexpr bool kCull = false;
     const Rec* prog;
     const float* extra;
     uint32_t n4;  // float4 slots of the LDS register file (scalar slots follow them)
@@ -140,6 +141,9 @@ template <int N> struct Cells {
         return pack(v);
     }
 };
+// x extent of a slab with n_cells cells (the brick path bounds its wavefronts with it)
+__device__ __forceinline__ uint32_t sx_slab(uint32_t n_cells, uint32_t sy, uint32_t sz) { return n_cells / (sy * sz); }
+
 // linear index of a lane's first grid cell and the stride to its next one: a wavefront owns 64 * N consecutive cells
 template <int N> __device__ __forceinline__ uint32_t first_cell(uint32_t block)
 {
@@ -214,31 +218,60 @@ k_grid_eval(const E ev, float cx, float cy, float cz, float step, uint32_t sx, D
     const uint32_t sy = dy.n, sz = dz.n;
     using T = typename Pack<N>::T;
     extern __shared__ float4 lds[];
-    if (E::kBricks && N == 2 && tiles) {
-        // blockIdx.x -> (bx, by, bz), bz fastest; tiles = bricks-of-32 along z, dz/dy constants divide by tz and ty
-        const uint32_t tz = sz >> 5, ty = sy >> 2;
-        const uint32_t bz = blockIdx.x % tz, t = blockIdx.x / tz, by = t % ty, bx = t / ty;
-        // lane -> (z: 8, y: 4, x: 2), its two voxels two x planes apart: a store instruction writes 128 contiguous
-        // bytes (eight float4 along z) per (x, y) row of the brick
-        const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-        const uint32_t x = bx * 4u + (lane >> 5), y = by * 4u + ((lane >> 3) & 3u);
-        const uint32_t z = bz * 32u + wave * 8u + (lane & 7u);
-        float xs[N];
+    if constexpr (E::kBricks && N == 2) {
+        if (tiles) {
+            // lane -> (z: 8, y: 4, x: 2), its two voxels two x planes apart: a store instruction writes 128 contiguous
+            // bytes (eight float4 along z) per (x, y) row of the brick
+            const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+            // A wavefront takes tiles = G bricks in a row along z (the index arithmetic and the launch of a wavefront are
+            // paid once per G bricks: 512^3 sponge(4), everything evaluated: 0.974 ms with one brick per wavefront, 0.886
+            // with sixteen).  With culling (E::kCull) the lanes first evaluate the tape ONCE at the centres of those G
+            // bricks (lane j: brick j) with interval bounds -> per brick a mask of the select operands that can win there
+            // (specialise.hpp tape_cull); then brick after brick is evaluated with its mask in scalar registers, the
+            // records of operands that cannot win skipped by wave-uniform branches.
+            const uint32_t G = tiles;
+            const uint32_t nbz = (sz >> 3) / G, nby = sy >> 2;      // groups of G bricks along z, bricks along y
+            const uint32_t wid = blockIdx.x * 4u + wave;
+            const uint32_t gz = wid % nbz, t = wid / nbz, by = t % nby, bx = t / nby;
+            if (bx * 4u >= sx_slab(n_cells, sy, sz)) return;        // wavefronts past the last group (uniform)
+            const uint32_t x = bx * 4u + (lane >> 5), y = by * 4u + ((lane >> 3) & 3u);
+            float xs[N];
 #pragma unroll
-        for (int i = 0; i < N; ++i) xs[i] = sample(cx, step, x0 + x + 2u * i);
-        const T px = pack(xs), py = (T)(sample(cy, step, y)), pz = (T)(sample(cz, step, z));
-        if (LAYOUT == 0) {
-            const sdf::V4<T> r = ev(px, py, pz, lds);
-            float4* o = static_cast<float4*>(out) + ((size_t)z + (size_t)sz * ((size_t)y + (size_t)sy * x));
+            for (int i = 0; i < N; ++i) xs[i] = sample(cx, step, x0 + x + 2u * i);
+            const T px = pack(xs), py = (T)(sample(cy, step, y));
+            uint32_t keep_all = 0xffffffffu;
+            if constexpr (E::kCull) {
+                const float ccx = sample(cx, step, x0 + bx * 4u) + 1.5f * step, ccy = sample(cy, step, by * 4u) + 1.5f * step;
+                const float ccz = sample(cz, step, (gz * G + lane % G) * 8u) + 3.5f * step;
+                keep_all = ev.cull(ccx, ccy, ccz, 1.5f * step, 1.5f * step, 3.5f * step);
+            }
+#pragma unroll 1
+            for (uint32_t j = 0; j < G; ++j) {
+                const uint32_t keep = E::kCull ? (uint32_t)__builtin_amdgcn_readlane((int)keep_all, (int)j) : 0xffffffffu;
+                const uint32_t z = (gz * G + j) * 8u + (lane & 7u);
+                const T pz = (T)(sample(cz, step, z));
+#ifdef SDF_CULL_STATS   // measurements only: a histogram of the masks instead of the grid (out[0..32]: bits set; out[64 + b]: bit b set)
+                if (lane == 0u) {
+                    atomicAdd(static_cast<uint32_t*>(out) + __popc(keep), 1u);
+                    for (uint32_t b = 0; b < 32u; ++b)
+                        if ((keep >> b) & 1u) atomicAdd(static_cast<uint32_t*>(out) + 64u + b, 1u);
+                }
+                continue;
+#endif
+                if (LAYOUT == 0) {
+                    const sdf::V4<T> r = ev.eval_kept(px, py, pz, keep);
+                    float4* o = static_cast<float4*>(out) + ((size_t)z + (size_t)sz * ((size_t)y + (size_t)sy * x));
 #pragma unroll
-            for (int i = 0; i < N; ++i) store_voxel(o + (size_t)i * 2u * sy * sz, sdf::voxel(r, i));
-        } else {
-            const T w = ev.dist(px, py, pz, lds);
-            float* o = static_cast<float*>(out) + ((size_t)z + ((size_t)(x0 + x) + (size_t)(sy - 1u - y) * sx) * sz);
+                    for (int i = 0; i < N; ++i) store_voxel(o + (size_t)i * 2u * sy * sz, sdf::voxel(r, i));
+                } else {
+                    const T w = ev.dist_kept(px, py, pz, keep);
+                    float* o = static_cast<float*>(out) + ((size_t)z + ((size_t)(x0 + x) + (size_t)(sy - 1u - y) * sx) * sz);
 #pragma unroll
-            for (int i = 0; i < N; ++i) store_voxel(o + (size_t)i * 2u * sz, sdf::get(w, i));
+                    for (int i = 0; i < N; ++i) store_voxel(o + (size_t)i * 2u * sz, sdf::get(w, i));
+                }
+            }
+            return;
         }
-        return;
     }
     const uint32_t lin0 = first_cell<N>(blockIdx.x);
     const Cells<N> c(lin0, n_cells, dy, dz, kLaneStride);
