@@ -193,22 +193,13 @@ __device__ __forceinline__ uint32_t wg_sum(uint32_t v, uint32_t* scratch)
     return total;
 }
 
+__device__ __forceinline__ uint32_t mc_row_mask(const McArgs& a, const McSeg& g);   // below
+
 __global__ void __launch_bounds__(256) k_mc_masks(const McArgs a)
 {
     const McSeg g = mc_segment(a);
     if (!g.valid) return;
-    const float* f = a.fields + (size_t)g.b * a.A0 * a.A1 * a.A2 + mc_first_sample(a, g);
-    uint32_t mask = 0;
-    if (g.cnt == 16u && (a.A2 & 3u) == 0u) {  // a row of a 16^3 block: four 16-byte loads in flight
-        const float4* f4 = reinterpret_cast<const float4*>(f);
-        const float4 v0 = f4[0], v1 = f4[1], v2 = f4[2], v3 = f4[3];
-        const float v[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
-#pragma unroll
-        for (int i = 0; i < 16; ++i) mask |= (v[i] <= 0.0f ? 1u : 0u) << i;
-    } else {
-        for (uint32_t i = 0; i < g.cnt; ++i) mask |= (f[i] <= 0.0f ? 1u : 0u) << i;
-    }
-    a.masks[(size_t)g.b * a.segments + g.seg] = mask;
+    a.masks[(size_t)g.b * a.segments + g.seg] = mc_row_mask(a, g);
 }
 
 __global__ void __launch_bounds__(256) k_mc_count(const McArgs a)
@@ -387,6 +378,193 @@ __global__ void __launch_bounds__(256) k_mc_triangles(const McArgs a)
             }
         }
         __syncthreads();
+    }
+}
+
+// ---- a whole block per workgroup -----------------------------------------------------------------------------
+// Blocks of at most 256 rows of at most 32 samples (the 16^3 leaf blocks of a subdivision are that): one workgroup
+// owns the block, so everything a lane needs from its neighbours -- their masks, their first vertex ids and edge
+// masks -- lives in LDS, and the two emitting passes become one:
+//   k_mc_block_count   = k_mc_masks + k_mc_count: the floats are read once, the neighbours' masks come from LDS
+//   k_mc_block_emit    = k_mc_vertices + k_mc_triangles: per row {first id, edge masks} stay in LDS (the general
+//                        kernels write 16 bytes per segment to memory and read them back three times per triangle),
+//                        the case tables are copied to LDS once per workgroup, a lane emits exactly one vertex or one
+//                        TRIANGLE at a time (cells have one to five), a triangle as one 12-byte store at a
+//                        lane-consecutive address; empty blocks leave before loading anything.
+// Same enumeration order, same arithmetic: the output is that of the general kernels.
+__device__ __forceinline__ McMasks mc_masks_block(const uint32_t* lmask, const McArgs& a, const McSeg& g)
+{
+    McMasks r;
+    r.m00 = lmask[threadIdx.x];           // 0 for a lane past the last row
+    r.m10 = g.e0 ? lmask[threadIdx.x + a.A1] : r.m00;
+    r.m01 = g.e1 ? lmask[threadIdx.x + 1u] : r.m00;
+    r.m11 = (g.e0 && g.e1) ? lmask[threadIdx.x + a.A1 + 1u] : r.m00;
+    r.ex = (r.m00 ^ r.m10) & g.xy_own;
+    r.ey = (r.m00 ^ r.m01) & g.xy_own;
+    r.ez = (r.m00 ^ (r.m00 >> 1)) & g.z_own;
+    const uint32_t any = r.m00 | r.m10 | r.m01 | r.m11, all = r.m00 & r.m10 & r.m01 & r.m11;
+    r.cells = (g.e0 && g.e1) ? ((any | (any >> 1)) ^ (all & (all >> 1))) & g.z_own : 0u;
+    return r;
+}
+
+__device__ __forceinline__ uint32_t mc_row_mask(const McArgs& a, const McSeg& g)
+{
+    const float* f = a.fields + (size_t)g.b * a.A0 * a.A1 * a.A2 + mc_first_sample(a, g);
+    uint32_t mask = 0;
+    if (g.cnt == 16u && (a.A2 & 3u) == 0u) {  // a row of a 16^3 block: four 16-byte loads in flight
+        const float4* f4 = reinterpret_cast<const float4*>(f);
+        const float4 v0 = f4[0], v1 = f4[1], v2 = f4[2], v3 = f4[3];
+        const float v[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mask |= (v[i] <= 0.0f ? 1u : 0u) << i;
+    } else {
+        for (uint32_t i = 0; i < g.cnt; ++i) mask |= (f[i] <= 0.0f ? 1u : 0u) << i;
+    }
+    return mask;
+}
+
+__global__ void __launch_bounds__(256) k_mc_block_count(const McArgs a)
+{
+    __shared__ uint32_t scratch[8];
+    __shared__ uint32_t lmask[kMcBlock];
+    __shared__ unsigned char lcount[256];
+    const McSeg g = mc_segment(a);
+    lcount[threadIdx.x] = kMcTriangleCountDev[threadIdx.x];
+    const uint32_t mask = g.valid ? mc_row_mask(a, g) : 0u;
+    if (g.valid) a.masks[(size_t)g.b * a.segments + g.seg] = mask;
+    lmask[threadIdx.x] = mask;
+    __syncthreads();
+    const McMasks k = mc_masks_block(lmask, a, g);
+    const uint32_t nv = __popc(k.ex) + __popc(k.ey) + __popc(k.ez);
+    uint32_t nt = 0;
+    for (uint32_t cells = k.cells; cells; cells &= cells - 1u) nt += lcount[mc_cube(k, __ffs(cells) - 1)];
+    const uint32_t total_v = wg_sum(nv, scratch), total_t = wg_sum(nt, scratch);
+    if (threadIdx.x == 0) a.wg_counts[blockIdx.x] = make_uint2(total_v, total_t);
+}
+
+// Every pass over a block is balanced over the workgroup -- one lane per OUTPUT, not per row: a row has two
+// active cells on average and up to fifteen, and a wavefront that walks its rows' cells in per-lane loops runs at
+// the pace of its busiest row.  Only the listing of the active cells is such a loop (one LDS store per iteration);
+// case indices and triangle counts are computed one cell per lane, and a vertex / a triangle finds its row / cell
+// by bisection over prefix sums in LDS.
+constexpr uint32_t kMcBlockCells = 3584;   // active cells of a block that fit the LDS list (a 16^3 block has 3375 cells)
+
+__device__ __forceinline__ uint32_t mc_bisect_steps(uint32_t n) { return n > 1u ? 32u - (uint32_t)__clz((int)(n - 1u)) : 0u; }
+
+__global__ void __launch_bounds__(256) k_mc_block_emit(const McArgs a)
+{
+    __shared__ uint32_t scratch[8];
+    __shared__ uint32_t lmask[kMcBlock];
+    __shared__ uint4 linfo[kMcBlock];          // per row: first vertex (within the block), x / y / z edge masks
+    __shared__ uint32_t cells[kMcBlockCells];  // active cells in output order: row | i << 8 | case << 13 | triangles << 21
+    __shared__ unsigned short cfirst[kMcBlockCells];   // first triangle (within the block) of each
+    __shared__ uint4 lrow[256];
+    __shared__ unsigned char lcount[256];
+    const uint2 first = a.wg_counts[blockIdx.x], next = a.wg_counts[blockIdx.x + 1u];   // the scan leaves the totals behind the last
+    const uint32_t total_v = next.x - first.x, total_t = next.y - first.y;
+    if (total_v == 0u) return;  // workgroup-uniform: nothing crosses zero in this block
+    const McSeg g = mc_segment(a);
+    lmask[threadIdx.x] = g.valid ? a.masks[(size_t)g.b * a.segments + g.seg] : 0u;
+    lrow[threadIdx.x] = *reinterpret_cast<const uint4*>(kMcPackedDev.row[threadIdx.x]);
+    lcount[threadIdx.x] = kMcTriangleCountDev[threadIdx.x];
+    __syncthreads();
+    const McMasks k = mc_masks_block(lmask, a, g);
+    uint32_t total, n_cells;
+    const uint32_t my_vertex = wg_exclusive_scan(__popc(k.ex) + __popc(k.ey) + __popc(k.ez), scratch, total);
+    uint32_t my_cell = wg_exclusive_scan(__popc(k.cells), scratch, n_cells);
+    linfo[threadIdx.x] = make_uint4(my_vertex, k.ex, k.ey, k.ez);
+    for (uint32_t c = k.cells; c; c &= c - 1u) cells[my_cell++] = threadIdx.x | ((uint32_t)(__ffs(c) - 1) << 8);
+    __syncthreads();
+
+    // one cell per lane: its case and how many triangles; then the prefix of those over the list, a chunk per lane
+    for (uint32_t e = threadIdx.x; e < n_cells; e += kMcBlock) {
+        const uint32_t entry = cells[e], row = entry & 255u, i = entry >> 8;
+        const uint32_t m00 = lmask[row], m10 = lmask[row + a.A1], m01 = lmask[row + 1u], m11 = lmask[row + a.A1 + 1u];
+        const uint32_t p00 = (m00 >> i) & 3u, p10 = (m10 >> i) & 3u, p11 = (m11 >> i) & 3u, p01 = (m01 >> i) & 3u;
+        const uint32_t cube = (p00 & 1u) | ((p10 & 1u) << 1) | ((p11 & 1u) << 2) | ((p01 & 1u) << 3) | ((p00 >> 1) << 4) |
+                              ((p10 >> 1) << 5) | ((p11 >> 1) << 6) | ((p01 >> 1) << 7);
+        cells[e] = entry | (cube << 13) | ((uint32_t)lcount[cube] << 21);
+    }
+    __syncthreads();
+    {
+        const uint32_t per_lane = (n_cells + kMcBlock - 1u) / kMcBlock, e0 = threadIdx.x * per_lane;
+        uint32_t sum = 0;
+        for (uint32_t j = 0; j < per_lane; ++j)
+            if (e0 + j < n_cells) sum += cells[e0 + j] >> 21;
+        uint32_t running = wg_exclusive_scan(sum, scratch, total);
+        for (uint32_t j = 0; j < per_lane; ++j)
+            if (e0 + j < n_cells) {
+                cfirst[e0 + j] = (unsigned short)running;
+                running += cells[e0 + j] >> 21;
+            }
+    }
+    __syncthreads();
+
+    // ---- vertices (mesh.py:65-68 in numpy float64: swap the first two array axes, negate y, scale, add the corner)
+    const uint32_t b = blockIdx.x;
+    const float* block_f = a.fields + (size_t)b * a.A0 * a.A1 * a.A2;
+    const int4 ic = a.blocks[b];
+    const double cx = (double)ic.x * a.res + a.ox, cy = (double)ic.y * a.res + a.oy, cz = (double)ic.z * a.res + a.oz;
+    const uint32_t stride[3] = {a.A1 * a.A2, a.A2, 1u};
+    const uint32_t row_steps = mc_bisect_steps(a.segments);
+    for (uint32_t e = threadIdx.x; e < total_v; e += kMcBlock) {
+        // the last row whose first vertex is <= e: rows without vertices share their successor's first vertex
+        uint32_t row = 0;
+        for (uint32_t s = row_steps; s-- > 0u;) {
+            const uint32_t probe = row + (1u << s);
+            if (probe < a.segments && linfo[probe].x <= e) row = probe;
+        }
+        const uint4 w = linfo[row];
+        // ... and in it the last sample with at most e - w.x edges before it (sample by sample, axis by axis)
+        const uint32_t kth = e - w.x;
+        uint32_t i = 0;
+#pragma unroll
+        for (int s = 4; s >= 0; --s) {
+            const uint32_t probe = i + (1u << s), below = (1u << probe) - 1u;   // probe <= 31
+            if (__popc(w.y & below) + __popc(w.z & below) + __popc(w.w & below) <= kth) i = probe;
+        }
+        const uint32_t below = (1u << i) - 1u, r = kth - (__popc(w.y & below) + __popc(w.z & below) + __popc(w.w & below));
+        const uint32_t bx = (w.y >> i) & 1u, by = (w.z >> i) & 1u;
+        const uint32_t axis = r == 0u ? (bx ? 0u : (by ? 1u : 2u)) : (r == 1u ? ((bx & by) ? 1u : 2u) : 2u);
+        const uint32_t a0 = a.div_A1.div(row), a1 = row - a0 * a.A1;
+        const uint32_t s = i + a.A2 * row;
+        const float f1 = block_f[s], f2 = block_f[s + stride[axis]];
+        const double t = (1.0 * (0.0 - (double)f1)) / ((double)f2 - (double)f1);
+        const uint32_t pos[3] = {a0, a1, i};
+        double v[3];
+#pragma unroll
+        for (uint32_t c = 0; c < 3; ++c) v[c] = (double)pos[c] + (c == axis ? t : 0.0);
+        double* out = a.vertices + 3 * (size_t)(first.x + e);
+        out[0] = v[1] * a.step + cx;
+        out[1] = ((-v[0]) * a.step + cy) + a.y_offset;
+        out[2] = v[2] * a.step + cz;
+    }
+
+    // ---- triangles: one lane, one 12-byte store each
+    const unsigned char* row_bytes = reinterpret_cast<const unsigned char*>(lrow);
+    const uint32_t cell_steps = mc_bisect_steps(n_cells);
+    for (uint32_t e = threadIdx.x; e < total_t; e += kMcBlock) {
+        uint32_t c = 0;   // the last cell whose first triangle is <= e (every listed cell has triangles)
+        for (uint32_t s = cell_steps; s-- > 0u;) {
+            const uint32_t probe = c + (1u << s);
+            if (probe < n_cells && cfirst[probe] <= e) c = probe;
+        }
+        const uint32_t entry = cells[c], row = entry & 255u, i = (entry >> 8) & 31u, cube = (entry >> 13) & 255u;
+        const unsigned char* rb = row_bytes + cube * 16u + 3u * (e - cfirst[c]);
+        uint32_t id[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const uint32_t pk = rb[j], axis = pk >> 3;
+            const uint32_t q = ((pk & 1u) ? a.A1 : 0u) + ((pk >> 1) & 1u), li = i + ((pk >> 2) & 1u);
+            const uint4 w = linfo[row + q];
+            const uint32_t below = low_bits(li);
+            id[j] = first.x + w.x + __popc(w.y & below) + __popc(w.z & below) + __popc(w.w & below) +
+                    (axis >= 1u ? (w.y >> li) & 1u : 0u) + (axis == 2u ? (w.z >> li) & 1u : 0u);
+        }
+        uint32_t* out = a.triangles + 3 * (size_t)(first.y + e);
+        out[0] = id[0];
+        out[1] = id[1];
+        out[2] = id[2];
     }
 }
 

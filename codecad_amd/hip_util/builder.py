@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.normpath(os.path.join(HERE, "..", "csrc"))
 INCLUDE = os.path.normpath(os.path.join(HERE, "..", "..", "include"))
 LIB_PATH = os.path.join(HERE, "libhip_util.so")
-SOURCES = ["hip_util.hip", "sort.hip", "exchange.hip"]
+SOURCES = ["hip_util.hip", "sort.hip", "exchange.hip", "mesh.hip"]
 HEADERS = ["interp.hpp", "kernels.hpp", "mesh_kernels.hpp", "mc_table.hpp", "tape.hpp", "tape_format.hpp", "sdf_math.hpp", "specialise.hpp"]
 
 # Strict IEEE arithmetic is part of the contract (DESIGN.md "Canonical arithmetic"):

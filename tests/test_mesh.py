@@ -211,7 +211,8 @@ def test_hip_marching_cubes_sizes_that_split_a_block_over_workgroups(hip):
     """257 and 1000+ samples per block: vertex ids and triangle slots cross workgroup boundaries."""
     rng = np.random.default_rng(5)
     # ... and rows longer than one 32-sample segment (33, 63, 70, 100 samples: segments share their end samples)
-    for shape in ((2, 1, 257, 1), (3, 10, 10, 11), (1, 2, 2, 2), (2, 33, 5, 17), (2, 3, 4, 32), (2, 3, 4, 33),
+    # (16^3 noise: a whole block per workgroup, ~10^4 triangles: several windows of its triangle queue)
+    for shape in ((2, 16, 16, 16), (2, 1, 257, 1), (3, 10, 10, 11), (2, 16, 16, 32), (2, 10, 10, 32), (1, 256, 1, 3), (1, 1, 256, 2), (1, 2, 2, 2), (2, 33, 5, 17), (2, 3, 4, 32), (2, 3, 4, 33),
                   (1, 5, 3, 63), (2, 4, 5, 70), (1, 20, 20, 100), (1, 1, 1, 40), (1, 2, 1, 40)):
         fields = rng.uniform(-1, 1, shape).astype(np.float32)
         v, t, starts = hip_marching_cubes(hip, fields)
