@@ -40,7 +40,7 @@ constexpr uint32_t kMcSegCells = 31;  // cells per segment; a segment spans kMcS
 __device__ __constant__ unsigned char kMcTriangleCountDev[256] = MC_TRIANGLE_COUNT_INIT;
 
 // The triangle table with each edge replaced by where its vertex lives: bits 0-2 = owning cube corner's
-// offset along a0, a1, a2, bits 3-4 = the edge's axis; 0xff ends the list.  One 16-byte row per case,
+// offset along a0, a1, a2, bits 3-4 = the edge's axis; 0xff ends the list (byte 15: the triangle count).  One 16-byte row per case,
 // so a cell's triangles cost one load instead of a chain of three byte lookups per triangle edge.
 struct McPackedTable {
     unsigned char row[256][MC_TABLE_WIDTH];
@@ -58,6 +58,9 @@ constexpr McPackedTable mc_make_packed_table()
                                 : (unsigned char)(corner[owner[e][0]][0] | (corner[owner[e][0]][1] << 1) |
                                                   (corner[owner[e][0]][2] << 2) | (owner[e][1] << 3));
         }
+    // a case has at most five triangles, so the sixteenth byte of a row is free: the number of triangles of the case
+    constexpr unsigned char count[256] = MC_TRIANGLE_COUNT_INIT;
+    for (int c = 0; c < 256; ++c) p.row[c][MC_TABLE_WIDTH - 1] = count[c];
     return p;
 }
 static_assert(MC_TABLE_WIDTH == 16, "a table row is loaded as one 16-byte vector");
@@ -155,7 +158,10 @@ __device__ __forceinline__ uint32_t mc_cube(const McMasks& k, uint32_t i)
            ((p11 >> 1) << 6) | ((p01 >> 1) << 7);
 }
 
-// exclusive scan of one value per lane over the workgroup; `total` = sum.  scratch: >= 8 uint32 of LDS.
+// exclusive scan of one value per lane over the workgroup of NW wavefronts; `total` = sum.  scratch: >= NW uint32 of
+// LDS.  (NW is a template argument: with blockDim.x read at run time the loop over the wavefronts' sums became an
+// eight-fold unrolled loop with remainder loops, ~100 vector instructions per scan.)
+template <uint32_t NW>
 __device__ __forceinline__ uint32_t wg_exclusive_scan(uint32_t v, uint32_t* scratch, uint32_t& total)
 {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -170,8 +176,8 @@ __device__ __forceinline__ uint32_t wg_exclusive_scan(uint32_t v, uint32_t* scra
     __syncthreads();
     uint32_t base = 0;
     total = 0;
-    const uint32_t nw = (blockDim.x + 63u) >> 6;
-    for (uint32_t w = 0; w < nw; ++w) {
+#pragma unroll
+    for (uint32_t w = 0; w < NW; ++w) {
         const uint32_t c = scratch[w];
         if (w < wave) base += c;
         total += c;
@@ -179,7 +185,8 @@ __device__ __forceinline__ uint32_t wg_exclusive_scan(uint32_t v, uint32_t* scra
     return base + incl - v;
 }
 
-// sum of one value per lane over the workgroup (every lane gets it).  scratch: >= 8 uint32 of LDS.
+// sum of one value per lane over the workgroup (every lane gets it).  scratch: >= NW uint32 of LDS.
+template <uint32_t NW>
 __device__ __forceinline__ uint32_t wg_sum(uint32_t v, uint32_t* scratch)
 {
 #pragma unroll
@@ -188,8 +195,8 @@ __device__ __forceinline__ uint32_t wg_sum(uint32_t v, uint32_t* scratch)
     if ((threadIdx.x & 63u) == 0u) scratch[threadIdx.x >> 6] = v;
     __syncthreads();
     uint32_t total = 0;
-    const uint32_t nw = (blockDim.x + 63u) >> 6;
-    for (uint32_t w = 0; w < nw; ++w) total += scratch[w];
+#pragma unroll
+    for (uint32_t w = 0; w < NW; ++w) total += scratch[w];
     return total;
 }
 
@@ -210,7 +217,7 @@ __global__ void __launch_bounds__(256) k_mc_count(const McArgs a)
     const uint32_t nv = __popc(k.ex) + __popc(k.ey) + __popc(k.ez);
     uint32_t nt = 0;
     for (uint32_t cells = k.cells; cells; cells &= cells - 1u) nt += kMcTriangleCountDev[mc_cube(k, __ffs(cells) - 1)];
-    const uint32_t total_v = wg_sum(nv, scratch), total_t = wg_sum(nt, scratch);
+    const uint32_t total_v = wg_sum<4>(nv, scratch), total_t = wg_sum<4>(nt, scratch);
     if (threadIdx.x == 0) a.wg_counts[blockIdx.x] = make_uint2(total_v, total_t);
 }
 
@@ -225,8 +232,8 @@ __global__ void __launch_bounds__(1024) k_mc_scan_tiles(uint2* counts, uint32_t 
     const uint32_t i = blockIdx.x * kMcScanTile + threadIdx.x;
     const uint2 c = i < n ? counts[i] : make_uint2(0u, 0u);
     uint32_t tv, tt;
-    const uint32_t pv = wg_exclusive_scan(c.x, scratch, tv);
-    const uint32_t pt = wg_exclusive_scan(c.y, scratch, tt);
+    const uint32_t pv = wg_exclusive_scan<16>(c.x, scratch, tv);
+    const uint32_t pt = wg_exclusive_scan<16>(c.y, scratch, tt);
     if (i < n) counts[i] = make_uint2(pv, pt);
     if (threadIdx.x == 0) tile_totals[blockIdx.x] = make_uint2(tv, tt);
 }
@@ -239,8 +246,8 @@ __global__ void __launch_bounds__(1024) k_mc_scan_totals(uint2* tile_totals, uin
         const uint32_t i = start + threadIdx.x;
         const uint2 c = i < n_tiles ? tile_totals[i] : make_uint2(0u, 0u);
         uint32_t tv, tt;
-        const uint32_t pv = wg_exclusive_scan(c.x, scratch, tv);
-        const uint32_t pt = wg_exclusive_scan(c.y, scratch, tt);
+        const uint32_t pv = wg_exclusive_scan<16>(c.x, scratch, tv);
+        const uint32_t pt = wg_exclusive_scan<16>(c.y, scratch, tt);
         if (i < n_tiles) tile_totals[i] = make_uint2(base_v + pv, base_t + pt);
         base_v += tv;
         base_t += tt;
@@ -271,7 +278,7 @@ __global__ void __launch_bounds__(256) k_mc_vertices(const McArgs a)
     const McSeg g = mc_segment(a);
     const McMasks k = mc_masks(a, g);
     uint32_t total;
-    const uint32_t mine = wg_exclusive_scan(__popc(k.ex) + __popc(k.ey) + __popc(k.ez), scratch, total);
+    const uint32_t mine = wg_exclusive_scan<4>(__popc(k.ex) + __popc(k.ey) + __popc(k.ez), scratch, total);
     const uint32_t wg_first = a.wg_counts[blockIdx.x].x;
     if (g.valid) a.seg_info[(size_t)g.b * a.segments + g.seg] = make_uint4(wg_first + mine, k.ex, k.ey, k.ez);
     if (total == 0u) return;  // workgroup-uniform
@@ -329,8 +336,8 @@ __global__ void __launch_bounds__(256) k_mc_triangles(const McArgs a)
         ncell += c ? 1u : 0u;
     }
     uint32_t total_t, total_c;
-    const uint32_t my_slot = a.wg_counts[blockIdx.x].y + wg_exclusive_scan(nt, scratch, total_t);
-    const uint32_t my_cell = wg_exclusive_scan(ncell, scratch, total_c);
+    const uint32_t my_slot = a.wg_counts[blockIdx.x].y + wg_exclusive_scan<4>(nt, scratch, total_t);
+    const uint32_t my_cell = wg_exclusive_scan<4>(ncell, scratch, total_c);
     if (total_c == 0u) return;  // workgroup-uniform
     const uint32_t b = blockIdx.x / a.chunks, seg0 = (blockIdx.x - b * a.chunks) * kMcBlock;
     const uint4* block_info = a.seg_info + (size_t)b * a.segments;
@@ -438,67 +445,67 @@ __global__ void __launch_bounds__(256) k_mc_block_count(const McArgs a)
     const uint32_t nv = __popc(k.ex) + __popc(k.ey) + __popc(k.ez);
     uint32_t nt = 0;
     for (uint32_t cells = k.cells; cells; cells &= cells - 1u) nt += lcount[mc_cube(k, __ffs(cells) - 1)];
-    const uint32_t total_v = wg_sum(nv, scratch), total_t = wg_sum(nt, scratch);
-    if (threadIdx.x == 0) a.wg_counts[blockIdx.x] = make_uint2(total_v, total_t);
+    // one sum for both: a block of this form has at most 3 * 8192 vertices and 5 * kMcBlockCells triangles (16 bits each)
+    const uint32_t both = wg_sum<4>(nv | (nt << 16), scratch);
+    if (threadIdx.x == 0) a.wg_counts[blockIdx.x] = make_uint2(both & 0xffffu, both >> 16);
 }
 
 // Every pass over a block is balanced over the workgroup -- one lane per OUTPUT, not per row: a row has two
 // active cells on average and up to fifteen, and a wavefront that walks its rows' cells in per-lane loops runs at
 // the pace of its busiest row.  Only the listing of the active cells is such a loop (one LDS store per iteration);
-// case indices and triangle counts are computed one cell per lane, and a vertex / a triangle finds its row / cell
-// by bisection over prefix sums in LDS.
-constexpr uint32_t kMcBlockCells = 3584;   // active cells of a block that fit the LDS list (a 16^3 block has 3375 cells)
+// case indices and triangle counts are computed for a chunk of consecutive listed cells per lane, a vertex finds
+// its row by bisection over the rows' first vertices, a triangle is told its cell by the cell.
+// The kernel waits more than it computes (dependent LDS reads, then two samples per vertex from memory), so what
+// it needs most is wavefronts to switch to: 20 KB of LDS per workgroup = eight workgroups per CU (at five, with the
+// cells' cases kept in LDS: 0.365 ms for the bench's 30 800 blocks; at six: 0.298).
+constexpr uint32_t kMcBlockCells = 3520;       // active cells of a block that fit the LDS list (a 16^3 block has 3375 cells)
+constexpr uint32_t kMcTriangleWindow = 1024;   // triangles emitted per round (a block of the bench has ~900)
 
 __device__ __forceinline__ uint32_t mc_bisect_steps(uint32_t n) { return n > 1u ? 32u - (uint32_t)__clz((int)(n - 1u)) : 0u; }
+
+// case index of cell i of row `row` from the block's masks in LDS
+__device__ __forceinline__ uint32_t mc_cube_block(const uint32_t* lmask, uint32_t row, uint32_t i, uint32_t A1)
+{
+    const uint32_t p00 = (lmask[row] >> i) & 3u, p10 = (lmask[row + A1] >> i) & 3u, p11 = (lmask[row + A1 + 1u] >> i) & 3u,
+                   p01 = (lmask[row + 1u] >> i) & 3u;
+    return (p00 & 1u) | ((p10 & 1u) << 1) | ((p11 & 1u) << 2) | ((p01 & 1u) << 3) | ((p00 >> 1) << 4) | ((p10 >> 1) << 5) |
+           ((p11 >> 1) << 6) | ((p01 >> 1) << 7);
+}
 
 __global__ void __launch_bounds__(256) k_mc_block_emit(const McArgs a)
 {
     __shared__ uint32_t scratch[8];
     __shared__ uint32_t lmask[kMcBlock];
-    __shared__ uint4 linfo[kMcBlock];          // per row: first vertex (within the block), x / y / z edge masks
-    __shared__ uint32_t cells[kMcBlockCells];  // active cells in output order: row | i << 8 | case << 13 | triangles << 21
-    __shared__ unsigned short cfirst[kMcBlockCells];   // first triangle (within the block) of each
-    __shared__ uint4 lrow[256];
-    __shared__ unsigned char lcount[256];
+    __shared__ uint4 linfo[kMcBlock];                    // per row: first vertex (within the block), x / y / z edge masks
+    __shared__ unsigned short cells[kMcBlockCells];      // active cells in output order: row | i << 8
+    __shared__ uint32_t which[kMcTriangleWindow];        // per triangle of the round: row | i << 8 | case << 13 | which of its triangles << 21
+    __shared__ uint4 lrow[256];                          // the case table
     const uint2 first = a.wg_counts[blockIdx.x], next = a.wg_counts[blockIdx.x + 1u];   // the scan leaves the totals behind the last
     const uint32_t total_v = next.x - first.x, total_t = next.y - first.y;
     if (total_v == 0u) return;  // workgroup-uniform: nothing crosses zero in this block
     const McSeg g = mc_segment(a);
     lmask[threadIdx.x] = g.valid ? a.masks[(size_t)g.b * a.segments + g.seg] : 0u;
     lrow[threadIdx.x] = *reinterpret_cast<const uint4*>(kMcPackedDev.row[threadIdx.x]);
-    lcount[threadIdx.x] = kMcTriangleCountDev[threadIdx.x];
     __syncthreads();
+    const unsigned char* row_bytes = reinterpret_cast<const unsigned char*>(lrow);
     const McMasks k = mc_masks_block(lmask, a, g);
-    uint32_t total, n_cells;
-    const uint32_t my_vertex = wg_exclusive_scan(__popc(k.ex) + __popc(k.ey) + __popc(k.ez), scratch, total);
-    uint32_t my_cell = wg_exclusive_scan(__popc(k.cells), scratch, n_cells);
+    uint32_t total;   // (one scan for both, 16 bits each: at most 3 * 8192 vertices and kMcBlockCells cells per block)
+    const uint32_t mine = wg_exclusive_scan<4>((__popc(k.ex) + __popc(k.ey) + __popc(k.ez)) | ((uint32_t)__popc(k.cells) << 16), scratch, total);
+    const uint32_t my_vertex = mine & 0xffffu, n_cells = total >> 16;
+    uint32_t my_cell = mine >> 16;
     linfo[threadIdx.x] = make_uint4(my_vertex, k.ex, k.ey, k.ez);
-    for (uint32_t c = k.cells; c; c &= c - 1u) cells[my_cell++] = threadIdx.x | ((uint32_t)(__ffs(c) - 1) << 8);
+    for (uint32_t c = k.cells; c; c &= c - 1u) cells[my_cell++] = (unsigned short)(threadIdx.x | ((uint32_t)(__ffs(c) - 1) << 8));
     __syncthreads();
 
-    // one cell per lane: its case and how many triangles; then the prefix of those over the list, a chunk per lane
-    for (uint32_t e = threadIdx.x; e < n_cells; e += kMcBlock) {
-        const uint32_t entry = cells[e], row = entry & 255u, i = entry >> 8;
-        const uint32_t m00 = lmask[row], m10 = lmask[row + a.A1], m01 = lmask[row + 1u], m11 = lmask[row + a.A1 + 1u];
-        const uint32_t p00 = (m00 >> i) & 3u, p10 = (m10 >> i) & 3u, p11 = (m11 >> i) & 3u, p01 = (m01 >> i) & 3u;
-        const uint32_t cube = (p00 & 1u) | ((p10 & 1u) << 1) | ((p11 & 1u) << 2) | ((p01 & 1u) << 3) | ((p00 >> 1) << 4) |
-                              ((p10 >> 1) << 5) | ((p11 >> 1) << 6) | ((p01 >> 1) << 7);
-        cells[e] = entry | (cube << 13) | ((uint32_t)lcount[cube] << 21);
-    }
-    __syncthreads();
-    {
-        const uint32_t per_lane = (n_cells + kMcBlock - 1u) / kMcBlock, e0 = threadIdx.x * per_lane;
-        uint32_t sum = 0;
-        for (uint32_t j = 0; j < per_lane; ++j)
-            if (e0 + j < n_cells) sum += cells[e0 + j] >> 21;
-        uint32_t running = wg_exclusive_scan(sum, scratch, total);
-        for (uint32_t j = 0; j < per_lane; ++j)
-            if (e0 + j < n_cells) {
-                cfirst[e0 + j] = (unsigned short)running;
-                running += cells[e0 + j] >> 21;
-            }
-    }
-    __syncthreads();
+    // a chunk of consecutive listed cells per lane: their triangles, and the prefix of that over the workgroup
+    const uint32_t per_lane = (n_cells + kMcBlock - 1u) / kMcBlock, chunk0 = threadIdx.x * per_lane;
+    uint32_t chunk_triangles = 0;
+    for (uint32_t j = 0; j < per_lane; ++j)
+        if (chunk0 + j < n_cells) {
+            const uint32_t entry = cells[chunk0 + j];
+            chunk_triangles += row_bytes[mc_cube_block(lmask, entry & 255u, entry >> 8, a.A1) * 16u + 15u];
+        }
+    const uint32_t chunk_first = wg_exclusive_scan<4>(chunk_triangles, scratch, total);
 
     // ---- vertices (mesh.py:65-68 in numpy float64: swap the first two array axes, negate y, scale, add the corner)
     const uint32_t b = blockIdx.x;
@@ -540,31 +547,41 @@ __global__ void __launch_bounds__(256) k_mc_block_emit(const McArgs a)
         out[2] = v[2] * a.step + cz;
     }
 
-    // ---- triangles: one lane, one 12-byte store each
-    const unsigned char* row_bytes = reinterpret_cast<const unsigned char*>(lrow);
-    const uint32_t cell_steps = mc_bisect_steps(n_cells);
-    for (uint32_t e = threadIdx.x; e < total_t; e += kMcBlock) {
-        uint32_t c = 0;   // the last cell whose first triangle is <= e (every listed cell has triangles)
-        for (uint32_t s = cell_steps; s-- > 0u;) {
-            const uint32_t probe = c + (1u << s);
-            if (probe < n_cells && cfirst[probe] <= e) c = probe;
-        }
-        const uint32_t entry = cells[c], row = entry & 255u, i = (entry >> 8) & 31u, cube = (entry >> 13) & 255u;
-        const unsigned char* rb = row_bytes + cube * 16u + 3u * (e - cfirst[c]);
-        uint32_t id[3];
+    // ---- triangles: one lane, one 12-byte store each.  A round takes kMcTriangleWindow of the block's triangles: the
+    // chunks' cells write {cell, case, which of its triangles} where the triangle's lane will look (a bisection over
+    // the cells' first triangles, per triangle, cost a third of this loop)
+    for (uint32_t w0 = 0; w0 < total_t; w0 += kMcTriangleWindow) {
+        uint32_t running = chunk_first;
+        for (uint32_t j = 0; j < per_lane; ++j)
+            if (chunk0 + j < n_cells) {
+                const uint32_t entry = cells[chunk0 + j], cube = mc_cube_block(lmask, entry & 255u, entry >> 8, a.A1);
+                const uint32_t c = row_bytes[cube * 16u + 15u];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const uint32_t pk = rb[j], axis = pk >> 3;
-            const uint32_t q = ((pk & 1u) ? a.A1 : 0u) + ((pk >> 1) & 1u), li = i + ((pk >> 2) & 1u);
-            const uint4 w = linfo[row + q];
-            const uint32_t below = low_bits(li);
-            id[j] = first.x + w.x + __popc(w.y & below) + __popc(w.z & below) + __popc(w.w & below) +
-                    (axis >= 1u ? (w.y >> li) & 1u : 0u) + (axis == 2u ? (w.z >> li) & 1u : 0u);
+                for (uint32_t t = 0; t < 5u; ++t)   // at most five triangles per case
+                    if (t < c && running + t - w0 < kMcTriangleWindow) which[running + t - w0] = entry | (cube << 13) | (t << 21);
+                running += c;
+            }
+        __syncthreads();
+        const uint32_t n = total_t - w0 < kMcTriangleWindow ? total_t - w0 : kMcTriangleWindow;
+        for (uint32_t e = threadIdx.x; e < n; e += kMcBlock) {
+            const uint32_t wh = which[e], row = wh & 255u, i = (wh >> 8) & 31u, cube = (wh >> 13) & 255u;
+            const unsigned char* rb = row_bytes + cube * 16u + 3u * (wh >> 21);
+            uint32_t id[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const uint32_t pk = rb[j], axis = pk >> 3;
+                const uint32_t q = ((pk & 1u) ? a.A1 : 0u) + ((pk >> 1) & 1u), li = i + ((pk >> 2) & 1u);
+                const uint4 w = linfo[row + q];
+                const uint32_t below = low_bits(li);
+                id[j] = first.x + w.x + __popc(w.y & below) + __popc(w.z & below) + __popc(w.w & below) +
+                        (axis >= 1u ? (w.y >> li) & 1u : 0u) + (axis == 2u ? (w.z >> li) & 1u : 0u);
+            }
+            uint32_t* out = a.triangles + 3 * (size_t)(first.y + w0 + e);
+            out[0] = id[0];
+            out[1] = id[1];
+            out[2] = id[2];
         }
-        uint32_t* out = a.triangles + 3 * (size_t)(first.y + e);
-        out[0] = id[0];
-        out[1] = id[1];
-        out[2] = id[2];
+        __syncthreads();
     }
 }
 
