@@ -414,6 +414,19 @@ __device__ __forceinline__ McMasks mc_masks_block(const uint32_t* lmask, const M
     return r;
 }
 
+// bits 0-15 of m moved to bits 0, 4, 8, ... 60
+__device__ __forceinline__ uint64_t mc_spread4(uint32_t m)
+{
+    uint32_t lo = m & 0xffu, hi = (m >> 8) & 0xffu;
+    lo = (lo | (lo << 12)) & 0x000f000fu;
+    hi = (hi | (hi << 12)) & 0x000f000fu;
+    lo = (lo | (lo << 6)) & 0x03030303u;
+    hi = (hi | (hi << 6)) & 0x03030303u;
+    lo = (lo | (lo << 3)) & 0x11111111u;
+    hi = (hi | (hi << 3)) & 0x11111111u;
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
 __device__ __forceinline__ uint32_t mc_row_mask(const McArgs& a, const McSeg& g)
 {
     const float* f = a.fields + (size_t)g.b * a.A0 * a.A1 * a.A2 + mc_first_sample(a, g);
@@ -444,7 +457,16 @@ __global__ void __launch_bounds__(256) k_mc_block_count(const McArgs a)
     const McMasks k = mc_masks_block(lmask, a, g);
     const uint32_t nv = __popc(k.ex) + __popc(k.ey) + __popc(k.ez);
     uint32_t nt = 0;
-    for (uint32_t cells = k.cells; cells; cells &= cells - 1u) nt += lcount[mc_cube(k, __ffs(cells) - 1)];
+    if (a.A2 <= 16u) {   // (uniform)
+        // The four masks interleaved, four bits per sample: the case of cell i is then ONE shift away -- bits
+        // [4i, 4i + 8) -- instead of eight extractions (the loop runs as long as the busiest row of the wavefront has
+        // cells: two thirds of this kernel's instructions).  Corner numbering of the table: 0 = (a0, a1), 1 = (a0+1, a1),
+        // 2 = (a0+1, a1+1), 3 = (a0, a1+1), 4-7 the same one sample further.
+        const uint64_t w = mc_spread4(k.m00) | (mc_spread4(k.m10) << 1) | (mc_spread4(k.m11) << 2) | (mc_spread4(k.m01) << 3);
+        for (uint32_t cells = k.cells; cells; cells &= cells - 1u) nt += lcount[(uint32_t)(w >> (4u * (uint32_t)(__ffs(cells) - 1))) & 0xffu];
+    } else {
+        for (uint32_t cells = k.cells; cells; cells &= cells - 1u) nt += lcount[mc_cube(k, __ffs(cells) - 1)];
+    }
     // one sum for both: a block of this form has at most 3 * 8192 vertices and 5 * kMcBlockCells triangles (16 bits each)
     const uint32_t both = wg_sum<4>(nv | (nt << 16), scratch);
     if (threadIdx.x == 0) a.wg_counts[blockIdx.x] = make_uint2(both & 0xffffu, both >> 16);
