@@ -643,6 +643,9 @@ static int grid_eval_blocks_impl(hu_tape t, const int32_t* blocks_dev, uint32_t 
     if (t->spec) {
         const uint32_t per_block = kSpecBlock * kSpecVoxelsPerLane;
         uint32_t chunks = (uint32_t)((cells + per_block - 1) / per_block);
+        // deferred-direction code over compact bricks (kernels.hpp): a wavefront per (x, y) column of 4 x 4 x 8 bricks
+        uint32_t bricks = t->spec->deferred && brick_tiles(dims[0], dims[1], 32u) && dims[2] % 8u == 0u && dims[2] <= 64u ? dims[2] / 8u : 0u;
+        if (bricks) chunks = ((dims[0] / 4u) * (dims[1] / 4u) + 3u) / 4u;
         SpecEval ev{t->extra_dev};
         const int4* b = (const int4*)blocks_dev;
         double res = resolution, ox = origin[0], oy = origin[1], oz = origin[2];
@@ -652,7 +655,7 @@ static int grid_eval_blocks_impl(hu_tape t, const int32_t* blocks_dev, uint32_t 
         for (uint32_t b0 = 0; b0 < n_blocks; b0 += piece) {
             uint32_t first = b0;
             const uint32_t count = n_blocks - b0 < piece ? n_blocks - b0 : piece;
-            void* args[] = {&ev, &b, &n_dev, &first, &chunks, &res, &ox, &oy, &oz, &step, &sx, &sy, &sz, &out_dev};
+            void* args[] = {&ev, &b, &n_dev, &first, &chunks, &bricks, &res, &ox, &oy, &oz, &step, &sx, &sy, &sz, &out_dev};
             HU_HIP(hipModuleLaunchKernel(t->spec->blocks[layout], chunks * count, 1, 1, kSpecBlock, 1, 1, 0, (hipStream_t)stream,
                                          args, nullptr));
         }
@@ -667,7 +670,7 @@ static int grid_eval_blocks_impl(hu_tape t, const int32_t* blocks_dev, uint32_t 
     const uint32_t piece = units_per_launch(chunks, ls.block);
 #define HU_LAUNCH_BLOCKS(L, D, NV)                                                                                 \
     hipLaunchKernelGGL((k_grid_eval_blocks<InterpEval<D>, L, NV>), grid, block, ls.lds, (hipStream_t)stream,           \
-                       (InterpEval<D>{ls.prog, t->extra_dev, ls.n4}), (const int4*)blocks_dev, n_dev, b0, chunks, resolution, \
+                       (InterpEval<D>{ls.prog, t->extra_dev, ls.n4}), (const int4*)blocks_dev, n_dev, b0, chunks, 0u, resolution, \
                        origin[0], origin[1], origin[2], step, dims[0], make_dim(dims[1]), make_dim(dims[2]), out_dev)
     const bool d_only = layout == 1 && distance_only(t);
     for (uint32_t b0 = 0; b0 < n_blocks; b0 += piece) {

@@ -300,8 +300,8 @@ k_grid_eval(const E ev, float cx, float cy, float cz, float step, uint32_t sx, D
 template <class E, int LAYOUT, int N>
 __global__ void __launch_bounds__(256)
 k_grid_eval_blocks(const E ev, const int4* __restrict__ blocks, const uint32_t* __restrict__ n_blocks_dev, uint32_t b0,
-                   uint32_t chunks, double res, double ox, double oy, double oz, float step, uint32_t sx, Dim dy, Dim dz,
-                   void* __restrict__ out)
+                   uint32_t chunks, uint32_t bricks, double res, double ox, double oy, double oz, float step, uint32_t sx,
+                   Dim dy, Dim dz, void* __restrict__ out)
 {
     const uint32_t sy = dy.n, sz = dz.n;
     using T = typename Pack<N>::T;
@@ -317,6 +317,39 @@ k_grid_eval_blocks(const E ev, const int4* __restrict__ blocks, const uint32_t* 
     const float cx = (float)((double)ic.x * res + ox);
     const float cy = (float)((double)ic.y * res + oy);
     const float cz = (float)((double)ic.z * res + oz);
+    if constexpr (E::kBricks && N == 2) {
+        if (bricks) {
+            // As in k_grid_eval: a wavefront evaluates compact 4 x 4 x 8 bricks (lane -> z: 8, y: 4, x: 2, its two voxels
+            // two x planes apart), here the `bricks` = sz / 8 of one (x, y) column of the block, one after the other.
+            // `chunks` counts workgroups of four such columns.
+            const uint32_t lane = threadIdx.x & 63u, column = chunk * 4u + (threadIdx.x >> 6);
+            const uint32_t nby = sy >> 2, by = column % nby, bx = column / nby;
+            if (bx * 4u >= sx) return;   // wavefronts past the last column (uniform)
+            const uint32_t x = bx * 4u + (lane >> 5), y = by * 4u + ((lane >> 3) & 3u);
+            float xs[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) xs[i] = sample(cx, step, x + 2u * i);
+            const T px = pack(xs), py = (T)(sample(cy, step, y));
+            const size_t base = (size_t)b * cells;
+#pragma unroll 1
+            for (uint32_t j = 0; j < bricks; ++j) {
+                const uint32_t z = j * 8u + (lane & 7u);
+                const T pz = (T)(sample(cz, step, z));
+                if (LAYOUT == 0) {
+                    const sdf::V4<T> r = ev(px, py, pz, lds);
+                    float4* o = static_cast<float4*>(out) + base + ((size_t)z + (size_t)sz * ((size_t)y + (size_t)sy * x));
+#pragma unroll
+                    for (int i = 0; i < N; ++i) store_voxel(o + (size_t)i * 2u * sy * sz, sdf::voxel(r, i));
+                } else {
+                    const T w = ev.dist(px, py, pz, lds);
+                    float* o = static_cast<float*>(out) + base + ((size_t)z + ((size_t)x + (size_t)(sy - 1u - y) * sx) * sz);
+#pragma unroll
+                    for (int i = 0; i < N; ++i) store_voxel(o + (size_t)i * 2u * sz, sdf::get(w, i));
+                }
+            }
+            return;
+        }
+    }
     const uint32_t lin0 = first_cell<N>(chunk);
     const Cells<N> c(lin0, cells, dy, dz, kLaneStride);
     const T px = c.position(cx, step, c.x), py = c.position(cy, step, c.y), pz = c.position(cz, step, c.z);

@@ -1,0 +1,9 @@
+set -e
+cd "$GRAFT_REPO_ROOT"
+timeout -k 10 900 python -m pytest tests -x -q -m gpu > gpurun_out/gpu_tests.log 2>&1 || { tail -30 gpurun_out/gpu_tests.log; exit 1; }
+tail -2 gpurun_out/gpu_tests.log
+timeout -k 10 300 python bench.py --steps 10 --warmup 3 --no-hbm-leg > gpurun_out/b_bricks.json
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/b_bricks.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['adaptive']['leaf_blocks_ms'], d['roofline']['kernel_ms'])
+PY
