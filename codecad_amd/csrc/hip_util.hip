@@ -12,6 +12,7 @@
 #include <hip/hiprtc.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -26,6 +27,7 @@
 #include "../../include/hip_util.h"
 #include "kernels.hpp"
 #include "tape.hpp"
+#include "cull.hpp"
 #include "specialise.hpp"
 
 using sdf::Rec;
@@ -138,6 +140,13 @@ struct hu_tape_s {
     int flags = 0;
     sdf::SpecProgram program;    // both programs on the host, kept for hu_tape_specialize (specialise.hpp)
     struct SpecKernels* spec = nullptr;
+    // per-brick culling of the dense interpreter kernels (cull.hpp): NULL when the tape has nothing to cull
+    uint32_t* needs_dev = nullptr;      // per record of the full program
+    uint32_t* needs_do_dev = nullptr;   // ... of the distance-only program
+    uint32_t n_records = 0, n_records_do = 0;
+    float* lipschitz_dev = nullptr;  // per numbered select
+    struct KeepBuffer { void* stream; uint32_t* words; size_t count; };
+    std::vector<KeepBuffer> keep_buffers;   // the bricks' keep words, one buffer per stream that evaluated this tape
 };
 
 namespace {
@@ -149,6 +158,40 @@ bool distance_only(const hu_tape_s* t)
 {
     static const bool forced_full = [] { const char* e = getenv("HU_FULL_INTERPRETER"); return e && e[0] == '1'; }();
     return !forced_full && t->recs_do_dev != nullptr;
+}
+
+// Per-brick culling of the dense interpreter kernels (cull.hpp): an experiment that works -- sponge(4) at 512^3: a third
+// of the records are skipped, every float still the oracle's -- and does not pay yet: the interpreter is so sensitive
+// to what surrounds a record that the walk over the records that run costs 22 % and the "which operand is out" logic
+// inside selects and fused leaves another 35 % (everything kept: 5.9 ms against 3.45 ms; with culling 4.0 ms).
+// HU_INTERP_CULL=1 turns it on (tests/test_gpu_variants.py runs the parity tests that way); DESIGN.md section 5.
+bool culling_wanted(const hu_tape_s* t)
+{
+    static const bool on = [] { const char* e = getenv("HU_INTERP_CULL"); return e && e[0] == '1'; }();
+    return on && t->needs_dev && t->needs_do_dev && t->lipschitz_dev && t->recs_do_dev;
+}
+
+// The keep words of a launch's bricks: one buffer per (tape, stream), grown when a larger grid comes along.  Launches
+// on one stream are ordered, so reusing its buffer is safe; hipFree waits for the device before it releases.
+int keep_buffer(hu_tape_s* t, void* stream, size_t count, uint32_t** out)
+{
+    for (auto& b : t->keep_buffers)
+        if (b.stream == stream) {
+            if (b.count < count) {
+                HU_HIP(hipFree(b.words));
+                b.words = nullptr;
+                b.count = 0;
+                HU_HIP(hipMalloc((void**)&b.words, count * sizeof(uint32_t)));
+                b.count = count;
+            }
+            *out = b.words;
+            return HU_OK;
+        }
+    uint32_t* words = nullptr;
+    HU_HIP(hipMalloc((void**)&words, count * sizeof(uint32_t)));
+    t->keep_buffers.push_back({stream, words, count});
+    *out = words;
+    return HU_OK;
 }
 
 // Voxels per lane and workgroup size from the register file.
@@ -228,6 +271,10 @@ int ensure_attrs()
     int rc;
     if ((rc = ensure_attrs_n<1>())) return rc;
     if ((rc = ensure_attrs_n<2>())) return rc;
+    if ((rc = allow_big_lds(k_brick_keep<InterpEval<true>>))) return rc;
+    if ((rc = allow_big_lds(k_grid_eval_culled<false, 0, 1>))) return rc;   // (one voxel per lane only: hu_grid_eval_slab)
+    if ((rc = allow_big_lds(k_grid_eval_culled<false, 1, 1>))) return rc;
+    if ((rc = allow_big_lds(k_grid_eval_culled<true, 1, 1>))) return rc;
     if ((rc = allow_big_lds(k_ray_caster<InterpEval<false>>))) return rc;
     if ((rc = allow_big_lds(k_bitmap<InterpEval<false>>))) return rc;
     if ((rc = allow_big_lds(k_bitmap<InterpEval<true>>))) return rc;
@@ -496,6 +543,18 @@ int hu_tape_create(const float* tape, size_t n, hu_tape* out)
     t->n_result_slots = d.n_result_slots;
     t->flags = d.direction_feeds_distance ? 1 : 0;
     keep_programs(t, d);
+    // per-brick culling (cull.hpp): the select numbers go into the fold words of the interpreter's programs (the
+    // padding records at their ends stay out of the analysis: their masks are 0).  Both programs must agree on the
+    // selects -- the centre pass runs the distance-only program whatever the evaluation runs.
+    sdf::CullInfo cull_full, cull_do;
+    if (!d.fused_do.empty()) {
+        sdf::analyse_culling(d.fused, false, cull_full);
+        sdf::analyse_culling(d.fused_do, true, cull_do);
+        bool same = cull_full.enabled && cull_do.enabled && cull_full.n_selects == cull_do.n_selects;
+        for (int k = 0; same && k < sdf::kMaxCullSelects; ++k)
+            same = cull_full.lipschitz[k] == cull_do.lipschitz[k] && cull_full.repetitions[k] == cull_do.repetitions[k];
+        cull_full.enabled = cull_do.enabled = same;
+    }
     // the device holds the interpreter's (fused) programs; per-tape code is generated from the unfused ones
     hipError_t e = hipMalloc((void**)&t->recs_dev, d.fused.size() * sizeof(Rec));
     if (e == hipSuccess && !d.fused_do.empty()) {
@@ -505,10 +564,28 @@ int hu_tape_create(const float* tape, size_t n, hu_tape* out)
     if (e == hipSuccess) e = hipMalloc((void**)&t->extra_dev, d.extra.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(t->recs_dev, d.fused.data(), d.fused.size() * sizeof(Rec), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(t->extra_dev, d.extra.data(), d.extra.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess && cull_full.enabled) {
+        auto upload = [&](const void* src, size_t bytes, void** dst) {
+            if (e == hipSuccess) e = hipMalloc(dst, bytes);
+            if (e == hipSuccess) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+        };
+        t->n_records = cull_full.n_records;
+        t->n_records_do = cull_do.n_records;
+        upload(cull_full.needs.data(), cull_full.needs.size() * 4, (void**)&t->needs_dev);
+        upload(cull_do.needs.data(), cull_do.needs.size() * 4, (void**)&t->needs_do_dev);
+        // [16 floats La + Lb | 16 words: the repetitions each select lies under]
+        uint32_t table[2 * sdf::kMaxCullSelects];
+        std::memcpy(table, cull_do.lipschitz, sizeof(cull_do.lipschitz));
+        std::memcpy(table + sdf::kMaxCullSelects, cull_do.repetitions, sizeof(cull_do.repetitions));
+        upload(table, sizeof(table), (void**)&t->lipschitz_dev);
+    }
     if (e != hipSuccess) {
         (void)hipFree(t->recs_dev);
         (void)hipFree(t->recs_do_dev);
         (void)hipFree(t->extra_dev);
+        (void)hipFree(t->needs_dev);
+        (void)hipFree(t->needs_do_dev);
+        (void)hipFree(t->lipschitz_dev);
         delete t;
         return fail(HU_ERR_HIP, std::string("tape upload: ") + hipGetErrorString(e));
     }
@@ -526,6 +603,10 @@ int hu_tape_destroy(hu_tape t)
     (void)hipFree(t->recs_dev);
     (void)hipFree(t->recs_do_dev);
     (void)hipFree(t->extra_dev);
+    (void)hipFree(t->needs_dev);
+    (void)hipFree(t->needs_do_dev);
+    (void)hipFree(t->lipschitz_dev);
+    for (auto& b : t->keep_buffers) (void)hipFree(b.words);
     delete t;
     return HU_OK;
 }
@@ -594,6 +675,56 @@ int hu_grid_eval_slab(hu_tape t, const float corner[4], float step, const uint32
         const uint32_t per_block = ls.block * ls.voxels_per_lane;
         const uint32_t blocks = (n_cells + per_block - 1) / per_block;
         void* o = (layout == 0) ? (void*)(static_cast<float4*>(out_dev) + (size_t)done * plane) : out_dev;
+        // per-brick culling (cull.hpp): the slab in compact bricks, a centre pass, then the bricks with what it left
+        const uint32_t brick_z = ls.voxels_per_lane == 2 ? 8u : 4u;
+        // (with two voxels per lane the compiler keeps the fetched records in scratch memory -- 12 ms --: one voxel per lane only)
+        if (culling_wanted(t) && ls.voxels_per_lane == 1 && nx % 4u == 0u && dims[1] % 4u == 0u && dims[2] % brick_z == 0u) {
+            const bool d_only = layout == 1 && distance_only(t);
+            const uint32_t nbx = nx / 4u, nby = dims[1] / 4u, nbz = dims[2] / brick_z;
+            const uint32_t n_bricks = nbx * nby * nbz;   // < 2^30 / 64
+            uint32_t* keep = nullptr;
+            if ((rc = keep_buffer(t, stream, n_bricks, &keep))) return rc;
+            LaunchShape centre;   // the distance-only program, one brick per lane
+            if ((rc = launch_shape(t, centre, true, 1))) return rc;
+            // a brick's centre to its farthest sample, with room for the rounding of the centre itself
+            const float radius = 0.5f * step * std::sqrt(18.0f + (float)((brick_z - 1u) * (brick_z - 1u))) * 1.001f;
+            hipLaunchKernelGGL((k_brick_keep<InterpEval<true>>), dim3((n_bricks + centre.block - 1) / centre.block), dim3(centre.block),
+                               centre.lds, (hipStream_t)stream, (InterpEval<true>{centre.prog, t->extra_dev, centre.n4}), t->lipschitz_dev,
+                               reinterpret_cast<const uint32_t*>(t->lipschitz_dev) + sdf::kMaxCullSelects,
+                               corner[0], corner[1], corner[2], step, x0 + done, make_dim(nby), make_dim(nbz), brick_z, n_bricks, radius, keep);
+            static const bool keep_all = [] { const char* e = getenv("HU_CULL_KEEP_ALL"); return e && e[0] == '1'; }();
+            if (keep_all) HU_HIP(hipMemsetAsync(keep, 0xff, (size_t)n_bricks * 4, (hipStream_t)stream));   // a measurement: the culled kernels' overhead alone
+            static const bool stats = [] { const char* e = getenv("HU_CULL_STATS"); return e && e[0] == '1'; }();
+            if (stats) {   // a diagnostic: how much the centre pass ruled out (waits for the stream)
+                std::vector<uint32_t> words(n_bricks);
+                HU_HIP(hipStreamSynchronize((hipStream_t)stream));
+                HU_HIP(hipMemcpy(words.data(), keep, (size_t)n_bricks * 4, hipMemcpyDeviceToHost));
+                uint64_t out_bits = 0, touched = 0;
+                uint64_t per_bit[32] = {0};
+                for (uint32_t w : words) {
+                    out_bits += (uint64_t)__builtin_popcount(~w);
+                    touched += w != 0xffffffffu;
+                    for (int b = 0; b < 32; ++b) per_bit[b] += !((w >> b) & 1u);
+                }
+                std::fprintf(stderr, "[hu] culling: %u bricks, %.3f operands out per brick, %.1f %% of the bricks with any; out per operand:",
+                             n_bricks, (double)out_bits / n_bricks, 100.0 * touched / n_bricks);
+                for (int b = 0; b < 32; ++b) std::fprintf(stderr, " %.2f", (double)per_bit[b] / n_bricks);
+                std::fprintf(stderr, "\n");
+            }
+            const uint32_t waves = ls.block / 64u;
+#define HU_LAUNCH_CULLED(L, D, NV)                                                                                          \
+    hipLaunchKernelGGL((k_grid_eval_culled<D, L, NV>), dim3((n_bricks + waves - 1) / waves), dim3(ls.block), ls.lds,        \
+                       (hipStream_t)stream, (InterpEval<D>{ls.prog, t->extra_dev, ls.n4}), D ? t->needs_do_dev : t->needs_dev, D ? t->n_records_do : t->n_records, \
+                       keep, corner[0], corner[1], corner[2], step, dims[0], make_dim(dims[1]), make_dim(dims[2]),          \
+                       make_dim(nby), make_dim(nbz), x0 + done, n_bricks, o)
+            if (layout == 0) HU_LAUNCH_CULLED(0, false, 1);
+            else if (d_only) HU_LAUNCH_CULLED(1, true, 1);
+            else HU_LAUNCH_CULLED(1, false, 1);
+#undef HU_LAUNCH_CULLED
+            HU_HIP(hipGetLastError());
+            done += nx;
+            continue;
+        }
 #define HU_LAUNCH_DENSE(L, D, NV)                                                                                  \
     hipLaunchKernelGGL((k_grid_eval<InterpEval<D>, L, NV>), dim3(blocks), dim3(ls.block), ls.lds, (hipStream_t)stream, \
                        (InterpEval<D>{ls.prog, t->extra_dev, ls.n4}), corner[0], corner[1], corner[2], step, dims[0],  \
@@ -1320,11 +1451,20 @@ int hu_tape_source(const float* tape, size_t n, char* buf, size_t capacity, size
 int hu_tape_listing(const float* tape, size_t n, int which, char* buf, size_t capacity, size_t* needed)
 {
     if (!tape || !needed || (!buf && capacity)) return fail(HU_ERR_BAD_ARG, "NULL argument");
-    if (which < 0 || which > 3) return fail(HU_ERR_BAD_ARG, "which must be 0..3");
+    if (which < 0 || which > 5) return fail(HU_ERR_BAD_ARG, "which must be 0..5");
     sdf::DecodedTape d;
     const std::string err = sdf::decode_tape(tape, n, d);
     if (!err.empty()) return fail(HU_ERR_BAD_TAPE, "malformed tape: " + err);
+    // 4, 5: the interpreter's programs with what per-brick culling adds (cull.hpp): select numbers, the records' masks
+    sdf::CullInfo cull;
+    const bool with_culling = which >= 4;
+    if (with_culling) {
+        which -= 2;
+        if (which == 3 && d.fused_do.empty()) return fail(HU_ERR_BAD_ARG, "the tape has no distance-only program");
+        sdf::analyse_culling(which == 2 ? d.fused : d.fused_do, which == 3, cull);
+    }
     const std::vector<Rec>& prog = which == 0 ? d.recs : which == 1 ? d.recs_do : which == 2 ? d.fused : d.fused_do;
+    size_t index = 0;
     static const char* const internal[] = {"FROM_SCALE", "FROM_X", "FROM_Y", "FROM_Z", "POINT", "TO_SCALE", "TO_X", "TO_Y", "TO_Z",
                                            "TO_ROW_X", "TO_ROWS_YZ", "FROM_MATRIX", "INIT_ROW_X", "INIT_ROWS_YZ", "LEAF"};
     static const char* const kinds[] = {"-", "scale", "x", "y", "z"};
@@ -1354,8 +1494,26 @@ int hu_tape_listing(const float* tape, size_t n, int which, char* buf, size_t ca
             o << " " << slot << ((r.hdr & sdf::kResultKind) ? "r" : "");
         }
         if (fold & sdf::kFoldStore) o << " [store " << ((fold >> 16) & 0xffu) << ((fold & sdf::kFoldStoreResult) ? "r" : "") << "]";
+        if (with_culling && op != sdf::OP_RETURN) {
+            const uint32_t k1 = (fold >> sdf::kSelShift1) & 31u, k2 = (fold >> sdf::kSelShift2) & 31u;
+            char masks[64];
+            std::snprintf(masks, sizeof masks, " | need %08x", cull.needs[index]);
+            o << masks;
+            const bool is_select = op == sdf::OP_UNION || op == sdf::OP_INTERSECTION || op == sdf::OP_SUBTRACTION;
+            if ((is_select || op == sdf::OPX_LEAF) && k1 != sdf::kSelNone) o << " select " << k1;
+            if (op == sdf::OPX_LEAF && k2 != sdf::kSelNone) o << " select " << k2;
+        }
         o << "\n";
+        ++index;
         if (op == sdf::OP_RETURN) break;
+    }
+    if (with_culling) {
+        o << "culling " << (cull.enabled ? "on" : "off") << ", " << cull.n_selects << " selects, La+Lb:";
+        for (int k = 0; k < cull.n_selects && k < sdf::kMaxCullSelects; ++k) {
+            o << " " << cull.lipschitz[k];
+            if (cull.repetitions[k]) o << "(under repetitions " << std::hex << cull.repetitions[k] << std::dec << ")";
+        }
+        o << "\n";
     }
     const std::string text = o.str();
     *needed = text.size() + 1;

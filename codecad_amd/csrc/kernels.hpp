@@ -297,6 +297,74 @@ k_grid_eval(const E ev, float cx, float cy, float cz, float step, uint32_t sx, D
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// dense grid evaluation by the interpreter with per-brick culling (cull.hpp tells the story)
+// ------------------------------------------------------------------------------------------
+// Bricks: 4 x 4 x 8 voxels with two voxels per lane (lane -> z: 8, y: 4, x: 2, the second voxel two x planes on), 4 x 4 x 4
+// with one (lane -> z: 4, y: 4, x: 4); brick number = (bx * nby + by) * nbz + bz in both kernels.
+//
+// k_brick_keep: one brick per LANE: the distance-only program at the brick's centre -> keep[brick] = for every
+// numbered select which operands may win somewhere in the brick.
+template <class E>   // E = InterpEval<true> (a template so that per-tape modules, which include this file, do not compile it)
+__global__ void __launch_bounds__(256)
+k_brick_keep(const E ev, const float* __restrict__ lipschitz, const uint32_t* __restrict__ repetitions, float cx, float cy, float cz, float step, uint32_t x0,
+             Dim nby, Dim nbz, uint32_t brick_z, uint32_t n_bricks, float radius, uint32_t* __restrict__ keep)
+{
+    extern __shared__ float4 lds[];
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = id < n_bricks ? id : n_bricks - 1u;   // idle tail lanes follow the (uniform) tape harmlessly
+    const uint32_t t = div(i, nbz), bz = i - t * nbz.n, bx = div(t, nby), by = t - bx * nby.n;
+    const float px = sample(cx, step, x0 + bx * 4u) + 1.5f * step, py = sample(cy, step, by * 4u) + 1.5f * step;
+    const float pz = sample(cz, step, bz * brick_z) + 0.5f * (float)(brick_z - 1u) * step;
+    sdf::Centre c{0u, 0u, repetitions[threadIdx.x & 15u], lipschitz[threadIdx.x & 15u], radius,
+                  1e-5f * (sdf::abs_(px) + sdf::abs_(py) + sdf::abs_(pz) + radius), 1.5f * step, 1.5f * step, 0.5f * (float)(brick_z - 1u) * step};
+    sdf::Regs<float> regs(lds, threadIdx.x, blockDim.x, ev.n4);
+    sdf::run_tape_centre(ev.prog, ev.extra, px, py, pz, regs, c);
+    if (id < n_bricks) keep[id] = ~c.kill;
+}
+
+// k_grid_eval_culled: one brick per WAVEFRONT, its keep word in a scalar register
+template <bool DO, int LAYOUT, int N>
+__global__ void __launch_bounds__(256) SDF_KERNEL_ATTRS
+k_grid_eval_culled(const InterpEval<DO> ev, const uint32_t* __restrict__ needs, uint32_t n_records, const uint32_t* __restrict__ keep_of, float cx, float cy,
+                   float cz, float step, uint32_t sx, Dim dy, Dim dz, Dim nby, Dim nbz, uint32_t x0, uint32_t n_bricks,
+                   void* __restrict__ out)
+{
+    const uint32_t sy = dy.n, sz = dz.n;
+    using T = typename Pack<N>::T;
+    extern __shared__ float4 lds[];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wid >= n_bricks) return;   // wavefronts past the last brick (uniform)
+    const uint32_t keep = (uint32_t)__builtin_amdgcn_readfirstlane((int)keep_of[wid]);
+    const uint32_t t = div(wid, nbz), bz = wid - t * nbz.n, bx = div(t, nby), by = t - bx * nby.n;
+    uint32_t x, y, z;
+    if (N == 2) {
+        x = bx * 4u + (lane >> 5);
+        y = by * 4u + ((lane >> 3) & 3u);
+        z = bz * 8u + (lane & 7u);
+    } else {
+        x = bx * 4u + (lane >> 4);
+        y = by * 4u + ((lane >> 2) & 3u);
+        z = bz * 4u + (lane & 3u);
+    }
+    float xs[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) xs[i] = sample(cx, step, x0 + x + 2u * i);
+    const T px = pack(xs), py = (T)(sample(cy, step, y)), pz = (T)(sample(cz, step, z));
+    sdf::Regs<T> regs(lds, threadIdx.x, blockDim.x, ev.n4);
+    const sdf::V4<T> r = sdf::run_tape_culled<T, DO>(ev.prog, needs, n_records, ev.extra, px, py, pz, regs, keep);
+    if (LAYOUT == 0) {
+        float4* o = static_cast<float4*>(out) + ((size_t)z + (size_t)sz * ((size_t)y + (size_t)sy * x));
+#pragma unroll
+        for (int i = 0; i < N; ++i) store_voxel(o + (size_t)i * 2u * sy * sz, sdf::voxel(r, i));
+    } else {
+        float* o = static_cast<float*>(out) + ((size_t)z + ((size_t)(x0 + x) + (size_t)(sy - 1u - y) * sx) * sz);
+#pragma unroll
+        for (int i = 0; i < N; ++i) store_voxel(o + (size_t)i * 2u * sz, sdf::get(r.w, i));
+    }
+}
+
 template <class E, int LAYOUT, int N>
 __global__ void __launch_bounds__(256)
 k_grid_eval_blocks(const E ev, const int4* __restrict__ blocks, const uint32_t* __restrict__ n_blocks_dev, uint32_t b0,
