@@ -21,11 +21,17 @@
 // What the decoder adds to a program, all of it ignored by the plain interpreter:
 //   * plain selects (r < 0) are numbered in program order, k = 0..15: bit 2k of a brick's `keep` word = "operand a may
 //     win", bit 2k+1 = "operand b (the register operand) may win".  k is written into the record's fold word
-//     (bits 10-14; a fused leaf's second select: bits 26-30; 31 = not culled);
-//   * per record a mask (CullInfo::needs): the record runs iff (keep & need) == need.  A value's mask is the AND over
+//     (bits 10-14; a fused leaf's second select: bits 26-30; 31 = not culled) for the centre pass;
+//   * per record two masks (CullInfo::masks): the record RUNS iff (keep & run) == run.  A value's mask is the AND over
 //     its consumers of (consumer's mask | the select bit through which it is consumed): common to all, so whenever a
-//     consumer runs, so does the producer; a record's mask is the AND over the values it defines;
-//   * per select the sum La + Lb (CullInfo::lipschitz).
+//     consumer runs, so does the producer; a record's mask is the AND over the values it defines.  A record that does
+//     not run while the select that takes its value does -- (keep & live) == live, live = the mask without that
+//     select's bit -- is replaced by its STAND-IN (CullInfo::stand_ins): "the constant +-infinity, stored where the
+//     record would have stored its value", so that the select, which runs unchanged, takes the other operand.  Nothing
+//     inside a record knows about culling: the interpreter is so sensitive to what surrounds its dispatch that tests
+//     inside selects and fused leaves cost more than the skipped records saved.  The price: a
+//     primitive fused into a leaf WITH its selects runs whenever the leaf's value is wanted;
+//   * per select the sum La + Lb (CullInfo::lipschitz) and the repetitions it lies under.
 // The reference has no counterpart (it evaluates every instruction for every sample: nodes/codegen.py:5-63).
 #pragma once
 
@@ -46,7 +52,8 @@ constexpr int kMaxCullSelects = 16;
 struct CullInfo {
     bool enabled = false;
     int n_selects = 0;                 // plain selects of the program (numbered ones: the first kMaxCullSelects)
-    std::vector<uint32_t> needs;       // per record: it runs iff (keep & need) == need
+    std::vector<uint32_t> masks;       // [record][2]: run, live (no stand-in: live == run)
+    std::vector<Rec> stand_ins;        // per record: what runs in its place when only `live` is satisfied
     uint32_t n_records = 0;            // records up to and including _return
     float lipschitz[kMaxCullSelects];  // La + Lb per select; infinity: never culled
     uint32_t repetitions[kMaxCullSelects];   // per select: the repetitions (by number) its operands lie under
@@ -59,6 +66,11 @@ struct Value {
     double l;               // a point: scale J of its frame against the sample frame; a result: Lipschitz constant
     int in[2] = {-1, -1};   // operands (a select: a, b)
     int sel = -1;           // plain select number
+    int kind = 0;           // a select: 1 union, 2 intersection, 3 subtraction
+    bool in_leaf = false;   // a select fused into a leaf: its operand a is the leaf's own value and not culled
+    int consumers = 0;
+    uint32_t live = 0;      // the mask without the bit of the select that takes the value
+    float stand_in = 0.0f;  // +-infinity: what that select must see when the value is out (0: no such select)
     uint32_t reps = 0;      // the repetitions (by number, at most 32) the value lies under
     bool aligned = false;   // a point whose frame has the sample frame's axes (only scalings, translations, repetitions so far)
     uint32_t need = 0;
@@ -107,9 +119,11 @@ inline void analyse_culling(std::vector<Rec>& prog, bool typed, CullInfo& out)
         if (fold & kFoldLoad) cur = slot_value((fold & kFoldLoadResult) != 0, fold & 0xffu);
         auto def = [&](int v) { defined[i].push_back(v); return v; };
         uint32_t sel1 = kSelNone, sel2 = kSelNone;
-        auto plain_select = [&](int a, int b) {
+        auto plain_select = [&](int a, int b, int kind, bool in_leaf) {
             const int k = n_sel++;
             const int v = def(make(false, std::fmax(l_of(a), l_of(b)), a, b, k));
+            vals[v].kind = kind;
+            vals[v].in_leaf = in_leaf;
             return std::make_pair(v, (uint32_t)(k < kMaxCullSelects ? k : (int)kSelNone));
         };
         if (op == OP_RETURN) { root = cur; end = i; break; }
@@ -164,7 +178,7 @@ inline void analyse_culling(std::vector<Rec>& prog, bool typed, CullInfo& out)
         case OP_UNION: case OP_INTERSECTION: case OP_SUBTRACTION: {
             const int b = slot_value(true, reg);
             if (p[0] < 0.0f) {
-                auto vs = plain_select(cur, b);
+                auto vs = plain_select(cur, b, op == OP_UNION ? 1 : op == OP_INTERSECTION ? 2 : 3, false);
                 cur = vs.first;
                 sel1 = vs.second;
             } else {
@@ -186,7 +200,7 @@ inline void analyse_culling(std::vector<Rec>& prog, bool typed, CullInfo& out)
             for (int s = 0; s < 2; ++s) {
                 const uint32_t cb = c >> (s == 0 ? kLeafComb1Shift : kLeafComb2Shift);
                 if ((cb & 3u) == 0u) continue;
-                auto vs = plain_select(v, slot_value(true, (cb >> 2) & 0xffu));
+                auto vs = plain_select(v, slot_value(true, (cb >> 2) & 0xffu), (int)(cb & 3u), true);
                 v = vs.first;
                 (s == 0 ? sel1 : sel2) = vs.second;
             }
@@ -203,31 +217,56 @@ inline void analyse_culling(std::vector<Rec>& prog, bool typed, CullInfo& out)
         if (fold & kFoldStore) slots[key((fold & kFoldStoreResult) != 0, (fold >> 16) & 0xffu)] = cur;
         after[i] = cur;
     }
-    // who needs what: consumers come after producers, so one pass from the back
-    if (root >= 0) vals[root].used = true;
+    // who needs what: consumers come after producers, so one pass from the back.  A select's bit goes to an operand
+    // only if the select is that value's only consumer (then "the value is out" has one meaning) and the operand is
+    // not a fused leaf's own value.
+    for (const Value& v : vals)
+        for (int side = 0; side < 2; ++side)
+            if (v.in[side] >= 0) ++vals[v.in[side]].consumers;
+    if (root >= 0) { vals[root].used = true; ++vals[root].consumers; }
     for (int id = (int)vals.size() - 1; id >= 0; --id) {
-        const Value& v = vals[id];
+        const Value v = vals[id];
         if (!v.used) continue;
         for (int side = 0; side < 2; ++side) {
             const int u = v.in[side];
             if (u < 0) continue;
-            const uint32_t through = v.need | ((v.sel >= 0 && v.sel < kMaxCullSelects) ? 1u << (2 * v.sel + side) : 0u);
+            const bool culled_through = v.sel >= 0 && v.sel < kMaxCullSelects && vals[u].consumers == 1 && !(v.in_leaf && side == 0) &&
+                                        !vals[u].point;
+            const uint32_t through = v.need | (culled_through ? 1u << (2 * v.sel + side) : 0u);
             if (!vals[u].used) { vals[u].used = true; vals[u].need = through; }
             else vals[u].need &= through;
+            if (culled_through) {
+                vals[u].live = v.need;
+                // what the select must see: union takes the minimum of (a, b), intersection of (-a, -b), subtraction of (-a, b)
+                const bool minus = v.kind == 2 || (v.kind == 3 && side == 0);
+                vals[u].stand_in = minus ? -std::numeric_limits<float>::infinity() : std::numeric_limits<float>::infinity();
+            }
         }
     }
     out.n_selects = n_sel;
-    out.needs.assign(n, 0u);
+    out.masks.assign(2 * n, 0u);
+    out.stand_ins.assign(n, Rec{});
     out.n_records = (uint32_t)(end < n ? end + 1 : n);
     for (size_t i = 0; i < end; ++i) {
-        uint32_t need_rec = 0xffffffffu;
+        uint32_t run = 0xffffffffu;
         bool any = false;
-        for (int v : defined[i])
-            if (vals[v].used) { need_rec &= vals[v].need; any = true; }
-            else { need_rec = 0u; any = true; }   // a value nobody reads: nothing is claimed, the record just runs
-        const int moved = after[i];   // a _store / _load moves a value some record defined earlier
-        if (!any) need_rec = (moved >= 0 && vals[moved].used) ? vals[moved].need : 0u;
-        out.needs[i] = need_rec;
+        for (int v : defined[i]) {
+            run &= vals[v].used ? vals[v].need : 0u;   // a value nobody reads: nothing is claimed, the record just runs
+            any = true;
+        }
+        const int moved = after[i];   // a _store / _load moves a value some record defined earlier: it runs while that value, or its stand-in, is wanted
+        if (!any) run = (moved >= 0 && vals[moved].used) ? (vals[moved].stand_in != 0.0f ? vals[moved].live : vals[moved].need) : 0u;
+        uint32_t live = run;
+        // the record's final value has a stand-in, and nothing else the record defines is wanted more widely
+        if (any && moved >= 0 && vals[moved].used && vals[moved].stand_in != 0.0f && run == vals[moved].need) {
+            live = vals[moved].live;
+            Rec& alt = out.stand_ins[i];
+            alt.hdr = OPX_CONST | (prog[i].hdr & kResultKind);
+            alt.p[0] = vals[moved].stand_in;
+            fold_word(alt) = fold_word(prog[i]) & (kFoldStore | kFoldStoreResult | 0xff0000u);
+        }
+        out.masks[2 * i] = run;
+        out.masks[2 * i + 1] = live;
     }
     for (int k = 0; k < kMaxCullSelects; ++k) {
         out.lipschitz[k] = std::numeric_limits<float>::infinity();

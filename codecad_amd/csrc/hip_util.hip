@@ -141,8 +141,9 @@ struct hu_tape_s {
     sdf::SpecProgram program;    // both programs on the host, kept for hu_tape_specialize (specialise.hpp)
     struct SpecKernels* spec = nullptr;
     // per-brick culling of the dense interpreter kernels (cull.hpp): NULL when the tape has nothing to cull
-    uint32_t* needs_dev = nullptr;      // per record of the full program
-    uint32_t* needs_do_dev = nullptr;   // ... of the distance-only program
+    uint2* needs_dev = nullptr;      // per record of the full program: {run, live}
+    uint2* needs_do_dev = nullptr;   // ... of the distance-only program
+    uint32_t stand_in_offset = 0, stand_in_offset_do = 0;   // the stand-in records follow the program in recs_dev / recs_do_dev
     uint32_t n_records = 0, n_records_do = 0;
     float* lipschitz_dev = nullptr;  // per numbered select
     struct KeepBuffer { void* stream; uint32_t* words; size_t count; };
@@ -160,11 +161,13 @@ bool distance_only(const hu_tape_s* t)
     return !forced_full && t->recs_do_dev != nullptr;
 }
 
-// Per-brick culling of the dense interpreter kernels (cull.hpp): an experiment that works -- sponge(4) at 512^3: a third
-// of the records are skipped, every float still the oracle's -- and does not pay yet: the interpreter is so sensitive
-// to what surrounds a record that the walk over the records that run costs 22 % and the "which operand is out" logic
-// inside selects and fused leaves another 35 % (everything kept: 5.9 ms against 3.45 ms; with culling 4.0 ms).
-// HU_INTERP_CULL=1 turns it on (tests/test_gpu_variants.py runs the parity tests that way); DESIGN.md section 5.
+// Per-brick culling of the dense interpreter kernels (cull.hpp): an experiment that works -- sponge(4) at 512^3: the
+// centre pass rules out 6.7 of 24 select operands per brick, every float still the oracle's -- and only breaks even: the
+// interpreter is so sensitive to what surrounds a record's dispatch that the walk over the records that take part costs
+// 14 % and the brick layout 4 % with everything kept (4.13 ms against 3.50 ms), and what is skipped then just pays for
+// that (3.44 ms; sponge(3): 2.47 against 2.74 ms; sponge(5): 4.91 against 4.78 ms).  Earlier forms, with tests for "which
+// operand is out" inside selects and fused leaves, cost 70 % before they saved 30 %.  So it is off unless
+// HU_INTERP_CULL=1 (tests/test_gpu_variants.py runs the parity tests that way); DESIGN.md section 5.
 bool culling_wanted(const hu_tape_s* t)
 {
     static const bool on = [] { const char* e = getenv("HU_INTERP_CULL"); return e && e[0] == '1'; }();
@@ -555,6 +558,12 @@ int hu_tape_create(const float* tape, size_t n, hu_tape* out)
             same = cull_full.lipschitz[k] == cull_do.lipschitz[k] && cull_full.repetitions[k] == cull_do.repetitions[k];
         cull_full.enabled = cull_do.enabled = same;
     }
+    if (cull_full.enabled) {   // the stand-in records follow the programs
+        t->stand_in_offset = (uint32_t)d.fused.size();
+        t->stand_in_offset_do = (uint32_t)d.fused_do.size();
+        d.fused.insert(d.fused.end(), cull_full.stand_ins.begin(), cull_full.stand_ins.end());
+        d.fused_do.insert(d.fused_do.end(), cull_do.stand_ins.begin(), cull_do.stand_ins.end());
+    }
     // the device holds the interpreter's (fused) programs; per-tape code is generated from the unfused ones
     hipError_t e = hipMalloc((void**)&t->recs_dev, d.fused.size() * sizeof(Rec));
     if (e == hipSuccess && !d.fused_do.empty()) {
@@ -571,8 +580,8 @@ int hu_tape_create(const float* tape, size_t n, hu_tape* out)
         };
         t->n_records = cull_full.n_records;
         t->n_records_do = cull_do.n_records;
-        upload(cull_full.needs.data(), cull_full.needs.size() * 4, (void**)&t->needs_dev);
-        upload(cull_do.needs.data(), cull_do.needs.size() * 4, (void**)&t->needs_do_dev);
+        upload(cull_full.masks.data(), cull_full.masks.size() * 4, (void**)&t->needs_dev);
+        upload(cull_do.masks.data(), cull_do.masks.size() * 4, (void**)&t->needs_do_dev);
         // [16 floats La + Lb | 16 words: the repetitions each select lies under]
         uint32_t table[2 * sdf::kMaxCullSelects];
         std::memcpy(table, cull_do.lipschitz, sizeof(cull_do.lipschitz));
@@ -714,7 +723,8 @@ int hu_grid_eval_slab(hu_tape t, const float corner[4], float step, const uint32
             const uint32_t waves = ls.block / 64u;
 #define HU_LAUNCH_CULLED(L, D, NV)                                                                                          \
     hipLaunchKernelGGL((k_grid_eval_culled<D, L, NV>), dim3((n_bricks + waves - 1) / waves), dim3(ls.block), ls.lds,        \
-                       (hipStream_t)stream, (InterpEval<D>{ls.prog, t->extra_dev, ls.n4}), D ? t->needs_do_dev : t->needs_dev, D ? t->n_records_do : t->n_records, \
+                       (hipStream_t)stream, (InterpEval<D>{ls.prog, t->extra_dev, ls.n4}), D ? t->stand_in_offset_do : t->stand_in_offset,                   \
+                       D ? t->needs_do_dev : t->needs_dev, D ? t->n_records_do : t->n_records,                               \
                        keep, corner[0], corner[1], corner[2], step, dims[0], make_dim(dims[1]), make_dim(dims[2]),          \
                        make_dim(nby), make_dim(nbz), x0 + done, n_bricks, o)
             if (layout == 0) HU_LAUNCH_CULLED(0, false, 1);
@@ -1496,8 +1506,10 @@ int hu_tape_listing(const float* tape, size_t n, int which, char* buf, size_t ca
         if (fold & sdf::kFoldStore) o << " [store " << ((fold >> 16) & 0xffu) << ((fold & sdf::kFoldStoreResult) ? "r" : "") << "]";
         if (with_culling && op != sdf::OP_RETURN) {
             const uint32_t k1 = (fold >> sdf::kSelShift1) & 31u, k2 = (fold >> sdf::kSelShift2) & 31u;
-            char masks[64];
-            std::snprintf(masks, sizeof masks, " | need %08x", cull.needs[index]);
+            char masks[128];
+            if (cull.masks[2 * index + 1] != cull.masks[2 * index])
+                std::snprintf(masks, sizeof masks, " | runs %08x, stand-in %+g while %08x", cull.masks[2 * index], (double)cull.stand_ins[index].p[0], cull.masks[2 * index + 1]);
+            else std::snprintf(masks, sizeof masks, " | runs %08x", cull.masks[2 * index]);
             o << masks;
             const bool is_select = op == sdf::OP_UNION || op == sdf::OP_INTERSECTION || op == sdf::OP_SUBTRACTION;
             if ((is_select || op == sdf::OPX_LEAF) && k1 != sdf::kSelNone) o << " select " << k1;

@@ -691,20 +691,14 @@ __device__ __forceinline__ f2 opaque(f2 x) { asm volatile("" : "+v"(x)); return 
 constexpr int kFetchGroup = SDF_FETCH_GROUP;  // tape.hpp pads the program with kTapePadding _return records
 
 // Per-brick culling (cull.hpp tells the story; kernels.hpp k_brick_keep / k_grid_eval_culled run it).  The
-// interpreter runs in one of three modes, chosen by the type of its last argument:
+// interpreter runs in one of two modes, chosen by the type of its last argument:
 //   NoCull    every record, as always (per-tape code, every kernel but the two above);
-//   Culled    `keep` = which operands of the numbered selects may win in this wavefront's brick (wave-uniform): a
-//             record runs iff (keep & need_rec) == need_rec (run_tape), a select whose operand is out takes the
-//             other one without looking;
+//   (a brick is then evaluated by run_tape_culled below: ordinary records, fewer of them)
 //   Centre    the distance-only program at a brick's centre, one brick per lane; every numbered select compares
 //             |a - b| with what the two can change over the brick and notes in `kill` the operand that is out.
 constexpr uint32_t kSelNoneBits = 31u;   // cull.hpp kSelNone / kSelShift1 / kSelShift2
 constexpr int kSelBits1 = 10, kSelBits2 = 26;
 struct NoCull { static constexpr int kMode = 0; };
-struct Culled {
-    static constexpr int kMode = 1;
-    uint32_t keep;       // bit 2k: operand a of select k may win; bit 2k + 1: operand b
-};
 struct Centre {
     static constexpr int kMode = 2;
     uint32_t kill;       // per lane
@@ -775,7 +769,6 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const floa
     // the compare tree
     if (SDF_LEAF_FIRST && !kStaticOp && op == OPX_LEAF) {
         exec_leaf<T, DISTANCE_ONLY, R, C>(cur, last, px, py, pz, regs, cull);
-        if constexpr (C::kMode == 1) return false;   // (a culled leaf does its folded store itself: only with its final value)
     } else
     switch (op) {
     case OP_RETURN: return true;
@@ -833,6 +826,10 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const floa
         break;
     }
     case OPX_POINT: last = v4<T>(px, py, pz, bc<T>(0.0f)); break;
+    case OPX_CONST:   // the stand-in of a record whose value is out (cull.hpp): +-infinity, no direction
+        if (DISTANCE_ONLY) last.w = bc<T>(p[0]);
+        else last = v4<T>(bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f), bc<T>(p[0]));
+        break;
     // a general quaternion as its matrix (tape_format.hpp): x' is parked in w, then y', z' and the assembly
     case OPX_TO_ROW_X:
         last.w = fma_(last.x, bc<T>(p[0]), fma_(last.y, bc<T>(p[1]), fma_(last.z, bc<T>(p[2]), bc<T>(p[3]))));
@@ -975,15 +972,6 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const floa
     case OP_INTERSECTION:
     case OP_SUBTRACTION: {
         const uint32_t k = (fold >> kSelBits1) & 31u;   // the select's number (cull.hpp); wave-uniform
-        if constexpr (C::kMode == 1) if (k != kSelNoneBits) {
-            const uint32_t alive = (cull.keep >> (2u * k)) & 3u;
-            if (!(alive & 1u)) {          // a is out: the register operand as it is (union, intersection) or negated
-                if (DISTANCE_ONLY) last.w = op == OP_SUBTRACTION ? -regs.load_res(reg) : regs.load_res(reg);
-                else last = op == OP_SUBTRACTION ? neg(regs.load(reg)) : regs.load(reg);
-                break;
-            }
-            if (!(alive & 2u)) break;     // b is out: `last` stays
-        }
         if constexpr (C::kMode == 2 && DISTANCE_ONLY) {
             const T b = regs.load_res(reg);
             note_select<T>(cull, k, op == OP_UNION ? last.w : -last.w, op == OP_INTERSECTION ? -b : b);
@@ -1002,7 +990,6 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const floa
     }
     case OPX_LEAF:
         exec_leaf<T, DISTANCE_ONLY, R, C>(cur, last, px, py, pz, regs, cull);
-        if constexpr (C::kMode == 1) return false;
         break;
     default: return true;  // unreachable: tapes are validated at upload
     }
@@ -1023,88 +1010,71 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const floa
 
 // OPX_LEAF (tape_format.hpp, tape.hpp fuse_leaves): the parts of a transformed primitive back to back, each exactly
 // the code of its single record above; which parts are present is wave-uniform (bits of the control word).
-// With culling (C = Culled): the primitive runs iff it may win every select it goes through; a select whose operand is out takes the other one; the transformed point is still computed when later
-// records read it (kLeafMidStore).  C = Centre: the selects note which operand is out at this brick's centre.
 template <class T, bool DISTANCE_ONLY, class R, class C>
 __device__ __forceinline__ void exec_leaf(const Rec& cur, V4<T>& last, T px, T py, T pz, R& regs, C& cull)
 {
     const float* p = cur.p;
     const uint32_t c = __float_as_uint(p[kLeafControl]);
     const T zero = bc<T>(0.0f);
-    // ---- what of this leaf is wanted (all wave-uniform; constants without culling)
-    const uint32_t fold = __float_as_uint(p[kFoldParam]);
-    const uint32_t kind1 = (c >> kLeafComb1Shift) & 3u, kind2 = (c >> kLeafComb2Shift) & 3u;
-    const uint32_t sel1 = (fold >> kSelBits1) & 31u, sel2 = (fold >> kSelBits2) & 31u;
-    bool prim_wanted = true;
-    uint32_t alive1 = 3u, alive2 = 3u;   // bit 0: the value coming down the leaf may win; bit 1: the register operand
-    if constexpr (C::kMode == 1) {
-        if (kind1 != 0u && sel1 != kSelNoneBits) alive1 = (cull.keep >> (2u * sel1)) & 3u;
-        if (kind2 != 0u && sel2 != kSelNoneBits) alive2 = (cull.keep >> (2u * sel2)) & 3u;
-        prim_wanted = (alive1 & 1u) && (alive2 & 1u);
-    }
     V4<T> q = last;
-    if (prim_wanted || (c & kLeafMidStore)) {
-        if (c & kLeafSample) q = v4<T>(px, py, pz, zero);
-        const uint32_t to = (c >> kLeafToShift) & 7u;
-        const float* t = p + kLeafTo;
-        if (to == 1u) {
-            q = v4<T>(fma_(q.x, bc<T>(t[0]), bc<T>(t[3])), fma_(q.y, bc<T>(t[0]), bc<T>(t[4])), fma_(q.z, bc<T>(t[0]), bc<T>(t[5])), zero);
-        } else if (to == 2u) {
-            T x, y, z;
-            axis_rotate<T>(t, q.x, q.y, q.z, t[3], t[4], t[5], x, y, z);
-            q = v4<T>(x, y, z, zero);
-        } else if (to == 3u) {
-            T x, y, z;
-            axis_rotate<T>(t, q.y, q.z, q.x, t[4], t[5], t[3], y, z, x);
-            q = v4<T>(x, y, z, zero);
-        } else if (to == 4u) {
-            T x, y, z;
-            axis_rotate<T>(t, q.z, q.x, q.y, t[5], t[3], t[4], z, x, y);
-            q = v4<T>(x, y, z, zero);
-        }
-        if (c & kLeafMidStore) regs.store((cur.hdr >> 8) & 0xffu, q);
+    if (c & kLeafSample) q = v4<T>(px, py, pz, zero);
+    const uint32_t to = (c >> kLeafToShift) & 7u;
+    const float* t = p + kLeafTo;
+    if (to == 1u) {
+        q = v4<T>(fma_(q.x, bc<T>(t[0]), bc<T>(t[3])), fma_(q.y, bc<T>(t[0]), bc<T>(t[4])), fma_(q.z, bc<T>(t[0]), bc<T>(t[5])), zero);
+    } else if (to == 2u) {
+        T x, y, z;
+        axis_rotate<T>(t, q.x, q.y, q.z, t[3], t[4], t[5], x, y, z);
+        q = v4<T>(x, y, z, zero);
+    } else if (to == 3u) {
+        T x, y, z;
+        axis_rotate<T>(t, q.y, q.z, q.x, t[4], t[5], t[3], y, z, x);
+        q = v4<T>(x, y, z, zero);
+    } else if (to == 4u) {
+        T x, y, z;
+        axis_rotate<T>(t, q.z, q.x, q.y, t[5], t[3], t[4], z, x, y);
+        q = v4<T>(x, y, z, zero);
     }
+    if (c & kLeafMidStore) regs.store((cur.hdr >> 8) & 0xffu, q);
+    // the primitive
+    const uint32_t prim = (c >> kLeafPrimShift) & 3u;
     V4<T> r = q;
+    if (prim == LEAF_RECTANGLE) {
+        if (DISTANCE_ONLY) r.w = perp_w<T>(abs_minus(q.x, p[kLeafPrim]), abs_minus(q.y, p[kLeafPrim + 1]));
+        else r = rectangle_op(p[kLeafPrim], p[kLeafPrim + 1], q);
+    } else if (prim == LEAF_CIRCLE) {
+        if (DISTANCE_ONLY) r.w = len2(q.x, q.y) - p[kLeafPrim];
+        else r = circle_op(p[kLeafPrim], q);
+    } else if (prim == LEAF_SPHERE) {
+        if (DISTANCE_ONLY) r.w = len3(q.x, q.y, q.z) - p[kLeafPrim];
+        else r = sphere_op(p[kLeafPrim], q);
+    } else {
+        if (DISTANCE_ONLY) r.w = -q.y;
+        else r = v4<T>(zero, bc<T>(-1.0f), zero, -q.y);
+    }
+    if (c & kLeafExtrusion) {
+        if (DISTANCE_ONLY) r.w = perp_w<T>(abs_minus(q.z, p[kLeafExtrude]), r.w);
+        else r = extrusion_op(p[kLeafExtrude], r, q);
+    }
     const uint32_t from = (c >> kLeafFromShift) & 7u;
     const float* f = p + kLeafFrom;
-    if (prim_wanted) {
-        // the primitive
-        const uint32_t prim = (c >> kLeafPrimShift) & 3u;
-        if (prim == LEAF_RECTANGLE) {
-            if (DISTANCE_ONLY) r.w = perp_w<T>(abs_minus(q.x, p[kLeafPrim]), abs_minus(q.y, p[kLeafPrim + 1]));
-            else r = rectangle_op(p[kLeafPrim], p[kLeafPrim + 1], q);
-        } else if (prim == LEAF_CIRCLE) {
-            if (DISTANCE_ONLY) r.w = len2(q.x, q.y) - p[kLeafPrim];
-            else r = circle_op(p[kLeafPrim], q);
-        } else if (prim == LEAF_SPHERE) {
-            if (DISTANCE_ONLY) r.w = len3(q.x, q.y, q.z) - p[kLeafPrim];
-            else r = sphere_op(p[kLeafPrim], q);
+    if (from != 0u && !(c & kLeafFromLast)) {
+        if (DISTANCE_ONLY) {
+            r.w = r.w * p[kLeafScale];
+        } else if (from == 1u) {
+            r = v4<T>(r.x * f[0], r.y * f[0], r.z * f[0], r.w * p[kLeafScale]);
+        } else if (from == 2u) {
+            T x, y, z;
+            axis_rotate_dir<T>(f, r.x, r.y, r.z, x, y, z);
+            r = v4<T>(x, y, z, r.w * p[kLeafScale]);
+        } else if (from == 3u) {
+            T x, y, z;
+            axis_rotate_dir<T>(f, r.y, r.z, r.x, y, z, x);
+            r = v4<T>(x, y, z, r.w * p[kLeafScale]);
         } else {
-            if (DISTANCE_ONLY) r.w = -q.y;
-            else r = v4<T>(zero, bc<T>(-1.0f), zero, -q.y);
-        }
-        if (c & kLeafExtrusion) {
-            if (DISTANCE_ONLY) r.w = perp_w<T>(abs_minus(q.z, p[kLeafExtrude]), r.w);
-            else r = extrusion_op(p[kLeafExtrude], r, q);
-        }
-        if (from != 0u && !(c & kLeafFromLast)) {
-            if (DISTANCE_ONLY) {
-                r.w = r.w * p[kLeafScale];
-            } else if (from == 1u) {
-                r = v4<T>(r.x * f[0], r.y * f[0], r.z * f[0], r.w * p[kLeafScale]);
-            } else if (from == 2u) {
-                T x, y, z;
-                axis_rotate_dir<T>(f, r.x, r.y, r.z, x, y, z);
-                r = v4<T>(x, y, z, r.w * p[kLeafScale]);
-            } else if (from == 3u) {
-                T x, y, z;
-                axis_rotate_dir<T>(f, r.y, r.z, r.x, y, z, x);
-                r = v4<T>(x, y, z, r.w * p[kLeafScale]);
-            } else {
-                T x, y, z;
-                axis_rotate_dir<T>(f, r.z, r.x, r.y, z, x, y);
-                r = v4<T>(x, y, z, r.w * p[kLeafScale]);
-            }
+            T x, y, z;
+            axis_rotate_dir<T>(f, r.z, r.x, r.y, z, x, y);
+            r = v4<T>(x, y, z, r.w * p[kLeafScale]);
         }
     }
 #pragma unroll
@@ -1112,19 +1082,12 @@ __device__ __forceinline__ void exec_leaf(const Rec& cur, V4<T>& last, T px, T p
         const uint32_t cb = c >> (k == 0 ? kLeafComb1Shift : kLeafComb2Shift);
         const uint32_t kind = cb & 3u, slot = (cb >> 2) & 0xffu;
         if (kind == 0u) continue;
-        if constexpr (C::kMode == 1) {
-            const uint32_t alive = k == 0 ? alive1 : alive2;
-            if (k == 0 && !(alive2 & 1u)) continue;   // the second select will not look at this one's value
-            if (!(alive & 1u)) {   // the value coming down the leaf is out: the register operand, negated by a subtraction
-                if (DISTANCE_ONLY) r.w = kind == 3u ? -regs.load_res(slot) : regs.load_res(slot);
-                else r = kind == 3u ? neg(regs.load(slot)) : regs.load(slot);
-                continue;
-            }
-            if (!(alive & 2u)) continue;   // the register operand is out
-        }
         if (DISTANCE_ONLY) {
             const T b = regs.load_res(slot);
-            if constexpr (C::kMode == 2) note_select<T>(cull, k == 0 ? sel1 : sel2, kind == 1u ? r.w : -r.w, kind == 2u ? -b : b);
+            if constexpr (C::kMode == 2) {   // the centre pass notes which operand is out (cull.hpp)
+                const uint32_t fold = __float_as_uint(p[kFoldParam]);
+                note_select<T>(cull, (fold >> (k == 0 ? kSelBits1 : kSelBits2)) & 31u, kind == 1u ? r.w : -r.w, kind == 2u ? -b : b);
+            }
             if (kind == 1u) r.w = min_(r.w, b);
             else if (kind == 2u) r.w = max_(r.w, b);
             else r.w = max_neg_(r.w, b);
@@ -1140,12 +1103,6 @@ __device__ __forceinline__ void exec_leaf(const Rec& cur, V4<T>& last, T px, T p
         else r = v4<T>(r.x * f[0], r.y * f[0], r.z * f[0], r.w * p[kLeafScale]);
     }
     last = r;
-    if constexpr (C::kMode == 1) {   // the folded store, which exec_one leaves to a culled leaf
-        if (fold & kFoldStore) {
-            if (DISTANCE_ONLY && (fold & kFoldStoreResult)) regs.store_res((fold >> 16) & 0xffu, last.w);
-            else regs.store((fold >> 16) & 0xffu, last);
-        }
-    }
 }
 
 template <class T, bool DISTANCE_ONLY, class R>
@@ -1183,58 +1140,44 @@ __device__ __forceinline__ void run_tape_centre(const Rec* __restrict__ prog, co
     }
 }
 
-// ... and the evaluation of a brick with what that left: needs[i] = the mask of record i (cull.hpp): it runs iff
-// (keep & needs[i]) == needs[i]; `keep` is wave-uniform.  Which records run is found 64 at a time -- a record per lane,
-// one ballot -- and the loop then walks the set bits: a record that does not run is neither fetched nor tested.
-// Records are still fetched in groups (the next kFetchGroup that run), all scalar loads of a group issued together.
+// ... and the evaluation of a brick with what that left.  masks[i] = {run, live} of record i (cull.hpp): the record runs
+// iff (keep & run) == run; if not, but (keep & live) == live, its stand-in runs in its place (a constant stored where the
+// record's value would have gone: record i + stand_in_offset of `prog`); else nothing does.  `keep` is wave-uniform.
+// 64 records at a time, a record per lane: which of them take part, and -- by a permute -- lane j gets the j-th of those,
+// so that the loop proper costs a v_readlane per record and the scalar unit, which bounds the interpreter, sees almost
+// nothing new (walking the set bits of a ballot -- count trailing zeros, clear the bit, pick the array, form the
+// address -- was a chain of fifteen dependent scalar instructions per record: 39 % on top of the plain interpreter).
+// The records that run are the plain interpreter's, unchanged, fetched four at a time like run_tape's.
 template <class T, bool DISTANCE_ONLY, class R>
-__device__ __forceinline__ V4<T> run_tape_culled(const Rec* __restrict__ prog, const uint32_t* __restrict__ needs, uint32_t n_records,
-                                                 const float* __restrict__ extra, T px, T py, T pz, R& regs, uint32_t keep)
+__device__ __forceinline__ V4<T> run_tape_culled(const Rec* __restrict__ prog, uint32_t stand_in_offset, const uint2* __restrict__ masks,
+                                                 uint32_t n_records, const float* __restrict__ extra, T px, T py, T pz, R& regs,
+                                                 uint32_t keep)
 {
     V4<T> last = v4<T>(bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f));
-    Culled cull{keep};
     const uint32_t lane = threadIdx.x & 63u;
-    for (uint32_t base = 0; base < n_records; base += 64u) {   // (the _return record, need 0, ends the walk)
+    for (uint32_t base = 0; base < n_records; base += 64u) {   // (the _return record, masks 0, ends the walk)
         const uint32_t mine = base + lane;
-        const uint32_t need = mine < n_records ? needs[mine] : 0u;
-        uint64_t runs = __ballot(mine < n_records && (keep & need) == need);
-        runs = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(runs >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)runs);
-        const Rec* chunk = prog + base;
-        while (runs) {
-#ifndef SDF_CULL_GROUP
-#define SDF_CULL_GROUP 2
-#endif
-#define SDF_CULL_EXEC(r) exec_one<T, DISTANCE_ONLY, R, -1, Culled>(r, last, extra, px, py, pz, regs, cull)
-            // the next SDF_CULL_GROUP records that run (written out, not as arrays indexed by an unrolled loop: those stayed in
-            // scratch memory, the records copied there by vector loads -- 12 ms instead of 2)
-#define SDF_NEXT_RECORD(k)                                                                                  \
-            const bool valid##k = runs != 0ull;                                                             \
-            const uint32_t at##k = (uint32_t)__builtin_amdgcn_readfirstlane(valid##k ? (int)__builtin_ctzll(runs) : 0); \
-            runs &= runs - 1ull; /* (0 stays 0) */
-            SDF_NEXT_RECORD(0)
-            SDF_NEXT_RECORD(1)
-#if SDF_CULL_GROUP >= 3
-            SDF_NEXT_RECORD(2)
-#endif
-#if SDF_CULL_GROUP >= 4
-            SDF_NEXT_RECORD(3)
-#endif
-#undef SDF_NEXT_RECORD
-            const Rec r0 = chunk[at0], r1 = chunk[at1];
-#if SDF_CULL_GROUP >= 3
-            const Rec r2 = chunk[at2];
-#endif
-#if SDF_CULL_GROUP >= 4
-            const Rec r3 = chunk[at3];
-#endif
-            if (valid0 && SDF_CULL_EXEC(r0)) return last;
-            if (valid1 && SDF_CULL_EXEC(r1)) return last;
-#if SDF_CULL_GROUP >= 3
-            if (valid2 && SDF_CULL_EXEC(r2)) return last;
-#endif
-#if SDF_CULL_GROUP >= 4
-            if (valid3 && SDF_CULL_EXEC(r3)) return last;
-#endif
+        const uint2 m = mine < n_records ? masks[mine] : make_uint2(0xffffffffu, 0xffffffffu);
+        const bool run = mine < n_records && (keep & m.x) == m.x;
+        const bool takes_part = run || (mine < n_records && (keep & m.y) == m.y);
+        const uint64_t parts = __ballot(takes_part);
+        const uint32_t count = (uint32_t)__builtin_amdgcn_readfirstlane((int)__popcll(parts));
+        // lane j <- the j-th record that takes part (the stand-in's index where that runs instead)
+        const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(parts >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)parts, 0u));
+        // (a permutation of all 64 lanes: the others send a 0 behind the list)
+        const int list = __builtin_amdgcn_ds_permute((int)((takes_part ? before : count + (lane - before)) * 4u),
+                                                     takes_part ? (int)(run ? mine : mine + stand_in_offset) : 0);
+        for (uint32_t j = 0; j < count; j += 4u) {
+            const uint32_t i0 = (uint32_t)__builtin_amdgcn_readlane(list, (int)j);
+            const uint32_t i1 = (uint32_t)__builtin_amdgcn_readlane(list, (int)((j + 1u) & 63u));
+            const uint32_t i2 = (uint32_t)__builtin_amdgcn_readlane(list, (int)((j + 2u) & 63u));
+            const uint32_t i3 = (uint32_t)__builtin_amdgcn_readlane(list, (int)((j + 3u) & 63u));
+            // (lanes past `count` hold 0: record 0 is fetched again and not run)
+            const Rec r0 = prog[i0], r1 = prog[i1], r2 = prog[i2], r3 = prog[i3];
+            if (exec_one<T, DISTANCE_ONLY, R>(r0, last, extra, px, py, pz, regs)) return last;
+            if (j + 1u < count && exec_one<T, DISTANCE_ONLY, R>(r1, last, extra, px, py, pz, regs)) return last;
+            if (j + 2u < count && exec_one<T, DISTANCE_ONLY, R>(r2, last, extra, px, py, pz, regs)) return last;
+            if (j + 3u < count && exec_one<T, DISTANCE_ONLY, R>(r3, last, extra, px, py, pz, regs)) return last;
         }
     }
     return last;

@@ -326,7 +326,8 @@ k_brick_keep(const E ev, const float* __restrict__ lipschitz, const uint32_t* __
 // k_grid_eval_culled: one brick per WAVEFRONT, its keep word in a scalar register
 template <bool DO, int LAYOUT, int N>
 __global__ void __launch_bounds__(256) SDF_KERNEL_ATTRS
-k_grid_eval_culled(const InterpEval<DO> ev, const uint32_t* __restrict__ needs, uint32_t n_records, const uint32_t* __restrict__ keep_of, float cx, float cy,
+k_grid_eval_culled(const InterpEval<DO> ev, uint32_t stand_in_offset, const uint2* __restrict__ masks, uint32_t n_records,
+                   const uint32_t* __restrict__ keep_of, float cx, float cy,
                    float cz, float step, uint32_t sx, Dim dy, Dim dz, Dim nby, Dim nbz, uint32_t x0, uint32_t n_bricks,
                    void* __restrict__ out)
 {
@@ -353,7 +354,7 @@ k_grid_eval_culled(const InterpEval<DO> ev, const uint32_t* __restrict__ needs, 
     for (int i = 0; i < N; ++i) xs[i] = sample(cx, step, x0 + x + 2u * i);
     const T px = pack(xs), py = (T)(sample(cy, step, y)), pz = (T)(sample(cz, step, z));
     sdf::Regs<T> regs(lds, threadIdx.x, blockDim.x, ev.n4);
-    const sdf::V4<T> r = sdf::run_tape_culled<T, DO>(ev.prog, needs, n_records, ev.extra, px, py, pz, regs, keep);
+    const sdf::V4<T> r = sdf::run_tape_culled<T, DO>(ev.prog, stand_in_offset, masks, n_records, ev.extra, px, py, pz, regs, keep);
     if (LAYOUT == 0) {
         float4* o = static_cast<float4*>(out) + ((size_t)z + (size_t)sz * ((size_t)y + (size_t)sy * x));
 #pragma unroll
