@@ -968,26 +968,22 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const floa
         last.x = sel(lt(ptx, 0.0f), -last.x, last.x);
         break;
     }
+    // (the centre pass notes which operand of a numbered select is out: cull.hpp)
     case OP_UNION:
-    case OP_INTERSECTION:
-    case OP_SUBTRACTION: {
-        const uint32_t k = (fold >> kSelBits1) & 31u;   // the select's number (cull.hpp); wave-uniform
-        if constexpr (C::kMode == 2 && DISTANCE_ONLY) {
-            const T b = regs.load_res(reg);
-            note_select<T>(cull, k, op == OP_UNION ? last.w : -last.w, op == OP_INTERSECTION ? -b : b);
-        }
-        if (op == OP_UNION) {
-            if (DISTANCE_ONLY) last.w = min_(last.w, regs.load_res(reg));
-            else last = rounded_union(p[0], last, regs.load(reg));
-        } else if (op == OP_INTERSECTION) {
-            if (DISTANCE_ONLY) last.w = max_(last.w, regs.load_res(reg));         // == -min(-a, -b), zeros and NaNs included
-            else last = neg(rounded_union(p[0], neg(last), neg(regs.load(reg))));
-        } else {
-            if (DISTANCE_ONLY) last.w = max_neg_(last.w, regs.load_res(reg));     // == -min(-a, b)
-            else last = neg(rounded_union(p[0], neg(last), regs.load(reg)));
-        }
+        if constexpr (C::kMode == 2 && DISTANCE_ONLY) note_select<T>(cull, (fold >> kSelBits1) & 31u, last.w, regs.load_res(reg));
+        if (DISTANCE_ONLY) last.w = min_(last.w, regs.load_res(reg));
+        else last = rounded_union(p[0], last, regs.load(reg));
         break;
-    }
+    case OP_INTERSECTION:
+        if constexpr (C::kMode == 2 && DISTANCE_ONLY) note_select<T>(cull, (fold >> kSelBits1) & 31u, -last.w, -regs.load_res(reg));
+        if (DISTANCE_ONLY) last.w = max_(last.w, regs.load_res(reg));         // == -min(-a, -b), zeros and NaNs included
+        else last = neg(rounded_union(p[0], neg(last), neg(regs.load(reg))));
+        break;
+    case OP_SUBTRACTION:
+        if constexpr (C::kMode == 2 && DISTANCE_ONLY) note_select<T>(cull, (fold >> kSelBits1) & 31u, -last.w, regs.load_res(reg));
+        if (DISTANCE_ONLY) last.w = max_neg_(last.w, regs.load_res(reg));     // == -min(-a, b)
+        else last = neg(rounded_union(p[0], neg(last), regs.load(reg)));
+        break;
     case OPX_LEAF:
         exec_leaf<T, DISTANCE_ONLY, R, C>(cur, last, px, py, pz, regs, cull);
         break;
@@ -1056,9 +1052,13 @@ __device__ __forceinline__ void exec_leaf(const Rec& cur, V4<T>& last, T px, T p
         if (DISTANCE_ONLY) r.w = perp_w<T>(abs_minus(q.z, p[kLeafExtrude]), r.w);
         else r = extrusion_op(p[kLeafExtrude], r, q);
     }
+#if SDF_LEAF_FROM_LAST
+    const uint32_t from = (c & kLeafFromLast) ? 0u : ((c >> kLeafFromShift) & 7u);
+#else
     const uint32_t from = (c >> kLeafFromShift) & 7u;
-    const float* f = p + kLeafFrom;
-    if (from != 0u && !(c & kLeafFromLast)) {
+#endif
+    if (from != 0u) {
+        const float* f = p + kLeafFrom;
         if (DISTANCE_ONLY) {
             r.w = r.w * p[kLeafScale];
         } else if (from == 1u) {
@@ -1098,10 +1098,12 @@ __device__ __forceinline__ void exec_leaf(const Rec& cur, V4<T>& last, T px, T p
             else r = neg(rounded_union(-1.0f, neg(r), b));
         }
     }
+#if SDF_LEAF_FROM_LAST
     if (c & kLeafFromLast) {   // a scaling applied to the combined value (OPX_FROM_SCALE after the selects)
         if (DISTANCE_ONLY) r.w = r.w * p[kLeafScale];
-        else r = v4<T>(r.x * f[0], r.y * f[0], r.z * f[0], r.w * p[kLeafScale]);
+        else r = v4<T>(r.x * p[kLeafFrom], r.y * p[kLeafFrom], r.z * p[kLeafFrom], r.w * p[kLeafScale]);
     }
+#endif
     last = r;
 }
 

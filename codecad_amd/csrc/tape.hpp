@@ -369,9 +369,6 @@ inline void fuse_leaves(const std::vector<Rec>& prog, bool typed, std::vector<Re
             ++parts;
         }
         // [from: a scaling of the combined value] -- `to prim select select from_scale`, the tail of a repeated cross
-#ifndef SDF_LEAF_FROM_LAST
-#define SDF_LEAF_FROM_LAST 1
-#endif
         if (SDF_LEAF_FROM_LAST && ok && !closed && j < n && !(control & (7u << kLeafFromShift)) && (control & (3u << kLeafComb1Shift)) &&
             op_of(prog[j]) == OPX_FROM_SCALE && !(fold_word(prog[j]) & kFoldLoad)) {
             const Rec& r = prog[j];

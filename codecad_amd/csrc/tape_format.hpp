@@ -60,6 +60,13 @@ constexpr uint32_t kLeafToShift = 1, kLeafPrimShift = 4, kLeafFromShift = 8;   /
 constexpr uint32_t kLeafExtrusion = 1u << 7;
 constexpr uint32_t kLeafComb1Shift = 11, kLeafComb2Shift = 21;   // 2 bits kind (1 union, 2 intersection, 3 subtraction) + 8 bits slot
 constexpr uint32_t kLeafMidStore = 1u << 31;         // the transformed point is also stored, to the slot in hdr
+// OFF: measured on one box, the same day: with the block that applies the late scaling compiled into the leaf the
+// interpreter runs sponge(4) in 3.45 ms (905 vector + 750 scalar instructions per wavefront, 22 records), without it
+// in 3.31 ms (863 + 654, 26 records) -- the four dispatches saved cost less than what the extra block does to the
+// leaf's code.  -DSDF_LEAF_FROM_LAST=1 brings it back.
+#ifndef SDF_LEAF_FROM_LAST
+#define SDF_LEAF_FROM_LAST 0
+#endif
 constexpr uint32_t kLeafFromLast = 1u << 6;          // the from-part (a scaling) runs AFTER the selects: to prim select select from
 enum LeafPrim : uint32_t { LEAF_RECTANGLE = 0, LEAF_CIRCLE = 1, LEAF_SPHERE = 2, LEAF_HALF_SPACE = 3 };
 

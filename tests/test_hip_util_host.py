@@ -347,12 +347,12 @@ def _listing(tape, which):
 
 def test_leaf_fusion_of_the_interpreter_programs():
     """The interpreter's programs fuse `to -> primitive -> extrusion -> from -> select` runs into single records
-    (tape.hpp fuse_leaves): sponge(4) 56 -> 22 dispatches, csg_example 20 -> 5; the unfused programs (what per-tape
+    (tape.hpp fuse_leaves): sponge(4) 56 -> 26 dispatches, csg_example 20 -> 5; the unfused programs (what per-tape
     code is generated from) are untouched; a store of the transformed point survives only where it is still read."""
     import codecad_amd as cc
     sponge = cc.nodes.make_program(cc.examples.sponge(4))
-    assert len(_listing(sponge, 0)) == 57 and len(_listing(sponge, 2)) == 23      # incl. _return
-    assert len(_listing(sponge, 1)) == 57 and len(_listing(sponge, 3)) == 23
+    assert len(_listing(sponge, 0)) == 57 and len(_listing(sponge, 2)) == 27      # incl. _return
+    assert len(_listing(sponge, 1)) == 57 and len(_listing(sponge, 3)) == 27
     assert sum(line.count("LEAF(") for line in _listing(sponge, 2)) == 13
     csg = _listing(cc.nodes.make_program(cc.examples.csg_example()), 2)
     assert len(csg) == 6 and all("LEAF(" in line for line in csg[:5])
