@@ -813,6 +813,7 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const floa
         last = per_voxel(last, none, [=](float4 l, float4) { return twist_revolution_to_op(a, b, l); });
         break;
     }
+#if !SDF_TO_SPECIAL || defined(SDF_EXP_KEEP_QUAT)   // (tape_format.hpp: the decoder leaves none of these)
     case OP_INITIAL_TRANSFORMATION_TO: {
         T ox, oy, oz;
         quat_xform<T>(p[0], p[1], p[2], p[3], p[7], px, py, pz, ox, oy, oz);
@@ -825,6 +826,7 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const floa
         last = v4<T>(ox + p[4], oy + p[5], oz + p[6], bc<T>(0.0f));
         break;
     }
+#endif
     case OPX_POINT: last = v4<T>(px, py, pz, bc<T>(0.0f)); break;
     // (OPX_CONST, the stand-in records of the culling experiment, is NOT a case here: run_tape_culled handles it itself.
     // One more case in this switch -- never taken by the plain interpreter -- changed the code of all the others:
@@ -861,6 +863,7 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const floa
         last = v4<T>(x, y, z, bc<T>(0.0f));
         break;
     }
+#if !SDF_FROM_SPECIAL || defined(SDF_EXP_KEEP_QUAT)
     case OP_TRANSFORMATION_FROM: {
         if (DISTANCE_ONLY) {
             last.w = last.w * p[5];
@@ -871,6 +874,7 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const floa
         last = v4<T>(ox * p[6], oy * p[6], oz * p[6], last.w * p[5]);
         break;
     }
+#endif
     case OPX_INIT_ROW_X:
         last.w = fma_(px, bc<T>(p[0]), fma_(py, bc<T>(p[1]), fma_(pz, bc<T>(p[2]), bc<T>(p[3]))));
         break;

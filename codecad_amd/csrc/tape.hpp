@@ -444,9 +444,6 @@ inline std::string decode_tape(const float* tape, size_t n, DecodedTape& out)
                 for (int i = 4; i < 7; ++i) r.p[i] = p[i] + 0.0f;
                 const bool zx = p[0] == 0.0f, zy = p[1] == 0.0f, zz = p[2] == 0.0f;
                 uint32_t special = op;
-#ifndef SDF_TO_SPECIAL
-#define SDF_TO_SPECIAL 1
-#endif
                 if (!SDF_TO_SPECIAL) special = op;
                 else if (zx && zy && zz) special = OPX_TO_SCALE;
                 else if (zy && zz) special = OPX_TO_AXIS_X;
@@ -487,9 +484,6 @@ inline std::string decode_tape(const float* tape, size_t n, DecodedTape& out)
                 r.p[6] = 1.0f / scale;
                 const bool zx = p[0] == 0.0f, zy = p[1] == 0.0f, zz = p[2] == 0.0f;
                 uint32_t special = op;
-#ifndef SDF_FROM_SPECIAL
-#define SDF_FROM_SPECIAL 1
-#endif
                 if (!SDF_FROM_SPECIAL) special = op;
                 else if (zx && zy && zz) special = OPX_FROM_SCALE;
                 else if (zy && zz) special = OPX_FROM_AXIS_X;

@@ -72,6 +72,15 @@ enum LeafPrim : uint32_t { LEAF_RECTANGLE = 0, LEAF_CIRCLE = 1, LEAF_SPHERE = 2,
 
 
 
+// The decoder rewrites every transformation_to / transformation_from into a reduced or a matrix form (tape.hpp), so the
+// quaternion forms of the tape never reach a kernel: their cases are compiled only when the rewriting is switched off.
+#ifndef SDF_TO_SPECIAL
+#define SDF_TO_SPECIAL 1
+#endif
+#ifndef SDF_FROM_SPECIAL
+#define SDF_FROM_SPECIAL 1
+#endif
+
 constexpr int kRefRegisterCount = 512;  // reference nodes/__init__.py:6
 constexpr int kVariableParams = -1;
 constexpr int kTapePadding = 8;         // >= interp.hpp kFetchGroup
