@@ -205,7 +205,8 @@ int keep_buffer(hu_tape_s* t, void* stream, size_t count, uint32_t** out)
 // always for the distance-only program (48-52 B per voxel), for the full program up to 6 live
 // float4 values (sponge(4): 5.3 vs 5.8 ms; sponge(5), 7 values: 8.0 vs 7.7 ms -> one voxel).
 // HU_VOXELS_PER_LANE=1|2 forces a choice (the parity tests run both).
-int launch_shape(const hu_tape_s* t, LaunchShape& ls, bool distance_only_kernel, int max_voxels_per_lane = 2)
+int launch_shape(const hu_tape_s* t, LaunchShape& ls, bool distance_only_kernel, int max_voxels_per_lane = 2,
+                 bool lanes_are_independent = false)
 {
     static const int forced = [] { const char* e = getenv("HU_VOXELS_PER_LANE"); return e ? atoi(e) : 0; }();
     const size_t lane_bytes = distance_only_kernel ? (size_t)t->n_point_slots * 16 + (size_t)t->n_result_slots * 4
@@ -224,6 +225,16 @@ int launch_shape(const hu_tape_s* t, LaunchShape& ls, bool distance_only_kernel,
                                                       : (size_t)t->n_slots * 16) * n;
         uint32_t bs = 256;
         while (bs > 64 && per_lane * bs > 48 * 1024) bs >>= 1;
+        // The grid kernels' lanes share nothing, and the interpreter waits more than it computes (forcing 5 waves per SIMD
+        // instead of 6 costs 14 %): where single-wavefront workgroups fit more wavefronts into a CU's LDS than workgroups of
+        // 256 lanes, take them (sponge(4), 6 float4 values: 26 against 24 per CU, -1 %; sponge(5), 7 values: 22 against 20, -3 %).
+        auto waves_per_cu = [&](uint32_t lanes) {
+            const size_t groups = kMaxLds / (per_lane * lanes + kScratchBytes), waves = groups * (lanes / 64u);
+            return waves < 32 ? waves : (size_t)32;
+        };
+        static const uint32_t forced_block = [] { const char* e = getenv("HU_BLOCK"); return e ? (uint32_t)atoi(e) : 0u; }();
+        if (forced_block == 64u || forced_block == 128u || forced_block == 256u) bs = forced_block < bs ? forced_block : bs;
+        else if (lanes_are_independent && bs == 256u && waves_per_cu(64u) > waves_per_cu(256u)) bs = 64u;
         const size_t regfile = per_lane * bs;
         if (regfile + kScratchBytes <= kMaxLds) {
             ls.block = bs;
@@ -674,7 +685,7 @@ int hu_grid_eval_slab(hu_tape t, const float corner[4], float step, const uint32
         return HU_OK;
     }
     LaunchShape ls;
-    if ((rc = launch_shape(t, ls, layout == 1 && distance_only(t)))) return rc;
+    if ((rc = launch_shape(t, ls, layout == 1 && distance_only(t), 2, true))) return rc;
     if ((rc = ensure_attrs())) return rc;
     // at most 2^30 cells per launch keeps every in-kernel index in 32 bits
     const uint32_t max_x = (uint32_t)((1ull << 30) / plane);
@@ -803,7 +814,7 @@ static int grid_eval_blocks_impl(hu_tape t, const int32_t* blocks_dev, uint32_t 
         return HU_OK;
     }
     LaunchShape ls;
-    if ((rc = launch_shape(t, ls, layout == 1 && distance_only(t)))) return rc;
+    if ((rc = launch_shape(t, ls, layout == 1 && distance_only(t), 2, true))) return rc;
     if ((rc = ensure_attrs())) return rc;
     const uint32_t per_block = ls.block * ls.voxels_per_lane;
     const uint32_t chunks = (uint32_t)((cells + per_block - 1) / per_block);
