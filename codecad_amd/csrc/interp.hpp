@@ -312,9 +312,10 @@ __device__ __forceinline__ V4<T> rectangle_op(float hw, float hh, V4<T> c, M wan
 template <class T> __device__ __forceinline__ T perp_w(T a, T b)
 {
     auto corner = gt(a, 0.0f) & gt(b, 0.0f);
-    T dist = a;
-    if (any_lane(corner)) dist = sqrt_cr(fma_(b, b, a * a), corner);
-    return sel(corner, dist, max_(a, b));
+    // (the corner region patched in only when some lane is in it, like rectangle_op: the common case pays no select)
+    T r = max_(a, b);
+    if (any_lane(corner)) r = sel(corner, sqrt_cr(fma_(b, b, a * a), corner), r);
+    return r;
 }
 
 // reference shapes/simple3d.cl:18-21 = perpendicular_intersection(slab_z(h, coords), in)
