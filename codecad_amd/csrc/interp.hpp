@@ -42,8 +42,15 @@ __device__ __forceinline__ float rint_(float x) { return __builtin_rintf(x); }
 // |x| - h per voxel: the absolute value rides in the subtraction's source modifier (one instruction per voxel),
 // where the packed form needs a v_and per voxel in front of the packed subtraction
 // (inline asm: written as fabsf(x) - h the compiler re-packs the two voxels and puts the v_and back)
+// SDF_ABS_MINUS_BUILTIN (per-tape code, HU_ABS_BUILTIN=1; an experiment that lost, specialise.hpp): the plain form, which
+// the compiler can hoist out of the loop over a wavefront's bricks where x and y do not change -- an inline asm it will not.
+#if defined(SDF_ABS_MINUS_BUILTIN) && SDF_ABS_MINUS_BUILTIN
+__device__ __forceinline__ float abs_minus(float x, float h) { return __builtin_fabsf(x) - h; }
+__device__ __forceinline__ f2 abs_minus(f2 x, float h) { return __builtin_elementwise_abs(x) - h; }
+#else
 __device__ __forceinline__ float abs_minus(float x, float h) { float r; asm("v_sub_f32 %0, |%1|, %2" : "=v"(r) : "v"(x), "s"(h)); return r; }
 __device__ __forceinline__ f2 abs_minus(f2 x, float h) { f2 r; r.x = abs_minus(x.x, h); r.y = abs_minus(x.y, h); return r; }
+#endif
 // The hardware's v_min_f32 / v_max_f32 (ISA pseudocode: a NaN operand yields the other one, -0 orders below
 // +0): one full-rate instruction where `a < b ? a : b` is a compare and a select.  The canonical distance of
 // union / intersection / subtraction and of the nearer-slab case; the oracle restates it in

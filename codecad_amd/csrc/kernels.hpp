@@ -239,6 +239,9 @@ k_grid_eval(const E ev, float cx, float cy, float cz, float step, uint32_t sx, D
 #pragma unroll
             for (int i = 0; i < N; ++i) xs[i] = sample(cx, step, x0 + x + 2u * i);
             const T px = pack(xs), py = (T)(sample(cy, step, y));
+            // what the tape computes from x and y alone is computed once for the wavefront's bricks (specialise.hpp)
+            [[maybe_unused]] typename E::template Hoisted<T> hoisted;
+            if constexpr (!E::kCull) hoisted = ev.template hoist<T>(px, py);
             uint32_t keep_all = 0xffffffffu;
             if constexpr (E::kCull) {
                 const float ccx = sample(cx, step, x0 + bx * 4u) + 1.5f * step, ccy = sample(cy, step, by * 4u) + 1.5f * step;
@@ -259,12 +262,16 @@ k_grid_eval(const E ev, float cx, float cy, float cz, float step, uint32_t sx, D
                 continue;
 #endif
                 if (LAYOUT == 0) {
-                    const sdf::V4<T> r = ev.eval_kept(px, py, pz, keep);
+                    sdf::V4<T> r;
+                    if constexpr (E::kCull) r = ev.eval_kept(px, py, pz, keep);
+                    else r = ev.eval_hoisted(px, py, pz, hoisted);
                     float4* o = static_cast<float4*>(out) + ((size_t)z + (size_t)sz * ((size_t)y + (size_t)sy * x));
 #pragma unroll
                     for (int i = 0; i < N; ++i) store_voxel(o + (size_t)i * 2u * sy * sz, sdf::voxel(r, i));
                 } else {
-                    const T w = ev.dist_kept(px, py, pz, keep);
+                    T w;
+                    if constexpr (E::kCull) w = ev.dist_kept(px, py, pz, keep);
+                    else w = ev.dist_hoisted(px, py, pz, hoisted);
                     float* o = static_cast<float*>(out) + ((size_t)z + ((size_t)(x0 + x) + (size_t)(sy - 1u - y) * sx) * sz);
 #pragma unroll
                     for (int i = 0; i < N; ++i) store_voxel(o + (size_t)i * 2u * sz, sdf::get(w, i));
@@ -400,6 +407,8 @@ k_grid_eval_blocks(const E ev, const int4* __restrict__ blocks, const uint32_t* 
             for (int i = 0; i < N; ++i) xs[i] = sample(cx, step, x + 2u * i);
             const T px = pack(xs), py = (T)(sample(cy, step, y));
             const size_t base = (size_t)b * cells;
+            // (no hoisting of what x and y alone decide, as k_grid_eval does: over two bricks the extra pass costs what it
+            // saves -- 0.61 against 0.59 ms for the bench's leaf blocks)
 #pragma unroll 1
             for (uint32_t j = 0; j < bricks; ++j) {
                 const uint32_t z = j * 8u + (lane & 7u);

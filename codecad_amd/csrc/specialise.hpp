@@ -326,7 +326,8 @@ inline std::string cond_expr(const std::vector<uint32_t>& masks)
 inline void emit_plain(std::ostringstream& o, const SpecProgram& p)
 {
     using namespace spec_detail;
-    o << "template <class T> __device__ __forceinline__ sdf::V4<T> tape_eval(T px, T py, T pz, const float* __restrict__ extra, uint32_t)\n{\n"
+    o << "constexpr int kHoisted = 0;\n"
+      << "template <class T, int PRE> __device__ __forceinline__ sdf::V4<T> tape_eval(T px, T py, T pz, const float* __restrict__ extra, uint32_t, T*)\n{\n"
       << "    using namespace sdf;\n    RegsV<T, " << p.n_slots << "> regs;\n"
       << "    V4<T> last = v4<T>(bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f));\n";
     for (const Rec& r : p.full) {
@@ -335,8 +336,8 @@ inline void emit_plain(std::ostringstream& o, const SpecProgram& p)
           << ">(r, last, extra, px, py, pz, regs); }\n";
     }
     o << "    return last;\n}\n"
-      << "template <class T> __device__ __forceinline__ T tape_dist(T px, T py, T pz, const float* __restrict__ extra, uint32_t)\n"
-      << "{ return tape_eval<T>(px, py, pz, extra, 0xffffffffu).w; }\n";
+      << "template <class T, int PRE> __device__ __forceinline__ T tape_dist(T px, T py, T pz, const float* __restrict__ extra, uint32_t, T*)\n"
+      << "{ return tape_eval<T, 0>(px, py, pz, extra, 0xffffffffu, nullptr).w; }\n";
 }
 
 // The centre pass of the culling (T = float, one brick centre per lane): the distance-only program once, with an
@@ -566,6 +567,89 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
             for (const Step& s : path.up)
                 if (s.node >= 0 && nodes[s.node].role == WITH_POINT) keep_pt[nodes[nodes[s.node].b].rec] = 1;
         }
+    // ---- what does not change along z.  The brick kernels walk a wavefront's bricks along z with x and y fixed
+    // (kernels.hpp), and a primitive whose distance only reads x and y -- the bar of a cross that runs along z -- is the
+    // same in all of them: its records are hoisted out of that loop (PRE == 1: phase 1 once with z = 0, the hoisted
+    // distances captured -- everything else is dead code there; PRE == 2: those records replaced by the captured
+    // distance; PRE == 0: everything in place).  A hoisted run is a private chain `to ... primitive from ...` of
+    // scalings, quarter turns (which permute the coordinates without touching them: interp.hpp axis_rotate with B == 0)
+    // and a rectangle or a circle (which read |x|, |y| or x^2 + y^2: no sign of a zero can differ).
+    std::vector<int> run_first, run_last, run_of(p.dist.size(), -1);
+    if (!plan.enabled) {
+        enum : uint8_t { X = 1, Y = 2, Z = 4 };
+        struct Deps { uint8_t c[3]; };
+        const Deps unknown{{X | Y | Z, X | Y | Z, X | Y | Z}};
+        Deps last_d = unknown;
+        std::vector<Deps> slot_d(256, unknown);
+        const int n = (int)p.dist.size();
+        std::vector<Deps> before(n, unknown);   // of `last` when the record's own operation starts (after its folded load)
+        std::vector<uint8_t> w_deps(n, X | Y | Z);
+        for (int i = 0; i < n; ++i) {
+            const Rec& r = p.dist[i];
+            const uint32_t op = r.hdr & 0xffu, fold = fold_of(r);
+            if (op == OP_RETURN) break;
+            if (fold & kFoldLoad) last_d = (fold & kFoldLoadResult) ? unknown : slot_d[fold & 0xffu];
+            before[i] = last_d;
+            Deps out = unknown;
+            uint8_t w = X | Y | Z;
+            const bool quarter = r.p[1] == 0.0f;
+            switch (op) {
+            case OPX_POINT: out = Deps{{X, Y, Z}}; break;
+            case OPX_TO_SCALE: case OP_REPETITION: out = last_d; break;
+            case OPX_TO_AXIS_X: if (quarter) out = Deps{{last_d.c[0], last_d.c[2], last_d.c[1]}}; break;
+            case OPX_TO_AXIS_Y: if (quarter) out = Deps{{last_d.c[2], last_d.c[1], last_d.c[0]}}; break;
+            case OPX_TO_AXIS_Z: if (quarter) out = Deps{{last_d.c[1], last_d.c[0], last_d.c[2]}}; break;
+            case OP_RECTANGLE: case OP_CIRCLE: w = last_d.c[0] | last_d.c[1]; break;
+            case OPX_FROM_SCALE: case OPX_FROM_AXIS_X: case OPX_FROM_AXIS_Y: case OPX_FROM_AXIS_Z:
+                w = i > 0 ? w_deps[i - 1] : (X | Y | Z);   // (only meaningful inside a run, where the previous record made the distance)
+                break;
+            default: break;
+            }
+            w_deps[i] = w;
+            last_d = out;
+            if ((fold & kFoldStore) && !(fold & kFoldStoreResult)) slot_d[(fold >> 16) & 0xffu] = last_d;
+            if (op == OP_STORE && !(r.hdr & kResultKind)) slot_d[(r.hdr >> 8) & 0xffu] = before[i];
+        }
+        auto in_run = [&](uint32_t op, const Rec& r) {
+            if (op == OPX_TO_SCALE || op == OP_RECTANGLE || op == OP_CIRCLE || op == OPX_FROM_SCALE || op == OPX_FROM_AXIS_X ||
+                op == OPX_FROM_AXIS_Y || op == OPX_FROM_AXIS_Z) return true;
+            return (op == OPX_TO_AXIS_X || op == OPX_TO_AXIS_Y || op == OPX_TO_AXIS_Z) && r.p[1] == 0.0f;
+        };
+        for (int a = 0; a < n;) {
+            const uint32_t op_a = p.dist[a].hdr & 0xffu;
+            if (op_a == OP_RETURN) break;
+            if (!in_run(op_a, p.dist[a]) || (fold_of(p.dist[a]) & kFoldLoadResult)) { ++a; continue; }
+            int b = a, prims = 0, prim_at = -1;
+            for (int i = a; i < n; ++i) {
+                const Rec& r = p.dist[i];
+                const uint32_t op = r.hdr & 0xffu, fold = fold_of(r);
+                if (!in_run(op, r) || keep_w[i] || is_choice[i] || keep_pt[i]) break;
+                if (i > a && (fold & kFoldLoad)) break;
+                const bool is_prim = op == OP_RECTANGLE || op == OP_CIRCLE;
+                const bool is_from = op == OPX_FROM_SCALE || op == OPX_FROM_AXIS_X || op == OPX_FROM_AXIS_Y || op == OPX_FROM_AXIS_Z;
+                if (is_prim && prims) break;
+                if (is_from && !prims) break;            // a direction's transformation ahead of any primitive: not this pattern
+                if (!is_prim && !is_from && prims) break;   // a point operation after the primitive: the next leaf starts
+                if (is_prim) { ++prims; prim_at = i; }
+                b = i;
+                if (fold & kFoldStore) break;            // the value leaves `last`: the run ends here
+            }
+            // a run must hold its primitive, keep every point it computes to itself, and end in a distance free of z
+            bool ok = prims == 1 && b >= prim_at;
+            for (int i = a; ok && i < b; ++i) ok = !(fold_of(p.dist[i]) & kFoldStore);
+            if (ok && (fold_of(p.dist[b]) & kFoldStore)) ok = (fold_of(p.dist[b]) & kFoldStoreResult) != 0;
+            if (ok) ok = !(w_deps[b] & Z);
+            if (ok) {
+                for (int i = a; i <= b; ++i) run_of[i] = (int)run_first.size();
+                run_first.push_back(a);
+                run_last.push_back(b);
+                a = b + 1;
+            } else {
+                ++a;
+            }
+        }
+    }
+    const int n_hoisted = (int)run_first.size();
     std::ostringstream body;
     body << "    using namespace sdf;\n    using M = typename mask_of<T>::type;\n"
          << "    RegsDO<T, " << p.n_point_slots << ", " << p.n_result_slots << "> regs;\n"
@@ -583,12 +667,14 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
         const bool guarded = plan.enabled && !plan.rec_conds[i].empty();
         const bool same_as_before = guarded && i > 0 && plan.rec_conds[i - 1] == plan.rec_conds[i];
         if (guarded && !same_as_before) body << "    if (" << cond_expr(plan.rec_conds[i]) << ") {\n";
+        const int run = run_of[i];
+        if (run >= 0 && run_first[run] == i) body << "    if constexpr (PRE != 2) {   // (free of z: hoisted out of the walk along z)\n";
         if (fold & kFoldLoad) {
             if (fold & kFoldLoadResult) body << "    last.w = regs.load_res(" << (fold & 0xffu) << ");\n";
             else body << "    last = regs.load(" << (fold & 0xffu) << ");\n";
         }
         if (keep_w[i]) body << "    w" << i << " = last.w;\n";
-        const std::string run = "{ const Rec r = " + rec_literal(r, true, r.hdr) + "; exec_one<T, true, decltype(regs), " + std::to_string(op) +
+        const std::string run_text = "{ const Rec r = " + rec_literal(r, true, r.hdr) + "; exec_one<T, true, decltype(regs), " + std::to_string(op) +
                                 ">(r, last, extra, px, py, pz, regs); }";
         if (is_select(op)) {
             // the comparison of rounded_union(r < 0) for this op, on the operands it would have seen
@@ -599,19 +685,21 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
             const int ks = plan.enabled ? plan.select_of_rec[i] : -1;
             if (ks >= 0 && (plan.guarded[ks][0] || plan.guarded[ks][1])) {
                 const uint32_t ba = 1u << (2 * ks), bb = 1u << (2 * ks + 1);
-                body << "    if ((keep & " << (ba | bb) << "u) == " << (ba | bb) << "u) { " << (is_choice[i] ? choice + "lt(" + a + ", " + b + "); " : std::string()) << run << " }\n"
+                body << "    if ((keep & " << (ba | bb) << "u) == " << (ba | bb) << "u) { " << (is_choice[i] ? choice + "lt(" + a + ", " + b + "); " : std::string()) << run_text << " }\n"
                      // operand a lost everywhere: the result is operand b as the op hands it on (subtraction: -b)
                      << "    else if (keep & " << bb << "u) { last.w = " << (op == OP_SUBTRACTION ? "-" : "") << b_raw << "; "
                      << (is_choice[i] ? choice + "~mask_of<T>::all(); " : std::string()) << "}\n"
                      << "    else { " << (is_choice[i] ? choice + "mask_of<T>::all(); " : std::string()) << "}\n";
             } else {
                 if (is_choice[i]) body << "    " << choice << "lt(" << a << ", " << b << ");\n";
-                body << "    " << run << "\n";
+                body << "    " << run_text << "\n";
             }
         } else {
-            body << "    " << run << "\n";
+            body << "    " << run_text << "\n";
         }
         if (keep_pt[i]) body << "    pt" << i << " = last;\n";
+        if (run >= 0 && run_last[run] == i)
+            body << "    if constexpr (PRE == 1) hoisted[" << run << "] = last.w;\n    } else {\n    last.w = hoisted[" << run << "];\n    }\n";
         if (fold & kFoldStore) {
             if (fold & kFoldStoreResult) body << "    regs.store_res(" << ((fold >> 16) & 0xffu) << ", last.w);\n";
             else body << "    regs.store(" << ((fold >> 16) & 0xffu) << ", last);\n";
@@ -621,13 +709,14 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
         if (guarded && !same_as_next) body << "    }\n";
     }
     if (plan.enabled) emit_cull(o, p, nodes, rec_node, plan);
-    o << "template <class T> __device__ __forceinline__ T tape_dist(T px, T py, T pz, const float* __restrict__ extra, uint32_t keep)\n{\n";
+    o << "constexpr int kHoisted = " << n_hoisted << ";   // distances that do not change along z (emit_deferred)\n"
+      << "template <class T, int PRE> __device__ __forceinline__ T tape_dist(T px, T py, T pz, const float* __restrict__ extra, uint32_t keep, T* hoisted)\n{\n";
     {   // the distance alone: phase 1 without the captures (they are dead there)
         std::string text = body.str();
         o << text << "    return last.w;\n}\n";
     }
     o << "// deferred directions: " << paths.size() << " (primitive, path) pairs" << (plan.enabled ? "; culling" : "") << "\n"
-      << "template <class T> __device__ __forceinline__ sdf::V4<T> tape_eval(T px, T py, T pz, const float* __restrict__ extra, uint32_t keep)\n{\n"
+      << "template <class T, int PRE> __device__ __forceinline__ sdf::V4<T> tape_eval(T px, T py, T pz, const float* __restrict__ extra, uint32_t keep, T* hoisted)\n{\n"
       << body.str()
       << "    const T w_root = last.w;\n"
       << "    // ---- phase 2\n"
@@ -693,7 +782,10 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
 inline std::string specialised_source(const SpecProgram& p, bool allow_deferred, bool* deferred = nullptr, bool* culled = nullptr)
 {
     std::ostringstream o;
-    o << "#include \"kernels.hpp\"\nnamespace sdfk {\nusing sdf::Rec;\n";
+    // HU_ABS_BUILTIN=1 (an experiment that lost): |x| - h written plainly in the brick kernels, so that the compiler hoists
+    // the terms in x and y out of the loop over a wavefront's bricks (interp.hpp abs_minus) -- it does, and the hoisted
+    // values cost 30 registers (85 -> 115, a wavefront less per SIMD): dense 0.83 -> 1.12 ms, leaf blocks 0.58 -> 0.92 ms
+    static const bool abs_builtin = [] { const char* e = getenv("HU_ABS_BUILTIN"); return e && e[0] == '1'; }();
     std::ostringstream d;
     static const bool save_points = [] { const char* e = getenv("HU_PHASE2_SAVE_POINTS"); return e && e[0] == '1'; }();
     // Per-brick culling is an experiment that lost: with it sponge(4) dense runs in
@@ -701,6 +793,7 @@ inline std::string specialised_source(const SpecProgram& p, bool allow_deferred,
     static const bool want_cull = [] { const char* e = getenv("HU_CULL"); return e && e[0] == '1'; }();
     bool culling = want_cull;
     const bool ok = allow_deferred && emit_deferred(d, p, 40, save_points, &culling);
+    o << (ok && abs_builtin ? "#define SDF_ABS_MINUS_BUILTIN 1\n" : "") << "#include \"kernels.hpp\"\nnamespace sdfk {\nusing sdf::Rec;\n";
     if (ok) o << d.str();
     else emit_plain(o, p);
     culling = culling && ok;
@@ -712,13 +805,21 @@ inline std::string specialised_source(const SpecProgram& p, bool allow_deferred,
       << "    static constexpr bool kCull = " << (culling ? "true" : "false") << ";   // bricks are evaluated with per-brick culling (kernels.hpp)\n"
       << "    const float* extra;\n"
       << "    template <class T> __device__ __forceinline__ sdf::V4<T> operator()(T px, T py, T pz, void*) const\n"
-      << "    { return tape_eval<T>(px, py, pz, extra, 0xffffffffu); }\n"
+      << "    { return tape_eval<T, 0>(px, py, pz, extra, 0xffffffffu, nullptr); }\n"
       << "    template <class T> __device__ __forceinline__ T dist(T px, T py, T pz, void*) const\n"
-      << "    { return tape_dist<T>(px, py, pz, extra, 0xffffffffu); }\n"
+      << "    { return tape_dist<T, 0>(px, py, pz, extra, 0xffffffffu, nullptr); }\n"
       << "    template <class T> __device__ __forceinline__ sdf::V4<T> eval_kept(T px, T py, T pz, uint32_t keep) const\n"
-      << "    { return tape_eval<T>(px, py, pz, extra, keep); }\n"
+      << "    { return tape_eval<T, 0>(px, py, pz, extra, keep, nullptr); }\n"
       << "    template <class T> __device__ __forceinline__ T dist_kept(T px, T py, T pz, uint32_t keep) const\n"
-      << "    { return tape_dist<T>(px, py, pz, extra, keep); }\n"
+      << "    { return tape_dist<T, 0>(px, py, pz, extra, keep, nullptr); }\n"
+      // what does not change along z, for kernels that walk bricks along z with x and y fixed (kernels.hpp)
+      << "    template <class T> struct Hoisted { T v[kHoisted > 0 ? kHoisted : 1]; };\n"
+      << "    template <class T> __device__ __forceinline__ Hoisted<T> hoist(T px, T py) const\n"
+      << "    { Hoisted<T> h; if constexpr (kHoisted > 0) tape_dist<T, 1>(px, py, sdf::bc<T>(0.0f), extra, 0xffffffffu, h.v); return h; }\n"
+      << "    template <class T> __device__ __forceinline__ sdf::V4<T> eval_hoisted(T px, T py, T pz, Hoisted<T>& h) const\n"
+      << "    { return tape_eval<T, (kHoisted > 0 ? 2 : 0)>(px, py, pz, extra, 0xffffffffu, h.v); }\n"
+      << "    template <class T> __device__ __forceinline__ T dist_hoisted(T px, T py, T pz, Hoisted<T>& h) const\n"
+      << "    { return tape_dist<T, (kHoisted > 0 ? 2 : 0)>(px, py, pz, extra, 0xffffffffu, h.v); }\n"
       << "    __device__ __forceinline__ uint32_t cull(float cx, float cy, float cz, float hx, float hy, float hz) const\n"
       << "    { return " << (culling ? "tape_cull(cx, cy, cz, hx, hy, hz, extra)" : "tape_cull_none()") << "; }\n};\n}  // namespace sdfk\n";
     return o.str();
