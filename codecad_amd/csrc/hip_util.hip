@@ -796,8 +796,9 @@ static int grid_eval_blocks_impl(hu_tape t, const int32_t* blocks_dev, uint32_t 
         const uint32_t per_block = kSpecBlock * kSpecVoxelsPerLane;
         uint32_t chunks = (uint32_t)((cells + per_block - 1) / per_block);
         // deferred-direction code over compact bricks (kernels.hpp): a wavefront per (x, y) column of 4 x 4 x 8 bricks
-        uint32_t bricks = t->spec->deferred && brick_tiles(dims[0], dims[1], 32u) && dims[2] % 8u == 0u && dims[2] <= 64u ? dims[2] / 8u : 0u;
-        if (bricks) chunks = ((dims[0] / 4u) * (dims[1] / 4u) + 3u) / 4u;
+        // (a wavefront per (y, z) column of 4 x 4 x 8 bricks, walking along x)
+        uint32_t bricks = t->spec->deferred && brick_tiles(dims[0], dims[1], 32u) && dims[2] % 8u == 0u && dims[0] <= 64u ? dims[0] / 4u : 0u;
+        if (bricks) chunks = ((dims[1] / 4u) * (dims[2] / 8u) + 3u) / 4u;
         SpecEval ev{t->extra_dev};
         const int4* b = (const int4*)blocks_dev;
         double res = resolution, ox = origin[0], oy = origin[1], oz = origin[2];

@@ -396,30 +396,30 @@ k_grid_eval_blocks(const E ev, const int4* __restrict__ blocks, const uint32_t* 
     if constexpr (E::kBricks && N == 2) {
         if (bricks) {
             // As in k_grid_eval: a wavefront evaluates compact 4 x 4 x 8 bricks (lane -> z: 8, y: 4, x: 2, its two voxels
-            // two x planes apart), here the `bricks` = sz / 8 of one (x, y) column of the block, one after the other.
-            // `chunks` counts workgroups of four such columns.
+            // two x planes apart) -- here the `bricks` = sx / 4 of one (y, z) column of the block, one after the other ALONG
+            // X (a 16^3 block: four; along z it would be two): what the tape computes from y and z alone is computed once
+            // for them (specialise.hpp: the bars of a cross that run along x).  `chunks` counts workgroups of four columns.
             const uint32_t lane = threadIdx.x & 63u, column = chunk * 4u + (threadIdx.x >> 6);
-            const uint32_t nby = sy >> 2, by = column % nby, bx = column / nby;
-            if (bx * 4u >= sx) return;   // wavefronts past the last column (uniform)
-            const uint32_t x = bx * 4u + (lane >> 5), y = by * 4u + ((lane >> 3) & 3u);
-            float xs[N];
-#pragma unroll
-            for (int i = 0; i < N; ++i) xs[i] = sample(cx, step, x + 2u * i);
-            const T px = pack(xs), py = (T)(sample(cy, step, y));
+            const uint32_t nbz = sz >> 3, bz = column % nbz, by = column / nbz;
+            if (by * 4u >= sy) return;   // wavefronts past the last column (uniform)
+            const uint32_t y = by * 4u + ((lane >> 3) & 3u), z = bz * 8u + (lane & 7u);
+            const T py = (T)(sample(cy, step, y)), pz = (T)(sample(cz, step, z));
             const size_t base = (size_t)b * cells;
-            // (no hoisting of what x and y alone decide, as k_grid_eval does: over two bricks the extra pass costs what it
-            // saves -- 0.61 against 0.59 ms for the bench's leaf blocks)
+            typename E::template Hoisted<T> hoisted = ev.template hoist_x<T>(py, pz);
 #pragma unroll 1
             for (uint32_t j = 0; j < bricks; ++j) {
-                const uint32_t z = j * 8u + (lane & 7u);
-                const T pz = (T)(sample(cz, step, z));
+                const uint32_t x = j * 4u + (lane >> 5);
+                float xs[N];
+#pragma unroll
+                for (int i = 0; i < N; ++i) xs[i] = sample(cx, step, x + 2u * i);
+                const T px = pack(xs);
                 if (LAYOUT == 0) {
-                    const sdf::V4<T> r = ev(px, py, pz, lds);
+                    const sdf::V4<T> r = ev.eval_hoisted_x(px, py, pz, hoisted);
                     float4* o = static_cast<float4*>(out) + base + ((size_t)z + (size_t)sz * ((size_t)y + (size_t)sy * x));
 #pragma unroll
                     for (int i = 0; i < N; ++i) store_voxel(o + (size_t)i * 2u * sy * sz, sdf::voxel(r, i));
                 } else {
-                    const T w = ev.dist(px, py, pz, lds);
+                    const T w = ev.dist_hoisted_x(px, py, pz, hoisted);
                     float* o = static_cast<float*>(out) + base + ((size_t)z + ((size_t)x + (size_t)(sy - 1u - y) * sx) * sz);
 #pragma unroll
                     for (int i = 0; i < N; ++i) store_voxel(o + (size_t)i * 2u * sz, sdf::get(w, i));

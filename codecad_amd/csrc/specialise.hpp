@@ -327,7 +327,7 @@ inline void emit_plain(std::ostringstream& o, const SpecProgram& p)
 {
     using namespace spec_detail;
     o << "constexpr int kHoisted = 0;\n"
-      << "template <class T, int PRE> __device__ __forceinline__ sdf::V4<T> tape_eval(T px, T py, T pz, const float* __restrict__ extra, uint32_t, T*)\n{\n"
+      << "template <class T, int PRE, uint32_t AXIS = 4u> __device__ __forceinline__ sdf::V4<T> tape_eval(T px, T py, T pz, const float* __restrict__ extra, uint32_t, T*)\n{\n"
       << "    using namespace sdf;\n    RegsV<T, " << p.n_slots << "> regs;\n"
       << "    V4<T> last = v4<T>(bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f));\n";
     for (const Rec& r : p.full) {
@@ -336,7 +336,7 @@ inline void emit_plain(std::ostringstream& o, const SpecProgram& p)
           << ">(r, last, extra, px, py, pz, regs); }\n";
     }
     o << "    return last;\n}\n"
-      << "template <class T, int PRE> __device__ __forceinline__ T tape_dist(T px, T py, T pz, const float* __restrict__ extra, uint32_t, T*)\n"
+      << "template <class T, int PRE, uint32_t AXIS = 4u> __device__ __forceinline__ T tape_dist(T px, T py, T pz, const float* __restrict__ extra, uint32_t, T*)\n"
       << "{ return tape_eval<T, 0>(px, py, pz, extra, 0xffffffffu, nullptr).w; }\n";
 }
 
@@ -569,12 +569,14 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
         }
     // ---- what does not change along z.  The brick kernels walk a wavefront's bricks along z with x and y fixed
     // (kernels.hpp), and a primitive whose distance only reads x and y -- the bar of a cross that runs along z -- is the
-    // same in all of them: its records are hoisted out of that loop (PRE == 1: phase 1 once with z = 0, the hoisted
+    // same in all of them (the leaf-block kernel walks along x: the same for the bar along x, AXIS): its records are
+    // hoisted out of that loop (PRE == 1: phase 1 once with z = 0, the hoisted
     // distances captured -- everything else is dead code there; PRE == 2: those records replaced by the captured
     // distance; PRE == 0: everything in place).  A hoisted run is a private chain `to ... primitive from ...` of
     // scalings, quarter turns (which permute the coordinates without touching them: interp.hpp axis_rotate with B == 0)
     // and a rectangle or a circle (which read |x|, |y| or x^2 + y^2: no sign of a zero can differ).
     std::vector<int> run_first, run_last, run_of(p.dist.size(), -1);
+    std::vector<uint32_t> run_free;   // bit a: the run's distance does not read sample coordinate a (x, y, z): free along a walk in that direction
     if (!plan.enabled) {
         enum : uint8_t { X = 1, Y = 2, Z = 4 };
         struct Deps { uint8_t c[3]; };
@@ -638,11 +640,14 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
             bool ok = prims == 1 && b >= prim_at;
             for (int i = a; ok && i < b; ++i) ok = !(fold_of(p.dist[i]) & kFoldStore);
             if (ok && (fold_of(p.dist[b]) & kFoldStore)) ok = (fold_of(p.dist[b]) & kFoldStoreResult) != 0;
-            if (ok) ok = !(w_deps[b] & Z);
+            // (walks are along z -- the dense kernel -- or along x -- the leaf-block kernel: kernels.hpp)
+            const uint32_t free_along = (uint32_t)(~w_deps[b]) & (X | Z);
+            if (ok) ok = free_along != 0u;
             if (ok) {
                 for (int i = a; i <= b; ++i) run_of[i] = (int)run_first.size();
                 run_first.push_back(a);
                 run_last.push_back(b);
+                run_free.push_back(free_along);
                 a = b + 1;
             } else {
                 ++a;
@@ -668,7 +673,9 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
         const bool same_as_before = guarded && i > 0 && plan.rec_conds[i - 1] == plan.rec_conds[i];
         if (guarded && !same_as_before) body << "    if (" << cond_expr(plan.rec_conds[i]) << ") {\n";
         const int run = run_of[i];
-        if (run >= 0 && run_first[run] == i) body << "    if constexpr (PRE != 2) {   // (free of z: hoisted out of the walk along z)\n";
+        // (AXIS: the direction of the walk, as a bit -- 1 x, 4 z; a run is hoisted in the instantiations whose walk it is free along)
+        if (run >= 0 && run_first[run] == i)
+            body << "    if constexpr (!(PRE == 2 && (" << run_free[run] << "u & AXIS))) {   // (hoisted out of walks along " << ((run_free[run] & 1u) ? "x " : "") << ((run_free[run] & 4u) ? "z" : "") << ")\n";
         if (fold & kFoldLoad) {
             if (fold & kFoldLoadResult) body << "    last.w = regs.load_res(" << (fold & 0xffu) << ");\n";
             else body << "    last = regs.load(" << (fold & 0xffu) << ");\n";
@@ -699,7 +706,7 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
         }
         if (keep_pt[i]) body << "    pt" << i << " = last;\n";
         if (run >= 0 && run_last[run] == i)
-            body << "    if constexpr (PRE == 1) hoisted[" << run << "] = last.w;\n    } else {\n    last.w = hoisted[" << run << "];\n    }\n";
+            body << "    if constexpr (PRE == 1 && (" << run_free[run] << "u & AXIS)) hoisted[" << run << "] = last.w;\n    } else {\n    last.w = hoisted[" << run << "];\n    }\n";
         if (fold & kFoldStore) {
             if (fold & kFoldStoreResult) body << "    regs.store_res(" << ((fold >> 16) & 0xffu) << ", last.w);\n";
             else body << "    regs.store(" << ((fold >> 16) & 0xffu) << ", last);\n";
@@ -710,13 +717,13 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
     }
     if (plan.enabled) emit_cull(o, p, nodes, rec_node, plan);
     o << "constexpr int kHoisted = " << n_hoisted << ";   // distances that do not change along z (emit_deferred)\n"
-      << "template <class T, int PRE> __device__ __forceinline__ T tape_dist(T px, T py, T pz, const float* __restrict__ extra, uint32_t keep, T* hoisted)\n{\n";
+      << "template <class T, int PRE, uint32_t AXIS = 4u> __device__ __forceinline__ T tape_dist(T px, T py, T pz, const float* __restrict__ extra, uint32_t keep, T* hoisted)\n{\n";
     {   // the distance alone: phase 1 without the captures (they are dead there)
         std::string text = body.str();
         o << text << "    return last.w;\n}\n";
     }
     o << "// deferred directions: " << paths.size() << " (primitive, path) pairs" << (plan.enabled ? "; culling" : "") << "\n"
-      << "template <class T, int PRE> __device__ __forceinline__ sdf::V4<T> tape_eval(T px, T py, T pz, const float* __restrict__ extra, uint32_t keep, T* hoisted)\n{\n"
+      << "template <class T, int PRE, uint32_t AXIS = 4u> __device__ __forceinline__ sdf::V4<T> tape_eval(T px, T py, T pz, const float* __restrict__ extra, uint32_t keep, T* hoisted)\n{\n"
       << body.str()
       << "    const T w_root = last.w;\n"
       << "    // ---- phase 2\n"
@@ -815,11 +822,18 @@ inline std::string specialised_source(const SpecProgram& p, bool allow_deferred,
       // what does not change along z, for kernels that walk bricks along z with x and y fixed (kernels.hpp)
       << "    template <class T> struct Hoisted { T v[kHoisted > 0 ? kHoisted : 1]; };\n"
       << "    template <class T> __device__ __forceinline__ Hoisted<T> hoist(T px, T py) const\n"
-      << "    { Hoisted<T> h; if constexpr (kHoisted > 0) tape_dist<T, 1>(px, py, sdf::bc<T>(0.0f), extra, 0xffffffffu, h.v); return h; }\n"
+      << "    { Hoisted<T> h; if constexpr (kHoisted > 0) tape_dist<T, 1, 4u>(px, py, sdf::bc<T>(0.0f), extra, 0xffffffffu, h.v); return h; }\n"
       << "    template <class T> __device__ __forceinline__ sdf::V4<T> eval_hoisted(T px, T py, T pz, Hoisted<T>& h) const\n"
-      << "    { return tape_eval<T, (kHoisted > 0 ? 2 : 0)>(px, py, pz, extra, 0xffffffffu, h.v); }\n"
+      << "    { return tape_eval<T, (kHoisted > 0 ? 2 : 0), 4u>(px, py, pz, extra, 0xffffffffu, h.v); }\n"
       << "    template <class T> __device__ __forceinline__ T dist_hoisted(T px, T py, T pz, Hoisted<T>& h) const\n"
-      << "    { return tape_dist<T, (kHoisted > 0 ? 2 : 0)>(px, py, pz, extra, 0xffffffffu, h.v); }\n"
+      << "    { return tape_dist<T, (kHoisted > 0 ? 2 : 0), 4u>(px, py, pz, extra, 0xffffffffu, h.v); }\n"
+      // ... and the same for a walk along x with y and z fixed (k_grid_eval_blocks)
+      << "    template <class T> __device__ __forceinline__ Hoisted<T> hoist_x(T py, T pz) const\n"
+      << "    { Hoisted<T> h; if constexpr (kHoisted > 0) tape_dist<T, 1, 1u>(sdf::bc<T>(0.0f), py, pz, extra, 0xffffffffu, h.v); return h; }\n"
+      << "    template <class T> __device__ __forceinline__ sdf::V4<T> eval_hoisted_x(T px, T py, T pz, Hoisted<T>& h) const\n"
+      << "    { return tape_eval<T, (kHoisted > 0 ? 2 : 0), 1u>(px, py, pz, extra, 0xffffffffu, h.v); }\n"
+      << "    template <class T> __device__ __forceinline__ T dist_hoisted_x(T px, T py, T pz, Hoisted<T>& h) const\n"
+      << "    { return tape_dist<T, (kHoisted > 0 ? 2 : 0), 1u>(px, py, pz, extra, 0xffffffffu, h.v); }\n"
       << "    __device__ __forceinline__ uint32_t cull(float cx, float cy, float cz, float hx, float hy, float hz) const\n"
       << "    { return " << (culling ? "tape_cull(cx, cy, cz, hx, hy, hz, extra)" : "tape_cull_none()") << "; }\n};\n}  // namespace sdfk\n";
     return o.str();
