@@ -1,0 +1,104 @@
+"""Per-tape code on the grids where its brick kernels run (csrc/kernels.hpp): dense grids whose extents are multiples of
+(4, 4, 32) -- a wavefront walks bricks along z and what x and y alone decide is hoisted out of the walk
+(specialise.hpp emit_deferred, PRE / AXIS) -- and leaf blocks of 16^3, walked along x.  Every float must equal the
+oracle's: hoisting moves records, it does not change them.  (The other parity tests use ragged grids, which take the
+kernels without bricks.)"""
+import ctypes
+import random
+
+import numpy as np
+import pytest
+
+import oracle
+import shapes_zoo
+from conftest import load_golden_tapes, same_bits
+from random_trees import random_3d
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = load_golden_tapes()
+ZOO_3D = sorted(name for name in shapes_zoo.all_named if GOLDEN[name]["dimension"] == 3)
+
+
+def check_dense(hip, handle, tape, corner, step, dims):
+    from codecad_amd import hip_util
+    c4 = np.zeros(4, np.float32)
+    c4[:3] = corner
+    out = hip_util.Buffer(hip_util.Buffer.quad_dtype(np.float32), dims)
+    hip.k.grid_eval(dims, None, handle, c4, step, out).wait()
+    got = out.read().view(np.float32).reshape(dims + (4,))
+    want = oracle.grid_eval(tape, corner, step, dims)
+    assert same_bits(got, want), "float4 grid differs: max |diff| = %g" % np.nanmax(np.abs(got - want))
+    outw = hip_util.Buffer(np.float32, dims)
+    hip.k.grid_eval_pymcubes(dims, None, handle, c4, step, outw).wait()
+    assert same_bits(outw.read().reshape(-1), oracle.grid_eval_pymcubes(tape, corner, step, dims)), "distance grid differs"
+    out.release()
+    outw.release()
+
+
+def check_blocks(hip, handle, tape, int_corners, resolution, origin, edge=16):
+    """hu_grid_eval_blocks over blocks of edge^3 samples at integer corners (subdivision.py:100: corner * resolution + origin)"""
+    from codecad_amd import hip_util
+    from codecad_amd.hip_util import check
+    n = len(int_corners)
+    blocks = np.zeros((n, 4), np.int32)
+    blocks[:, :3] = int_corners
+    blocks_dev = hip_util.Buffer(np.int32, blocks.shape)
+    blocks_dev.enqueue_write(blocks).wait()
+    dims = (ctypes.c_uint32 * 3)(edge, edge, edge)
+    o = (ctypes.c_double * 3)(*origin)
+    step = np.float32(resolution)
+    for layout, per_voxel in ((0, 4), (1, 1)):
+        out = hip_util.Buffer(np.float32, (n, edge, edge, edge, per_voxel) if layout == 0 else (n, edge ** 3))
+        check(hip.lib.hu_grid_eval_blocks(handle.device_ptr, blocks_dev.device_ptr, n, float(resolution), o, step, dims, layout,
+                                          out.device_ptr, hip.queue.handle), "hu_grid_eval_blocks")
+        hip.queue.finish()
+        got = out.read()
+        for i in range(n):
+            corner = (np.array(int_corners[i], np.float64) * float(resolution) + np.array(origin, np.float64)).astype(np.float32)
+            if layout == 0:
+                want = oracle.grid_eval(tape, corner, step, (edge, edge, edge))
+                assert same_bits(got[i], want), "block %d float4 differs" % i
+            else:
+                want = oracle.grid_eval_pymcubes(tape, corner, step, (edge, edge, edge))
+                assert same_bits(got[i].reshape(-1), want.reshape(-1)), "block %d distances differ" % i
+        out.release()
+    blocks_dev.release()
+
+
+def run(hip, tape, grids, block_sets):
+    from codecad_amd import hip_util
+    handle = hip_util.Tape(tape)
+    handle.specialize()
+    for corner, step, dims in grids:
+        check_dense(hip, handle, tape, corner, step, dims)
+    for int_corners, resolution, origin in block_sets:
+        check_blocks(hip, handle, tape, int_corners, resolution, origin)
+    handle.release()
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_trees_through_the_brick_kernels(hip, seed):
+    from codecad_amd import nodes
+    rng = random.Random(7000 + seed)
+    tape = nodes.make_program(random_3d(rng, rng.choice([2, 3, 4])))
+    grids = [(np.array([-4.0, -4.0, -8.0]), np.float32(0.5), (16, 16, 32)),       # through exact zeros, symmetric pairs
+             (np.array([-1.53, -0.97, -2.11]), np.float32(0.13), (8, 12, 64))]     # four bricks along z per wavefront
+    blocks = [([(-8, -8, -8), (0, -8, -8), (-3, 1, 2), (8, 8, -24)], 0.25, (0.0, 0.0, 0.0)),
+              ([(0, 0, 0), (16, 0, 0), (5, -7, 3)], 0.07, (-0.31, 0.12, -0.55))]
+    run(hip, tape, grids, blocks)
+
+
+@pytest.mark.parametrize("name", ZOO_3D)
+def test_the_zoo_through_the_brick_kernels(hip, name):
+    ref = GOLDEN[name]
+    a, b = np.array(ref["bbox_a"], dtype=np.float64), np.array(ref["bbox_b"], dtype=np.float64)
+    a = np.where(np.isfinite(a), a, -2.0)
+    b = np.where(np.isfinite(b), b, 2.0)
+    size = float(np.max(b - a)) * 1.2 + 1e-3
+    mid = (a + b) / 2
+    step = np.float32(size / 32)
+    grids = [(mid - float(step) * np.array([8, 8, 16]) + float(step) / 2, step, (16, 16, 32))]
+    res = size / 48
+    blocks = [([(-24, -24, -24), (-8, -8, -8), (8, -8, 0)], res, tuple(mid))]
+    run(hip, ref["tape"], grids, blocks)
