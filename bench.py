@@ -162,7 +162,11 @@ def main():
     for c in cells[:-1]:
         capacities.append(cc.subdivision.child_capacity(parents_bound, c))
         parents_bound = capacities[-1]
-    pipe = build_pipeline(capacities)
+    # Two pipelines, taken in turn: the traversal of step k + 1 (latency-bound at 8 GPUs: two levels of classify +
+    # all-gather + slice) runs on its stream while step k's leaf blocks are still being evaluated from the other
+    # pipeline's list; it only waits for the leaf-block launch that last read ITS list (step k - 1).
+    pipes = [build_pipeline(capacities), build_pipeline(capacities)]
+    list_free = [torch.cuda.Event(), torch.cuda.Event()]   # recorded after the leaf-block launch that read pipes[i]'s list
     leaf_out = [None]
 
     # one set of events per step: nothing in a step waits for the host, the elapsed times are read after the timed region
@@ -174,8 +178,9 @@ def main():
     warm_events = new_events()
     step_events = [new_events() for _ in range(args.steps)]
 
-    def one_step(evs):
+    def one_step(evs, k):
         ev0, ev1, ev2, evb0, evb1, evc0 = evs
+        pipe = pipes[k % 2]
         # A
         if dense_leg:
             check(lib.hu_event_record(ev0, stream), "record")
@@ -184,6 +189,7 @@ def main():
             check(lib.hu_event_record(ev1, stream), "record")
         # B, concurrently with A, on the side stream
         with torch.cuda.stream(side_stream):
+            side_stream.wait_event(list_free[k % 2])   # (never recorded yet: no wait)
             check(lib.hu_event_record(evb0, side), "record")
             mine = pipe.enqueue()                     # [header | this rank's share of the leaf blocks], all on the device
             check(lib.hu_event_record(evb1, side), "record")
@@ -197,7 +203,7 @@ def main():
                                                np.float32(leaf_int_step * resolution), ld, 1, leaf_out[0].data_ptr(), stream),
               "hu_grid_eval_blocks_indirect")
         check(lib.hu_event_record(ev2, stream), "record")
-        side_stream.wait_stream(main_stream)          # the next step's B must not overwrite the list C is reading
+        list_free[k % 2].record(main_stream)          # the traversal after next may overwrite this list once C has read it
         return mine
 
     def elapsed(a, b):
@@ -216,8 +222,9 @@ def main():
     # warm-up: the first traversals also settle the list capacities at what the lists need + 12 % (a launch is
     # sized for the capacity, and workgroups past the list's end cost their dispatch: 80 000 spare leaf blocks are 0.2 ms)
     totals, settled, done = None, False, 0
-    for i in range(max(args.warmup, 1) + 4):
-        mine = one_step(warm_events)
+    for i in range(2 * max(args.warmup, 1) + 8):
+        pipe = pipes[i % 2]
+        mine = one_step(warm_events, i)
         try:
             totals = pipe.check()
             tight = [int(v * 1.125) + 16 for v in pipe.needed]
@@ -225,13 +232,14 @@ def main():
             totals, tight = None, [int(v * 1.125) + 16 for v in e.needed]
         if totals is None or (not settled and any(c > t for c, t in zip(pipe.capacities, tight))):
             barrier()
-            pipe = build_pipeline(tight)
+            pipes[0], pipes[1] = build_pipeline(tight), build_pipeline(tight)
             leaf_out[0] = None
             settled = totals is not None
             totals = None
+            done = 0
             continue
         done += 1
-        if done >= max(args.warmup, 1):
+        if done >= max(args.warmup, 2):   # (both pipelines have run with the settled capacities)
             break
     assert totals is not None, "list capacities did not settle"
     my_leaves = int(mine[0, 0].item())
@@ -250,8 +258,8 @@ def main():
                 interp_ms.append(elapsed(ev0, ev1))
     barrier()
     t0 = time.perf_counter()
-    for evs in step_events:
-        one_step(evs)
+    for k, evs in enumerate(step_events):
+        one_step(evs, k)
     enqueue_s = time.perf_counter() - t0            # host time to enqueue the steps (they run behind it)
     barrier()
     wall = time.perf_counter() - t0
@@ -261,7 +269,8 @@ def main():
     b_ms = [elapsed(e[3], e[4]) for e in step_events]   # B: the whole traversal on its stream (kernels + all-gathers)
     c_ms = [elapsed(e[5], e[2]) for e in step_events]   # C: every sample of every leaf block of this rank
     # the timed traversals were not looked at while they ran: validate now (identical work every step)
-    assert pipe.check() == totals, "the timed steps did not reproduce the warm-up traversal"
+    for used in (pipes[:1] if args.steps == 1 else pipes):
+        assert used.check() == totals, "the timed steps did not reproduce the warm-up traversal"
 
     # samples of one step over ALL ranks: dense voxels + every classified cell + every leaf sample
     parents_per_level = [n_objects] + totals[:-1]
