@@ -262,9 +262,10 @@ class Tape:
             self._specialize(only_if_cached=True)   # a program compiled before costs milliseconds: take it now
 
     # measured on MI355X: the interpreter retires ~2.5e12 (tape instruction x sample) per second whatever the
-    # tape (sponge(4): 85 x 29e9; planetary: 467 x 6.2e9); hipRTC takes ~0.3 s + 4.5 ms per instruction
+    # tape (sponge(4): 85 x 29e9; planetary: 467 x 6.2e9); hipRTC takes ~0.7 s + 8 ms per instruction (round 2's brick
+    # kernels and their hoisted forms: csg_example 1.0 s, sponge(4) 1.7 s, planetary 3.1 s; round 1: 0.3 s + 4.5 ms)
     _INTERPRETER_RATE = 2.5e12
-    _JIT_SECONDS = (0.3, 0.0045)
+    _JIT_SECONDS = (0.7, 0.008)
 
     def note_samples(self, n):
         """Called by the launch wrappers with the number of samples about to be evaluated with this tape."""
