@@ -26,8 +26,8 @@
 
 #include "../../include/hip_util.h"
 #include "kernels.hpp"
+#include "launchers.hpp"
 #include "tape.hpp"
-#include "cull.hpp"
 #include "specialise.hpp"
 
 using sdf::Rec;
@@ -52,65 +52,6 @@ int fail(int code, const std::string& msg)
         }                                                                                    \
     } while (0)
 
-// ------------------------------------------------------------------------------------------
-// mass_properties: per-parent index sums -> the ten integrals of this level, on the device.
-// The reference does this on the host, block by block, in Python doubles with Kahan sums
-// (mass_properties.py:119-148).  Same per-block formulas in fp64 (no contraction), summed
-// deterministically: workgroup g takes the g-th contiguous slice of the parents, thread t of it
-// Kahan-accumulates the slice's parents t, t+1024, ... and the 1024 partial sums are combined by a
-// fixed tree into row g of the output; the caller adds the rows in order.  Nothing depends on launch
-// timing.  (One workgroup for a whole level -- the first version -- took 172 us for the 167 k leaf
-// parents of sponge(4) at 1/512, 15 % of the whole mass_properties call.)
-// out[g][10] order: 1, x, y, z, xx, yy, zz, xy, xz, yz.
-// ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024)
-k_mass_integrals(const double4* __restrict__ parents, const uint32_t* __restrict__ sums, uint32_t n, uint32_t per_row,
-                 double s, double* __restrict__ out)
-{
-    const uint64_t first = (uint64_t)blockIdx.x * per_row;              // rows past the last parent get an empty slice
-    const uint32_t begin = first < n ? (uint32_t)first : n;
-    const uint32_t end = (n - begin < per_row) ? n : begin + per_row;
-    __shared__ double part[10][1024];
-    double acc[10], comp[10];
-#pragma unroll
-    for (int k = 0; k < 10; ++k) acc[k] = comp[k] = 0.0;
-    const double s2 = s * s, s3 = s * s2, h = s / 2, twelfth = s2 / 12;
-    for (uint32_t p = begin + threadIdx.x; p < end; p += 1024) {
-        const double4 c = parents[p];
-        const uint32_t* u = sums + (size_t)p * 10;
-        const double sxx = u[0], sxy = u[1], sxz = u[2], sx = u[3], syy = u[4], syz = u[5], sy = u[6], szz = u[7],
-                     sz = u[8], cnt = u[9];
-        const double bx = c.x + h, by = c.y + h, bz = c.z + h;
-        const double tx = s * sx, ty = s * sy, tz = s * sz;
-        const double v[10] = {
-            s3 * cnt,
-            s3 * (cnt * bx + tx), s3 * (cnt * by + ty), s3 * (cnt * bz + tz),
-            s3 * (cnt * (bx * bx + twelfth) + 2 * bx * tx + s2 * sxx),
-            s3 * (cnt * (by * by + twelfth) + 2 * by * ty + s2 * syy),
-            s3 * (cnt * (bz * bz + twelfth) + 2 * bz * tz + s2 * szz),
-            s3 * (cnt * bx * by + bx * ty + by * tx + s2 * sxy),
-            s3 * (cnt * bx * bz + bx * tz + bz * tx + s2 * sxz),
-            s3 * (cnt * by * bz + by * tz + bz * ty + s2 * syz)};
-#pragma unroll
-        for (int k = 0; k < 10; ++k) {  // Kahan, like the reference's util.KahanSummation
-            const double y = v[k] - comp[k];
-            const double t = acc[k] + y;
-            comp[k] = (t - acc[k]) - y;
-            acc[k] = t;
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 10; ++k) part[k][threadIdx.x] = acc[k];
-    __syncthreads();
-    for (uint32_t stride = 512; stride > 0; stride >>= 1) {
-        if (threadIdx.x < stride) {
-#pragma unroll
-            for (int k = 0; k < 10; ++k) part[k][threadIdx.x] += part[k][threadIdx.x + stride];
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x < 10) out[(size_t)blockIdx.x * 10 + threadIdx.x] = part[threadIdx.x][0];
-}
 
 // ------------------------------------------------------------------------------------------
 // host side
@@ -140,14 +81,6 @@ struct hu_tape_s {
     int flags = 0;
     sdf::SpecProgram program;    // both programs on the host, kept for hu_tape_specialize (specialise.hpp)
     struct SpecKernels* spec = nullptr;
-    // per-brick culling of the dense interpreter kernels (cull.hpp): NULL when the tape has nothing to cull
-    uint2* needs_dev = nullptr;      // per record of the full program: {run, live}
-    uint2* needs_do_dev = nullptr;   // ... of the distance-only program
-    uint32_t stand_in_offset = 0, stand_in_offset_do = 0;   // the stand-in records follow the program in recs_dev / recs_do_dev
-    uint32_t n_records = 0, n_records_do = 0;
-    float* lipschitz_dev = nullptr;  // per numbered select
-    struct KeepBuffer { void* stream; uint32_t* words; size_t count; };
-    std::vector<KeepBuffer> keep_buffers;   // the bricks' keep words, one buffer per stream that evaluated this tape
 };
 
 namespace {
@@ -159,42 +92,6 @@ bool distance_only(const hu_tape_s* t)
 {
     static const bool forced_full = [] { const char* e = getenv("HU_FULL_INTERPRETER"); return e && e[0] == '1'; }();
     return !forced_full && t->recs_do_dev != nullptr;
-}
-
-// Per-brick culling of the dense interpreter kernels (cull.hpp): an experiment that works -- sponge(4) at 512^3: the
-// centre pass rules out 6.7 of 24 select operands per brick, every float still the oracle's -- and only breaks even: the
-// interpreter is so sensitive to what surrounds a record's dispatch that the walk over the records that take part costs
-// 14 % and the brick layout 4 % with everything kept (4.13 ms against 3.50 ms), and what is skipped then just pays for
-// that (3.44 ms; sponge(3): 2.47 against 2.74 ms; sponge(5): 4.91 against 4.78 ms).  Earlier forms, with tests for "which
-// operand is out" inside selects and fused leaves, cost 70 % before they saved 30 %.  So it is off unless
-// HU_INTERP_CULL=1 (tests/test_gpu_variants.py runs the parity tests that way); DESIGN.md section 5.
-bool culling_wanted(const hu_tape_s* t)
-{
-    static const bool on = [] { const char* e = getenv("HU_INTERP_CULL"); return e && e[0] == '1'; }();
-    return on && t->needs_dev && t->needs_do_dev && t->lipschitz_dev && t->recs_do_dev;
-}
-
-// The keep words of a launch's bricks: one buffer per (tape, stream), grown when a larger grid comes along.  Launches
-// on one stream are ordered, so reusing its buffer is safe; hipFree waits for the device before it releases.
-int keep_buffer(hu_tape_s* t, void* stream, size_t count, uint32_t** out)
-{
-    for (auto& b : t->keep_buffers)
-        if (b.stream == stream) {
-            if (b.count < count) {
-                HU_HIP(hipFree(b.words));
-                b.words = nullptr;
-                b.count = 0;
-                HU_HIP(hipMalloc((void**)&b.words, count * sizeof(uint32_t)));
-                b.count = count;
-            }
-            *out = b.words;
-            return HU_OK;
-        }
-    uint32_t* words = nullptr;
-    HU_HIP(hipMalloc((void**)&words, count * sizeof(uint32_t)));
-    t->keep_buffers.push_back({stream, words, count});
-    *out = words;
-    return HU_OK;
 }
 
 // Voxels per lane and workgroup size from the register file.
@@ -285,13 +182,7 @@ int ensure_attrs()
     int rc;
     if ((rc = ensure_attrs_n<1>())) return rc;
     if ((rc = ensure_attrs_n<2>())) return rc;
-    if ((rc = allow_big_lds(k_brick_keep<InterpEval<true>>))) return rc;
-    if ((rc = allow_big_lds(k_grid_eval_culled<false, 0, 1>))) return rc;   // (one voxel per lane only: hu_grid_eval_slab)
-    if ((rc = allow_big_lds(k_grid_eval_culled<false, 1, 1>))) return rc;
-    if ((rc = allow_big_lds(k_grid_eval_culled<true, 1, 1>))) return rc;
-    if ((rc = allow_big_lds(k_ray_caster<InterpEval<false>>))) return rc;
-    if ((rc = allow_big_lds(k_bitmap<InterpEval<false>>))) return rc;
-    if ((rc = allow_big_lds(k_bitmap<InterpEval<true>>))) return rc;
+    HU_HIP(hu_render::allow_big_lds(kMaxLds));   // the ray caster and the bitmap kernels (render.hip)
     done_for_device = dev;
     return HU_OK;
 }
@@ -343,7 +234,6 @@ struct SpecKernels {
     hipFunction_t classify[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [MASS][BATCH]
     hipFunction_t ray_caster = nullptr, bitmap = nullptr;
     bool deferred = false;   // the module was generated with deferred directions (specialise.hpp): dense launches use bricks
-    bool culling = false;    // ... and with per-brick culling: a wavefront takes several bricks
 };
 
 namespace {
@@ -358,9 +248,9 @@ bool defer_directions()
     return !off;
 }
 
-std::string generate_source(const hu_tape_s* t, bool* deferred = nullptr, bool* culling = nullptr)
+std::string generate_source(const hu_tape_s* t, bool* deferred = nullptr)
 {
-    return sdf::specialised_source(t->program, defer_directions(), deferred, culling);
+    return sdf::specialised_source(t->program, defer_directions(), deferred);
 }
 
 void keep_programs(hu_tape_s* t, const sdf::DecodedTape& d)
@@ -557,24 +447,6 @@ int hu_tape_create(const float* tape, size_t n, hu_tape* out)
     t->n_result_slots = d.n_result_slots;
     t->flags = d.direction_feeds_distance ? 1 : 0;
     keep_programs(t, d);
-    // per-brick culling (cull.hpp): the select numbers go into the fold words of the interpreter's programs (the
-    // padding records at their ends stay out of the analysis: their masks are 0).  Both programs must agree on the
-    // selects -- the centre pass runs the distance-only program whatever the evaluation runs.
-    sdf::CullInfo cull_full, cull_do;
-    if (!d.fused_do.empty()) {
-        sdf::analyse_culling(d.fused, false, cull_full);
-        sdf::analyse_culling(d.fused_do, true, cull_do);
-        bool same = cull_full.enabled && cull_do.enabled && cull_full.n_selects == cull_do.n_selects;
-        for (int k = 0; same && k < sdf::kMaxCullSelects; ++k)
-            same = cull_full.lipschitz[k] == cull_do.lipschitz[k] && cull_full.repetitions[k] == cull_do.repetitions[k];
-        cull_full.enabled = cull_do.enabled = same;
-    }
-    if (cull_full.enabled) {   // the stand-in records follow the programs
-        t->stand_in_offset = (uint32_t)d.fused.size();
-        t->stand_in_offset_do = (uint32_t)d.fused_do.size();
-        d.fused.insert(d.fused.end(), cull_full.stand_ins.begin(), cull_full.stand_ins.end());
-        d.fused_do.insert(d.fused_do.end(), cull_do.stand_ins.begin(), cull_do.stand_ins.end());
-    }
     // the device holds the interpreter's (fused) programs; per-tape code is generated from the unfused ones
     hipError_t e = hipMalloc((void**)&t->recs_dev, d.fused.size() * sizeof(Rec));
     if (e == hipSuccess && !d.fused_do.empty()) {
@@ -584,28 +456,10 @@ int hu_tape_create(const float* tape, size_t n, hu_tape* out)
     if (e == hipSuccess) e = hipMalloc((void**)&t->extra_dev, d.extra.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(t->recs_dev, d.fused.data(), d.fused.size() * sizeof(Rec), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(t->extra_dev, d.extra.data(), d.extra.size() * sizeof(float), hipMemcpyHostToDevice);
-    if (e == hipSuccess && cull_full.enabled) {
-        auto upload = [&](const void* src, size_t bytes, void** dst) {
-            if (e == hipSuccess) e = hipMalloc(dst, bytes);
-            if (e == hipSuccess) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
-        };
-        t->n_records = cull_full.n_records;
-        t->n_records_do = cull_do.n_records;
-        upload(cull_full.masks.data(), cull_full.masks.size() * 4, (void**)&t->needs_dev);
-        upload(cull_do.masks.data(), cull_do.masks.size() * 4, (void**)&t->needs_do_dev);
-        // [16 floats La + Lb | 16 words: the repetitions each select lies under]
-        uint32_t table[2 * sdf::kMaxCullSelects];
-        std::memcpy(table, cull_do.lipschitz, sizeof(cull_do.lipschitz));
-        std::memcpy(table + sdf::kMaxCullSelects, cull_do.repetitions, sizeof(cull_do.repetitions));
-        upload(table, sizeof(table), (void**)&t->lipschitz_dev);
-    }
     if (e != hipSuccess) {
         (void)hipFree(t->recs_dev);
         (void)hipFree(t->recs_do_dev);
         (void)hipFree(t->extra_dev);
-        (void)hipFree(t->needs_dev);
-        (void)hipFree(t->needs_do_dev);
-        (void)hipFree(t->lipschitz_dev);
         delete t;
         return fail(HU_ERR_HIP, std::string("tape upload: ") + hipGetErrorString(e));
     }
@@ -623,10 +477,6 @@ int hu_tape_destroy(hu_tape t)
     (void)hipFree(t->recs_dev);
     (void)hipFree(t->recs_do_dev);
     (void)hipFree(t->extra_dev);
-    (void)hipFree(t->needs_dev);
-    (void)hipFree(t->needs_do_dev);
-    (void)hipFree(t->lipschitz_dev);
-    for (auto& b : t->keep_buffers) (void)hipFree(b.words);
     delete t;
     return HU_OK;
 }
@@ -668,14 +518,13 @@ int hu_grid_eval_slab(hu_tape t, const float corner[4], float step, const uint32
             const uint32_t per_block = kSpecBlock * kSpecVoxelsPerLane;
             uint32_t grid = (n_cells + per_block - 1) / per_block;
             if (tiles) {
-                // a wavefront takes G bricks in a row along z: up to 16, with culling up to 64 (one centre evaluation per
-                // lane) -- while the launch still has a few thousand wavefronts
+                // a wavefront takes G bricks in a row along z: up to 16 while the launch still has a few thousand wavefronts
                 const uint32_t nbz = dims[2] / 8u;   // a multiple of four (sz % 32 == 0)
                 const uint64_t bricks = (uint64_t)(nx / 4u) * (dims[1] / 4u) * nbz;
                 tiles = 4u;
                 // (16 384: a rank's 64-plane slab of a 512^3 grid on eight GPUs takes 0.1225 ms with 8 bricks per wavefront,
                 // 0.129 ms with 16 -- 8 192 wavefronts are 1.3 rounds of the chip -- and 0.128 ms with 4)
-                for (uint32_t g = t->spec->culling ? 64u : 16u; g > 4u; g >>= 1)
+                for (uint32_t g = 16u; g > 4u; g >>= 1)
                     if (nbz % g == 0u && bricks / g >= 16384u) { tiles = g; break; }
                 grid = (uint32_t)((bricks / tiles + 3u) / 4u);
             }
@@ -697,57 +546,6 @@ int hu_grid_eval_slab(hu_tape t, const float corner[4], float step, const uint32
         const uint32_t per_block = ls.block * ls.voxels_per_lane;
         const uint32_t blocks = (n_cells + per_block - 1) / per_block;
         void* o = (layout == 0) ? (void*)(static_cast<float4*>(out_dev) + (size_t)done * plane) : out_dev;
-        // per-brick culling (cull.hpp): the slab in compact bricks, a centre pass, then the bricks with what it left
-        const uint32_t brick_z = ls.voxels_per_lane == 2 ? 8u : 4u;
-        // (with two voxels per lane the compiler keeps the fetched records in scratch memory -- 12 ms --: one voxel per lane only)
-        if (culling_wanted(t) && ls.voxels_per_lane == 1 && nx % 4u == 0u && dims[1] % 4u == 0u && dims[2] % brick_z == 0u) {
-            const bool d_only = layout == 1 && distance_only(t);
-            const uint32_t nbx = nx / 4u, nby = dims[1] / 4u, nbz = dims[2] / brick_z;
-            const uint32_t n_bricks = nbx * nby * nbz;   // < 2^30 / 64
-            uint32_t* keep = nullptr;
-            if ((rc = keep_buffer(t, stream, n_bricks, &keep))) return rc;
-            LaunchShape centre;   // the distance-only program, one brick per lane
-            if ((rc = launch_shape(t, centre, true, 1))) return rc;
-            // a brick's centre to its farthest sample, with room for the rounding of the centre itself
-            const float radius = 0.5f * step * std::sqrt(18.0f + (float)((brick_z - 1u) * (brick_z - 1u))) * 1.001f;
-            hipLaunchKernelGGL((k_brick_keep<InterpEval<true>>), dim3((n_bricks + centre.block - 1) / centre.block), dim3(centre.block),
-                               centre.lds, (hipStream_t)stream, (InterpEval<true>{centre.prog, t->extra_dev, centre.n4}), t->lipschitz_dev,
-                               reinterpret_cast<const uint32_t*>(t->lipschitz_dev) + sdf::kMaxCullSelects,
-                               corner[0], corner[1], corner[2], step, x0 + done, make_dim(nby), make_dim(nbz), brick_z, n_bricks, radius, keep);
-            static const bool keep_all = [] { const char* e = getenv("HU_CULL_KEEP_ALL"); return e && e[0] == '1'; }();
-            if (keep_all) HU_HIP(hipMemsetAsync(keep, 0xff, (size_t)n_bricks * 4, (hipStream_t)stream));   // a measurement: the culled kernels' overhead alone
-            static const bool stats = [] { const char* e = getenv("HU_CULL_STATS"); return e && e[0] == '1'; }();
-            if (stats) {   // a diagnostic: how much the centre pass ruled out (waits for the stream)
-                std::vector<uint32_t> words(n_bricks);
-                HU_HIP(hipStreamSynchronize((hipStream_t)stream));
-                HU_HIP(hipMemcpy(words.data(), keep, (size_t)n_bricks * 4, hipMemcpyDeviceToHost));
-                uint64_t out_bits = 0, touched = 0;
-                uint64_t per_bit[32] = {0};
-                for (uint32_t w : words) {
-                    out_bits += (uint64_t)__builtin_popcount(~w);
-                    touched += w != 0xffffffffu;
-                    for (int b = 0; b < 32; ++b) per_bit[b] += !((w >> b) & 1u);
-                }
-                std::fprintf(stderr, "[hu] culling: %u bricks, %.3f operands out per brick, %.1f %% of the bricks with any; out per operand:",
-                             n_bricks, (double)out_bits / n_bricks, 100.0 * touched / n_bricks);
-                for (int b = 0; b < 32; ++b) std::fprintf(stderr, " %.2f", (double)per_bit[b] / n_bricks);
-                std::fprintf(stderr, "\n");
-            }
-            const uint32_t waves = ls.block / 64u;
-#define HU_LAUNCH_CULLED(L, D, NV)                                                                                          \
-    hipLaunchKernelGGL((k_grid_eval_culled<D, L, NV>), dim3((n_bricks + waves - 1) / waves), dim3(ls.block), ls.lds,        \
-                       (hipStream_t)stream, (InterpEval<D>{ls.prog, t->extra_dev, ls.n4}), D ? t->stand_in_offset_do : t->stand_in_offset,                   \
-                       D ? t->needs_do_dev : t->needs_dev, D ? t->n_records_do : t->n_records,                               \
-                       keep, corner[0], corner[1], corner[2], step, dims[0], make_dim(dims[1]), make_dim(dims[2]),          \
-                       make_dim(nby), make_dim(nbz), x0 + done, n_bricks, o)
-            if (layout == 0) HU_LAUNCH_CULLED(0, false, 1);
-            else if (d_only) HU_LAUNCH_CULLED(1, true, 1);
-            else HU_LAUNCH_CULLED(1, false, 1);
-#undef HU_LAUNCH_CULLED
-            HU_HIP(hipGetLastError());
-            done += nx;
-            continue;
-        }
 #define HU_LAUNCH_DENSE(L, D, NV)                                                                                  \
     hipLaunchKernelGGL((k_grid_eval<InterpEval<D>, L, NV>), dim3(blocks), dim3(ls.block), ls.lds, (hipStream_t)stream, \
                        (InterpEval<D>{ls.prog, t->extra_dev, ls.n4}), corner[0], corner[1], corner[2], step, dims[0],  \
@@ -1012,9 +810,7 @@ int hu_mass_integrals(const double* parents_dev, const uint32_t* sums_dev, uint3
     if (!out_dev || ((!parents_dev || !sums_dev) && n_parents)) return fail(HU_ERR_BAD_ARG, "NULL argument");
     if (rows == 0 || rows > 65535u) return fail(HU_ERR_BAD_ARG, "rows must be in 1..65535");
     const uint32_t per_row = (n_parents + rows - 1) / rows;   // rows past the end get an empty slice and write zeros
-    hipLaunchKernelGGL(k_mass_integrals, dim3(rows), dim3(1024), 0, (hipStream_t)stream, (const double4*)parents_dev,
-                       sums_dev, n_parents, per_row, s, out_dev);
-    HU_HIP(hipGetLastError());
+    HU_HIP(hu_render::mass_integrals((const double4*)parents_dev, sums_dev, n_parents, per_row, s, out_dev, rows, (hipStream_t)stream));
     return HU_OK;
 }
 
@@ -1055,9 +851,7 @@ int hu_ray_caster(hu_tape t, const float origin[4], const float forward[4], cons
                                      args, nullptr));
         return HU_OK;
     }
-    hipLaunchKernelGGL((k_ray_caster<InterpEval<false>>), dim3((uint32_t)blocks), dim3(ls.block), ls.lds, (hipStream_t)stream,
-                       (InterpEval<false>{ls.prog, t->extra_dev, ls.n4}), a);
-    HU_HIP(hipGetLastError());
+    HU_HIP(hu_render::ray_caster(InterpEval<false>{ls.prog, t->extra_dev, ls.n4}, a, (uint32_t)blocks, ls.block, ls.lds, (hipStream_t)stream));
     return HU_OK;
 }
 
@@ -1082,16 +876,8 @@ int hu_bitmap(hu_tape t, const float origin[4], float step_size, uint32_t width,
     int rc;
     if ((rc = launch_shape(t, ls, d_only, 1))) return rc;
     if ((rc = ensure_attrs())) return rc;
-    const dim3 grid((uint32_t)((pixels + ls.block - 1) / ls.block)), block(ls.block);
-    if (d_only)
-        hipLaunchKernelGGL((k_bitmap<InterpEval<true>>), grid, block, ls.lds, (hipStream_t)stream,
-                           (InterpEval<true>{ls.prog, t->extra_dev, ls.n4}), origin[0], origin[1], origin[2], step_size,
-                           width, height, out);
-    else
-        hipLaunchKernelGGL((k_bitmap<InterpEval<false>>), grid, block, ls.lds, (hipStream_t)stream,
-                           (InterpEval<false>{ls.prog, t->extra_dev, ls.n4}), origin[0], origin[1], origin[2], step_size,
-                           width, height, out);
-    HU_HIP(hipGetLastError());
+    HU_HIP(hu_render::bitmap(d_only, ls.prog, t->extra_dev, ls.n4, origin[0], origin[1], origin[2], step_size, width, height, out,
+                             (uint32_t)((pixels + ls.block - 1) / ls.block), ls.block, ls.lds, (hipStream_t)stream));
     return HU_OK;
 }
 
@@ -1348,8 +1134,8 @@ int hu_tape_specialize_cached(hu_tape t, const char* include_dir, const char* ca
     if (from_cache) *from_cache = 0;
     if (!t || !include_dir) return fail(HU_ERR_BAD_ARG, "NULL argument");
     if (t->spec) return HU_OK;
-    bool deferred = false, culling = false;
-    const std::string src = generate_source(t, &deferred, &culling);
+    bool deferred = false;
+    const std::string src = generate_source(t, &deferred);
     int cached = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         SpecImage img;
@@ -1366,7 +1152,6 @@ int hu_tape_specialize_cached(hu_tape t, const char* include_dir, const char* ca
             e = hipModuleGetFunction(slots[i], k->module, img.lowered[i].c_str());
         if (e == hipSuccess) {
             k->deferred = deferred;
-            k->culling = culling;
             t->spec = k;
             if (from_cache) *from_cache = cached;
             return HU_OK;
@@ -1389,10 +1174,7 @@ static int launch_process_polygon(bool batch, PolygonArgs& a, uint32_t n_blocks,
     if (n_blocks == 0) return HU_OK;
     if (n_blocks > 65535u) return fail(HU_ERR_BAD_ARG, "at most 65535 blocks per launch");
     const uint32_t cells = (a.gx - 1u) * (a.gy - 1u) * 2u;
-    const dim3 grid((cells + 255u) / 256u, n_blocks), block(256);
-    if (batch) hipLaunchKernelGGL(k_process_polygon<true>, grid, block, 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(k_process_polygon<false>, grid, block, 0, (hipStream_t)stream, a);
-    HU_HIP(hipGetLastError());
+    HU_HIP(hu_render::process_polygon(batch, a, dim3((cells + 255u) / 256u, n_blocks), (hipStream_t)stream));
     return HU_OK;
 }
 
@@ -1446,8 +1228,7 @@ int hu_selftest_math(uint64_t counts[4])
     HU_HIP(hipMalloc((void**)&dev, 4 * sizeof(unsigned long long)));
     hipError_t e = hipMemset(dev, 0, 4 * sizeof(unsigned long long));
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_selftest_math, dim3(256 * 32), dim3(256), 0, nullptr, dev);
-        e = hipGetLastError();
+        e = hu_render::selftest_math(dev);
     }
     unsigned long long host[4] = {0, 0, 0, 0};
     if (e == hipSuccess) e = hipMemcpy(host, dev, sizeof host, hipMemcpyDeviceToHost);
@@ -1475,20 +1256,11 @@ int hu_tape_source(const float* tape, size_t n, char* buf, size_t capacity, size
 int hu_tape_listing(const float* tape, size_t n, int which, char* buf, size_t capacity, size_t* needed)
 {
     if (!tape || !needed || (!buf && capacity)) return fail(HU_ERR_BAD_ARG, "NULL argument");
-    if (which < 0 || which > 5) return fail(HU_ERR_BAD_ARG, "which must be 0..5");
+    if (which < 0 || which > 3) return fail(HU_ERR_BAD_ARG, "which must be 0..3");
     sdf::DecodedTape d;
     const std::string err = sdf::decode_tape(tape, n, d);
     if (!err.empty()) return fail(HU_ERR_BAD_TAPE, "malformed tape: " + err);
-    // 4, 5: the interpreter's programs with what per-brick culling adds (cull.hpp): select numbers, the records' masks
-    sdf::CullInfo cull;
-    const bool with_culling = which >= 4;
-    if (with_culling) {
-        which -= 2;
-        if (which == 3 && d.fused_do.empty()) return fail(HU_ERR_BAD_ARG, "the tape has no distance-only program");
-        sdf::analyse_culling(which == 2 ? d.fused : d.fused_do, which == 3, cull);
-    }
     const std::vector<Rec>& prog = which == 0 ? d.recs : which == 1 ? d.recs_do : which == 2 ? d.fused : d.fused_do;
-    size_t index = 0;
     static const char* const internal[] = {"FROM_SCALE", "FROM_X", "FROM_Y", "FROM_Z", "POINT", "TO_SCALE", "TO_X", "TO_Y", "TO_Z",
                                            "TO_ROW_X", "TO_ROWS_YZ", "FROM_MATRIX", "INIT_ROW_X", "INIT_ROWS_YZ", "LEAF"};
     static const char* const kinds[] = {"-", "scale", "x", "y", "z"};
@@ -1518,28 +1290,8 @@ int hu_tape_listing(const float* tape, size_t n, int which, char* buf, size_t ca
             o << " " << slot << ((r.hdr & sdf::kResultKind) ? "r" : "");
         }
         if (fold & sdf::kFoldStore) o << " [store " << ((fold >> 16) & 0xffu) << ((fold & sdf::kFoldStoreResult) ? "r" : "") << "]";
-        if (with_culling && op != sdf::OP_RETURN) {
-            const uint32_t k1 = (fold >> sdf::kSelShift1) & 31u, k2 = (fold >> sdf::kSelShift2) & 31u;
-            char masks[128];
-            if (cull.masks[2 * index + 1] != cull.masks[2 * index])
-                std::snprintf(masks, sizeof masks, " | runs %08x, stand-in %+g while %08x", cull.masks[2 * index], (double)cull.stand_ins[index].p[0], cull.masks[2 * index + 1]);
-            else std::snprintf(masks, sizeof masks, " | runs %08x", cull.masks[2 * index]);
-            o << masks;
-            const bool is_select = op == sdf::OP_UNION || op == sdf::OP_INTERSECTION || op == sdf::OP_SUBTRACTION;
-            if ((is_select || op == sdf::OPX_LEAF) && k1 != sdf::kSelNone) o << " select " << k1;
-            if (op == sdf::OPX_LEAF && k2 != sdf::kSelNone) o << " select " << k2;
-        }
         o << "\n";
-        ++index;
         if (op == sdf::OP_RETURN) break;
-    }
-    if (with_culling) {
-        o << "culling " << (cull.enabled ? "on" : "off") << ", " << cull.n_selects << " selects, La+Lb:";
-        for (int k = 0; k < cull.n_selects && k < sdf::kMaxCullSelects; ++k) {
-            o << " " << cull.lipschitz[k];
-            if (cull.repetitions[k]) o << "(under repetitions " << std::hex << cull.repetitions[k] << std::dec << ")";
-        }
-        o << "\n";
     }
     const std::string text = o.str();
     *needed = text.size() + 1;

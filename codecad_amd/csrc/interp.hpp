@@ -452,33 +452,24 @@ __device__ __noinline__ float4 polygon2d_op(const float* __restrict__ pts, uint3
         float dx = cx - px, dy = cy - py;
         float tqx = qx - px, tqy = qy - py;
         float snx = -dy, sny = dx;
-        if (((py < qy) != (cy < qy)) && (dy * dot2(snx, sny, tqx, tqy) > 0.0f)) outside = -outside;
-        float t = dot2(dx, dy, tqx, tqy) / dot2(dx, dy, dx, dy);
-        if (t > 1.0f) continue;
-        float cnx, cny, cd2;
-        bool cvert;
-        if (t >= 0.0f) {
-            float tcx = fma_(-t, dx, tqx), tcy = fma_(-t, dy, tqy);
-            cd2 = dot2(tcx, tcy, tcx, tcy);
-            cnx = snx;
-            cny = sny;
-            cvert = false;
-        } else {
-            cnx = tqx;
-            cny = tqy;
-            cd2 = dot2(cnx, cny, cnx, cny);
-            cvert = cd2 > 1.1920928955078125e-7f;  // FLT_EPSILON
-            if (!cvert) {
-                cnx = snx;
-                cny = sny;
-            }
-        }
-        if (cd2 < nearest_d2) {
-            nearest_d2 = cd2;
-            nnx = cnx;
-            nny = cny;
-            nearest_is_vertex = cvert;
-        }
+        // branch-free on purpose: this function lives in the translation unit that is built with
+        // -structurizecfg-skip-uniform-regions (hip_util/builder.py), where a loop must not hold a divergent branch
+        // beside its uniform exit; every value below is the one the reference's if / else / continue picks
+        const bool crosses = ((py < qy) != (cy < qy)) && (dy * dot2(snx, sny, tqx, tqy) > 0.0f);
+        outside = crosses ? -outside : outside;
+        const float t = dot2(dx, dy, tqx, tqy) / dot2(dx, dy, dx, dy);
+        const bool beyond = t > 1.0f;        // the reference's `continue`: the next edge owns this end
+        const bool on_edge = t >= 0.0f;      // (false for NaN: a zero-length edge is its first vertex)
+        const float tcx = fma_(-t, dx, tqx), tcy = fma_(-t, dy, tqy);
+        const float edge_d2 = dot2(tcx, tcy, tcx, tcy), vertex_d2 = dot2(tqx, tqy, tqx, tqy);
+        const bool cvert = !on_edge && vertex_d2 > 1.1920928955078125e-7f;  // FLT_EPSILON
+        const float cd2 = on_edge ? edge_d2 : vertex_d2;
+        const float cnx = cvert ? tqx : snx, cny = cvert ? tqy : sny;
+        const bool nearer = !beyond && cd2 < nearest_d2;
+        nearest_d2 = nearer ? cd2 : nearest_d2;
+        nnx = nearer ? cnx : nnx;
+        nny = nearer ? cny : nny;
+        nearest_is_vertex = nearer ? cvert : nearest_is_vertex;
     }
     float distance = outside * sqrt_(nearest_d2);
     float inv = 1.0f / (nearest_is_vertex ? distance : length2(nnx, nny));
@@ -698,66 +689,16 @@ __device__ __forceinline__ f2 opaque(f2 x) { asm volatile("" : "+v"(x)); return 
 #endif
 constexpr int kFetchGroup = SDF_FETCH_GROUP;  // tape.hpp pads the program with kTapePadding _return records
 
-// Per-brick culling (cull.hpp tells the story; kernels.hpp k_brick_keep / k_grid_eval_culled run it).  The
-// interpreter runs in one of two modes, chosen by the type of its last argument:
-//   NoCull    every record, as always (per-tape code, every kernel but the two above);
-//   (a brick is then evaluated by run_tape_culled below: ordinary records, fewer of them)
-//   Centre    the distance-only program at a brick's centre, one brick per lane; every numbered select compares
-//             |a - b| with what the two can change over the brick and notes in `kill` the operand that is out.
-constexpr uint32_t kSelNoneBits = 31u;   // cull.hpp kSelNone / kSelShift1 / kSelShift2
-constexpr int kSelBits1 = 10, kSelBits2 = 26;
-struct NoCull { static constexpr int kMode = 0; };
-struct Centre {
-    static constexpr int kMode = 2;
-    uint32_t kill;       // per lane
-    uint32_t crossed;    // per lane: the repetitions (by number) whose cell faces this brick may cross
-    uint32_t under;      // lane k: the repetitions select k lies under
-    float lipschitz;     // lane k: La + Lb of select k
-    float radius;        // of the brick: its centre to its farthest sample
-    float slack;         // per lane: rounding allowance that does not depend on the values (1e-5 * |centre|_1)
-    float hx, hy, hz;    // the brick's half extents along the sample frame's axes
-};
-// Centre mode: a, b = the operands in the form the select takes the minimum of
-template <class T> __device__ __forceinline__ void note_select(Centre& c, uint32_t k, T a, T b) {}
-template <> __device__ __forceinline__ void note_select<float>(Centre& c, uint32_t k, float a, float b)
-{
-    if (k == kSelNoneBits) return;   // (uniform)
-    const float l = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c.lipschitz), (int)k));
-    const uint32_t under = (uint32_t)__builtin_amdgcn_readlane((int)c.under, (int)k);
-    const float thr = l * c.radius * 1.0001f + 1e-5f * (abs_(a) + abs_(b)) + l * c.slack;
-    if (c.crossed & under) return;   // folded differently in different parts of the brick: no bound
-    // (an infinite or NaN threshold, or NaN operands: both comparisons are false)
-    if (a - b > thr) c.kill |= 1u << (2u * k);
-    else if (b - a > thr) c.kill |= 2u << (2u * k);
-}
-// Centre mode, after a repetition: does the brick keep clear of the faces of the cell its centre fell into?
-// p = the record (spacings, their reciprocals -- 0: not repeated along that axis --, J, the repetition's number)
-template <class T> __device__ __forceinline__ void note_repetition(Centre& c, const float* p, const V4<T>& folded) {}
-template <> __device__ __forceinline__ void note_repetition<float>(Centre& c, const float* p, const V4<float>& folded)
-{
-    // how far the brick reaches along each axis of this frame: its own extents scaled where the axes are the sample
-    // frame's (p[8]), else its radius
-    const bool box = p[8] != 0.0f;
-    const float more = 4.0f * c.slack * p[6];
-    const float rx = (box ? c.hx : c.radius) * p[6] * 1.0625f + more, ry = (box ? c.hy : c.radius) * p[6] * 1.0625f + more,
-                rz = (box ? c.hz : c.radius) * p[6] * 1.0625f + more;
-    bool inside = p[6] < __builtin_inff();
-    if (p[3] != 0.0f) inside = inside && abs_(folded.x) + rx < 0.4999f * abs_(p[0]);
-    if (p[4] != 0.0f) inside = inside && abs_(folded.y) + ry < 0.4999f * abs_(p[1]);
-    if (p[5] != 0.0f) inside = inside && abs_(folded.z) + rz < 0.4999f * abs_(p[2]);
-    if (!inside) c.crossed |= 1u << (__float_as_uint(p[7]) & 31u);
-}
-
-template <class T, bool DISTANCE_ONLY, class R, class C>
-__device__ __forceinline__ void exec_leaf(const Rec& cur, V4<T>& last, T px, T py, T pz, R& regs, C& cull);   // below
+template <class T, bool DISTANCE_ONLY, class R>
+__device__ __forceinline__ void exec_leaf(const Rec& cur, V4<T>& last, T px, T py, T pz, R& regs);   // below
 
 // STATIC_OP >= 0 (per-tape code, where the generator knows each record's opcode): the switch below is on a
 // compile-time constant, so the front end emits only that case.  Leaving it to the optimiser to discover
 // that a literal record selects one case of 38 made hipRTC spend 94 % of its time in the inliner and in
 // correlated-value-propagation over dead cases (planetary, 467 records: 18 s -> see DESIGN.md).
-template <class T, bool DISTANCE_ONLY, class R, int STATIC_OP = -1, class C = NoCull>
+template <class T, bool DISTANCE_ONLY, class R, int STATIC_OP = -1>
 __device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const float* __restrict__ extra, T px, T py,
-                                         T pz, R& regs, C& cull)
+                                         T pz, R& regs)
 {
     constexpr bool kStaticOp = STATIC_OP >= 0;
     const uint32_t op = kStaticOp ? (uint32_t)STATIC_OP : (cur.hdr & 0xffu);
@@ -776,7 +717,7 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const floa
     // the interpreter's programs are mostly fused leaves (tape.hpp fuse_leaves): one test instead of the walk down
     // the compare tree
     if (SDF_LEAF_FIRST && !kStaticOp && op == OPX_LEAF) {
-        exec_leaf<T, DISTANCE_ONLY, R, C>(cur, last, px, py, pz, regs, cull);
+        exec_leaf<T, DISTANCE_ONLY, R>(cur, last, px, py, pz, regs);
     } else
     switch (op) {
     case OP_RETURN: return true;
@@ -836,9 +777,6 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const floa
     }
 #endif
     case OPX_POINT: last = v4<T>(px, py, pz, bc<T>(0.0f)); break;
-    // (OPX_CONST, the stand-in records of the culling experiment, is NOT a case here: run_tape_culled handles it itself.
-    // One more case in this switch -- never taken by the plain interpreter -- changed the code of all the others:
-    // 785 -> 863 vector instructions per wavefront of sponge(4), 3.20 -> 3.30 ms.)
     // a general quaternion as its matrix (tape_format.hpp): x' is parked in w, then y', z' and the assembly
     case OPX_TO_ROW_X:
         last.w = fma_(last.x, bc<T>(p[0]), fma_(last.y, bc<T>(p[1]), fma_(last.z, bc<T>(p[2]), bc<T>(p[3]))));
@@ -942,7 +880,6 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const floa
     case OP_REPETITION:
         last = v4<T>(remainder_t(last.x, p[0], p[3]), remainder_t(last.y, p[1], p[4]), remainder_t(last.z, p[2], p[5]),
                      bc<T>(0.0f));
-        if constexpr (C::kMode == 2) note_repetition<T>(cull, p, last);
         break;
     case OP_CIRCULAR_REPETITION_TO: {
         const float a = p[0], b = p[1];
@@ -979,24 +916,20 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const floa
         last.x = sel(lt(ptx, 0.0f), -last.x, last.x);
         break;
     }
-    // (the centre pass notes which operand of a numbered select is out: cull.hpp)
     case OP_UNION:
-        if constexpr (C::kMode == 2 && DISTANCE_ONLY) note_select<T>(cull, (fold >> kSelBits1) & 31u, last.w, regs.load_res(reg));
         if (DISTANCE_ONLY) last.w = min_(last.w, regs.load_res(reg));
         else last = rounded_union(p[0], last, regs.load(reg));
         break;
     case OP_INTERSECTION:
-        if constexpr (C::kMode == 2 && DISTANCE_ONLY) note_select<T>(cull, (fold >> kSelBits1) & 31u, -last.w, -regs.load_res(reg));
         if (DISTANCE_ONLY) last.w = max_(last.w, regs.load_res(reg));         // == -min(-a, -b), zeros and NaNs included
         else last = neg(rounded_union(p[0], neg(last), neg(regs.load(reg))));
         break;
     case OP_SUBTRACTION:
-        if constexpr (C::kMode == 2 && DISTANCE_ONLY) note_select<T>(cull, (fold >> kSelBits1) & 31u, -last.w, regs.load_res(reg));
         if (DISTANCE_ONLY) last.w = max_neg_(last.w, regs.load_res(reg));     // == -min(-a, b)
         else last = neg(rounded_union(p[0], neg(last), regs.load(reg)));
         break;
     case OPX_LEAF:
-        exec_leaf<T, DISTANCE_ONLY, R, C>(cur, last, px, py, pz, regs, cull);
+        exec_leaf<T, DISTANCE_ONLY, R>(cur, last, px, py, pz, regs);
         break;
     default: return true;  // unreachable: tapes are validated at upload
     }
@@ -1007,18 +940,10 @@ __device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const floa
     return false;
 }
 
-template <class T, bool DISTANCE_ONLY, class R, int STATIC_OP = -1>
-__device__ __forceinline__ bool exec_one(const Rec& cur, V4<T>& last, const float* __restrict__ extra, T px, T py,
-                                         T pz, R& regs)
-{
-    NoCull none;
-    return exec_one<T, DISTANCE_ONLY, R, STATIC_OP, NoCull>(cur, last, extra, px, py, pz, regs, none);
-}
-
 // OPX_LEAF (tape_format.hpp, tape.hpp fuse_leaves): the parts of a transformed primitive back to back, each exactly
 // the code of its single record above; which parts are present is wave-uniform (bits of the control word).
-template <class T, bool DISTANCE_ONLY, class R, class C>
-__device__ __forceinline__ void exec_leaf(const Rec& cur, V4<T>& last, T px, T py, T pz, R& regs, C& cull)
+template <class T, bool DISTANCE_ONLY, class R>
+__device__ __forceinline__ void exec_leaf(const Rec& cur, V4<T>& last, T px, T py, T pz, R& regs)
 {
     const float* p = cur.p;
     const uint32_t c = __float_as_uint(p[kLeafControl]);
@@ -1095,10 +1020,6 @@ __device__ __forceinline__ void exec_leaf(const Rec& cur, V4<T>& last, T px, T p
         if (kind == 0u) continue;
         if (DISTANCE_ONLY) {
             const T b = regs.load_res(slot);
-            if constexpr (C::kMode == 2) {   // the centre pass notes which operand is out (cull.hpp)
-                const uint32_t fold = __float_as_uint(p[kFoldParam]);
-                note_select<T>(cull, (fold >> (k == 0 ? kSelBits1 : kSelBits2)) & 31u, kind == 1u ? r.w : -r.w, kind == 2u ? -b : b);
-            }
             if (kind == 1u) r.w = min_(r.w, b);
             else if (kind == 2u) r.w = max_(r.w, b);
             else r.w = max_neg_(r.w, b);
@@ -1133,80 +1054,6 @@ __device__ __forceinline__ V4<T> run_tape(const Rec* __restrict__ prog, const fl
         for (int k = 0; k < kFetchGroup; ++k)
             if (exec_one<T, DISTANCE_ONLY, R>(group[k], last, extra, px, py, pz, regs)) return last;
     }
-}
-
-// The distance-only program at a brick's centre, noting which select operands are out (k_brick_keep)
-template <class R>
-__device__ __forceinline__ void run_tape_centre(const Rec* __restrict__ prog, const float* __restrict__ extra, float px, float py,
-                                                float pz, R& regs, Centre& cull)
-{
-    V4<float> last = v4<float>(0.0f, 0.0f, 0.0f, 0.0f);
-    const Rec* pc = prog;
-    for (;;) {
-        Rec group[kFetchGroup];
-#pragma unroll
-        for (int k = 0; k < kFetchGroup; ++k) group[k] = pc[k];
-        pc += kFetchGroup;
-#pragma unroll
-        for (int k = 0; k < kFetchGroup; ++k)
-            if (exec_one<float, true, R, -1, Centre>(group[k], last, extra, px, py, pz, regs, cull)) return;
-    }
-}
-
-// ... and the evaluation of a brick with what that left.  masks[i] = {run, live} of record i (cull.hpp): the record runs
-// iff (keep & run) == run; if not, but (keep & live) == live, its stand-in runs in its place (a constant stored where the
-// record's value would have gone: record i + stand_in_offset of `prog`); else nothing does.  `keep` is wave-uniform.
-// 64 records at a time, a record per lane: which of them take part, and -- by a permute -- lane j gets the j-th of those,
-// so that the loop proper costs a v_readlane per record and the scalar unit, which bounds the interpreter, sees almost
-// nothing new (walking the set bits of a ballot -- count trailing zeros, clear the bit, pick the array, form the
-// address -- was a chain of fifteen dependent scalar instructions per record: 39 % on top of the plain interpreter).
-// The records that run are the plain interpreter's, unchanged, fetched four at a time like run_tape's.
-template <class T, bool DISTANCE_ONLY, class R>
-__device__ __forceinline__ V4<T> run_tape_culled(const Rec* __restrict__ prog, uint32_t stand_in_offset, const uint2* __restrict__ masks,
-                                                 uint32_t n_records, const float* __restrict__ extra, T px, T py, T pz, R& regs,
-                                                 uint32_t keep)
-{
-    V4<T> last = v4<T>(bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f));
-    const uint32_t lane = threadIdx.x & 63u;
-    for (uint32_t base = 0; base < n_records; base += 64u) {   // (the _return record, masks 0, ends the walk)
-        const uint32_t mine = base + lane;
-        const uint2 m = mine < n_records ? masks[mine] : make_uint2(0xffffffffu, 0xffffffffu);
-        const bool run = mine < n_records && (keep & m.x) == m.x;
-        const bool takes_part = run || (mine < n_records && (keep & m.y) == m.y);
-        const uint64_t parts = __ballot(takes_part);
-        const uint32_t count = (uint32_t)__builtin_amdgcn_readfirstlane((int)__popcll(parts));
-        // lane j <- the j-th record that takes part (the stand-in's index where that runs instead)
-        const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(parts >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)parts, 0u));
-        // (a permutation of all 64 lanes: the others send a 0 behind the list)
-        const int list = __builtin_amdgcn_ds_permute((int)((takes_part ? before : count + (lane - before)) * 4u),
-                                                     takes_part ? (int)(run ? mine : mine + stand_in_offset) : 0);
-        for (uint32_t j = 0; j < count; j += 4u) {
-            const uint32_t i0 = (uint32_t)__builtin_amdgcn_readlane(list, (int)j);
-            const uint32_t i1 = (uint32_t)__builtin_amdgcn_readlane(list, (int)((j + 1u) & 63u));
-            const uint32_t i2 = (uint32_t)__builtin_amdgcn_readlane(list, (int)((j + 2u) & 63u));
-            const uint32_t i3 = (uint32_t)__builtin_amdgcn_readlane(list, (int)((j + 3u) & 63u));
-            // (lanes past `count` hold 0: record 0 is fetched again and not run)
-            const Rec r0 = prog[i0], r1 = prog[i1], r2 = prog[i2], r3 = prog[i3];
-            // a stand-in (OPX_CONST: the constant p[0] as the distance, no direction, stored where the record it stands
-            // for would have stored its value) is run here, not by exec_one
-            auto run = [&](const Rec& r) -> bool {
-                if ((r.hdr & 0xffu) != OPX_CONST) return exec_one<T, DISTANCE_ONLY, R>(r, last, extra, px, py, pz, regs);
-                const uint32_t fold = __float_as_uint(r.p[kFoldParam]);
-                if (DISTANCE_ONLY) last.w = bc<T>(r.p[0]);
-                else last = v4<T>(bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f), bc<T>(r.p[0]));
-                if (fold & kFoldStore) {
-                    if (DISTANCE_ONLY && (fold & kFoldStoreResult)) regs.store_res((fold >> 16) & 0xffu, last.w);
-                    else regs.store((fold >> 16) & 0xffu, last);
-                }
-                return false;
-            };
-            if (run(r0)) return last;
-            if (j + 1u < count && run(r1)) return last;
-            if (j + 2u < count && run(r2)) return last;
-            if (j + 3u < count && run(r3)) return last;
-        }
-    }
-    return last;
 }
 
 }  // namespace sdf

@@ -29,7 +29,6 @@ using sdf::Rec;
 // Evaluate through the interpreter.  `prog` is the full or the distance-only program (DO).
 template <bool DO> struct InterpEval {
     static constexpr bool kBricks = false;   // every primitive is evaluated anyway: runs along z (k_grid_eval)
-    static constexpr bool kCull = false;
     const Rec* prog;
     const float* extra;
     uint32_t n4;  // float4 slots of the LDS register file (scalar slots follow them)
@@ -224,11 +223,7 @@ k_grid_eval(const E ev, float cx, float cy, float cz, float step, uint32_t sx, D
             // bytes (eight float4 along z) per (x, y) row of the brick
             const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
             // A wavefront takes tiles = G bricks in a row along z (the index arithmetic and the launch of a wavefront are
-            // paid once per G bricks: 512^3 sponge(4), everything evaluated: 0.974 ms with one brick per wavefront, 0.886
-            // with sixteen).  With culling (E::kCull) the lanes first evaluate the tape ONCE at the centres of those G
-            // bricks (lane j: brick j) with interval bounds -> per brick a mask of the select operands that can win there
-            // (specialise.hpp tape_cull); then brick after brick is evaluated with its mask in scalar registers, the
-            // records of operands that cannot win skipped by wave-uniform branches.
+            // paid once per G bricks: 512^3 sponge(4): 0.974 ms with one brick per wavefront, 0.886 with sixteen).
             const uint32_t G = tiles;
             const uint32_t nbz = (sz >> 3) / G, nby = sy >> 2;      // groups of G bricks along z, bricks along y
             const uint32_t wid = blockIdx.x * 4u + wave;
@@ -240,38 +235,18 @@ k_grid_eval(const E ev, float cx, float cy, float cz, float step, uint32_t sx, D
             for (int i = 0; i < N; ++i) xs[i] = sample(cx, step, x0 + x + 2u * i);
             const T px = pack(xs), py = (T)(sample(cy, step, y));
             // what the tape computes from x and y alone is computed once for the wavefront's bricks (specialise.hpp)
-            [[maybe_unused]] typename E::template Hoisted<T> hoisted;
-            if constexpr (!E::kCull) hoisted = ev.template hoist<T>(px, py);
-            uint32_t keep_all = 0xffffffffu;
-            if constexpr (E::kCull) {
-                const float ccx = sample(cx, step, x0 + bx * 4u) + 1.5f * step, ccy = sample(cy, step, by * 4u) + 1.5f * step;
-                const float ccz = sample(cz, step, (gz * G + lane % G) * 8u) + 3.5f * step;
-                keep_all = ev.cull(ccx, ccy, ccz, 1.5f * step, 1.5f * step, 3.5f * step);
-            }
+            typename E::template Hoisted<T> hoisted = ev.template hoist<T>(px, py);
 #pragma unroll 1
             for (uint32_t j = 0; j < G; ++j) {
-                const uint32_t keep = E::kCull ? (uint32_t)__builtin_amdgcn_readlane((int)keep_all, (int)j) : 0xffffffffu;
                 const uint32_t z = (gz * G + j) * 8u + (lane & 7u);
                 const T pz = (T)(sample(cz, step, z));
-#ifdef SDF_CULL_STATS   // measurements only: a histogram of the masks instead of the grid (out[0..32]: bits set; out[64 + b]: bit b set)
-                if (lane == 0u) {
-                    atomicAdd(static_cast<uint32_t*>(out) + __popc(keep), 1u);
-                    for (uint32_t b = 0; b < 32u; ++b)
-                        if ((keep >> b) & 1u) atomicAdd(static_cast<uint32_t*>(out) + 64u + b, 1u);
-                }
-                continue;
-#endif
                 if (LAYOUT == 0) {
-                    sdf::V4<T> r;
-                    if constexpr (E::kCull) r = ev.eval_kept(px, py, pz, keep);
-                    else r = ev.eval_hoisted(px, py, pz, hoisted);
+                    const sdf::V4<T> r = ev.eval_hoisted(px, py, pz, hoisted);
                     float4* o = static_cast<float4*>(out) + ((size_t)z + (size_t)sz * ((size_t)y + (size_t)sy * x));
 #pragma unroll
                     for (int i = 0; i < N; ++i) store_voxel(o + (size_t)i * 2u * sy * sz, sdf::voxel(r, i));
                 } else {
-                    T w;
-                    if constexpr (E::kCull) w = ev.dist_kept(px, py, pz, keep);
-                    else w = ev.dist_hoisted(px, py, pz, hoisted);
+                    const T w = ev.dist_hoisted(px, py, pz, hoisted);
                     float* o = static_cast<float*>(out) + ((size_t)z + ((size_t)(x0 + x) + (size_t)(sy - 1u - y) * sx) * sz);
 #pragma unroll
                     for (int i = 0; i < N; ++i) store_voxel(o + (size_t)i * 2u * sz, sdf::get(w, i));
@@ -301,75 +276,6 @@ k_grid_eval(const E ev, float cx, float cy, float cz, float step, uint32_t sx, D
             const size_t idx = (size_t)c.z[i] + ((size_t)(x0 + c.x[i]) + (size_t)(sy - 1u - c.y[i]) * sx) * sz;
             store_voxel(static_cast<float*>(out) + idx, sdf::get(w, i));
         }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// dense grid evaluation by the interpreter with per-brick culling (cull.hpp tells the story)
-// ------------------------------------------------------------------------------------------
-// Bricks: 4 x 4 x 8 voxels with two voxels per lane (lane -> z: 8, y: 4, x: 2, the second voxel two x planes on), 4 x 4 x 4
-// with one (lane -> z: 4, y: 4, x: 4); brick number = (bx * nby + by) * nbz + bz in both kernels.
-//
-// k_brick_keep: one brick per LANE: the distance-only program at the brick's centre -> keep[brick] = for every
-// numbered select which operands may win somewhere in the brick.
-template <class E>   // E = InterpEval<true> (a template so that per-tape modules, which include this file, do not compile it)
-__global__ void __launch_bounds__(256)
-k_brick_keep(const E ev, const float* __restrict__ lipschitz, const uint32_t* __restrict__ repetitions, float cx, float cy, float cz, float step, uint32_t x0,
-             Dim nby, Dim nbz, uint32_t brick_z, uint32_t n_bricks, float radius, uint32_t* __restrict__ keep)
-{
-    extern __shared__ float4 lds[];
-    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t i = id < n_bricks ? id : n_bricks - 1u;   // idle tail lanes follow the (uniform) tape harmlessly
-    const uint32_t t = div(i, nbz), bz = i - t * nbz.n, bx = div(t, nby), by = t - bx * nby.n;
-    const float px = sample(cx, step, x0 + bx * 4u) + 1.5f * step, py = sample(cy, step, by * 4u) + 1.5f * step;
-    const float pz = sample(cz, step, bz * brick_z) + 0.5f * (float)(brick_z - 1u) * step;
-    sdf::Centre c{0u, 0u, repetitions[threadIdx.x & 15u], lipschitz[threadIdx.x & 15u], radius,
-                  1e-5f * (sdf::abs_(px) + sdf::abs_(py) + sdf::abs_(pz) + radius), 1.5f * step, 1.5f * step, 0.5f * (float)(brick_z - 1u) * step};
-    sdf::Regs<float> regs(lds, threadIdx.x, blockDim.x, ev.n4);
-    sdf::run_tape_centre(ev.prog, ev.extra, px, py, pz, regs, c);
-    if (id < n_bricks) keep[id] = ~c.kill;
-}
-
-// k_grid_eval_culled: one brick per WAVEFRONT, its keep word in a scalar register
-template <bool DO, int LAYOUT, int N>
-__global__ void __launch_bounds__(256) SDF_KERNEL_ATTRS
-k_grid_eval_culled(const InterpEval<DO> ev, uint32_t stand_in_offset, const uint2* __restrict__ masks, uint32_t n_records,
-                   const uint32_t* __restrict__ keep_of, float cx, float cy,
-                   float cz, float step, uint32_t sx, Dim dy, Dim dz, Dim nby, Dim nbz, uint32_t x0, uint32_t n_bricks,
-                   void* __restrict__ out)
-{
-    const uint32_t sy = dy.n, sz = dz.n;
-    using T = typename Pack<N>::T;
-    extern __shared__ float4 lds[];
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (wid >= n_bricks) return;   // wavefronts past the last brick (uniform)
-    const uint32_t keep = (uint32_t)__builtin_amdgcn_readfirstlane((int)keep_of[wid]);
-    const uint32_t t = div(wid, nbz), bz = wid - t * nbz.n, bx = div(t, nby), by = t - bx * nby.n;
-    uint32_t x, y, z;
-    if (N == 2) {
-        x = bx * 4u + (lane >> 5);
-        y = by * 4u + ((lane >> 3) & 3u);
-        z = bz * 8u + (lane & 7u);
-    } else {
-        x = bx * 4u + (lane >> 4);
-        y = by * 4u + ((lane >> 2) & 3u);
-        z = bz * 4u + (lane & 3u);
-    }
-    float xs[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i) xs[i] = sample(cx, step, x0 + x + 2u * i);
-    const T px = pack(xs), py = (T)(sample(cy, step, y)), pz = (T)(sample(cz, step, z));
-    sdf::Regs<T> regs(lds, threadIdx.x, blockDim.x, ev.n4);
-    const sdf::V4<T> r = sdf::run_tape_culled<T, DO>(ev.prog, stand_in_offset, masks, n_records, ev.extra, px, py, pz, regs, keep);
-    if (LAYOUT == 0) {
-        float4* o = static_cast<float4*>(out) + ((size_t)z + (size_t)sz * ((size_t)y + (size_t)sy * x));
-#pragma unroll
-        for (int i = 0; i < N; ++i) store_voxel(o + (size_t)i * 2u * sy * sz, sdf::voxel(r, i));
-    } else {
-        float* o = static_cast<float*>(out) + ((size_t)z + ((size_t)(x0 + x) + (size_t)(sy - 1u - y) * sx) * sz);
-#pragma unroll
-        for (int i = 0; i < N; ++i) store_voxel(o + (size_t)i * 2u * sz, sdf::get(r.w, i));
     }
 }
 
@@ -970,35 +876,5 @@ __device__ __forceinline__ bool same_bits(float a, float b)
 {
     return __float_as_uint(a) == __float_as_uint(b) || (a != a && b != b);
 }
-#ifndef __HIPCC_RTC__  // not part of the per-tape modules
-__global__ void __launch_bounds__(256) k_selftest_math(unsigned long long* counts)
-{
-    unsigned long long bad[3] = {0, 0, 0}, fast = 0;
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += stride) {
-        const float x0 = __uint_as_float((uint32_t)i), x1 = __uint_as_float(~(uint32_t)i);
-        const float s_ref0 = sdf::sqrt_(x0), s_ref1 = sdf::sqrt_(x1);
-        const float r_ref0 = 1.0f / s_ref0, r_ref1 = 1.0f / s_ref1;
-        // one voxel per lane
-        float s, r;
-        sdf::sqrt_inv_cr(x0, sdf::mask_of<float>::all(), s, r);
-        bad[0] += !same_bits(sdf::sqrt_cr(x0, sdf::mask_of<float>::all()), s_ref0);
-        bad[1] += !same_bits(s, s_ref0);
-        bad[2] += !same_bits(r, r_ref0);
-        // two voxels per lane
-        const sdf::f2 x = sdf::make_f2(x0, x1);
-        sdf::f2 s2, r2;
-        sdf::sqrt_inv_cr(x, sdf::mask_of<sdf::f2>::all(), s2, r2);
-        const sdf::f2 q2 = sdf::sqrt_cr(x, sdf::mask_of<sdf::f2>::all());
-        bad[0] += !same_bits(q2.x, s_ref0) + !same_bits(q2.y, s_ref1);
-        bad[1] += !same_bits(s2.x, s_ref0) + !same_bits(s2.y, s_ref1);
-        bad[2] += !same_bits(r2.x, r_ref0) + !same_bits(r2.y, r_ref1);
-        fast += !sdf::outside_fast_range(x0).v;
-    }
-    for (int k = 0; k < 3; ++k)
-        if (bad[k]) atomicAdd(&counts[k], bad[k]);
-    atomicAdd(&counts[3], fast);
-}
-#endif
 
 }  // namespace sdfk

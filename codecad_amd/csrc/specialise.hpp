@@ -208,118 +208,6 @@ inline bool collect_paths(const std::vector<Node>& nodes, int at, Path cur, std:
     }
 }
 
-// ---- culling (round 2): which records a wavefront may skip ------------------------------------------------------
-// A select whose one operand provably never wins inside the wavefront's brick reduces to the other operand there, and
-// the records that only feed the loser need not run.  `keep` (a wave-uniform uint32 handed to tape_dist / tape_eval)
-// has two bits per select, in record order: bit 2k = "operand a (in `last`) of select k may win", bit 2k+1 = "operand b
-// (the register) may win"; tape_cull computes it for a brick from ONE evaluation at the brick's centre with interval
-// bounds (every supported primitive is 1-Lipschitz in its own frame; a repetition is the identity while the brick
-// stays inside one cell, else everything under it is unbounded).  A record runs iff every select on the way from it
-// to the root keeps its side: `(keep & mask) == mask`, OR-ed over the ways when a value is shared.
-struct CullPlan {
-    bool enabled = false;
-    std::vector<std::array<bool, 2>> guarded;       // per select k: is operand a / b skippable (worth a branch)?
-    std::vector<int> select_of_rec;                 // record -> k, or -1
-    std::vector<std::vector<uint32_t>> rec_conds;   // record -> masks (OR); empty = always runs
-};
-
-inline void add_cond(std::vector<uint32_t>& set, uint32_t m, bool& always)
-{
-    if (always) return;
-    if (m == 0u) { always = true; set.clear(); return; }
-    for (uint32_t have : set) if ((m & have) == have) return;   // implied by a weaker condition already there
-    set.push_back(m);
-    if (set.size() > 4) { always = true; set.clear(); }
-}
-
-inline CullPlan plan_culling(const std::vector<Rec>& recs, const std::vector<Node>& nodes, int root, const std::vector<int>& rec_node)
-{
-    CullPlan plan;
-    plan.select_of_rec.assign(recs.size(), -1);
-    int k = 0;
-    for (const Node& n : nodes)
-        if (n.role == SELECT) plan.select_of_rec[n.rec] = k++;
-    plan.rec_conds.assign(recs.size(), {});
-    plan.guarded.assign((size_t)k, {false, false});
-    if (k == 0 || k > 16) return plan;
-    // What a skipped operand saves, in vector instructions per voxel pair (rough): a wave-uniform branch costs a
-    // wavefront ~10 cycles of fetch bubble whether taken or not and splits the schedule, so only operands worth a
-    // few dozen instructions get one (sponge(4): the four crosses and the box, not the twelve bars -- guards around
-    // every bar made the kernel SLOWER than no culling at all: 1.06 against 0.86 ms).
-    std::vector<int> cost(nodes.size(), 0);
-    for (int n = 0; n < (int)nodes.size(); ++n) {   // operands come before their consumers
-        const Node& nd = nodes[n];
-        if (nd.kind == POINT) continue;
-        int c = 0;
-        if (nd.role == LEAF) c = (nd.op == OP_RECTANGLE ? 22 : nd.op == OP_CIRCLE || nd.op == OP_SPHERE ? 16 : nd.op == OP_HALF_SPACE ? 2 : 80) + 6;
-        else if (nd.role == UNARY) c = 3 + cost[nd.a];
-        else if (nd.role == WITH_POINT) c = 20 + cost[nd.a];
-        else if (nd.role == SELECT) c = 3 + cost[nd.a] + cost[nd.b];
-        cost[n] = c;
-    }
-    int kWorthABranch = 40;
-    if (const char* e = std::getenv("HU_CULL_WORTH")) kWorthABranch = std::atoi(e);
-    for (const Node& nd : nodes)
-        if (nd.role == SELECT) {
-            const int ks = plan.select_of_rec[nd.rec];
-            plan.guarded[ks] = {cost[nd.a] >= kWorthABranch, cost[nd.b] >= kWorthABranch};
-        }
-    // result nodes: the masks of the ways from the root
-    std::vector<std::vector<uint32_t>> conds(nodes.size());
-    std::vector<char> always(nodes.size(), 0);
-    struct Visit { int node; uint32_t mask; };
-    std::vector<Visit> stack{{root, 0u}};
-    size_t visits = 0;
-    while (!stack.empty()) {
-        const Visit v = stack.back();
-        stack.pop_back();
-        if (++visits > 4096) return plan;   // a heavily shared DAG: not worth it
-        bool a = always[v.node] != 0;
-        add_cond(conds[v.node], v.mask, a);
-        always[v.node] = a;
-        const Node& n = nodes[v.node];
-        if (n.role == UNARY || n.role == WITH_POINT) stack.push_back({n.a, v.mask});
-        else if (n.role == SELECT) {
-            const int ks = plan.select_of_rec[n.rec];
-            stack.push_back({n.a, plan.guarded[ks][0] ? v.mask | (1u << (2 * ks)) : v.mask});
-            stack.push_back({n.b, plan.guarded[ks][1] ? v.mask | (1u << (2 * ks + 1)) : v.mask});
-        }
-    }
-    // point nodes: needed by any of their consumers (consumers were created after their producers)
-    for (int i = (int)nodes.size() - 1; i >= 0; --i) {
-        const Node& n = nodes[i];
-        auto feed = [&](int producer) {
-            if (producer < 0 || nodes[producer].kind != POINT) return;
-            bool a = always[producer] != 0;
-            if (always[i] || conds[i].empty()) { a = true; conds[producer].clear(); }
-            else for (uint32_t m : conds[i]) add_cond(conds[producer], m, a);
-            always[producer] = a;
-        };
-        if (n.role == LEAF || n.role == POINT_OP) feed(n.a);
-        if (n.role == WITH_POINT) feed(n.b);
-    }
-    for (size_t i = 0; i < recs.size(); ++i) {
-        const int nd = rec_node[i];
-        const uint32_t op = recs[i].hdr & 0xffu;
-        if (nd < 0 || op == OP_LOAD || op == OP_RETURN) continue;          // runs always (a _load is a register move)
-        if (!always[nd]) plan.rec_conds[i] = conds[nd];
-        // a value nobody reaches from the root (dead code in the tape) keeps conds empty = always: harmless
-    }
-    plan.enabled = true;
-    return plan;
-}
-
-inline std::string cond_expr(const std::vector<uint32_t>& masks)
-{
-    std::ostringstream o;
-    char buf[16];
-    for (size_t i = 0; i < masks.size(); ++i) {
-        std::snprintf(buf, sizeof buf, "0x%08xu", masks[i]);
-        o << (i ? " || " : "") << "(keep & " << buf << ") == " << buf;
-    }
-    return o.str();
-}
-
 }  // namespace spec_detail
 
 // The straight-line full program (the only form of round 1; still the form of every tape the deferral does not cover).
@@ -327,7 +215,7 @@ inline void emit_plain(std::ostringstream& o, const SpecProgram& p)
 {
     using namespace spec_detail;
     o << "constexpr int kHoisted = 0;\n"
-      << "template <class T, int PRE, uint32_t AXIS = 4u> __device__ __forceinline__ sdf::V4<T> tape_eval(T px, T py, T pz, const float* __restrict__ extra, uint32_t, T*)\n{\n"
+      << "template <class T, int PRE, uint32_t AXIS = 4u> __device__ __forceinline__ sdf::V4<T> tape_eval(T px, T py, T pz, const float* __restrict__ extra, T*)\n{\n"
       << "    using namespace sdf;\n    RegsV<T, " << p.n_slots << "> regs;\n"
       << "    V4<T> last = v4<T>(bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f));\n";
     for (const Rec& r : p.full) {
@@ -336,207 +224,12 @@ inline void emit_plain(std::ostringstream& o, const SpecProgram& p)
           << ">(r, last, extra, px, py, pz, regs); }\n";
     }
     o << "    return last;\n}\n"
-      << "template <class T, int PRE, uint32_t AXIS = 4u> __device__ __forceinline__ T tape_dist(T px, T py, T pz, const float* __restrict__ extra, uint32_t, T*)\n"
-      << "{ return tape_eval<T, 0>(px, py, pz, extra, 0xffffffffu, nullptr).w; }\n";
-}
-
-// The centre pass of the culling (T = float, one brick centre per lane): the distance-only program once, with an
-// interval [lo, hi] per result value.  h = the brick's half extents in the current frame (permuted and scaled by the
-// transformations), rad = |h| the Lipschitz radius there.
-inline void emit_cull(std::ostringstream& o, const SpecProgram& p, const std::vector<spec_detail::Node>& nodes,
-                      const std::vector<int>& rec_node, const spec_detail::CullPlan& plan)
-{
-    using namespace spec_detail;
-    o << "__device__ __forceinline__ uint32_t tape_cull(float px, float py, float pz, float hx, float hy, float hz, const float* __restrict__ extra)\n{\n"
-      << "    using namespace sdf;\n    using T = float;\n"
-      << "    RegsDO<T, " << p.n_point_slots << ", " << p.n_result_slots << "> regs;\n"
-      << "    V4<T> last = v4<T>(0.0f, 0.0f, 0.0f, 0.0f);\n    uint32_t keep = 0xffffffffu;\n"
-      << "    const float inf = __builtin_inff();\n"
-      // the Lipschitz radius of the sample frame (one square root; every frame below is a uniform scaling of it)
-      << "    const float rad0 = __builtin_sqrtf(hx * hx + hy * hy + hz * hz) * 1.0625f;\n";
-    // J[n]: by how much the frame of point node n is scaled against the sample frame (every supported point op scales
-    // uniformly: |Q|^2 of its quaternion; a quarter turn permutes the axes besides)
-    std::vector<double> J(nodes.size(), 1.0);
-    for (int n = 0; n < (int)nodes.size(); ++n) {
-        if (nodes[n].kind != POINT) continue;
-        const double up = nodes[n].a >= 0 ? J[nodes[n].a] : 1.0;
-        const uint32_t nop = nodes[n].op;
-        const float* q = p.dist[nodes[n].rec].p;
-        J[n] = (nop == OPX_TO_SCALE || nop == OPX_TO_AXIS_X || nop == OPX_TO_AXIS_Y || nop == OPX_TO_AXIS_Z) ? up * std::fabs((double)q[0]) : up;
-    }
-    auto N = [](int n) { return std::to_string(n); };
-    // inner[n]: a union (intersection) whose only consumer is a select of the same op, directly: part of a longer chain
-    std::vector<int> consumers(nodes.size(), 0), consumer(nodes.size(), -1);
-    for (int n = 0; n < (int)nodes.size(); ++n) {
-        auto use = [&](int x) { if (x >= 0) { ++consumers[x]; consumer[x] = n; } };
-        if (nodes[n].role == UNARY || nodes[n].role == WITH_POINT) use(nodes[n].a);
-        if (nodes[n].role == SELECT) { use(nodes[n].a); use(nodes[n].b); }
-    }
-    std::vector<char> inner(nodes.size(), 0);
-    for (int n = 0; n < (int)nodes.size(); ++n)
-        inner[n] = nodes[n].role == SELECT && nodes[n].op != OP_SUBTRACTION && consumers[n] == 1 &&
-                   nodes[consumer[n]].role == SELECT && nodes[consumer[n]].op == nodes[n].op;
-    for (int i = 0; i < (int)p.dist.size(); ++i) {
-        const Rec& r = p.dist[i];
-        const uint32_t op = r.hdr & 0xffu, slot = (r.hdr >> 8) & 0xffffu, fold = fold_of(r);
-        if (op == OP_RETURN) break;
-        const int nd = rec_node[i];
-        const bool produces = nd >= 0 && nodes[nd].rec == i;   // (a _store / _load record only moves an older node)
-        if (fold & kFoldLoad) {
-            if (fold & kFoldLoadResult) o << "    last.w = regs.load_res(" << (fold & 0xffu) << ");\n";
-            else o << "    last = regs.load(" << (fold & 0xffu) << ");\n";
-        }
-        if (produces && nodes[nd].role == LEAF) o << "    const float m" << nd << " = abs_(last.x) + abs_(last.y) + abs_(last.z);\n";
-        const int ks = plan.select_of_rec[i];
-        if (ks >= 0) {   // the operands as rounded_union sees them, before the record runs
-            const char* a = op == OP_UNION ? "last.w" : "-last.w";
-            std::string b = "regs.load_res(" + N(slot) + ")";
-            if (op == OP_INTERSECTION) b = "-" + b;
-            (void)a;
-            (void)b;
-        }
-        o << "    { const Rec r = " << rec_literal(r, true, r.hdr) << "; exec_one<T, true, decltype(regs), " << op
-          << ">(r, last, extra, px, py, pz, regs); }\n";
-        if (produces) {
-            const Node& n = nodes[nd];
-            const std::string id = N(nd), A = n.a >= 0 ? N(n.a) : std::string();
-            if (n.kind == POINT) {
-                // half extents and "still inside one cell of every repetition above" of this frame
-                const float* q = r.p;
-                if (op == OPX_POINT) o << "    const float hx" << id << " = hx, hy" << id << " = hy, hz" << id << " = hz; const bool ok" << id << " = true;\n";
-                else if (op == OPX_TO_SCALE)
-                    o << "    const float hx" << id << " = hx" << A << " * " << flit(std::fabs(q[0])) << ", hy" << id << " = hy" << A << " * " << flit(std::fabs(q[0]))
-                      << ", hz" << id << " = hz" << A << " * " << flit(std::fabs(q[0])) << "; const bool ok" << id << " = ok" << A << ";\n";
-                else if ((op == OPX_TO_AXIS_X || op == OPX_TO_AXIS_Y || op == OPX_TO_AXIS_Z) && q[1] == 0.0f) {
-                    // a quarter turn: the two coordinates of the plane swap; along the axis |A|, in the plane |C|
-                    const char* c[3] = {"hx", "hy", "hz"};
-                    const int ax = op == OPX_TO_AXIS_X ? 0 : op == OPX_TO_AXIS_Y ? 1 : 2, u = (ax + 1) % 3, v = (ax + 2) % 3;
-                    std::string e[3];
-                    e[ax] = std::string(c[ax]) + A + " * " + flit(std::fabs(q[0]));
-                    e[u] = std::string(c[v]) + A + " * " + flit(std::fabs(q[2]));
-                    e[v] = std::string(c[u]) + A + " * " + flit(std::fabs(q[2]));
-                    o << "    const float hx" << id << " = " << e[0] << ", hy" << id << " = " << e[1] << ", hz" << id << " = " << e[2]
-                      << "; const bool ok" << id << " = ok" << A << ";\n";
-                } else if (op == OPX_TO_AXIS_X || op == OPX_TO_AXIS_Y || op == OPX_TO_AXIS_Z) {
-                    // a general angle: a ball of the frame's radius (scale = A, the quaternion's squared norm)
-                    o << "    const float hx" << id << " = rad0 * " << flit((float)(J[nd] * 1.000001)) << ", hy" << id
-                      << " = hx" << id << ", hz" << id << " = hx" << id << "; const bool ok" << id << " = ok" << A << ";\n";
-                } else if (op == OP_REPETITION) {
-                    o << "    const float hx" << id << " = hx" << A << ", hy" << id << " = hy" << A << ", hz" << id << " = hz" << A << ";\n"
-                      << "    const bool ok" << id << " = ok" << A;
-                    const char* comp[3] = {"x", "y", "z"};
-                    for (int c = 0; c < 3; ++c)
-                        if (q[3 + c] != 0.0f)   // a finite spacing: the brick must keep clear of the cell's faces
-                            o << " && (abs_(last." << comp[c] << ") + h" << comp[c] << A << " * 1.0625f < " << flit(0.4999f * std::fabs(q[c])) << ")";
-                    o << ";\n";
-                } else if (op == OP_SYMMETRICAL_TO || op == OP_MIRROR)
-                    o << "    const float hx" << id << " = hx" << A << ", hy" << id << " = hy" << A << ", hz" << id << " = hz" << A
-                      << "; const bool ok" << id << " = ok" << A << ";\n";
-                else   // everything else (general matrices, revolutions, circular repetitions, twists): no bounds below here
-                    o << "    const float hx" << id << " = 0.0f, hy" << id << " = 0.0f, hz" << id << " = 0.0f; const bool ok" << id << " = false;\n";
-            } else if (n.role == LEAF) {
-                const bool lipschitz = op == OP_RECTANGLE || op == OP_CIRCLE || op == OP_SPHERE || op == OP_HALF_SPACE;
-                if (lipschitz)
-                    o << "    const float r" << id << " = rad0 * " << flit((float)(J[n.a] * 1.000001)) << " + 1e-5f * (abs_(last.w) + m" << id << ");\n"
-                      << "    const float lo" << id << " = ok" << A << " ? last.w - r" << id << " : -inf, hi" << id << " = ok" << A << " ? last.w + r" << id << " : inf;\n";
-                else
-                    o << "    const float lo" << id << " = -inf, hi" << id << " = inf;\n";
-            } else if (n.role == UNARY) {
-                if (op == OP_OFFSET) o << "    const float lo" << id << " = lo" << A << " - " << flit(r.p[0]) << " - 1e-6f * abs_(lo" << A << "), hi" << id << " = hi" << A << " - " << flit(r.p[0]) << " + 1e-6f * abs_(hi" << A << ");\n";
-                else if (op == OP_SHELL)
-                    o << "    const float lo" << id << " = (lo" << A << " > 0.0f ? lo" << A << " : (hi" << A << " < 0.0f ? -hi" << A << " : 0.0f)) * 0.99999f - " << flit(r.p[0])
-                      << ", hi" << id << " = __builtin_fmaxf(abs_(lo" << A << "), abs_(hi" << A << ")) * 1.00001f - " << flit(r.p[0]) << ";\n";
-                else if (op == OP_MIRROR) o << "    const float lo" << id << " = lo" << A << ", hi" << id << " = hi" << A << ";\n";
-                else {   // the from-transformations: the distance times the scale (p[5]; the matrix form: p[9])
-                    const float scale = op == OPX_FROM_MATRIX ? r.p[9] : r.p[5];
-                    if (scale > 0.0f)
-                        o << "    const float lo" << id << " = lo" << A << " * " << flit(scale) << " - 1e-6f * abs_(lo" << A << " * " << flit(scale) << "), hi" << id << " = hi" << A << " * " << flit(scale)
-                          << " + 1e-6f * abs_(hi" << A << " * " << flit(scale) << ");\n";
-                    else o << "    const float lo" << id << " = -inf, hi" << id << " = inf;\n";
-                }
-            } else if (n.role == WITH_POINT) {
-                const std::string B = N(n.b);
-                if (op == OP_EXTRUSION)   // 1-Lipschitz when the extruded value is: centre value +- the frame's radius
-                    o << "    const bool fin" << id << " = ok" << B << " && lo" << A << " > -inf && hi" << A << " < inf;\n"
-                      << "    const float r" << id << " = rad0 * " << flit((float)(J[n.b] * 1.000001)) << " + 1e-5f * (abs_(last.w) + abs_(regs.load(" << slot << ").x) + abs_(regs.load("
-                      << slot << ").y) + abs_(regs.load(" << slot << ").z));\n"
-                      << "    const float lo" << id << " = fin" << id << " ? last.w - r" << id << " : -inf, hi" << id << " = fin" << id << " ? last.w + r" << id << " : inf;\n";
-                else if (op == OP_SYMMETRICAL_FROM || op == OP_REVOLUTION_FROM || op == OP_CIRCULAR_REPETITION_FROM)
-                    o << "    const float lo" << id << " = lo" << A << ", hi" << id << " = hi" << A << ";\n";   // the distance passes through
-                else o << "    const float lo" << id << " = -inf, hi" << id << " = inf;\n";
-            } else if (n.role == SELECT) {
-                const std::string B = N(n.b);
-                // in the space where rounded_union takes a minimum: a' = a (union) or -a, b' = b (union, subtraction) or -b
-                std::string alo = "lo" + A, ahi = "hi" + A, blo = "lo" + B, bhi = "hi" + B;
-                if (op != OP_UNION) { std::string t = alo; alo = "(-" + ahi + ")"; ahi = "(-" + t + ")"; }
-                if (op == OP_INTERSECTION) { std::string t = blo; blo = "(-" + bhi + ")"; bhi = "(-" + t + ")"; }
-                const std::string mlo = "__builtin_fminf(" + alo + ", " + blo + ")", mhi = "__builtin_fminf(" + ahi + ", " + bhi + ")";
-                if (op == OP_UNION) o << "    const float lo" << id << " = " << mlo << ", hi" << id << " = " << mhi << ";\n";
-                else o << "    const float lo" << id << " = -" << mhi << ", hi" << id << " = -" << mlo << ";\n";
-                if (op == OP_SUBTRACTION) {
-                    const int ks = plan.select_of_rec[i], bit = 2 * ks;
-                    if (plan.guarded[ks][0]) o << "    if (" << alo << " > " << bhi << ") keep &= ~" << (1u << bit) << "u;        // a never wins here\n";
-                    if (plan.guarded[ks][1]) o << "    if (" << ahi << " < " << blo << ") keep &= ~" << (1u << (bit + 1)) << "u;   // b never wins here\n";
-                } else if (!inner[nd]) {
-                    // the root of a chain of unions (intersections): min (max) is associative, so a MEMBER of the chain that
-                    // loses against the best upper bound of all the others can never be the chain's value nor its winner,
-                    // whichever sub-union holds it; a sub-union whose two sides are gone is gone itself
-                    struct Member { int node, sel_rec, side; };
-                    std::vector<Member> members, inners;
-                    std::vector<std::pair<int, std::pair<int, int>>> work{{nd, {-1, 0}}};   // (node, (select record above, side))
-                    while (!work.empty()) {
-                        const auto w = work.back();
-                        work.pop_back();
-                        const Node& m = nodes[w.first];
-                        if (m.role == SELECT && m.op == op && (w.first == nd || inner[w.first])) {
-                            if (w.first != nd) inners.push_back({w.first, w.second.first, w.second.second});
-                            work.push_back({m.a, {m.rec, 0}});
-                            work.push_back({m.b, {m.rec, 1}});
-                        } else members.push_back({w.first, w.second.first, w.second.second});
-                    }
-                    const bool neg = op == OP_INTERSECTION;   // min-space of an intersection: (-hi, -lo)
-                    auto LO = [&](int node) { return neg ? "(-hi" + N(node) + ")" : "lo" + N(node); };
-                    auto HI = [&](int node) { return neg ? "(-lo" + N(node) + ")" : "hi" + N(node); };
-                    for (size_t a0 = 0; a0 < members.size(); ++a0) {
-                        std::string others;
-                        for (size_t b0 = 0; b0 < members.size(); ++b0) {
-                            if (b0 == a0) continue;
-                            others = others.empty() ? HI(members[b0].node) : "__builtin_fminf(" + others + ", " + HI(members[b0].node) + ")";
-                        }
-                        // (a member that is not worth a branch is always evaluated: it is never "gone")
-                        const bool worth = plan.guarded[plan.select_of_rec[members[a0].sel_rec]][members[a0].side];
-                        o << "    const bool x" << members[a0].node << "_" << id << " = " << (worth ? LO(members[a0].node) + " > " + others : std::string("false")) << ";\n";
-                        if (worth) o << "    if (x" << members[a0].node << "_" << id << ") keep &= ~" << (1u << (2 * plan.select_of_rec[members[a0].sel_rec] + members[a0].side)) << "u;\n";
-                    }
-                    // inner selects, innermost first (they were collected outermost first)
-                    for (auto it = inners.rbegin(); it != inners.rend(); ++it) {
-                        const Node& m = nodes[it->node];
-                        // gone as a whole: both sides gone -- or it loses, as one member, against the others of the chain
-                        const bool worth = plan.guarded[plan.select_of_rec[it->sel_rec]][it->side];
-                        std::string others;
-                        for (const Member& mb : members) {
-                            bool below = false;   // is mb a member underneath this inner select?
-                            for (int at = mb.node; at >= 0 && at != nd; at = consumer[at]) if (at == it->node) { below = true; break; }
-                            if (!below) others = others.empty() ? HI(mb.node) : "__builtin_fminf(" + others + ", " + HI(mb.node) + ")";
-                        }
-                        o << "    const bool x" << it->node << "_" << id << " = (x" << m.a << "_" << id << " && x" << m.b << "_" << id << ")"
-                          << (worth && !others.empty() ? " || " + LO(it->node) + " > " + others : std::string()) << ";\n";
-                        if (worth) o << "    if (x" << it->node << "_" << id << ") keep &= ~" << (1u << (2 * plan.select_of_rec[it->sel_rec] + it->side)) << "u;\n";
-                    }
-                }
-            }
-        }
-        if (fold & kFoldStore) {
-            if (fold & kFoldStoreResult) o << "    regs.store_res(" << ((fold >> 16) & 0xffu) << ", last.w);\n";
-            else o << "    regs.store(" << ((fold >> 16) & 0xffu) << ", last);\n";
-        }
-    }
-    o << "    return keep;\n}\n";
+      << "template <class T, int PRE, uint32_t AXIS = 4u> __device__ __forceinline__ T tape_dist(T px, T py, T pz, const float* __restrict__ extra, T*)\n"
+      << "{ return tape_eval<T, 0>(px, py, pz, extra, nullptr).w; }\n";
 }
 
 // true: the deferred form was emitted; false: nothing was written (use emit_plain)
-inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t max_paths = 40, bool save_points = false,
-                          bool* culling = nullptr)
+inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t max_paths = 40, bool save_points = false)
 {
     using namespace spec_detail;
     if (p.dist.empty() || p.dist.size() != p.full.size()) return false;
@@ -547,9 +240,6 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
     std::vector<Path> paths;
     if (!collect_paths(nodes, root, Path(), paths, max_paths)) return false;
     if (paths.size() < 2) return false;   // a single primitive: nothing to defer
-    // `culling` in: is per-brick culling wanted; out: was it emitted
-    const CullPlan plan = culling && *culling ? plan_culling(p.full, nodes, root, rec_node) : CullPlan();
-    if (culling) *culling = plan.enabled;
 
     // ---- phase 1: the distance-only program; `keep` = what phase 2 wants from it
     std::vector<char> is_choice(p.full.size(), 0), keep_w(p.full.size(), 0);
@@ -577,7 +267,7 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
     // and a rectangle or a circle (which read |x|, |y| or x^2 + y^2: no sign of a zero can differ).
     std::vector<int> run_first, run_last, run_of(p.dist.size(), -1);
     std::vector<uint32_t> run_free;   // bit a: the run's distance does not read sample coordinate a (x, y, z): free along a walk in that direction
-    if (!plan.enabled) {
+    {
         enum : uint8_t { X = 1, Y = 2, Z = 4 };
         struct Deps { uint8_t c[3]; };
         const Deps unknown{{X | Y | Z, X | Y | Z, X | Y | Z}};
@@ -661,7 +351,7 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
     std::vector<Half> half(p.dist.size());
     int n_hoisted = (int)run_first.size();
     static const bool halves = [] { const char* e = getenv("HU_HOIST_HALVES"); return !(e && e[0] == '0'); }();
-    if (!plan.enabled && halves) {
+    if (halves) {
         // (the analysis above, once more, for what it did not keep: the components' dependencies where a rectangle starts)
         enum : uint8_t { X = 1, Y = 2, Z = 4 };
         struct Deps { uint8_t c[3]; };
@@ -716,9 +406,6 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
         const Rec& r = p.dist[i];
         const uint32_t op = r.hdr & 0xffu, slot = (r.hdr >> 8) & 0xffffu, fold = fold_of(r);
         if (op == OP_RETURN) break;
-        const bool guarded = plan.enabled && !plan.rec_conds[i].empty();
-        const bool same_as_before = guarded && i > 0 && plan.rec_conds[i - 1] == plan.rec_conds[i];
-        if (guarded && !same_as_before) body << "    if (" << cond_expr(plan.rec_conds[i]) << ") {\n";
         const int run = run_of[i];
         // (AXIS: the direction of the walk, as a bit -- 1 x, 4 z; a run is hoisted in the instantiations whose walk it is free along)
         if (run >= 0 && run_first[run] == i)
@@ -736,15 +423,7 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
             const std::string b_raw = "regs.load_res(" + std::to_string(slot) + ")";
             const std::string b = op == OP_INTERSECTION ? "-" + b_raw : b_raw;
             const std::string choice = is_choice[i] ? "c" + std::to_string(i) + " = " : std::string();
-            const int ks = plan.enabled ? plan.select_of_rec[i] : -1;
-            if (ks >= 0 && (plan.guarded[ks][0] || plan.guarded[ks][1])) {
-                const uint32_t ba = 1u << (2 * ks), bb = 1u << (2 * ks + 1);
-                body << "    if ((keep & " << (ba | bb) << "u) == " << (ba | bb) << "u) { " << (is_choice[i] ? choice + "lt(" + a + ", " + b + "); " : std::string()) << run_text << " }\n"
-                     // operand a lost everywhere: the result is operand b as the op hands it on (subtraction: -b)
-                     << "    else if (keep & " << bb << "u) { last.w = " << (op == OP_SUBTRACTION ? "-" : "") << b_raw << "; "
-                     << (is_choice[i] ? choice + "~mask_of<T>::all(); " : std::string()) << "}\n"
-                     << "    else { " << (is_choice[i] ? choice + "mask_of<T>::all(); " : std::string()) << "}\n";
-            } else {
+            {
                 if (is_choice[i]) body << "    " << choice << "lt(" << a << ", " << b << ");\n";
                 body << "    " << run_text << "\n";
             }
@@ -778,19 +457,15 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
             if (fold & kFoldStoreResult) body << "    regs.store_res(" << ((fold >> 16) & 0xffu) << ", last.w);\n";
             else body << "    regs.store(" << ((fold >> 16) & 0xffu) << ", last);\n";
         }
-        const bool same_as_next = guarded && i + 1 < (int)p.dist.size() && (p.dist[i + 1].hdr & 0xffu) != OP_RETURN &&
-                                  plan.rec_conds[i + 1] == plan.rec_conds[i];
-        if (guarded && !same_as_next) body << "    }\n";
     }
-    if (plan.enabled) emit_cull(o, p, nodes, rec_node, plan);
     o << "constexpr int kHoisted = " << n_hoisted << ";   // distances that do not change along z (emit_deferred)\n"
-      << "template <class T, int PRE, uint32_t AXIS = 4u> __device__ __forceinline__ T tape_dist(T px, T py, T pz, const float* __restrict__ extra, uint32_t keep, T* hoisted)\n{\n";
+      << "template <class T, int PRE, uint32_t AXIS = 4u> __device__ __forceinline__ T tape_dist(T px, T py, T pz, const float* __restrict__ extra, T* hoisted)\n{\n";
     {   // the distance alone: phase 1 without the captures (they are dead there)
         std::string text = body.str();
         o << text << "    return last.w;\n}\n";
     }
-    o << "// deferred directions: " << paths.size() << " (primitive, path) pairs" << (plan.enabled ? "; culling" : "") << "\n"
-      << "template <class T, int PRE, uint32_t AXIS = 4u> __device__ __forceinline__ sdf::V4<T> tape_eval(T px, T py, T pz, const float* __restrict__ extra, uint32_t keep, T* hoisted)\n{\n"
+    o << "// deferred directions: " << paths.size() << " (primitive, path) pairs" << "\n"
+      << "template <class T, int PRE, uint32_t AXIS = 4u> __device__ __forceinline__ sdf::V4<T> tape_eval(T px, T py, T pz, const float* __restrict__ extra, T* hoisted)\n{\n"
       << body.str()
       << "    const T w_root = last.w;\n"
       << "    // ---- phase 2\n"
@@ -853,7 +528,7 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
 }
 
 // The whole translation unit handed to hipRTC.  `deferred` (may be NULL) <- whether the deferred form was used.
-inline std::string specialised_source(const SpecProgram& p, bool allow_deferred, bool* deferred = nullptr, bool* culled = nullptr)
+inline std::string specialised_source(const SpecProgram& p, bool allow_deferred, bool* deferred = nullptr)
 {
     std::ostringstream o;
     // HU_ABS_BUILTIN=1 (an experiment that lost): |x| - h written plainly in the brick kernels, so that the compiler hoists
@@ -862,47 +537,33 @@ inline std::string specialised_source(const SpecProgram& p, bool allow_deferred,
     static const bool abs_builtin = [] { const char* e = getenv("HU_ABS_BUILTIN"); return e && e[0] == '1'; }();
     std::ostringstream d;
     static const bool save_points = [] { const char* e = getenv("HU_PHASE2_SAVE_POINTS"); return e && e[0] == '1'; }();
-    // Per-brick culling is an experiment that lost: with it sponge(4) dense runs in
-    // 1.06-1.23 ms, without in 0.86 ms.  HU_CULL=1 turns it on (the parity tests cover both).
-    static const bool want_cull = [] { const char* e = getenv("HU_CULL"); return e && e[0] == '1'; }();
-    bool culling = want_cull;
-    const bool ok = allow_deferred && emit_deferred(d, p, 40, save_points, &culling);
+    const bool ok = allow_deferred && emit_deferred(d, p, 40, save_points);
     o << (ok && abs_builtin ? "#define SDF_ABS_MINUS_BUILTIN 1\n" : "") << "#include \"kernels.hpp\"\nnamespace sdfk {\nusing sdf::Rec;\n";
     if (ok) o << d.str();
     else emit_plain(o, p);
-    culling = culling && ok;
     if (deferred) *deferred = ok;
-    if (culled) *culled = culling;
-    if (!culling)   // a stand-in so that the kernels compile: never called (kCull is false)
-        o << "__device__ __forceinline__ uint32_t tape_cull_none() { return 0xffffffffu; }\n";
     o << "struct JitEval {\n    static constexpr bool kBricks = " << (ok ? "true" : "false") << ";\n"
-      << "    static constexpr bool kCull = " << (culling ? "true" : "false") << ";   // bricks are evaluated with per-brick culling (kernels.hpp)\n"
       << "    const float* extra;\n"
       << "    template <class T> __device__ __forceinline__ sdf::V4<T> operator()(T px, T py, T pz, void*) const\n"
-      << "    { return tape_eval<T, 0>(px, py, pz, extra, 0xffffffffu, nullptr); }\n"
+      << "    { return tape_eval<T, 0>(px, py, pz, extra, nullptr); }\n"
       << "    template <class T> __device__ __forceinline__ T dist(T px, T py, T pz, void*) const\n"
-      << "    { return tape_dist<T, 0>(px, py, pz, extra, 0xffffffffu, nullptr); }\n"
-      << "    template <class T> __device__ __forceinline__ sdf::V4<T> eval_kept(T px, T py, T pz, uint32_t keep) const\n"
-      << "    { return tape_eval<T, 0>(px, py, pz, extra, keep, nullptr); }\n"
-      << "    template <class T> __device__ __forceinline__ T dist_kept(T px, T py, T pz, uint32_t keep) const\n"
-      << "    { return tape_dist<T, 0>(px, py, pz, extra, keep, nullptr); }\n"
+      << "    { return tape_dist<T, 0>(px, py, pz, extra, nullptr); }\n"
       // what does not change along z, for kernels that walk bricks along z with x and y fixed (kernels.hpp)
       << "    template <class T> struct Hoisted { T v[kHoisted > 0 ? kHoisted : 1]; };\n"
       << "    template <class T> __device__ __forceinline__ Hoisted<T> hoist(T px, T py) const\n"
-      << "    { Hoisted<T> h; if constexpr (kHoisted > 0) tape_dist<T, 1, 4u>(px, py, sdf::bc<T>(0.0f), extra, 0xffffffffu, h.v); return h; }\n"
+      << "    { Hoisted<T> h; if constexpr (kHoisted > 0) tape_dist<T, 1, 4u>(px, py, sdf::bc<T>(0.0f), extra, h.v); return h; }\n"
       << "    template <class T> __device__ __forceinline__ sdf::V4<T> eval_hoisted(T px, T py, T pz, Hoisted<T>& h) const\n"
-      << "    { return tape_eval<T, (kHoisted > 0 ? 2 : 0), 4u>(px, py, pz, extra, 0xffffffffu, h.v); }\n"
+      << "    { return tape_eval<T, (kHoisted > 0 ? 2 : 0), 4u>(px, py, pz, extra, h.v); }\n"
       << "    template <class T> __device__ __forceinline__ T dist_hoisted(T px, T py, T pz, Hoisted<T>& h) const\n"
-      << "    { return tape_dist<T, (kHoisted > 0 ? 2 : 0), 4u>(px, py, pz, extra, 0xffffffffu, h.v); }\n"
+      << "    { return tape_dist<T, (kHoisted > 0 ? 2 : 0), 4u>(px, py, pz, extra, h.v); }\n"
       // ... and the same for a walk along x with y and z fixed (k_grid_eval_blocks)
       << "    template <class T> __device__ __forceinline__ Hoisted<T> hoist_x(T py, T pz) const\n"
-      << "    { Hoisted<T> h; if constexpr (kHoisted > 0) tape_dist<T, 1, 1u>(sdf::bc<T>(0.0f), py, pz, extra, 0xffffffffu, h.v); return h; }\n"
+      << "    { Hoisted<T> h; if constexpr (kHoisted > 0) tape_dist<T, 1, 1u>(sdf::bc<T>(0.0f), py, pz, extra, h.v); return h; }\n"
       << "    template <class T> __device__ __forceinline__ sdf::V4<T> eval_hoisted_x(T px, T py, T pz, Hoisted<T>& h) const\n"
-      << "    { return tape_eval<T, (kHoisted > 0 ? 2 : 0), 1u>(px, py, pz, extra, 0xffffffffu, h.v); }\n"
+      << "    { return tape_eval<T, (kHoisted > 0 ? 2 : 0), 1u>(px, py, pz, extra, h.v); }\n"
       << "    template <class T> __device__ __forceinline__ T dist_hoisted_x(T px, T py, T pz, Hoisted<T>& h) const\n"
-      << "    { return tape_dist<T, (kHoisted > 0 ? 2 : 0), 1u>(px, py, pz, extra, 0xffffffffu, h.v); }\n"
-      << "    __device__ __forceinline__ uint32_t cull(float cx, float cy, float cz, float hx, float hy, float hz) const\n"
-      << "    { return " << (culling ? "tape_cull(cx, cy, cz, hx, hy, hz, extra)" : "tape_cull_none()") << "; }\n};\n}  // namespace sdfk\n";
+      << "    { return tape_dist<T, (kHoisted > 0 ? 2 : 0), 1u>(px, py, pz, extra, h.v); }\n"
+      << "};\n}  // namespace sdfk\n";
     return o.str();
 }
 

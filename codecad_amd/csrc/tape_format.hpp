@@ -42,10 +42,7 @@ enum Op : uint32_t {
     //   -> extrusion -> from (scale / axis rotation) -> up to two of union | intersection | subtraction -> [store]
     // every part optional except the primitive.  The SAME operations in the same order as the single records (the
     // results are identical); what goes is the dispatch between them: sponge(4) 56 -> 26 records.
-    OPX_LEAF = 43,
-    // A constant result (0, 0, 0, p[0]): the stand-in for a record whose value cannot win the select that takes it
-    // (cull.hpp); only ever in a stand-in program.
-    OPX_CONST = 44
+    OPX_LEAF = 43
 };
 
 // OPX_LEAF parameter layout (16-dword records) and its control word p[kLeafControl]

@@ -11,8 +11,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.normpath(os.path.join(HERE, "..", "csrc"))
 INCLUDE = os.path.normpath(os.path.join(HERE, "..", "..", "include"))
 LIB_PATH = os.path.join(HERE, "libhip_util.so")
-SOURCES = ["hip_util.hip", "sort.hip", "exchange.hip", "mesh.hip"]
-HEADERS = ["interp.hpp", "kernels.hpp", "mesh_kernels.hpp", "mc_table.hpp", "tape.hpp", "tape_format.hpp", "sdf_math.hpp", "specialise.hpp"]
+SOURCES = ["hip_util.hip", "render.hip", "sort.hip", "exchange.hip", "mesh.hip"]
+
+
+def headers():
+    """Every header under csrc/ (a glob, like bench.csrc_hash(): a new header cannot be forgotten here)."""
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp"))
+
 
 # Strict IEEE arithmetic is part of the contract (DESIGN.md "Canonical arithmetic"):
 # no contraction, no fast-math, correctly rounded sqrt/divide.
@@ -21,9 +26,16 @@ HIPCC_FLAGS = [
     "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
     "-Wall", "-Wno-unused-function",
 ]
-# Only for the translation unit that holds the tape interpreter (hip_util.hip).  NOT harmless elsewhere: with
-# -structurizecfg-skip-uniform-regions a divergent loop with a second, uniform exit got its exit-dependent value
-# from a scalar branch (csrc/exchange.hip tells the story), so every other source is compiled without these.
+# Which translation unit carries INTERPRETER_FLAGS, and why.  -structurizecfg-skip-uniform-regions is NOT harmless:
+# it once gave a divergent loop with a second, uniform exit its exit-dependent value from a scalar branch
+# (csrc/exchange.hip tells the story).  So it is confined to ONE unit, hip_util.hip, whose kernels are only
+#   k_grid_eval / k_grid_eval_blocks / k_classify over InterpEval: the interpreter's wave-uniform dispatch loop around
+#   branch-free ops (ops with divergent branches or loops are __noinline__ functions), plus straight-line index
+#   arithmetic, stores and the ballot compaction -- no divergent loop with more than one exit;
+# every other kernel -- ray caster, bitmap, 2D contouring, mass integrals, self-test (render.hip), the exchange step,
+# the sort and marching cubes -- is built without it.  tests/test_hip_util_host.py checks both halves of that from the
+# ISA: which kernels the flagged object holds, and that its loops have the shape described here.
+FLAGGED_SOURCES = ("hip_util.hip",)
 INTERPRETER_FLAGS = [
     # The tape dispatch loop is wave-uniform control flow (scalar branches).  By default the
     # AMDGPU backend still runs StructurizeCFG over it and turns the opcode switch into a
@@ -50,7 +62,7 @@ def is_stale():
     if not os.path.exists(LIB_PATH):
         return True
     built = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(INCLUDE, "hip_util.h"), __file__]
+    deps = [os.path.join(CSRC, f) for f in SOURCES + headers()] + [os.path.join(INCLUDE, "hip_util.h"), __file__]
     return any(os.path.getmtime(d) > built for d in deps)
 
 
@@ -73,7 +85,7 @@ def _compile(LIB_PATH, extra_flags, verbose):
     objects, procs = [], []
     for s in SOURCES:      # one object per source, each with its own flags, compiled side by side
         obj = "%s.%s.o" % (tmp, s)
-        flags = HIPCC_FLAGS + (INTERPRETER_FLAGS if s == "hip_util.hip" else []) + extra_flags
+        flags = HIPCC_FLAGS + (INTERPRETER_FLAGS if s in FLAGGED_SOURCES else []) + extra_flags
         cmd = [hipcc] + flags + ["-I", INCLUDE, "-c", "-o", obj, os.path.join(CSRC, s)]
         objects.append(obj)
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))

@@ -263,9 +263,7 @@ int hu_tape_specialized(hu_tape t, int* out_flag);
 int hu_tape_source(const float* tape, size_t n_floats, char* buf, size_t capacity, size_t* needed);
 /* A readable listing of a tape's decoded programs, one record per line (host only, no device needed): which = 0 the
  * full program, 1 the distance-only program (empty for tapes with a rounded blend), 2 / 3 the same as the
- * interpreter runs them, transformed primitives fused into single records; 4 / 5 = 2 / 3 with what per-brick culling
- * (csrc/cull.hpp; HU_INTERP_CULL=1) adds: the numbers of the plain selects, per record the mask of select operands that
- * must be able to win for the record to run, and per select the Lipschitz sum that decides it.  Same calling convention. */
+ * interpreter runs them, transformed primitives fused into single records.  Same calling convention. */
 int hu_tape_listing(const float* tape, size_t n_floats, int which, char* buf, size_t capacity, size_t* needed);
 /* Compile that source with hipRTC without loading it (host only, no device needed): checks that the
  * op library headers in `include_dir` build under hipRTC and that all ten kernels are present.

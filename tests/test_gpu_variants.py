@@ -27,33 +27,6 @@ def test_forced_variant_matches_oracle(hip, voxels_per_lane, full_interpreter):
     assert " passed" in proc.stdout
 
 
-def test_interpreter_per_brick_culling_matches_oracle(hip):
-    """HU_INTERP_CULL=1: the dense interpreter kernels with per-brick culling (csrc/cull.hpp; off by default, DESIGN.md
-    section 5): tests/test_gpu_culling.py holds the cases (grids whose extents are multiples of 8, coarse to fine),
-    the golden tapes' grid parity runs the same way."""
-    env = dict(os.environ, HU_INTERP_CULL="1")
-    cmd = [sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
-           os.path.join(ROOT, "tests", "test_gpu_culling.py"), os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-k", "grid_eval"]
-    proc = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
-    assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-2000:]
-    assert " passed" in proc.stdout
-
-
-def test_per_brick_culling_matches_oracle(hip):
-    """HU_CULL=1: per-tape code with per-brick culling (specialise.hpp emit_cull; off by default, DESIGN.md
-    section 5) skips operands that cannot win inside a brick; the surviving arithmetic is unchanged, so every
-    parity test of the per-tape code must still hold bit for bit."""
-    env = dict(os.environ, HU_CULL="1")
-    cmd = [sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
-           os.path.join(ROOT, "tests", "test_gpu_random_shapes.py"),
-           os.path.join(ROOT, "tests", "test_gpu_configs.py"),
-           os.path.join(ROOT, "tests", "test_gpu_variants.py"), "-k",
-           "not forced_variant and not per_brick_culling and not code_cache and not tiered"]
-    proc = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
-    assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-2000:]
-    assert " passed" in proc.stdout
-
-
 SPEC_SHAPES = ["sphere_plus_box", "csg_example", "sponge4", "gear", "mirror_3d", "kat_circle", "nonconvex_shell2",
                "torus", "extreme_twisted_revolve", "revolved_pentagon", "rotated_pattern_2d", "planetary"]
 

@@ -389,11 +389,45 @@ def test_interpreter_kernels_keep_their_program_in_scalar_registers(tmp_path):
         scratch = re.search(r"; ScratchSize: (\d+)", chunk)
         assert scratch and int(scratch.group(1)) == 0, m.group(1)
         body = chunk.split(".section")[0]
-        if "k_grid_eval_culled" in m.group(1):
-            # (its vector loads: the brick's keep word and one mask per lane -- not the records)
-            assert len(re.findall(r"\tglobal_load", body)) <= 3 and not re.search(r"\tscratch_", body), m.group(1)
-            assert re.search(r"\ts_load_dwordx(4|8|16)", body), m.group(1)
-        elif "k_grid_eval" in m.group(1) and "blocks" not in m.group(1):
+        if "k_grid_eval" in m.group(1) and "blocks" not in m.group(1):
             assert not re.search(r"\tglobal_load|\tscratch_", body), m.group(1)
             assert re.search(r"\ts_load_dwordx(8|16)", body), m.group(1)
     assert seen >= 20
+    _check_flagged_unit(text)
+
+
+def _check_flagged_unit(text):
+    """The translation unit built with -mllvm -structurizecfg-skip-uniform-regions (builder.FLAGGED_SOURCES).  That option
+    once let a scalar branch choose a per-lane value in a DIVERGENT loop with a second exit (csrc/exchange.hip), so:
+    the unit holds only the grid / leaf-block / classification kernels over the tape interpreter -- the renderers,
+    contouring, reductions, the exchange step, the sort and marching cubes are built without the option --, and no loop
+    of it that wavefront lanes leave one by one (a back edge on EXEC) has another way out."""
+    import re
+    from codecad_amd.hip_util import builder
+    assert tuple(builder.FLAGGED_SOURCES) == ("hip_util.hip",)
+    kernels = re.findall(r"\.amdhsa_kernel (\w+)", text)
+    assert len(kernels) >= 28
+    for k in kernels:
+        assert re.match(r"_ZN4sdfk(11k_grid_eval|18k_grid_eval_blocks|10k_classify)INS_10InterpEval", k), k
+    checked = 0
+    for chunk in re.split(r"\n(?=_Z\w+:\s+; @)", text):
+        m = re.match(r"(_Z\w+):", chunk)
+        if not m:
+            continue
+        lines = chunk.split("\n.Lfunc_end")[0].split("\n")
+        labels = {}
+        for i, line in enumerate(lines):
+            lm = re.match(r"(\.LBB\d+_\d+):", line)
+            if lm:
+                labels[lm.group(1)] = i
+        branches = []
+        for i, line in enumerate(lines):
+            bm = re.match(r"\s+(s_cbranch_\w+|s_branch)\s+(\.LBB\d+_\d+)", line)
+            if bm and bm.group(2) in labels:
+                branches.append((i, bm.group(1), labels[bm.group(2)]))
+        for i, op, target in branches:
+            if target <= i and op in ("s_cbranch_execnz", "s_cbranch_execz"):     # a loop that lanes leave one by one
+                other_exits = [k for k, _, t in branches if target <= k < i and not (target <= t <= i + 1)]
+                assert not other_exits, "%s: a divergent loop with a second exit under -structurizecfg-skip-uniform-regions" % m.group(1)
+                checked += 1
+    assert checked >= 1    # (the gear's bisection, the rounded blend: the check has something to look at)
