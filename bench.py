@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--weak", action="store_true", help="N objects (one per GPU) instead of one object over N GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-leg", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph leg (steps captured once and replayed)")
+    ap.add_argument("--graph", action="store_true", help="run the hipGraph leg on more than one rank too (default: one rank only)")
     ap.add_argument("--n", type=int, default=None, help="grid edge (default: the config's)")
     ap.add_argument("--evaluator", choices=["auto", "specialised", "interpreter"], default="auto",
                     help="auto = per-tape hipRTC specialisation when it builds, else the tape interpreter")
@@ -89,6 +91,12 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
+
+    # ONE line on stdout, whatever the libraries underneath print there (RCCL announces its version on stdout when a
+    # process group comes up): everything else this process writes to file descriptor 1 goes to stderr
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -124,7 +132,9 @@ def main():
     # A and C are enqueued on torch's current stream.  The subdivision (B) is a chain of tiny kernels and
     # (N > 1) all-gathers: latency, not work.  It runs on a second, high-priority stream -- made torch's current
     # stream while it is enqueued, so that the collectives order against it -- and hides behind A; C waits for both.
-    main_stream = torch.cuda.current_stream()
+    # (its own stream, not the legacy default one: a step is also captured into a hipGraph, which the default stream cannot do)
+    main_stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(main_stream)
     stream = main_stream.cuda_stream
     side_stream = torch.cuda.Stream(device=dev, priority=-1)
     side = side_stream.cuda_stream
@@ -158,10 +168,7 @@ def main():
 
     # first capacities: every cell of a level while that is small, else a surface estimate; a traversal that
     # overflows says what it needed (dist.Overflow) and the pipeline is rebuilt -- during warm-up only
-    capacities, parents_bound = [], n_objects
-    for c in cells[:-1]:
-        capacities.append(cc.subdivision.child_capacity(parents_bound, c))
-        parents_bound = capacities[-1]
+    capacities = cc.subdivision.first_capacities(cells[:-1], n_top=n_objects)
     # Two pipelines, taken in turn: the traversal of step k + 1 (latency-bound at 8 GPUs: two levels of classify +
     # all-gather + slice) runs on its stream while step k's leaf blocks are still being evaluated from the other
     # pipeline's list; it only waits for the leaf-block launch that last read ITS list (step k - 1).
@@ -178,14 +185,26 @@ def main():
     warm_events = new_events()
     step_events = [new_events() for _ in range(args.steps)]
 
+    def launch_a():
+        check(lib.hu_grid_eval_slab(tape.device_ptr, corner.ctypes.data_as(fptr), step_f, dims, x0, x1 - x0, 0,
+                                    dense_out.data_ptr(), stream), "hu_grid_eval_slab")
+
+    def launch_c(mine):
+        # the launch is sized for the list's capacity, the length is read on the device
+        cap = int(mine.shape[0]) - 1
+        if leaf_out[0] is None or leaf_out[0].shape[0] < cap:
+            leaf_out[0] = torch.empty((cap, leaf_cells), dtype=torch.float32, device=dev)
+        check(lib.hu_grid_eval_blocks_indirect(tape.device_ptr, mine[1:].data_ptr(), mine.data_ptr(), cap, resolution, origin,
+                                               np.float32(leaf_int_step * resolution), ld, 1, leaf_out[0].data_ptr(), stream),
+              "hu_grid_eval_blocks_indirect")
+
     def one_step(evs, k):
         ev0, ev1, ev2, evb0, evb1, evc0 = evs
         pipe = pipes[k % 2]
         # A
         if dense_leg:
             check(lib.hu_event_record(ev0, stream), "record")
-            check(lib.hu_grid_eval_slab(tape.device_ptr, corner.ctypes.data_as(fptr), step_f, dims, x0, x1 - x0, 0,
-                                        dense_out.data_ptr(), stream), "hu_grid_eval_slab")
+            launch_a()
             check(lib.hu_event_record(ev1, stream), "record")
         # B, concurrently with A, on the side stream
         with torch.cuda.stream(side_stream):
@@ -194,17 +213,40 @@ def main():
             mine = pipe.enqueue()                     # [header | this rank's share of the leaf blocks], all on the device
             check(lib.hu_event_record(evb1, side), "record")
         main_stream.wait_stream(side_stream)
-        # C, after A and B: the launch is sized for the list's capacity, the length is read on the device
-        cap = int(mine.shape[0]) - 1
-        if leaf_out[0] is None or leaf_out[0].shape[0] < cap:
-            leaf_out[0] = torch.empty((cap, leaf_cells), dtype=torch.float32, device=dev)
+        # C, after A and B
         check(lib.hu_event_record(evc0, stream), "record")
-        check(lib.hu_grid_eval_blocks_indirect(tape.device_ptr, mine[1:].data_ptr(), mine.data_ptr(), cap, resolution, origin,
-                                               np.float32(leaf_int_step * resolution), ld, 1, leaf_out[0].data_ptr(), stream),
-              "hu_grid_eval_blocks_indirect")
+        launch_c(mine)
         check(lib.hu_event_record(ev2, stream), "record")
         list_free[k % 2].record(main_stream)          # the traversal after next may overwrite this list once C has read it
         return mine
+
+    def capture_steps(n_steps):
+        """n_steps whole steps -- A, the traversal with its collectives, C -- captured into ONE hipGraph, with the
+        dependencies of the direct form: the traversals run on the side stream beside A and the previous step's C,
+        pipelines taken in turn (traversal k waits for C of step k - 2, which read its lists); each C joins its
+        traversal.  Replaying it costs the host one call per n_steps steps."""
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=main_stream):
+            fork = torch.cuda.Event()
+            fork.record(main_stream)
+            side_stream.wait_event(fork)
+            c_done = []
+            for k in range(n_steps):
+                with torch.cuda.stream(side_stream):
+                    if k >= 2:
+                        side_stream.wait_event(c_done[k - 2])
+                    mine = pipes[k % 2].enqueue()
+                    joined = torch.cuda.Event()
+                    joined.record(side_stream)
+                if dense_leg:
+                    launch_a()
+                main_stream.wait_event(joined)
+                launch_c(mine)
+                done = torch.cuda.Event()
+                done.record(main_stream)
+                c_done.append(done)
+            main_stream.wait_stream(side_stream)
+        return g
 
     def elapsed(a, b):
         ms = ctypes.c_float()
@@ -271,6 +313,39 @@ def main():
     # the timed traversals were not looked at while they ran: validate now (identical work every step)
     for used in (pipes[:1] if args.steps == 1 else pipes):
         assert used.check() == totals, "the timed steps did not reproduce the warm-up traversal"
+
+    # ---- the same steps captured into a hipGraph and replayed (reported beside the headline, never instead of it):
+    # up to eight steps per graph + one graph for the remainder, EXACTLY --steps steps in all; what it shows is the
+    # host's share of a step -- ~25 ctypes / torch calls enqueued directly, one graph launch per eight steps replayed
+    graph_leg = None
+    if not args.no_graph and (world == 1 or args.graph):
+        try:
+            barrier()
+            unit = min(8, args.steps)
+            g_unit = capture_steps(unit)
+            g_rest = capture_steps(args.steps % unit) if args.steps % unit else None
+            g_unit.replay()                               # (warm: the first launch of a graph uploads it)
+            if g_rest is not None:
+                g_rest.replay()
+            barrier()
+            tg = time.perf_counter()
+            for _ in range(args.steps // unit):
+                g_unit.replay()
+            if g_rest is not None:
+                g_rest.replay()
+            g_enqueue = time.perf_counter() - tg
+            barrier()
+            g_wall = time.perf_counter() - tg
+            if world > 1:
+                g_wall = float(dist.allreduce_max(torch.tensor([g_wall], dtype=torch.float64, device=dev)).item())
+            for used in pipes:
+                assert used.check() == totals, "the replayed steps did not reproduce the warm-up traversal"
+            graph_leg = {"captured": True, "steps_per_graph": unit, "steps": args.steps,
+                         "ms_per_step": round(g_wall / args.steps * 1e3, 4),
+                         "host_enqueue_ms_per_step": round(g_enqueue / args.steps * 1e3, 4),
+                         "collectives_in_graph": bool(dist.exchanging())}
+        except Exception as e:   # (a runtime that cannot capture a collective: said, not hidden)
+            graph_leg = {"captured": False, "error": ("%s: %s" % (type(e).__name__, e))[:400]}
 
     # samples of one step over ALL ranks: dense voxels + every classified cell + every leaf sample
     parents_per_level = [n_objects] + totals[:-1]
@@ -360,14 +435,24 @@ def main():
                          "effective_mvoxels_per_s": round(n ** 3 * n_objects / adaptive_ms / 1e3, 1)},
             "roofline": roofline,
         }
+        if graph_leg is not None:
+            if graph_leg.get("captured"):
+                graph_leg["value"] = round(job_samples / graph_leg["ms_per_step"] / 1e3, 1)
+                graph_leg["host_enqueue_ms_per_step_direct"] = line["host_enqueue_ms_per_step"]
+            line["graph_replay"] = graph_leg
+        if dist.exchanging() and world == 1:
+            line["config"]["forced_collectives"] = ("CODECAD_AMD_FORCE_COLLECTIVES=1: one rank, a real process group (backend %s): every "
+                                                    "level goes through all_gather_into_tensor -> hu_slice_rows -> indirect launches"
+                                                    % torch.distributed.get_backend())
         if interp_ms:
             line["interpreter_dense_kernel_ms"] = round(avg(interp_ms), 4)
         if hbm_leg is not None:
             line["roofline_hbm"] = hbm_leg
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(host_tape, n if dense_leg else 512)
-        print(json.dumps(line))
-    if world > 1:
+        real_stdout.write(json.dumps(line) + "\n")
+        real_stdout.flush()
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         dist.barrier()
         torch.distributed.destroy_process_group()
 

@@ -810,7 +810,33 @@ int hu_mass_integrals(const double* parents_dev, const uint32_t* sums_dev, uint3
     if (!out_dev || ((!parents_dev || !sums_dev) && n_parents)) return fail(HU_ERR_BAD_ARG, "NULL argument");
     if (rows == 0 || rows > 65535u) return fail(HU_ERR_BAD_ARG, "rows must be in 1..65535");
     const uint32_t per_row = (n_parents + rows - 1) / rows;   // rows past the end get an empty slice and write zeros
-    HU_HIP(hu_render::mass_integrals((const double4*)parents_dev, sums_dev, n_parents, per_row, s, out_dev, rows, (hipStream_t)stream));
+    HU_HIP(hu_render::mass_integrals((const double4*)parents_dev, sums_dev, n_parents, per_row, nullptr, s, out_dev, rows, (hipStream_t)stream));
+    return HU_OK;
+}
+
+int hu_mass_properties_level_indirect(hu_tape t, const double* parents_dev, const uint32_t* n_parents_dev, uint32_t max_parents, double s,
+                                      const uint32_t dims[3], float step, float threshold, uint32_t* sums_dev,
+                                      uint32_t* counter_dev, double* children_dev, uint32_t capacity, void* stream)
+{
+    if (!t || !sums_dev || !counter_dev || !n_parents_dev || (!children_dev && capacity) || (!parents_dev && max_parents))
+        return fail(HU_ERR_BAD_ARG, "NULL argument");
+    ClassifyArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.parents = parents_dev;
+    a.n_parents_dev = n_parents_dev;
+    a.s = s;
+    a.step = step; a.thr = threshold;
+    a.counter = counter_dev; a.list = children_dev; a.capacity = capacity;
+    a.sums = sums_dev;
+    return launch_classify<true, true>(t, a, max_parents, dims, stream);
+}
+
+int hu_mass_integrals_indirect(const double* parents_dev, const uint32_t* sums_dev, const uint32_t* n_parents_dev, uint32_t max_parents,
+                               double s, double* out_dev, uint32_t rows, void* stream)
+{
+    if (!out_dev || !n_parents_dev || ((!parents_dev || !sums_dev) && max_parents)) return fail(HU_ERR_BAD_ARG, "NULL argument");
+    if (rows == 0 || rows > 65535u) return fail(HU_ERR_BAD_ARG, "rows must be in 1..65535");
+    HU_HIP(hu_render::mass_integrals((const double4*)parents_dev, sums_dev, max_parents, 0u, n_parents_dev, s, out_dev, rows, (hipStream_t)stream));
     return HU_OK;
 }
 

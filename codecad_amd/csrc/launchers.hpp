@@ -23,8 +23,8 @@ hipError_t bitmap(bool distance_only, const sdf::Rec* prog, const float* extra, 
                   float step_size, uint32_t width, uint32_t height, uint8_t* out, uint32_t blocks, uint32_t block, size_t lds,
                   hipStream_t stream);
 hipError_t process_polygon(bool batch, const sdfk::PolygonArgs& a, dim3 grid, hipStream_t stream);
-hipError_t mass_integrals(const double4* parents, const uint32_t* sums, uint32_t n_parents, uint32_t per_row, double s, double* out,
-                          uint32_t rows, hipStream_t stream);
+hipError_t mass_integrals(const double4* parents, const uint32_t* sums, uint32_t n_parents, uint32_t per_row, const uint32_t* n_parents_dev,
+                          double s, double* out, uint32_t rows, hipStream_t stream);
 hipError_t selftest_math(unsigned long long* counts_dev);
 
 }  // namespace hu_render

@@ -24,8 +24,15 @@ namespace {
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024)
 k_mass_integrals(const double4* __restrict__ parents, const uint32_t* __restrict__ sums, uint32_t n, uint32_t per_row,
-                 double s, double* __restrict__ out)
+                 const uint32_t* __restrict__ n_dev, double s, double* __restrict__ out)
 {
+    // indirect form (hu_mass_integrals_indirect): the number of parents lives on the device (at most `n`, the list's
+    // capacity, are there); the slices are cut from it, so the rows mean the same as in the direct form
+    if (n_dev) {
+        const uint32_t have = *n_dev;
+        n = have < n ? have : n;
+        per_row = (n + gridDim.x - 1) / gridDim.x;
+    }
     const uint64_t first = (uint64_t)blockIdx.x * per_row;              // rows past the last parent get an empty slice
     const uint32_t begin = first < n ? (uint32_t)first : n;
     const uint32_t end = (n - begin < per_row) ? n : begin + per_row;
@@ -139,10 +146,10 @@ hipError_t process_polygon(bool batch, const PolygonArgs& a, dim3 grid, hipStrea
     return hipGetLastError();
 }
 
-hipError_t mass_integrals(const double4* parents, const uint32_t* sums, uint32_t n_parents, uint32_t per_row, double s, double* out,
-                          uint32_t rows, hipStream_t stream)
+hipError_t mass_integrals(const double4* parents, const uint32_t* sums, uint32_t n_parents, uint32_t per_row, const uint32_t* n_parents_dev,
+                          double s, double* out, uint32_t rows, hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_mass_integrals, dim3(rows), dim3(1024), 0, stream, parents, sums, n_parents, per_row, s, out);
+    hipLaunchKernelGGL(k_mass_integrals, dim3(rows), dim3(1024), 0, stream, parents, sums, n_parents, per_row, n_parents_dev, s, out);
     return hipGetLastError();
 }
 

@@ -22,12 +22,33 @@ import torch
 import torch.distributed as dist
 
 
+def force_collectives():
+    """CODECAD_AMD_FORCE_COLLECTIVES=1: a single rank still joins a process group and walks the multi-rank path --
+    fixed-size all-gather of its one piece, hu_slice_rows, indirect launches, the final all-reduce -- so that every
+    line of the N > 1 code runs on the one GPU a developer has (same results as the plain path; RCCL is the backend)."""
+    return os.environ.get("CODECAD_AMD_FORCE_COLLECTIVES", "0") == "1"
+
+
+def exchanging():
+    """Do the level exchanges go through collectives?  (more than one rank, or forced with a process group up)"""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or force_collectives()
+
+
 def init(backend=None):
     """Join the process group described by RANK/WORLD_SIZE/MASTER_* (torchrun).  Returns
-    (rank, world).  Single process when WORLD_SIZE is unset or 1."""
+    (rank, world).  Single process when WORLD_SIZE is unset or 1 (unless collectives are forced: then a
+    one-rank group is created, on 127.0.0.1 with a free port when no launcher set the rendezvous up)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    if world <= 1 and not force_collectives():
         return 0, 1
+    if world <= 1 and "MASTER_ADDR" not in os.environ:
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK=os.environ.get("LOCAL_RANK", "0"))
     if not dist.is_initialized():
         if backend is None:
             backend = os.environ.get("CODECAD_AMD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -120,8 +141,7 @@ def allgather_rows(rows, group=None, hint=None, return_counts=False):
 
 
 def allreduce_sum(t, group=None):
-    _, world = rank_world()
-    if world > 1:
+    if exchanging():
         if t.device.type != "cpu" and _host_staged():
             c = t.cpu()
             dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
@@ -132,8 +152,7 @@ def allreduce_sum(t, group=None):
 
 
 def allreduce_max(t, group=None):
-    _, world = rank_world()
-    if world > 1:
+    if exchanging():
         if t.device.type != "cpu" and _host_staged():
             c = t.cpu()
             dist.all_reduce(c, op=dist.ReduceOp.MAX, group=group)
@@ -144,8 +163,7 @@ def allreduce_max(t, group=None):
 
 
 def barrier():
-    _, world = rank_world()
-    if world > 1:
+    if exchanging():
         dist.barrier()
 
 
@@ -214,8 +232,9 @@ class LevelPipeline:
     the gathered lists -- is what a step consists of (a 512^3 level is ~10 us of kernel per rank).  Here every
     list is a fixed-capacity device buffer [header row | rows...] whose header holds its length:
 
-      classify(level)  counts into the header of `send[level]`, appends to its rows   (hu_subdivision_level_indirect)
-      all-gather       of the whole fixed-size piece, one collective, no sizes on the host        (world > 1)
+      classify(level)  counts into the header of `send[level]`, appends to its rows   (hu_subdivision_level_indirect,
+                                                                                        hu_mass_properties_level_indirect)
+      all-gather       of the whole fixed-size piece, one collective, no sizes on the host     (when `exchanging()`)
       slice            the rank's balanced share of the concatenation -> `mine[level]`, again
                        [header | rows], on the device                                             (hu_slice_rows)
       next level       reads its parent count from that header; its launch is sized for the capacity.
@@ -224,38 +243,48 @@ class LevelPipeline:
     afterwards (`check`): a list that outgrew its capacity raises Overflow with the sizes needed.  Capacities
     are per level: survivors PER RANK, hence also an upper bound of a rank's share.
 
+    Rows are int32 words (k = 4: the 16-byte rows of subdivision; k = 8: the 32-byte rows of mass properties, four
+    doubles seen as words), so the header's count is the uint32 the kernels read, whatever the rows hold.
+
     `classify(level, parents, n_parents, max_parents, out)`: parents = (max_parents, k) tensor of rows,
     n_parents = the 1-element view of the header holding their count, out = the (capacity + 1, k) buffer to
-    count into / append to (header already zeroed).  For the HIP path see `subdivision_pipeline`."""
+    count into / append to (header already zeroed).  For the HIP path see `subdivision_pipeline`, `mass_pipeline`."""
 
-    def __init__(self, top_rows, capacities, classify, slice_rows=None, device=None):
+    def __init__(self, top_rows, capacities, classify, slice_rows=None, device=None, stream=None):
+        assert top_rows.dtype == torch.int32, "rows are int32 words (view 32-byte double rows as (n, 8) int32)"
         self.rank, self.world = rank_world()
+        self.exchange = exchanging()
         self.classify = classify
         self.slice_rows = slice_rows or slice_rows_reference
         self.capacities = [int(c) for c in capacities]
         device = device if device is not None else top_rows.device
+        self.device, self.stream = device, stream
         k = int(top_rows.shape[1])
         begin, end = balanced_slice(int(top_rows.shape[0]), self.rank, self.world)   # the top list is host knowledge
-        self.top = torch.zeros((max(end - begin, 1) + 1, k), dtype=top_rows.dtype, device=device)
+        self.top = torch.zeros((max(end - begin, 1) + 1, k), dtype=torch.int32, device=device)
         self.top[0, 0] = end - begin
         self.top[1:1 + end - begin] = top_rows[begin:end]
         self.top_max = max(end - begin, 1)
-        self.send = [torch.zeros((c + 1, k), dtype=top_rows.dtype, device=device) for c in self.capacities]
+        self.send = [torch.zeros((c + 1, k), dtype=torch.int32, device=device) for c in self.capacities]
         self.gathered = self.mine = self.stats = None
-        if self.world > 1:
-            self.gathered = [torch.zeros((self.world, c + 1, k), dtype=top_rows.dtype, device=device) for c in self.capacities]
-            self.mine = [torch.zeros((c + 1, k), dtype=top_rows.dtype, device=device) for c in self.capacities]
+        if self.exchange:
+            self.gathered = [torch.zeros((self.world, c + 1, k), dtype=torch.int32, device=device) for c in self.capacities]
+            self.mine = [torch.zeros((c + 1, k), dtype=torch.int32, device=device) for c in self.capacities]
             self.stats = torch.zeros((len(self.capacities), 2), dtype=torch.int32, device=device)
 
     def enqueue(self):
         """Enqueue the whole traversal on the current stream.  Returns the buffer [header | rows] holding this
-        rank's share of the last level's survivors (world 1: all of them)."""
+        rank's share of the last level's survivors (no exchange: all of them)."""
+        if self.exchange and self.stream is not None and torch.device(self.device).type == "cuda":
+            # the kernels go to a raw hipStream_t, the collectives to torch's current stream: they must be the same one
+            assert self.stream == torch.cuda.current_stream(self.device).cuda_stream, \
+                "LevelPipeline.enqueue: make the pipeline's stream torch's current stream (torch.cuda.stream(...))"
         parents, max_parents = self.top, self.top_max
         for level, capacity in enumerate(self.capacities):
             out = self.send[level]
             out[:1].zero_()
             self.classify(level, parents[1:], parents[0, :1], max_parents, out)
-            if self.world == 1:
+            if not self.exchange:
                 parents = out
             else:
                 g = self.gathered[level]
@@ -279,7 +308,7 @@ class LevelPipeline:
             self.needed = []
             return []
         own = [int(b[0, 0].item()) for b in self.send]       # synchronises
-        if self.world == 1:
+        if not self.exchange:
             totals, needed = own, own
         else:
             st = self.stats.cpu().tolist()
@@ -292,11 +321,19 @@ class LevelPipeline:
         return totals
 
 
+def _hip_slice_rows(lib, check, stream):
+    def slice_rows(gathered, rank, out, stats):
+        check(lib.hu_slice_rows(gathered.data_ptr(), int(gathered.shape[0]), int(gathered.shape[1]),
+                                int(gathered.shape[2]) * gathered.element_size(), rank, out.data_ptr(), int(out.shape[0]) - 1,
+                                stats.data_ptr(), stream), "hu_slice_rows")
+    return slice_rows
+
+
 def subdivision_pipeline(tape, levels, resolution, origin, dimension, capacities, device, stream, top_rows=None):
     """A LevelPipeline over the HIP kernels: `levels` as calculate_block_sizes returns them (the leaf level,
     the last one, is left to the consumer like in subdivision_device), `origin` the box corner.  The launches
-    go to `stream` (a raw hipStream_t; it must be the current torch stream when world > 1, the collectives
-    follow that)."""
+    go to `stream` (a raw hipStream_t; it must be the current torch stream when the levels are exchanged, the
+    collectives follow that: LevelPipeline.enqueue asserts it)."""
     import ctypes
     import math
     import numpy
@@ -315,14 +352,70 @@ def subdivision_pipeline(tape, levels, resolution, origin, dimension, capacities
                                                 numpy.float32(thr), out.data_ptr(), out[1:].data_ptr(), int(out.shape[0]) - 1,
                                                 stream), "hu_subdivision_level_indirect")
 
-    def slice_rows(gathered, rank, out, stats):
-        check(lib.hu_slice_rows(gathered.data_ptr(), int(gathered.shape[0]), int(gathered.shape[1]),
-                                int(gathered.shape[2]) * gathered.element_size(), rank, out.data_ptr(), int(out.shape[0]) - 1,
-                                stats.data_ptr(), stream), "hu_slice_rows")
-
     if top_rows is None:
         top_rows = torch.zeros((1, 4), dtype=torch.int32, device=device)
-    return LevelPipeline(top_rows, capacities, classify, slice_rows, device)
+    return LevelPipeline(top_rows, capacities, classify, _hip_slice_rows(lib, check, stream), device, stream)
+
+
+class MassPipeline:
+    """mass_properties over the ranks without a host round trip inside the traversal: a LevelPipeline whose rows are
+    the 32-byte `double[4]` rows of hu_mass_properties_level_indirect (seen as eight int32 words), every level also
+    reducing its inside cells' ten integrals on the device (hu_mass_integrals_indirect) into its own small buffer.
+    `enqueue()` puts the whole integration on the stream; `finish()` waits once, validates the lists (Overflow ->
+    rebuild with larger ones, every rank alike) and returns this rank's ten partial integrals, a (10,) float64 tensor
+    on the device, for ONE all-reduce.  `levels` = [(cell size, dims)], the last one being the leaf level."""
+
+    def __init__(self, tape, levels, box_a, capacities, device, stream):
+        import ctypes
+        import math
+        import numpy
+        from .hip_util import manager as hip_manager, check
+        from .mass_properties import integral_rows
+
+        lib = hip_manager.lib
+        self.levels, self.device = levels, device
+        capacities = list(capacities) + [0]     # the leaf level lists nothing
+        top = torch.zeros((1, 4), dtype=torch.float64, device=device)
+        top[0, :3] = torch.tensor([float(v) for v in box_a], dtype=torch.float64)
+        # what a level's launches read and write besides the lists: index sums per parent, the integrals' rows
+        self.sums, self.pieces = [], []
+        max_parents = 1
+        for capacity in capacities:
+            self.sums.append(torch.zeros((max_parents, 10), dtype=torch.int32, device=device))
+            self.pieces.append(torch.zeros((integral_rows(max_parents), 10), dtype=torch.float64, device=device))
+            max_parents = max(capacity, 1)
+
+        def classify(level, parents, n_parents, max_parents, out):
+            s, dims = levels[level]
+            leaf = level + 1 == len(levels)
+            thr = 0.0 if leaf else s * math.sqrt(3) / 2
+            d = (ctypes.c_uint32 * 3)(int(dims[0]), int(dims[1]), int(dims[2]))
+            sums, pieces = self.sums[level], self.pieces[level]
+            assert int(sums.shape[0]) >= int(max_parents)
+            sums.zero_()
+            check(lib.hu_mass_properties_level_indirect(tape.device_ptr, parents.data_ptr(), n_parents.data_ptr(), int(max_parents),
+                                                        float(s), d, numpy.float32(s), numpy.float32(thr), sums.data_ptr(),
+                                                        out.data_ptr(), out[1:].data_ptr(), int(out.shape[0]) - 1, stream),
+                  "hu_mass_properties_level_indirect")
+            check(lib.hu_mass_integrals_indirect(parents.data_ptr(), sums.data_ptr(), n_parents.data_ptr(), int(max_parents), float(s),
+                                                 pieces.data_ptr(), int(pieces.shape[0]), stream), "hu_mass_integrals_indirect")
+
+        self.pipe = LevelPipeline(top.view(torch.int32).reshape(1, 8), capacities, classify, _hip_slice_rows(lib, check, stream),
+                                  device, stream)
+
+    def enqueue(self):
+        self.pipe.enqueue()
+
+    def finish(self):
+        """-> (this rank's (10,) partial integrals, global ambiguous-cell count per level)"""
+        try:
+            totals = self.pipe.check()
+        except Overflow as e:
+            raise Overflow(e.needed[:-1])       # (the leaf level's "list" has no capacity to speak of)
+        partial = torch.zeros(10, dtype=torch.float64, device=self.device)
+        for pieces in self.pieces:
+            partial = partial + pieces.sum(dim=0)     # a fixed reduction over <= 64 rows per level
+        return partial, totals[:-1]
 
 
 def integrate_levels(top_parents, n_levels, level_fn):
@@ -350,69 +443,43 @@ def integrate_levels(top_parents, n_levels, level_fn):
 
 
 def mass_properties(shape, resolution, grid_size=None):
-    """`codecad_amd.mass_properties` sharded over the ranks of the process group (one GPU each): every
-    level's parent list is cut into balanced slices, `hu_mass_properties_level` + `hu_mass_integrals` run
-    on the slice, ambiguous cells are all-gathered, the ten integrals all-reduced once.  Same volume,
-    centroid and inertia as the single-GPU driver up to the order of the fp64 sums (~1e-15 relative)."""
-    import ctypes
-    import math
-    import numpy
+    """`codecad_amd.mass_properties` sharded over the ranks of the process group (one GPU each): every level's parent
+    list is cut into balanced slices, `hu_mass_properties_level_indirect` + `hu_mass_integrals_indirect` run on the
+    slice, the ambiguous cells go through ONE fixed-size all-gather per level and `hu_slice_rows`, the ten integrals are
+    all-reduced once -- the whole integration enqueued without a host round trip (MassPipeline).  Same volume, centroid
+    and inertia as the single-GPU driver up to the order of the fp64 sums (~1e-15 relative)."""
     from . import nodes, subdivision
-    from .mass_properties import finish, integral_rows, _KEYS   # (the package attribute of that name is the function)
-    from .hip_util import manager as hip_manager, check
+    from .mass_properties import finish, _KEYS   # (the package attribute of that name is the function)
+    from .hip_util import manager as hip_manager
 
     if grid_size is None:
         grid_size = 64
     assert shape.dimension() == 3 and resolution > 0 and grid_size > 1 and grid_size ** 5 <= 2 ** 32
     device = torch.device("cuda", local_device())
     hip_manager.use_device(device.index)
-    lib = hip_manager.lib
     stream = torch.cuda.current_stream(device).cuda_stream
     tape = nodes.make_program_buffer(shape)
     box = shape.bounding_box()
     levels = [(resolution * cell, tuple(int(v) for v in dims)) for cell, dims in
               subdivision.calculate_block_sizes(box, 3, resolution, grid_size, overlap=False)]
-    counter = torch.zeros(1, dtype=torch.int32, device=device)
-
-    def level_fn(level, parents):
-        s, dims = levels[level]
-        leaf = level + 1 == len(levels)
-        n = int(parents.shape[0])
-        partial = torch.zeros(10, dtype=torch.float64, device=device)
-        if n == 0:
-            return parents[:0], partial
-        parents = parents.contiguous()
-        cells = dims[0] * dims[1] * dims[2]
-        thr = 0.0 if leaf else s * math.sqrt(3) / 2
-        d = (ctypes.c_uint32 * 3)(*dims)
-        capacity = 0 if leaf else subdivision.child_capacity(n, cells)
-        while True:
-            children = torch.empty((max(capacity, 1), 4), dtype=torch.float64, device=device)
-            sums = torch.zeros((n, 10), dtype=torch.int32, device=device)
-            counter.zero_()
-            check(lib.hu_mass_properties_level(tape.device_ptr, parents.data_ptr(), n, float(s), d, numpy.float32(s),
-                                               numpy.float32(thr), sums.data_ptr(), counter.data_ptr(),
-                                               children.data_ptr(), capacity, stream), "hu_mass_properties_level")
-            count = int(counter.item())
-            if leaf or count <= capacity:
-                break
-            capacity = count
-        rows = integral_rows(n)
-        pieces = torch.empty((rows, 10), dtype=torch.float64, device=device)
-        check(lib.hu_mass_integrals(parents.data_ptr(), sums.data_ptr(), n, float(s), pieces.data_ptr(), rows, stream),
-              "hu_mass_integrals")
-        partial = pieces.sum(dim=0)     # a fixed reduction over <= 64 rows
-        return children[:0 if leaf else count], partial
-
-    top = torch.tensor([[box.a.x, box.a.y, box.a.z, 0.0]], dtype=torch.float64, device=device)
-    totals = integrate_levels(top, len(levels), level_fn)
+    cells = [d[0] * d[1] * d[2] for _, d in levels]
+    capacities = subdivision.first_capacities(cells[:-1], row_bytes=32 + 40)
+    while True:
+        pipe = MassPipeline(tape, levels, (box.a.x, box.a.y, box.a.z), capacities, device, stream)
+        pipe.enqueue()
+        try:
+            partial, _ = pipe.finish()
+            break
+        except Overflow as e:     # every rank sees the same sizes: all rebuild together
+            capacities = [subdivision.checked_capacity(max(int(v * 1.125) + 16, c)) for v, c in zip(e.needed, capacities)]
+    totals = allreduce_sum(partial)
     return finish(dict(zip(_KEYS, totals.tolist())))
 
 
 def subdivision(shape, resolution, overlap_edge_samples=True, grid_size=None):
     """`codecad_amd.subdivision.subdivision_device` sharded over the ranks of the process group: every
-    level's parent list is cut into balanced slices, `hu_subdivision_level` classifies and compacts the
-    slice, the survivors are all-gathered.  Returns (leaves, info): `leaves` an (n, 4) int32 device tensor of
+    level's parent list is cut into balanced slices, `hu_subdivision_level_indirect` classifies and compacts the
+    slice, the survivors go through one fixed-size all-gather and `hu_slice_rows` (LevelPipeline).  Returns (leaves, info): `leaves` an (n, 4) int32 device tensor of
     integer leaf corners, identical (as a set; ordered by rank slice) on every rank, and `info` with
     `dims`, `int_step`, `step`, `resolution`, `origin`, `level_counts` like LeafBlocks, plus `share`: this rank's
     balanced share of the leaves (what a sharded consumer evaluates, e.g. hu_grid_eval_blocks: bench.py step C)."""
@@ -435,10 +502,7 @@ def subdivision(shape, resolution, overlap_edge_samples=True, grid_size=None):
     # the whole traversal is enqueued without a host round trip (LevelPipeline); the list capacities start at the
     # single-GPU driver's first guess and grow to what an overflowing traversal reports
     cells = [int(d[0]) * int(d[1]) * int(d[2]) for _, d in levels]
-    capacities, bound = [], 1
-    for c in cells[:-1]:
-        capacities.append(sub.child_capacity(bound, c))
-        bound = capacities[-1]
+    capacities = sub.first_capacities(cells[:-1])
     while True:
         pipe = subdivision_pipeline(tape, levels, resolution, (box.a.x, box.a.y, box.a.z), dimension, capacities, device, stream)
         mine = pipe.enqueue()
@@ -446,9 +510,15 @@ def subdivision(shape, resolution, overlap_edge_samples=True, grid_size=None):
             counts = pipe.check()
             break
         except Overflow as e:
-            capacities = [max(int(v * 1.125) + 16, c) for v, c in zip(e.needed, capacities)]
-    share = mine[1:1 + int(mine[0, 0])] if len(levels) > 1 else torch.zeros((1, 4), dtype=torch.int32, device=device)
-    leaves = allgather_rows(share) if len(levels) > 1 else share
+            capacities = [sub.checked_capacity(max(int(v * 1.125) + 16, c)) for v, c in zip(e.needed, capacities)]
+    # tighten: the lists of a traversal that is repeated (bench.py does) need not stay at their first guesses
+    if len(levels) > 1:
+        share = mine[1:1 + int(mine[0, 0])]
+        leaves = allgather_rows(share)
+    else:
+        # the whole shape is one leaf block: it is rank 0's, the other ranks' shares are empty
+        leaves = torch.zeros((1, 4), dtype=torch.int32, device=device)
+        share = leaves if pipe.rank == 0 else leaves[:0]
     leaf_int_step, leaf_dims = levels[-1]
     info = {"tape": tape, "dims": leaf_dims, "int_step": leaf_int_step, "step": leaf_int_step * resolution,
             "resolution": resolution, "origin": box.a, "level_counts": counts, "share": share}

@@ -52,6 +52,8 @@ PROTOTYPES = {
     "hu_slice_rows": [_vp, _u32, _u32, _u32, _u32, _vp, _u32, _vp, _vp],
     "hu_mass_properties_level": [_vp, _vp, _u32, _d, _u3, _f, _f, _vp, _vp, _vp, _u32, _vp],
     "hu_mass_integrals": [_vp, _vp, _u32, _d, _vp, _u32, _vp],
+    "hu_mass_properties_level_indirect": [_vp, _vp, _vp, _u32, _d, _u3, _f, _f, _vp, _vp, _vp, _u32, _vp],
+    "hu_mass_integrals_indirect": [_vp, _vp, _vp, _u32, _d, _vp, _u32, _vp],
     "hu_ray_caster": [_vp, _f4, _f4, _f4, _f4, _f, _f, _f, _f, _f, _u32, _u32, _u32, _vp, _vp],
     "hu_bitmap": [_vp, _f4, _f, _u32, _u32, _vp, _vp],
     "hu_process_polygon": [_f4, _f, _vp, _u3, _vp, _vp, _vp, _vp, _vp],

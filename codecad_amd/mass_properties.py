@@ -5,10 +5,11 @@ inertia_tensor)` with the reference's semantics (reference mass_properties.py:30
 provably inside contribute closed-form moments of their integer indices, ambiguous cells are
 subdivided, the finest level classifies by the sign at the cell centre.
 
-Device side: one launch per LEVEL (`hu_mass_properties_level`) instead of one per block with
-three fresh allocations and two blocking reads each (reference :75-114); per-parent moment
+Device side: one launch per LEVEL (`hu_mass_properties_level_indirect`) instead of one per block with
+three fresh allocations and two blocking reads each (reference :75-114), all levels enqueued back to
+back with their list lengths on the device and ONE synchronisation at the end; per-parent moment
 sums stay uint32 exactly like the reference's kernel so the integers are identical, and the
-fp64 conversion below applies the same formulas (reference :119-148) to whole arrays.
+fp64 conversion (`hu_mass_integrals_indirect`) applies the same formulas (reference :119-148).
 """
 import collections
 import ctypes
@@ -85,39 +86,52 @@ def finish(total):
     return MassProperties(volume, c, tensor)
 
 
-def level_integrals(tape, parents, n_parents, s, dims, leaf, queue, counter):
-    """Launch one level; returns (integral dict, children Buffer, child count)."""
+def _enqueue_levels(tape, levels, box_a, capacities, queue):
+    """Every level of the integration enqueued back to back, no host round trip between them: a list is a
+    `[header row | rows...]` buffer of 32-byte rows whose header word 0 is its length; a level counts its ambiguous cells
+    into the header of its child list, the next launch -- sized for the capacity -- reads its parent count from there
+    (`hu_mass_properties_level_indirect`), and the level's ten integrals are reduced on the device from the same count
+    (`hu_mass_integrals_indirect`).  The reference waits for the host after every block (mass_properties.py:98-114).
+    Returns (survivor count per level, [rows x 10 array of integrals per level]) after ONE synchronisation; a count
+    above its capacity means "repeat with larger lists"."""
     lib = hip_manager.lib
-    cells = int(dims[0]) * int(dims[1]) * int(dims[2])
-    thr = 0.0 if leaf else s * math.sqrt(3) / 2  # reference mass_properties.py:87-90
-    d = (ctypes.c_uint32 * 3)(int(dims[0]), int(dims[1]), int(dims[2]))
-    sums = hip_util.Buffer(numpy.uint32, (n_parents, 10), queue=queue)
-    capacity = 0 if leaf else subdivision.child_capacity(n_parents, cells)
-    # the ten integrals of this level are reduced on the device, one row per slice of ~2048 parents: at most
-    # 5 KB come back, and the rows are added here in order (deterministic whatever the launch did)
-    rows = integral_rows(n_parents)
-    out = hip_util.Buffer(numpy.float64, (rows, 10), queue=queue)
-    while True:
-        children = hip_util.Buffer(numpy.float64, (max(capacity, 1), 4), queue=queue)
-        sums.enqueue_fill(0)
-        counter.enqueue_fill(0)
-        tape.note_samples(n_parents * cells)
-        check(lib.hu_mass_properties_level(tape.device_ptr, parents.device_ptr, n_parents, float(s), d,
-                                           numpy.float32(s), numpy.float32(thr), sums.device_ptr,
-                                           counter.device_ptr, children.device_ptr, capacity, queue.handle),
-              "hu_mass_properties_level")
-        # enqueued before the host waits for the counter: the reduction runs during that round trip
-        check(lib.hu_mass_integrals(parents.device_ptr, sums.device_ptr, n_parents, float(s), out.device_ptr, rows,
-                                    queue.handle), "hu_mass_integrals")
-        count = int(counter.read()[0])
-        if count <= capacity or leaf:
+    top = hip_util.Buffer(numpy.float64, (2, 4), queue=queue)
+    first = numpy.zeros((2, 4), dtype=numpy.float64)
+    first.view(numpy.uint32)[0, 0] = 1
+    first[1, :3] = box_a
+    top.enqueue_write(first)
+    parents, max_parents = top, 1
+    buffers, heads, partials = [top], [], []
+    for i, (s, dims) in enumerate(levels):
+        leaf = i == len(levels) - 1
+        capacity = 0 if leaf else capacities[i]
+        thr = 0.0 if leaf else s * math.sqrt(3) / 2  # reference mass_properties.py:87-90
+        d = (ctypes.c_uint32 * 3)(int(dims[0]), int(dims[1]), int(dims[2]))
+        children = hip_util.Buffer(numpy.float64, (capacity + 1, 4), queue=queue)
+        sums = hip_util.Buffer(numpy.uint32, (max_parents, 10), queue=queue)
+        rows = integral_rows(max_parents)
+        out = hip_util.Buffer(numpy.float64, (rows, 10), queue=queue)
+        check(lib.hu_memset(children.device_ptr, 0, 32, queue.handle), "hu_memset")
+        check(lib.hu_memset(sums.device_ptr, 0, max_parents * 40, queue.handle), "hu_memset")
+        check(lib.hu_mass_properties_level_indirect(tape.device_ptr, parents.device_ptr + 32, parents.device_ptr, max_parents, float(s), d,
+                                                    numpy.float32(s), numpy.float32(thr), sums.device_ptr, children.device_ptr,
+                                                    children.device_ptr + 32, capacity, queue.handle),
+              "hu_mass_properties_level_indirect")
+        check(lib.hu_mass_integrals_indirect(parents.device_ptr + 32, sums.device_ptr, parents.device_ptr, max_parents, float(s),
+                                             out.device_ptr, rows, queue.handle), "hu_mass_integrals_indirect")
+        head, part = numpy.zeros(8, dtype=numpy.uint32), numpy.zeros((rows, 10), dtype=numpy.float64)
+        check(lib.hu_memcpy_d2h(head.ctypes.data, children.device_ptr, 32, queue.handle), "hu_memcpy_d2h")
+        check(lib.hu_memcpy_d2h(part.ctypes.data, out.device_ptr, part.nbytes, queue.handle), "hu_memcpy_d2h")
+        heads.append(head)
+        partials.append(part)
+        buffers += [children, sums, out]
+        if leaf:
             break
-        children.release()
-        capacity = count
-    values = [math.fsum(column) for column in out.read().T.tolist()]
-    sums.release()
-    out.release()
-    return dict(zip(_KEYS, values)), children, (0 if leaf else count)
+        parents, max_parents = children, capacity
+    queue.synchronize()
+    for b in buffers:
+        b.release()
+    return [int(h[0]) for h in heads], partials
 
 
 def integral_rows(n_parents):
@@ -138,26 +152,27 @@ def mass_properties(shape, resolution, grid_size=None):
     box = shape.bounding_box()
     levels = [(resolution * cell, dims) for cell, dims in
               subdivision.calculate_block_sizes(box, 3, resolution, grid_size, overlap=False)]
-
-    parents = hip_util.Buffer(numpy.float64, (1, 4), queue=queue)
-    parents.enqueue_write(numpy.array([[box.a.x, box.a.y, box.a.z, 0.0]], dtype=numpy.float64))
-    counter = hip_util.Buffer(numpy.uint32, 1, queue=queue)
-    total = {k: util.KahanSummation() for k in _KEYS}
-    count = 1
-    stats = {"kernel_invocations": 0, "function_evaluations": 0}
-    for i, (s, dims) in enumerate(levels):
-        leaf = (i == len(levels) - 1)
-        stats["kernel_invocations"] += 1
-        stats["function_evaluations"] += count * int(dims[0]) * int(dims[1]) * int(dims[2])
-        part, children, n_children = level_integrals(tape, parents, count, s, dims, leaf, queue, counter)
-        for k in total:
-            total[k] += part[k]
-        parents.release()
-        parents, count = children, n_children
-        if count == 0:
+    cells = [int(d[0]) * int(d[1]) * int(d[2]) for _, d in levels]
+    # the whole hierarchy is enqueued at once (device-counted lists); it is repeated with the sizes it reported when a
+    # list was too short -- the first guesses are generous, so that is rare
+    capacities = subdivision.first_capacities(cells[:-1], row_bytes=32 + 40)
+    while True:
+        counts, partials = _enqueue_levels(tape, levels, (box.a.x, box.a.y, box.a.z), capacities, queue)
+        if all(n <= c for n, c in zip(counts, capacities)):
             break
-    parents.release()
-    counter.release()
+        capacities = [subdivision.checked_capacity(max(c, int(n * 1.125) + 16)) for n, c in zip(counts, capacities)]
+    total = {k: util.KahanSummation() for k in _KEYS}
+    stats = {"kernel_invocations": 0, "function_evaluations": 0}
+    parents_n = 1
+    for i, part in enumerate(partials):
+        stats["kernel_invocations"] += 1
+        stats["function_evaluations"] += parents_n * cells[i]
+        tape.note_samples(parents_n * cells[i])
+        for k, column in zip(_KEYS, part.T.tolist()):   # the rows of a level are added in order: deterministic
+            total[k] += math.fsum(column)
+        parents_n = counts[i] if i < len(counts) else 0
+        if parents_n == 0:
+            break
     result = finish({k: v.result for k, v in total.items()})
     mass_properties.last_stats = stats
     return result

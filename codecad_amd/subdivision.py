@@ -15,6 +15,7 @@ converts the final list to the reference's tuples.
 """
 import ctypes
 import math
+import os
 
 import numpy
 
@@ -114,6 +115,36 @@ def child_capacity(n_parents, cells):
     return min(upper, max(1 << 21, 4 * int(n_parents) * int(round(cells ** (2.0 / 3.0)))))
 
 
+def checked_capacity(rows):
+    """A list capacity as the C ABI takes it (uint32).  Lists that long cannot be launched in one piece anyway."""
+    rows = int(rows)
+    if rows >= 2 ** 32 - 1:
+        raise MemoryError("a level's list would hold %d rows: more than the 32-bit list lengths of the device code "
+                          "(use a coarser resolution or a larger grid_size)" % rows)
+    return rows
+
+
+def list_budget_rows(row_bytes):
+    """Rows a FIRST-GUESS list may hold: CODECAD_AMD_LIST_BUDGET_MB (default 64 MiB) per list, at least 65 536 rows."""
+    budget = int(float(os.environ.get("CODECAD_AMD_LIST_BUDGET_MB", "64")) * (1 << 20))
+    return max(1 << 16, budget // int(row_bytes))
+
+
+def first_capacities(cells_per_level, n_top=1, row_bytes=16):
+    """First guesses for the lists of a device-counted traversal, one per classified level.  Chained from level to
+    level like the per-level driver's sizes, but every guess is capped by a memory budget: the chain runs on
+    CAPACITIES (the counts are not known before the traversal has run), so uncapped it compounds -- 1/8192 at grid 16
+    asked for a 1.7 GB list, 1/40000 for 32 GB, where the per-level driver sized each list from the count before it.
+    A traversal that overflows a guess reports what it needed and is repeated with that (Overflow / the drivers'
+    retry loops), so a tight cap costs one repeat, never a wrong result."""
+    cap_rows = list_budget_rows(row_bytes)
+    capacities, bound = [], int(n_top)
+    for c in cells_per_level:
+        capacities.append(checked_capacity(min(child_capacity(bound, c), cap_rows)))
+        bound = capacities[-1]
+    return capacities
+
+
 def _level_launch(tape, parents, n_parents, int_step, dims, dimension, resolution, origin, counter, queue,
                   capacity_hint=None):
     """Run one level, growing the child list until everything fits.  Returns (children, count)."""
@@ -195,17 +226,15 @@ def subdivision_device(shape, resolution, overlap_edge_samples=True, grid_size=N
 
     # first sizes as before (every cell while that is small, else the surface estimate); the whole traversal is
     # repeated with the sizes it reported when a list was too short (fractal shapes keep most cells: rare)
-    capacities, bound = [], 1
-    for c in cells[:-1]:
-        capacities.append(child_capacity(bound, c))
-        bound = capacities[-1]
+    capacities = first_capacities(cells[:-1])
     while True:
         buffers, counts = _traverse_device_counted(tape, levels, dimension, resolution, box.a, capacities, queue)
         if all(n <= c for n, c in zip(counts, capacities)):
             break
         for b in buffers:
             b.release()
-        capacities = [max(c, int(n * 1.125) + 16) for n, c in zip(counts, capacities)]
+        # (a level behind an overflowed one saw only the parents that fitted: its count may still grow next time)
+        capacities = [checked_capacity(max(c, int(n * 1.125) + 16)) for n, c in zip(counts, capacities)]
     level_counts, samples, parents_n = [], 0, 1
     for n, c in zip(counts, cells[:-1]):
         samples += parents_n * c

@@ -164,6 +164,18 @@ int hu_mass_properties_level(hu_tape t, const double* parents_dev, uint32_t n_pa
 int hu_mass_integrals(const double* parents_dev, const uint32_t* sums_dev, uint32_t n_parents, double s,
                       double* out_dev, uint32_t rows, void* stream);
 
+/* The two above with the number of parents ON THE DEVICE (the launches cover max_parents, the list's capacity), so
+ * that mass_properties() enqueues all its levels without a host round trip, like hu_subdivision_level_indirect:
+ * counter_dev = word 0 of the children's [header row | rows...] buffer (32-byte rows), children_dev its row 1; the
+ * caller zeroes sums_dev for max_parents parents and checks counter <= capacity once, at the end.  The integrals'
+ * rows are cut from the actual count: the same slices as hu_mass_integrals(n_parents = the count). */
+int hu_mass_properties_level_indirect(hu_tape t, const double* parents_dev, const uint32_t* n_parents_dev,
+                                      uint32_t max_parents, double s, const uint32_t dims[3], float step,
+                                      float threshold, uint32_t* sums_dev, uint32_t* counter_dev,
+                                      double* children_dev, uint32_t capacity, void* stream);
+int hu_mass_integrals_indirect(const double* parents_dev, const uint32_t* sums_dev, const uint32_t* n_parents_dev,
+                               uint32_t max_parents, double s, double* out_dev, uint32_t rows, void* stream);
+
 /* ---- renderers on the same evaluate() -------------------- */
 /* rendering/ray_caster.cl:146-159, launched by rendering/ray_caster.py:93-110 with global size
  * (width, height).  origin/forward/up/right: float4 as the reference passes them (forward already

@@ -110,6 +110,47 @@ def _integrate(tape, box_a, levels):
     return dist.integrate_levels(top, len(levels), level_fn)
 
 
+def _integrate_pipeline(tape, box_a, levels, capacities):
+    """The same integration through dist.LevelPipeline as dist.MassPipeline drives it on the GPU: 32-byte rows of four
+    doubles seen as eight int32 words, the count in the header's first word, every level (the leaf level too) a
+    classify call, nothing looked at by the host until check().  -> the ten integrals, all-reduced."""
+    import math
+    import oracle
+    from codecad_amd import dist
+    from codecad_amd.mass_properties import integrals_host, _KEYS
+
+    partial = torch.zeros(10, dtype=torch.float64)
+
+    def classify(level, parents, n_parents, max_parents, out):
+        s, dims = levels[level]
+        leaf = level + 1 == len(levels)
+        thr = 0.0 if leaf else s * math.sqrt(3) / 2
+        k = min(int(n_parents.item()), max_parents)
+        rows = parents[:k].contiguous().view(torch.float64).reshape(-1, 4)
+        children, corners, sums = [], [], []
+        for cx, cy, cz, tag in rows.tolist():
+            shifted = np.array([cx + s / 2, cy + s / 2, cz + s / 2])
+            su, n, cells = oracle.mass_properties(tape, shifted.astype(np.float32), np.float32(s), np.float32(thr), dims)
+            corners.append([cx, cy, cz])
+            sums.append(su)
+            if not leaf:
+                children += [[i * s + cx, j * s + cy, k_ * s + cz, tag] for i, j, k_, _ in cells.tolist()]
+        if corners:
+            d = integrals_host(np.array(sums, dtype=np.uint32), np.array(corners, dtype=np.float64), s)
+            partial.add_(torch.tensor([d[key] for key in _KEYS], dtype=torch.float64))
+        capacity = out.shape[0] - 1
+        out[0, 0] = len(children)
+        children = children[:capacity]
+        if children:
+            out[1:1 + len(children)] = torch.tensor(children, dtype=torch.float64).view(torch.int32).reshape(-1, 8)
+
+    top = torch.tensor([[box_a[0], box_a[1], box_a[2], 0.0]], dtype=torch.float64).view(torch.int32).reshape(1, 8)
+    pipe = dist.LevelPipeline(top, list(capacities) + [0], classify)
+    pipe.enqueue()
+    totals = pipe.check()
+    return dist.allreduce_sum(partial), totals[:-1]
+
+
 def _setup_mass():
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -178,6 +219,14 @@ def _worker(rank, world, port, queue):
         assert err.needed[0] > 2
     mtape, box_a, mlevels = _setup_mass()
     integrals = _integrate(mtape, box_a, mlevels)
+    # the device-counted form (what dist.mass_properties runs): same integrals, no count seen by the host on the way
+    piped, ambiguous = _integrate_pipeline(mtape, box_a, mlevels, [800] * (len(mlevels) - 1))
+    assert np.allclose(piped.tolist(), integrals.tolist(), rtol=1e-13, atol=1e-15) and all(a > 0 for a in ambiguous)
+    try:
+        _integrate_pipeline(mtape, box_a, mlevels, [1] * (len(mlevels) - 1))
+        raise AssertionError("overflow went unnoticed")
+    except dist.Overflow:
+        pass
     if rank == 0:
         queue.put((leaves.numpy().tolist(), counts, integrals.tolist()))
     torch.distributed.barrier()
@@ -255,6 +304,15 @@ def test_pipeline_single_rank_and_slice_rule():
     out = torch.zeros((2, 4), dtype=torch.int32)
     dist.slice_rows_reference(gathered, 1, out, stats)
     assert stats.tolist() == [4, 1] and int(out[0, 0]) == 1
+
+
+def test_mass_pipeline_protocol_single_rank():
+    """World 1: the device-counted integration (32-byte rows, leaf level included) equals the level-by-level one."""
+    mtape, box_a, mlevels = _setup_mass()
+    single = _integrate(mtape, box_a, mlevels).tolist()
+    piped, ambiguous = _integrate_pipeline(mtape, box_a, mlevels, [800] * (len(mlevels) - 1))
+    assert np.allclose(piped.tolist(), single, rtol=1e-13, atol=1e-15)
+    assert piped[0].item() == pytest.approx((20 / 27) ** 2, rel=1e-12)
 
 
 def test_single_process_helpers():

@@ -75,3 +75,38 @@ def test_bench_config_c5_reduced(hip):
     assert line["scaling"] == "strong" and line["config"]["baseline_config"] == "c5"
     assert line["samples_per_step"]["dense"] == 0 and line["samples_per_step"]["leaf_blocks"] > 0
     assert "k_grid_eval_blocks" in line["roofline"]["kernel"]
+
+
+def run_bench_env(env, *extra):
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--n", "128",
+                           "--no-hbm-leg", "--no-cpu-baseline"] + list(extra), capture_output=True, text=True, timeout=600, cwd=ROOT,
+                          env=dict(os.environ, **env))
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [l for l in proc.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, proc.stdout
+    return json.loads(lines[0])
+
+
+def test_forced_collectives_walk_the_multi_rank_path_on_one_gpu(hip):
+    """CODECAD_AMD_FORCE_COLLECTIVES=1: ONE rank in a real RCCL process group -- every level's piece goes through
+    all_gather_into_tensor on the side stream, hu_slice_rows takes the (whole) share, the next level and the leaf blocks
+    are launched from the sliced list.  Same counts as the plain single-GPU step; the step is also captured into a
+    hipGraph, collectives included, and replayed."""
+    plain = run_bench_env({"CODECAD_AMD_FORCE_COLLECTIVES": "0"})
+    forced = run_bench_env({"CODECAD_AMD_FORCE_COLLECTIVES": "1"})
+    assert "forced_collectives" in forced["config"] and "nccl" in forced["config"]["forced_collectives"]
+    assert "forced_collectives" not in plain["config"]
+    assert forced["samples_per_step"] == plain["samples_per_step"]
+    assert forced["n_gpus"] == 1 and forced["value"] > 0
+    for line in (plain, forced):
+        g = line["graph_replay"]
+        assert g["captured"], g
+        assert g["steps"] == 4 and g["ms_per_step"] > 0 and g["host_enqueue_ms_per_step"] < line["host_enqueue_ms_per_step"]
+    assert forced["graph_replay"]["collectives_in_graph"] is True and plain["graph_replay"]["collectives_in_graph"] is False
+
+
+def test_step_counts_are_replayed_exactly(hip):
+    for steps, per_graph in ((3, 3), (11, 8)):
+        line = run_bench_env({}, "--steps", str(steps))
+        g = line["graph_replay"]
+        assert line["steps"] == steps and g["captured"] and g["steps"] == steps and g["steps_per_graph"] == per_graph

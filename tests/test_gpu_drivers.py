@@ -1,6 +1,7 @@
 """GPU drivers (level-batched kernels, torch interop, full-size properties) against the oracle."""
 import ctypes
 import math
+import os
 
 import numpy as np
 import pytest
@@ -302,6 +303,20 @@ def test_device_integrals_match_host_formulas(hip):
                 assert v == pytest.approx(want[k], rel=1e-12, abs=1e-13 * scale * n)
             ob.release()
         assert hip.lib.hu_mass_integrals(pb.device_ptr, sb.device_ptr, n, s, pb.device_ptr, 0, hip.queue.handle) != 0
+        # the indirect form: the count on the device, the launch sized for a larger capacity -> the same rows
+        nb = hip_util.Buffer(np.uint32, 1)
+        nb.enqueue_write(np.array([n], np.uint32))
+        big_p, big_s = hip_util.Buffer(np.float64, (n + 100, 4)), hip_util.Buffer(np.uint32, (n + 100, 10))
+        big_p.enqueue_fill(0xff)
+        big_s.enqueue_fill(0xff)
+        check(hip.lib.hu_memcpy_d2d(big_p.device_ptr, pb.device_ptr, n * 32, hip.queue.handle), "copy")
+        check(hip.lib.hu_memcpy_d2d(big_s.device_ptr, sb.device_ptr, n * 40, hip.queue.handle), "copy")
+        for rows in (1, 3, 64):
+            direct, indirect = hip_util.Buffer(np.float64, (rows, 10)), hip_util.Buffer(np.float64, (rows, 10))
+            check(hip.lib.hu_mass_integrals(pb.device_ptr, sb.device_ptr, n, s, direct.device_ptr, rows, hip.queue.handle), "integrals")
+            check(hip.lib.hu_mass_integrals_indirect(big_p.device_ptr, big_s.device_ptr, nb.device_ptr, n + 100, s, indirect.device_ptr, rows,
+                                                     hip.queue.handle), "integrals")
+            assert np.array_equal(direct.read(), indirect.read())
 
 
 def _wide_tape(k):
@@ -560,3 +575,19 @@ def test_lists_longer_than_one_grid_are_launched_in_pieces(hip):
             corner = rows[b, :3].cpu().numpy().astype(np.float64) * 1.0 + np.array([0.25, -0.5, 0.125])
             want = oracle.grid_eval_pymcubes(ref["tape"], corner.astype(np.float32), step, (2, 2, 2))
             assert same_bits(out[b].cpu().numpy(), np.asarray(want).reshape(-1)), (specialise, b)
+
+
+@pytest.mark.parametrize("forced", ["0", "1"])
+def test_library_forms_over_a_process_group(hip, forced):
+    """dist.mass_properties and dist.subdivision (tools/rehearse_dist.py compares them with the single-GPU drivers) --
+    plainly, and with CODECAD_AMD_FORCE_COLLECTIVES=1: one rank in a real RCCL group, every level through
+    all_gather_into_tensor -> hu_slice_rows -> indirect launches, the integrals through an all-reduce."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, CODECAD_AMD_FORCE_COLLECTIVES=forced)
+    for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_RANK"):
+        env.pop(k, None)
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rehearse_dist.py")], capture_output=True, text=True,
+                          timeout=600, cwd=ROOT, env=env)
+    assert proc.returncode == 0 and "rehearsal ok" in proc.stdout, proc.stdout[-2000:] + proc.stderr[-3000:]

@@ -30,3 +30,6 @@ if rank == 0:
     assert a == b and list(info["level_counts"]) == list(single.level_counts)
     print("rehearsal ok")
 dist.barrier()
+if dist.exchanging():
+    import torch.distributed
+    torch.distributed.destroy_process_group()
