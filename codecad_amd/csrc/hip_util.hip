@@ -262,7 +262,7 @@ void keep_programs(hu_tape_s* t, const sdf::DecodedTape& d)
     t->program.n_result_slots = d.n_result_slots;
 }
 
-struct SpecEval { const float* extra; };  // same layout as the generated sdfk::JitEval
+struct SpecEval { const float* extra; uint32_t flags; };  // same layout as the generated sdfk::JitEval
 
 constexpr int kSpecKernelCount = 10;
 const char* const kSpecKernelNames[kSpecKernelCount] = {
@@ -503,7 +503,7 @@ int hu_grid_eval_slab(hu_tape t, const float corner[4], float step, const uint32
     if (plane >= (1ull << 30)) return fail(HU_ERR_BAD_ARG, "dims[1]*dims[2] must be below 2^30");
     if (t->spec) {
         const uint32_t max_x = (uint32_t)((1ull << 30) / plane);
-        SpecEval ev{t->extra_dev};
+        SpecEval ev{t->extra_dev, 0u};
         float cx = corner[0], cy = corner[1], cz = corner[2];
         uint32_t sx = dims[0];
         Dim sy = make_dim(dims[1]), sz = make_dim(dims[2]);
@@ -599,7 +599,7 @@ static int grid_eval_blocks_impl(hu_tape t, const int32_t* blocks_dev, uint32_t 
         // (a wavefront per (y, z) column of 4 x 4 x 8 bricks, walking along x)
         uint32_t bricks = t->spec->deferred && brick_tiles(dims[0], dims[1], 32u) && dims[2] % 8u == 0u && dims[0] <= 64u ? dims[0] / 4u : 0u;
         if (bricks) chunks = ((dims[1] / 4u) * (dims[2] / 8u) + 3u) / 4u;
-        SpecEval ev{t->extra_dev};
+        SpecEval ev{t->extra_dev, 0u};
         const int4* b = (const int4*)blocks_dev;
         double res = resolution, ox = origin[0], oy = origin[1], oz = origin[2];
         uint32_t sx = dims[0];
@@ -678,7 +678,7 @@ int launch_classify(hu_tape t, ClassifyArgs& a, uint32_t n_parents, const uint32
         a.dy = make_dim(dims[1]); a.dz = make_dim(dims[2]);
         a.chunks = (uint32_t)((cells + per_block - 1) / per_block);
         a.scratch_offset = 0;
-        SpecEval ev{t->extra_dev};
+        SpecEval ev{t->extra_dev, 0u};
         const uint32_t piece = units_per_launch(a.chunks, kSpecBlock);
         for (uint32_t p0 = 0; p0 < n_parents; p0 += piece) {
             a.parent_base = p0;
@@ -870,7 +870,7 @@ int hu_ray_caster(hu_tape t, const float origin[4], const float forward[4], cons
     a.h = height;
     a.out = static_cast<uint8_t*>(out_dev);
     if (t->spec) {
-        SpecEval ev{t->extra_dev};
+        SpecEval ev{t->extra_dev, 0u};
         void* args[] = {&ev, &a};
         const uint64_t spec_blocks = (tiles + kSpecBlock / 64u - 1) / (kSpecBlock / 64u);
         HU_HIP(hipModuleLaunchKernel(t->spec->ray_caster, (uint32_t)spec_blocks, 1, 1, kSpecBlock, 1, 1, 0, (hipStream_t)stream,
@@ -890,7 +890,7 @@ int hu_bitmap(hu_tape t, const float origin[4], float step_size, uint32_t width,
     if (pixels > 0x7fffffffull) return fail(HU_ERR_BAD_ARG, "image too large for one launch");
     uint8_t* out = static_cast<uint8_t*>(out_dev);
     if (t->spec) {
-        SpecEval ev{t->extra_dev};
+        SpecEval ev{t->extra_dev, 0u};
         float ox = origin[0], oy = origin[1], oz = origin[2];
         void* args[] = {&ev, &ox, &oy, &oz, &step_size, &width, &height, &out};
         HU_HIP(hipModuleLaunchKernel(t->spec->bitmap, (uint32_t)((pixels + kSpecBlock - 1) / kSpecBlock), 1, 1, kSpecBlock, 1, 1, 0,

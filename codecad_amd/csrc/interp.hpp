@@ -325,6 +325,87 @@ template <class T> __device__ __forceinline__ T perp_w(T a, T b)
     return r;
 }
 
+// ---- values of mixed width (per-tape code, specialise.hpp) ------------------------------------------------------
+// Per-tape code gives every value the narrowest type that holds it: f2 where the two voxels of a lane may differ,
+// float where they cannot -- in the brick kernels (kernels.hpp) a lane's two voxels differ in x only, so whatever
+// is computed from y and z alone is ONE number per lane: half the instructions, half the registers.  Each helper
+// below computes in the wider of its operands' types; a float operand is the same IEEE binary32 value in both
+// halves of the packed form and every packed operation is two IEEE operations, so the bits are those of the all-f2
+// evaluation (tests/test_gpu_bricks.py, test_gpu_random_shapes.py compare them with the oracle).
+template <class A, class B> struct wider { using type = f2; };
+template <> struct wider<float, float> { using type = float; };
+template <class A, class B> using wider_t = typename wider<A, B>::type;
+template <class R, class X> struct as_impl;
+template <> struct as_impl<float, float> { static __device__ __forceinline__ float go(float x) { return x; } };
+template <> struct as_impl<f2, float> { static __device__ __forceinline__ f2 go(float x) { return (f2)(x); } };
+template <> struct as_impl<f2, f2> { static __device__ __forceinline__ f2 go(f2 x) { return x; } };
+template <class R, class X> __device__ __forceinline__ R as(X x) { return as_impl<R, X>::go(x); }
+template <class M> struct lanes_type { using type = float; };
+template <> struct lanes_type<m2> { using type = f2; };
+__device__ __forceinline__ m1 as_mask(m1 a, float) { return a; }
+__device__ __forceinline__ m2 as_mask(m1 a, f2) { return m2{a.v, a.v, a.w, a.w}; }
+__device__ __forceinline__ m2 as_mask(m2 a, f2) { return a; }
+template <class A, class B, class C> __device__ __forceinline__ auto fma_x(A a, B b, C c)
+{
+    using R = wider_t<wider_t<A, B>, C>;
+    return fma_(as<R>(a), as<R>(b), as<R>(c));
+}
+template <class A, class B> __device__ __forceinline__ auto min_x(A a, B b) { using R = wider_t<A, B>; return min_(as<R>(a), as<R>(b)); }
+template <class A, class B> __device__ __forceinline__ auto max_x(A a, B b) { using R = wider_t<A, B>; return max_(as<R>(a), as<R>(b)); }
+template <class A, class B> __device__ __forceinline__ auto max_neg_x(A a, B b) { using R = wider_t<A, B>; return max_neg_(as<R>(a), as<R>(b)); }
+template <class A, class B> __device__ __forceinline__ auto lt_x(A a, B b) { using R = wider_t<A, B>; return lt(as<R>(a), as<R>(b)); }
+// a point or a result whose components have different widths, widened for an op of the library (exec_one)
+template <class X, class Y, class Z, class W> __device__ __forceinline__ auto v4x(X x, Y y, Z z, W w)
+{
+    using R = wider_t<wider_t<X, Y>, wider_t<Z, W>>;
+    return v4<R>(as<R>(x), as<R>(y), as<R>(z), as<R>(w));
+}
+template <class R, class T> __device__ __forceinline__ V4<R> widen4(const V4<T>& v) { return v4<R>(as<R>(v.x), as<R>(v.y), as<R>(v.z), as<R>(v.w)); }
+
+// sqrt_cr with what the launch knows (kernels.hpp JitEval::flags): bit 0 set = every sample coordinate of this launch
+// is so far inside the fast range that no sum of squares of local coordinates can leave [2^-100, 2^100] unless it is
+// exactly the square of a tape constant's difference (specialise.hpp coordinate_bound) -- then the four compares of
+// the range test are skipped by a scalar branch on a kernel argument.
+constexpr uint32_t kFlagInRange = 1u;
+template <class T, class M> __device__ __forceinline__ T sqrt_cr(T x, M used, uint32_t flags)
+{
+#if SDF_FAST_CR_MATH
+    const T y = rsq_hw(x);
+    const T s0 = x * y, h = 0.5f * y;
+    T s = fma_(fma_(-s0, s0, x), h, s0);
+    if (!(flags & kFlagInRange)) {
+        SDF_KEEP_BRANCH("range test of the fast sqrt");
+        if (wave_any(used & outside_fast_range(x))) {
+            SDF_KEEP_BRANCH("IEEE sqrt for out-of-range input");
+            s = sqrt_(x);
+        }
+    }
+    return s;
+#else
+    return sqrt_(x);
+#endif
+}
+// perp_w for operands of different widths (same operations as perp_w above, in the wider type)
+template <class A, class B> __device__ __forceinline__ wider_t<A, B> perp_w_x(A a, B b, uint32_t flags)
+{
+    using R = wider_t<A, B>;
+    const auto corner = as_mask(gt(a, 0.0f), R()) & as_mask(gt(b, 0.0f), R());
+    R r = max_(as<R>(a), as<R>(b));
+    if (any_lane(corner)) r = sel(corner, sqrt_cr(fma_(as<R>(b), as<R>(b), as<R>(a * a)), corner, flags), r);
+    return r;
+}
+template <class A, class B> __device__ __forceinline__ wider_t<A, B> len2_x(A x, B y, uint32_t flags)
+{
+    using R = wider_t<A, B>;
+    return sqrt_cr(fma_(as<R>(y), as<R>(y), as<R>(x * x)), mask_of<R>::all(), flags);
+}
+template <class A, class B, class C> __device__ __forceinline__ wider_t<wider_t<A, B>, C> len3_x(A x, B y, C z, uint32_t flags)
+{
+    using R = wider_t<wider_t<A, B>, C>;
+    using RXY = wider_t<A, B>;
+    return sqrt_cr(fma_(as<R>(z), as<R>(z), as<R>(fma_(as<RXY>(y), as<RXY>(y), as<RXY>(x * x)))), mask_of<R>::all(), flags);
+}
+
 // reference shapes/simple3d.cl:18-21 = perpendicular_intersection(slab_z(h, coords), in)
 template <class T, class M = typename mask_of<T>::type>
 __device__ __forceinline__ V4<T> extrusion_op(float hh, V4<T> in, V4<T> coords, M wanted = mask_of<T>::all())
@@ -1054,6 +1135,20 @@ __device__ __forceinline__ V4<T> run_tape(const Rec* __restrict__ prog, const fl
         for (int k = 0; k < kFetchGroup; ++k)
             if (exec_one<T, DISTANCE_ONLY, R>(group[k], last, extra, px, py, pz, regs)) return last;
     }
+}
+
+// One record of the library on values of mixed width (per-tape code, specialise.hpp: the ops its phase 1 does not
+// restate component by component): `last` and the record's register operand widened to a common type, the
+// distance-only form of the op run on them.
+template <int OP, class TA, class TB>
+__device__ __forceinline__ auto run_record(const Rec& r, const float* __restrict__ extra, V4<TA> last, V4<TB> operand)
+{
+    using R = wider_t<TA, TB>;
+    V4<R> v = widen4<R>(last);
+    RegsOne<R> one;
+    one.v = widen4<R>(operand);
+    exec_one<R, true, RegsOne<R>, OP>(r, v, extra, bc<R>(0.0f), bc<R>(0.0f), bc<R>(0.0f), one);
+    return v;
 }
 
 }  // namespace sdf

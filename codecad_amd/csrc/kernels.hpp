@@ -233,13 +233,16 @@ k_grid_eval(const E ev, float cx, float cy, float cz, float step, uint32_t sx, D
             float xs[N];
 #pragma unroll
             for (int i = 0; i < N; ++i) xs[i] = sample(cx, step, x0 + x + 2u * i);
-            const T px = pack(xs), py = (T)(sample(cy, step, y));
+            // a lane's two voxels differ in x only: y and z are ONE number per lane (per-tape code computes what depends
+            // on them alone in scalars per lane, not in packed pairs: interp.hpp "values of mixed width")
+            const T px = pack(xs);
+            const float py = sample(cy, step, y);
             // what the tape computes from x and y alone is computed once for the wavefront's bricks (specialise.hpp)
-            typename E::template Hoisted<T> hoisted = ev.template hoist<T>(px, py);
+            const auto hoisted = ev.hoist(px, py);
 #pragma unroll 1
             for (uint32_t j = 0; j < G; ++j) {
                 const uint32_t z = (gz * G + j) * 8u + (lane & 7u);
-                const T pz = (T)(sample(cz, step, z));
+                const float pz = sample(cz, step, z);
                 if (LAYOUT == 0) {
                     const sdf::V4<T> r = ev.eval_hoisted(px, py, pz, hoisted);
                     float4* o = static_cast<float4*>(out) + ((size_t)z + (size_t)sz * ((size_t)y + (size_t)sy * x));
@@ -309,9 +312,9 @@ k_grid_eval_blocks(const E ev, const int4* __restrict__ blocks, const uint32_t* 
             const uint32_t nbz = sz >> 3, bz = column % nbz, by = column / nbz;
             if (by * 4u >= sy) return;   // wavefronts past the last column (uniform)
             const uint32_t y = by * 4u + ((lane >> 3) & 3u), z = bz * 8u + (lane & 7u);
-            const T py = (T)(sample(cy, step, y)), pz = (T)(sample(cz, step, z));
+            const float py = sample(cy, step, y), pz = sample(cz, step, z);   // (one number per lane: its voxels differ in x)
             const size_t base = (size_t)b * cells;
-            typename E::template Hoisted<T> hoisted = ev.template hoist_x<T>(py, pz);
+            const auto hoisted = ev.hoist_x(py, pz);
 #pragma unroll 1
             for (uint32_t j = 0; j < bricks; ++j) {
                 const uint32_t x = j * 4u + (lane >> 5);

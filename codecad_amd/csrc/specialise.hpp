@@ -29,6 +29,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -214,8 +215,7 @@ inline bool collect_paths(const std::vector<Node>& nodes, int at, Path cur, std:
 inline void emit_plain(std::ostringstream& o, const SpecProgram& p)
 {
     using namespace spec_detail;
-    o << "constexpr int kHoisted = 0;\n"
-      << "template <class T, int PRE, uint32_t AXIS = 4u> __device__ __forceinline__ sdf::V4<T> tape_eval(T px, T py, T pz, const float* __restrict__ extra, T*)\n{\n"
+    o << "template <class T> __device__ __forceinline__ sdf::V4<T> tape_eval(T px, T py, T pz, const float* __restrict__ extra)\n{\n"
       << "    using namespace sdf;\n    RegsV<T, " << p.n_slots << "> regs;\n"
       << "    V4<T> last = v4<T>(bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f));\n";
     for (const Rec& r : p.full) {
@@ -224,346 +224,470 @@ inline void emit_plain(std::ostringstream& o, const SpecProgram& p)
           << ">(r, last, extra, px, py, pz, regs); }\n";
     }
     o << "    return last;\n}\n"
-      << "template <class T, int PRE, uint32_t AXIS = 4u> __device__ __forceinline__ T tape_dist(T px, T py, T pz, const float* __restrict__ extra, T*)\n"
-      << "{ return tape_eval<T, 0>(px, py, pz, extra, nullptr).w; }\n";
+      << "template <class T> __device__ __forceinline__ T tape_dist(T px, T py, T pz, const float* __restrict__ extra)\n"
+      << "{ return tape_eval<T>(px, py, pz, extra).w; }\n";
 }
 
+namespace spec_detail {
+
+// ---- phase 1 as a little compiler ---------------------------------------------------------------------------------
+// The distance-only program is executed SYMBOLICALLY, component by component: every coordinate of every point and
+// every distance becomes one statement `const auto t<id> = <expression of earlier values>;`, with the sample
+// coordinates it depends on noted beside it.  Three things fall out of that which record-by-record code (one exec_one
+// call per record on a four-component value) could not give:
+//   * width: `auto` takes the narrowest type -- float where the two voxels of a lane cannot differ (in the brick kernels
+//     they differ in x only), f2 elsewhere (interp.hpp "values of mixed width");
+//   * hoisting: a statement that does not read the coordinate a wavefront walks along is computed once per walk (`pre`)
+//     and handed on (`h.t<id>`) -- whole primitives, single coordinates, |x| - h of a rectangle, whatever it is;
+//   * sharing: equal expressions are one statement (the bars of a cross read the same |z| - h).
+// The arithmetic is exec_one's, operation for operation (the statement texts below restate its distance-only cases).
+struct Stmt {
+    std::string text;        // "$0", "$1": the operands
+    std::vector<int> ops;
+    uint8_t deps = 0;        // DX | DY | DZ: the sample coordinates the value depends on
+    bool mask = false;       // a predicate (wavefront masks live in scalar registers: never handed from `pre`)
+};
+enum : uint8_t { DX = 1, DY = 2, DZ = 4 };
+
+struct Emitter {
+    std::vector<Stmt> st;
+    std::vector<int> neg_of;                 // value id -> the value it negates, or -1
+    std::vector<std::pair<std::string, int>> seen;
+    int add(const std::string& text, const std::vector<int>& ops, uint8_t deps = 0, bool mask = false)
+    {
+        std::string key = text;
+        for (int o : ops) key += "|" + std::to_string(o);
+        for (auto& k : seen) if (k.first == key) return k.second;
+        Stmt s;
+        s.text = text; s.ops = ops; s.deps = deps; s.mask = mask;
+        for (int o : ops) s.deps |= st[o].deps;
+        st.push_back(s);
+        neg_of.push_back(-1);
+        seen.emplace_back(key, (int)st.size() - 1);
+        return (int)st.size() - 1;
+    }
+    int neg(int v)
+    {
+        if (neg_of[v] >= 0) return neg_of[v];
+        const int r = add("-$0", {v});
+        neg_of[r] = v;
+        return r;
+    }
+    int abs_minus(int v, float h)            // |-x| - h is |x| - h, bit for bit
+    {
+        if (neg_of[v] >= 0) v = neg_of[v];
+        return add("abs_minus($0, " + flit(h) + ")", {v});
+    }
+};
+
+inline std::string render(const Stmt& s, const std::function<std::string(int)>& name)
+{
+    std::string out;
+    for (size_t i = 0; i < s.text.size(); ++i) {
+        if (s.text[i] == '$' && i + 1 < s.text.size() && s.text[i + 1] >= '0' && s.text[i + 1] <= '9') {
+            out += name(s.ops[(size_t)(s.text[i + 1] - '0')]);
+            ++i;
+        } else out += s.text[i];
+    }
+    return out;
+}
+
+struct Phase1 {
+    Emitter e;
+    std::vector<int> dist_of;                 // node -> value id of its distance (RESULT nodes)
+    std::vector<int> choice_of_rec;           // record -> value id of its choice mask, or -1
+    std::vector<int> keep_w_of_rec;           // record -> value id of the distance that entered it, or -1
+    int root = -1;
+    int px = -1, py = -1, pz = -1;
+};
+
+// false: an op this generator does not restate (the plain form is used instead)
+inline bool symbolic_phase1(const SpecProgram& p, const std::vector<Node>& nodes, int root, const std::vector<char>& is_choice,
+                            const std::vector<char>& keep_w, Phase1& out)
+{
+    Emitter& e = out.e;
+    struct Pt { int c[3] = {-1, -1, -1}; int w = -1; };
+    std::vector<Pt> pt(nodes.size());
+    out.dist_of.assign(nodes.size(), -1);
+    out.choice_of_rec.assign(p.full.size(), -1);
+    out.keep_w_of_rec.assign(p.full.size(), -1);
+    out.px = e.add("px", {}, DX);
+    out.py = e.add("py", {}, DY);
+    out.pz = e.add("pz", {}, DZ);
+    const int zero = e.add("0.0f", {});
+    auto fma_c = [&](int v, float a, float b) { return e.add("fma_x($0, " + flit(a) + ", " + flit(b) + ")", {v}); };
+    auto fma_v = [&](int v, float a, int acc) { return e.add("fma_x($0, " + flit(a) + ", $1)", {v, acc}); };
+    // a record of the library run on widened values (ops that are rare in CAD tapes and branchy inside: polygons, gears,
+    // twists, circular repetitions): last = ($0, $1, $2, $3), its register operand = ($4, $5, $6, $7)
+    auto run_record = [&](const Rec& r, const int (&last)[4], const int (&operand)[4]) {
+        const uint32_t op = r.hdr & 0xffu;
+        return e.add("run_record<" + std::to_string(op) + ">(" + rec_literal(r, true, op) + ", extra, v4x($0, $1, $2, $3), v4x($4, $5, $6, $7))",
+                     {last[0], last[1], last[2], last[3], operand[0], operand[1], operand[2], operand[3]});
+    };
+    for (int n = 0; n < (int)nodes.size(); ++n) {
+        const Node& nd = nodes[n];
+        const Rec& r = p.full[nd.rec];
+        const float* q = r.p;
+        const uint32_t op = nd.op;
+        const int none4[4] = {zero, zero, zero, zero};
+        if (nd.kind == POINT) {
+            Pt in;
+            if (nd.a >= 0) in = pt[nd.a];
+            Pt o;
+            switch (op) {
+            case OPX_POINT: o.c[0] = out.px; o.c[1] = out.py; o.c[2] = out.pz; break;
+            case OPX_TO_SCALE:
+                for (int c = 0; c < 3; ++c) o.c[c] = fma_c(in.c[c], q[0], q[4 + c]);
+                break;
+            case OPX_TO_AXIS_X: case OPX_TO_AXIS_Y: case OPX_TO_AXIS_Z: {
+                // interp.hpp axis_rotate: (along, u, v) = the axis and the other two in cyclic order
+                const int ax = op == OPX_TO_AXIS_X ? 0 : op == OPX_TO_AXIS_Y ? 1 : 2, u = (ax + 1) % 3, v = (ax + 2) % 3;
+                o.c[ax] = fma_c(in.c[ax], q[0], q[4 + ax]);
+                int ru = fma_c(e.neg(in.c[v]), q[2], q[4 + u]);
+                int rv = fma_c(in.c[u], q[2], q[4 + v]);
+                if (q[1] != 0.0f) {
+                    ru = fma_v(in.c[u], q[1], ru);
+                    rv = fma_v(in.c[v], q[1], rv);
+                }
+                o.c[u] = ru;
+                o.c[v] = rv;
+                break;
+            }
+            case OPX_TO_ROW_X: case OPX_INIT_ROW_X: {
+                const Pt src = op == OPX_INIT_ROW_X ? Pt{{out.px, out.py, out.pz}, -1} : in;
+                o = src;
+                o.w = e.add("fma_x($0, " + flit(q[0]) + ", fma_x($1, " + flit(q[1]) + ", fma_x($2, " + flit(q[2]) + ", " + flit(q[3]) + ")))",
+                            {src.c[0], src.c[1], src.c[2]});
+                break;
+            }
+            case OPX_TO_ROWS_YZ: case OPX_INIT_ROWS_YZ: {
+                if (in.w < 0) return false;
+                const Pt src = op == OPX_INIT_ROWS_YZ ? Pt{{out.px, out.py, out.pz}, -1} : in;
+                o.c[0] = in.w;
+                o.c[1] = e.add("fma_x($0, " + flit(q[0]) + ", fma_x($1, " + flit(q[1]) + ", fma_x($2, " + flit(q[2]) + ", " + flit(q[3]) + ")))",
+                               {src.c[0], src.c[1], src.c[2]});
+                o.c[2] = e.add("fma_x($0, " + flit(q[4]) + ", fma_x($1, " + flit(q[5]) + ", fma_x($2, " + flit(q[6]) + ", " + flit(q[7]) + ")))",
+                               {src.c[0], src.c[1], src.c[2]});
+                break;
+            }
+            case OP_REPETITION:
+                for (int c = 0; c < 3; ++c)   // remainder_t: inv == 0 (an infinite spacing) returns the coordinate itself
+                    o.c[c] = q[3 + c] == 0.0f ? in.c[c] : e.add("remainder_t($0, " + flit(q[c]) + ", " + flit(q[3 + c]) + ")", {in.c[c]});
+                break;
+            case OP_MIRROR: o = in; o.c[0] = e.neg(in.c[0]); break;
+            case OP_SYMMETRICAL_TO: o = in; o.c[0] = e.add("abs_($0)", {in.c[0]}); break;
+            case OP_REVOLUTION_TO:
+                o.c[0] = e.add("len2_x($0, $1, flags)", {in.c[0], in.c[2]});
+                o.c[1] = in.c[1];
+                o.c[2] = zero;
+                break;
+            case OP_CIRCULAR_REPETITION_TO: case OP_TWIST_REVOLUTION_TO: {
+                const int last[4] = {in.c[0], in.c[1], in.c[2], zero};
+                const int v = run_record(r, last, none4);
+                o.c[0] = e.add("$0.x", {v}); o.c[1] = e.add("$0.y", {v}); o.c[2] = e.add("$0.z", {v});
+                break;
+            }
+            default: return false;
+            }
+            pt[n] = o;
+            continue;
+        }
+        // ---- results: the distance alone
+        int w = -1;
+        const int a = nd.a;
+        switch (nd.role) {
+        case LEAF: {
+            const Pt& c = pt[a];
+            if (op == OP_RECTANGLE) w = e.add("perp_w_x($0, $1, flags)", {e.abs_minus(c.c[0], q[0]), e.abs_minus(c.c[1], q[1])});
+            else if (op == OP_CIRCLE) w = e.add("len2_x($0, $1, flags) - " + flit(q[0]), {c.c[0], c.c[1]});
+            else if (op == OP_SPHERE) w = e.add("len3_x($0, $1, $2, flags) - " + flit(q[0]), {c.c[0], c.c[1], c.c[2]});
+            else if (op == OP_HALF_SPACE) w = e.neg(c.c[1]);
+            else {   // polygons, the gear
+                const int last[4] = {c.c[0], c.c[1], c.c[2], zero};
+                w = e.add("$0.w", {run_record(r, last, none4)});
+            }
+            break;
+        }
+        case UNARY: {
+            const int in = out.dist_of[a];
+            if (keep_w[nd.rec]) out.keep_w_of_rec[nd.rec] = in;
+            switch (op) {
+            case OP_TRANSFORMATION_FROM: case OPX_FROM_SCALE: case OPX_FROM_AXIS_X: case OPX_FROM_AXIS_Y: case OPX_FROM_AXIS_Z:
+                w = e.add("$0 * " + flit(q[5]), {in});
+                break;
+            case OPX_FROM_MATRIX: w = e.add("$0 * " + flit(q[9]), {in}); break;
+            case OP_OFFSET: w = e.add("$0 - " + flit(q[0]), {in}); break;
+            case OP_SHELL: w = e.add("sel(ge($0, 0.0f), $0, -$0) - " + flit(q[0]), {in}); break;
+            case OP_MIRROR: w = in; break;      // (flips the direction's x: the distance stays)
+            default: return false;
+            }
+            break;
+        }
+        case WITH_POINT: {
+            const int in = out.dist_of[a];
+            const Pt& c = pt[nd.b];
+            if (keep_w[nd.rec]) out.keep_w_of_rec[nd.rec] = in;
+            if (op == OP_EXTRUSION) w = e.add("perp_w_x($0, $1, flags)", {e.abs_minus(c.c[2], q[0]), in});
+            else if (op == OP_SYMMETRICAL_FROM || op == OP_CIRCULAR_REPETITION_FROM || op == OP_REVOLUTION_FROM) w = in;   // directions only
+            else if (op == OP_TWIST_REVOLUTION_FROM) {
+                const int last[4] = {zero, zero, zero, in}, operand[4] = {c.c[0], c.c[1], c.c[2], zero};
+                w = e.add("$0.w", {run_record(r, last, operand)});
+            } else return false;
+            break;
+        }
+        case SELECT: {
+            const int x = out.dist_of[a], y = out.dist_of[nd.b];
+            if (is_choice[nd.rec]) {
+                // the comparison of rounded_union(r < 0) for this op, on the operands it would have seen (union: a, b;
+                // intersection: -a, -b; subtraction: -a, b)
+                const int ca = op == OP_UNION ? x : e.neg(x), cb = op == OP_INTERSECTION ? e.neg(y) : y;
+                out.choice_of_rec[nd.rec] = e.add("lt_x($0, $1)", {ca, cb}, 0, true);
+            }
+            w = e.add(std::string(op == OP_UNION ? "min_x" : op == OP_INTERSECTION ? "max_x" : "max_neg_x") + "($0, $1)", {x, y});
+            break;
+        }
+        default: return false;
+        }
+        out.dist_of[n] = w;
+    }
+    out.root = out.dist_of[root];
+    return out.root >= 0;
+}
+
+// One variant of phase 1 as text.  walk = 0: everything in place; walk = DX / DZ: the statements that do not read the
+// walk's coordinate go to `pre` (returned in a struct, one member per value the walk-dependent part reads).
+struct Variant {
+    std::string pre;      // body of the hoisting function ("" when nothing is hoisted)
+    std::string main;     // body of the evaluation up to the root distance
+    int n_hoisted = 0;
+};
+inline Variant render_variant(const Phase1& ph, uint8_t walk, const std::vector<int>& roots)
+{
+    const std::vector<Stmt>& st = ph.e.st;
+    const int n = (int)st.size();
+    auto invariant = [&](int i) { return walk != 0 && !(st[i].deps & walk) && !st[i].mask && !st[i].ops.empty(); };
+    // (statements without operands -- the sample coordinates, constants -- are names, not work: never handed on)
+    std::vector<char> in_main(n, 0), frontier(n, 0), in_pre(n, 0);
+    std::vector<int> stack(roots.begin(), roots.end());
+    while (!stack.empty()) {
+        const int i = stack.back();
+        stack.pop_back();
+        if (i < 0) continue;
+        if (invariant(i)) { frontier[i] = 1; continue; }
+        if (in_main[i]) continue;
+        in_main[i] = 1;
+        for (int o : st[i].ops) stack.push_back(o);
+    }
+    for (int i = 0; i < n; ++i) if (frontier[i]) stack.push_back(i);
+    while (!stack.empty()) {
+        const int i = stack.back();
+        stack.pop_back();
+        if (in_pre[i]) continue;
+        in_pre[i] = 1;
+        for (int o : st[i].ops) stack.push_back(o);
+    }
+    Variant v;
+    auto plain = [&](int i) { return st[i].ops.empty() ? st[i].text : "t" + std::to_string(i); };
+    std::ostringstream pre, main;
+    for (int i = 0; i < n; ++i) {
+        if (st[i].ops.empty()) continue;
+        if (in_pre[i]) pre << "    const auto t" << i << " = " << render(st[i], plain) << ";\n";
+    }
+    std::ostringstream members, values;
+    for (int i = 0; i < n; ++i)
+        if (frontier[i]) {
+            members << " decltype(t" << i << ") t" << i << ";";
+            values << (v.n_hoisted ? ", " : "") << "t" << i;
+            ++v.n_hoisted;
+        }
+    if (v.n_hoisted) {
+        pre << "    struct Hoisted {" << members.str() << " };\n    return Hoisted{" << values.str() << "};\n";
+        v.pre = pre.str();
+    }
+    auto in_walk = [&](int i) { return st[i].ops.empty() ? st[i].text : (frontier[i] ? "h.t" : "t") + std::to_string(i); };
+    for (int i = 0; i < n; ++i) {
+        if (st[i].ops.empty() || !in_main[i]) continue;
+        main << "    const auto t" << i << " = " << render(st[i], in_walk) << ";\n";
+    }
+    v.main = main.str();
+    return v;
+}
+
+}  // namespace spec_detail
+
 // true: the deferred form was emitted; false: nothing was written (use emit_plain)
-inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t max_paths = 40, bool save_points = false)
+inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t max_paths = 40)
 {
     using namespace spec_detail;
     if (p.dist.empty() || p.dist.size() != p.full.size()) return false;
     std::vector<Node> nodes;
-    std::vector<int> rec_node;
     int root;
-    if (!build_graph(p.full, nodes, root, &rec_node)) return false;
+    if (!build_graph(p.full, nodes, root)) return false;
     std::vector<Path> paths;
     if (!collect_paths(nodes, root, Path(), paths, max_paths)) return false;
     if (paths.size() < 2) return false;   // a single primitive: nothing to defer
 
-    // ---- phase 1: the distance-only program; `keep` = what phase 2 wants from it
+    // ---- phase 1: distances; what phase 2 wants from it: the comparison at every select on a path, the distance that
+    // entered an op whose direction reads it
     std::vector<char> is_choice(p.full.size(), 0), keep_w(p.full.size(), 0);
     for (const Path& path : paths) {
         for (auto& c : path.choices) is_choice[c.first] = 1;
         for (const Step& s : path.up)
             if (s.node >= 0 && reads_input_distance(nodes[s.node].op)) keep_w[nodes[s.node].rec] = 1;
     }
-    // save_points: keep each primitive's local coordinates from phase 1 instead of recomputing them in phase 2
-    // (registers against instructions: measured per tape family)
-    std::vector<char> keep_pt(p.full.size(), 0);
-    if (save_points)
-        for (const Path& path : paths) {
-            keep_pt[nodes[nodes[path.leaf].a].rec] = 1;
-            for (const Step& s : path.up)
-                if (s.node >= 0 && nodes[s.node].role == WITH_POINT) keep_pt[nodes[nodes[s.node].b].rec] = 1;
-        }
-    // ---- what does not change along z.  The brick kernels walk a wavefront's bricks along z with x and y fixed
-    // (kernels.hpp), and a primitive whose distance only reads x and y -- the bar of a cross that runs along z -- is the
-    // same in all of them (the leaf-block kernel walks along x: the same for the bar along x, AXIS): its records are
-    // hoisted out of that loop (PRE == 1: phase 1 once with z = 0, the hoisted
-    // distances captured -- everything else is dead code there; PRE == 2: those records replaced by the captured
-    // distance; PRE == 0: everything in place).  A hoisted run is a private chain `to ... primitive from ...` of
-    // scalings, quarter turns (which permute the coordinates without touching them: interp.hpp axis_rotate with B == 0)
-    // and a rectangle or a circle (which read |x|, |y| or x^2 + y^2: no sign of a zero can differ).
-    std::vector<int> run_first, run_last, run_of(p.dist.size(), -1);
-    std::vector<uint32_t> run_free;   // bit a: the run's distance does not read sample coordinate a (x, y, z): free along a walk in that direction
-    {
-        enum : uint8_t { X = 1, Y = 2, Z = 4 };
-        struct Deps { uint8_t c[3]; };
-        const Deps unknown{{X | Y | Z, X | Y | Z, X | Y | Z}};
-        Deps last_d = unknown;
-        std::vector<Deps> slot_d(256, unknown);
-        const int n = (int)p.dist.size();
-        std::vector<Deps> before(n, unknown);   // of `last` when the record's own operation starts (after its folded load)
-        std::vector<uint8_t> w_deps(n, X | Y | Z);
-        for (int i = 0; i < n; ++i) {
-            const Rec& r = p.dist[i];
-            const uint32_t op = r.hdr & 0xffu, fold = fold_of(r);
-            if (op == OP_RETURN) break;
-            if (fold & kFoldLoad) last_d = (fold & kFoldLoadResult) ? unknown : slot_d[fold & 0xffu];
-            before[i] = last_d;
-            Deps out = unknown;
-            uint8_t w = X | Y | Z;
-            const bool quarter = r.p[1] == 0.0f;
-            switch (op) {
-            case OPX_POINT: out = Deps{{X, Y, Z}}; break;
-            case OPX_TO_SCALE: case OP_REPETITION: out = last_d; break;
-            case OPX_TO_AXIS_X: if (quarter) out = Deps{{last_d.c[0], last_d.c[2], last_d.c[1]}}; break;
-            case OPX_TO_AXIS_Y: if (quarter) out = Deps{{last_d.c[2], last_d.c[1], last_d.c[0]}}; break;
-            case OPX_TO_AXIS_Z: if (quarter) out = Deps{{last_d.c[1], last_d.c[0], last_d.c[2]}}; break;
-            case OP_RECTANGLE: case OP_CIRCLE: w = last_d.c[0] | last_d.c[1]; break;
-            case OPX_FROM_SCALE: case OPX_FROM_AXIS_X: case OPX_FROM_AXIS_Y: case OPX_FROM_AXIS_Z:
-                w = i > 0 ? w_deps[i - 1] : (X | Y | Z);   // (only meaningful inside a run, where the previous record made the distance)
-                break;
-            default: break;
-            }
-            w_deps[i] = w;
-            last_d = out;
-            if ((fold & kFoldStore) && !(fold & kFoldStoreResult)) slot_d[(fold >> 16) & 0xffu] = last_d;
-            if (op == OP_STORE && !(r.hdr & kResultKind)) slot_d[(r.hdr >> 8) & 0xffu] = before[i];
-        }
-        auto in_run = [&](uint32_t op, const Rec& r) {
-            if (op == OPX_TO_SCALE || op == OP_RECTANGLE || op == OP_CIRCLE || op == OPX_FROM_SCALE || op == OPX_FROM_AXIS_X ||
-                op == OPX_FROM_AXIS_Y || op == OPX_FROM_AXIS_Z) return true;
-            return (op == OPX_TO_AXIS_X || op == OPX_TO_AXIS_Y || op == OPX_TO_AXIS_Z) && r.p[1] == 0.0f;
-        };
-        for (int a = 0; a < n;) {
-            const uint32_t op_a = p.dist[a].hdr & 0xffu;
-            if (op_a == OP_RETURN) break;
-            if (!in_run(op_a, p.dist[a]) || (fold_of(p.dist[a]) & kFoldLoadResult)) { ++a; continue; }
-            int b = a, prims = 0, prim_at = -1;
-            for (int i = a; i < n; ++i) {
-                const Rec& r = p.dist[i];
-                const uint32_t op = r.hdr & 0xffu, fold = fold_of(r);
-                if (!in_run(op, r) || keep_w[i] || is_choice[i] || keep_pt[i]) break;
-                if (i > a && (fold & kFoldLoad)) break;
-                const bool is_prim = op == OP_RECTANGLE || op == OP_CIRCLE;
-                const bool is_from = op == OPX_FROM_SCALE || op == OPX_FROM_AXIS_X || op == OPX_FROM_AXIS_Y || op == OPX_FROM_AXIS_Z;
-                if (is_prim && prims) break;
-                if (is_from && !prims) break;            // a direction's transformation ahead of any primitive: not this pattern
-                if (!is_prim && !is_from && prims) break;   // a point operation after the primitive: the next leaf starts
-                if (is_prim) { ++prims; prim_at = i; }
-                b = i;
-                if (fold & kFoldStore) break;            // the value leaves `last`: the run ends here
-            }
-            // a run must hold its primitive, keep every point it computes to itself, and end in a distance free of z
-            bool ok = prims == 1 && b >= prim_at;
-            for (int i = a; ok && i < b; ++i) ok = !(fold_of(p.dist[i]) & kFoldStore);
-            if (ok && (fold_of(p.dist[b]) & kFoldStore)) ok = (fold_of(p.dist[b]) & kFoldStoreResult) != 0;
-            // (walks are along z -- the dense kernel -- or along x -- the leaf-block kernel: kernels.hpp)
-            const uint32_t free_along = (uint32_t)(~w_deps[b]) & (X | Z);
-            if (ok) ok = free_along != 0u;
-            if (ok) {
-                for (int i = a; i <= b; ++i) run_of[i] = (int)run_first.size();
-                run_first.push_back(a);
-                run_last.push_back(b);
-                run_free.push_back(free_along);
-                a = b + 1;
-            } else {
-                ++a;
-            }
-        }
-    }
-    // ... and a rectangle that is not free of the walk's coordinate as a whole may still be in ONE of its two: the bars of
-    // a cross that do not run along the walk.  Its `|x| - h` (or `|y| - h`) for that coordinate is hoisted the same way
-    // (half[i]: per walk direction, which of the two, and under which number).
-    struct Half { int which[3] = {-1, -1, -1}; int number[3] = {-1, -1, -1}; };   // index: 0 walk along x, 2 along z
-    std::vector<Half> half(p.dist.size());
-    int n_hoisted = (int)run_first.size();
-    static const bool halves = [] { const char* e = getenv("HU_HOIST_HALVES"); return !(e && e[0] == '0'); }();
-    if (halves) {
-        // (the analysis above, once more, for what it did not keep: the components' dependencies where a rectangle starts)
-        enum : uint8_t { X = 1, Y = 2, Z = 4 };
-        struct Deps { uint8_t c[3]; };
-        const Deps unknown{{X | Y | Z, X | Y | Z, X | Y | Z}};
-        Deps last_d = unknown;
-        std::vector<Deps> slot_d(256, unknown);
-        for (int i = 0; i < (int)p.dist.size(); ++i) {
-            const Rec& r = p.dist[i];
-            const uint32_t op = r.hdr & 0xffu, fold = fold_of(r);
-            if (op == OP_RETURN) break;
-            if (fold & kFoldLoad) last_d = (fold & kFoldLoadResult) ? unknown : slot_d[fold & 0xffu];
-            const Deps in = last_d;
-            Deps out = unknown;
-            const bool quarter = r.p[1] == 0.0f;
-            switch (op) {
-            case OPX_POINT: out = Deps{{X, Y, Z}}; break;
-            case OPX_TO_SCALE: case OP_REPETITION: out = in; break;
-            case OPX_TO_AXIS_X: if (quarter) out = Deps{{in.c[0], in.c[2], in.c[1]}}; break;
-            case OPX_TO_AXIS_Y: if (quarter) out = Deps{{in.c[2], in.c[1], in.c[0]}}; break;
-            case OPX_TO_AXIS_Z: if (quarter) out = Deps{{in.c[1], in.c[0], in.c[2]}}; break;
-            case OP_RECTANGLE:
-                // (only for the walk along x, the leaf-block kernel's: 0.52 -> 0.495 ms for the bench's blocks; in the dense
-                // kernel's walk along z the eight extra registers cost more than the subtractions saved: 0.757 -> 0.782 ms)
-                if (run_of[i] < 0 && !keep_w[i] && !keep_pt[i] && !is_choice[i])
-                    for (int axis : {0}) {
-                        const uint8_t bit = (uint8_t)(1u << axis);
-                        const bool free0 = !(in.c[0] & bit), free1 = !(in.c[1] & bit);
-                        if (free0 != free1) {   // (both: a whole run above; neither: nothing to hoist)
-                            half[i].which[axis] = free0 ? 0 : 1;
-                            half[i].number[axis] = n_hoisted++;
-                        }
-                    }
-                break;
-            default: break;
-            }
-            last_d = out;
-            if ((fold & kFoldStore) && !(fold & kFoldStoreResult)) slot_d[(fold >> 16) & 0xffu] = last_d;
-            if (op == OP_STORE && !(r.hdr & kResultKind)) slot_d[(r.hdr >> 8) & 0xffu] = in;
-        }
-    }
-    std::ostringstream body;
-    body << "    using namespace sdf;\n    using M = typename mask_of<T>::type;\n"
-         << "    RegsDO<T, " << p.n_point_slots << ", " << p.n_result_slots << "> regs;\n"
-         << "    V4<T> last = v4<T>(bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f));\n";
-    for (int i = 0; i < (int)p.dist.size(); ++i) {   // what phase 2 reads is declared up front: records may sit inside branches
-        if ((p.dist[i].hdr & 0xffu) == OP_RETURN) break;
-        if (keep_w[i]) body << "    T w" << i << " = bc<T>(0.0f);\n";
-        if (is_choice[i]) body << "    M c" << i << " = ~mask_of<T>::all();\n";
-        if (keep_pt[i]) body << "    V4<T> pt" << i << " = last;\n";
-    }
-    for (int i = 0; i < (int)p.dist.size(); ++i) {
-        const Rec& r = p.dist[i];
-        const uint32_t op = r.hdr & 0xffu, slot = (r.hdr >> 8) & 0xffffu, fold = fold_of(r);
-        if (op == OP_RETURN) break;
-        const int run = run_of[i];
-        // (AXIS: the direction of the walk, as a bit -- 1 x, 4 z; a run is hoisted in the instantiations whose walk it is free along)
-        if (run >= 0 && run_first[run] == i)
-            body << "    if constexpr (!(PRE == 2 && (" << run_free[run] << "u & AXIS))) {   // (hoisted out of walks along " << ((run_free[run] & 1u) ? "x " : "") << ((run_free[run] & 4u) ? "z" : "") << ")\n";
-        if (fold & kFoldLoad) {
-            if (fold & kFoldLoadResult) body << "    last.w = regs.load_res(" << (fold & 0xffu) << ");\n";
-            else body << "    last = regs.load(" << (fold & 0xffu) << ");\n";
-        }
-        if (keep_w[i]) body << "    w" << i << " = last.w;\n";
-        const std::string run_text = "{ const Rec r = " + rec_literal(r, true, r.hdr) + "; exec_one<T, true, decltype(regs), " + std::to_string(op) +
-                                ">(r, last, extra, px, py, pz, regs); }";
-        if (is_select(op)) {
-            // the comparison of rounded_union(r < 0) for this op, on the operands it would have seen
-            const char* a = op == OP_UNION ? "last.w" : "-last.w";
-            const std::string b_raw = "regs.load_res(" + std::to_string(slot) + ")";
-            const std::string b = op == OP_INTERSECTION ? "-" + b_raw : b_raw;
-            const std::string choice = is_choice[i] ? "c" + std::to_string(i) + " = " : std::string();
-            {
-                if (is_choice[i]) body << "    " << choice << "lt(" << a << ", " << b << ");\n";
-                body << "    " << run_text << "\n";
-            }
-        } else if (op == OP_RECTANGLE && (half[i].number[0] >= 0 || half[i].number[2] >= 0)) {
-            // exec_one's distance-only rectangle, last.w = perp_w(|x| - hw, |y| - hh), with the term that the walk does
-            // not change taken from (PRE == 2) or left in (PRE == 1) the hoisted values
-            body << "    {\n        T ax, ay;\n";
-            for (int c = 0; c < 2; ++c) {
-                const char* name = c == 0 ? "ax" : "ay";
-                const std::string plain = std::string(name) + " = abs_minus(last." + (c == 0 ? "x" : "y") + ", " + flit(r.p[c]) + ");";
-                std::string cond;   // the instantiations in which THIS term is hoisted
-                for (int axis : {0, 2})
-                    if (half[i].which[axis] == c)
-                        cond += (cond.empty() ? "" : " || ") + std::string("(AXIS == ") + std::to_string(1u << axis) + "u)";
-                if (cond.empty()) { body << "        " << plain << "\n"; continue; }
-                // (each term is hoisted along at most one of the two walks, so one number per term and instantiation)
-                const int number = half[i].which[0] == c ? half[i].number[0] : half[i].number[2];
-                const int number2 = (half[i].which[0] == c && half[i].which[2] == c) ? half[i].number[2] : number;
-                body << "        if constexpr (PRE == 2 && (" << cond << ")) " << name << " = hoisted[AXIS == 1u ? " << number << " : " << number2 << "];\n"
-                     << "        else {\n            " << plain << "\n"
-                     << "            if constexpr (PRE == 1 && (" << cond << ")) hoisted[AXIS == 1u ? " << number << " : " << number2 << "] = " << name << ";\n        }\n";
-            }
-            body << "        last.w = perp_w<T>(ax, ay);\n    }\n";
-        } else {
-            body << "    " << run_text << "\n";
-        }
-        if (keep_pt[i]) body << "    pt" << i << " = last;\n";
-        if (run >= 0 && run_last[run] == i)
-            body << "    if constexpr (PRE == 1 && (" << run_free[run] << "u & AXIS)) hoisted[" << run << "] = last.w;\n    } else {\n    last.w = hoisted[" << run << "];\n    }\n";
-        if (fold & kFoldStore) {
-            if (fold & kFoldStoreResult) body << "    regs.store_res(" << ((fold >> 16) & 0xffu) << ", last.w);\n";
-            else body << "    regs.store(" << ((fold >> 16) & 0xffu) << ", last);\n";
-        }
-    }
-    o << "constexpr int kHoisted = " << n_hoisted << ";   // distances that do not change along z (emit_deferred)\n"
-      << "template <class T, int PRE, uint32_t AXIS = 4u> __device__ __forceinline__ T tape_dist(T px, T py, T pz, const float* __restrict__ extra, T* hoisted)\n{\n";
-    {   // the distance alone: phase 1 without the captures (they are dead there)
-        std::string text = body.str();
-        o << text << "    return last.w;\n}\n";
-    }
-    o << "// deferred directions: " << paths.size() << " (primitive, path) pairs" << "\n"
-      << "template <class T, int PRE, uint32_t AXIS = 4u> __device__ __forceinline__ sdf::V4<T> tape_eval(T px, T py, T pz, const float* __restrict__ extra, T* hoisted)\n{\n"
-      << body.str()
-      << "    const T w_root = last.w;\n"
-      << "    // ---- phase 2\n"
-      << "    const T qx = opaque(px), qy = opaque(py), qz = opaque(pz);\n"
-      << "    V4<T> dir = v4<T>(bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f));\n"
-      << "    RegsOne<T> one;\n";
+    Phase1 ph;
+    if (!symbolic_phase1(p, nodes, root, is_choice, keep_w, ph)) return false;
+    std::vector<int> dist_roots{ph.root}, eval_roots{ph.root};
+    for (int v : ph.choice_of_rec) if (v >= 0) eval_roots.push_back(v);
+    for (int v : ph.keep_w_of_rec) if (v >= 0) eval_roots.push_back(v);
+
+    // ---- phase 2, as text (the same for every variant): the directions of the primitives that win somewhere in the
+    // wavefront, each through the library's full ops on its path (exec_one)
+    std::ostringstream p2;
+    auto value_name = [&](int id, bool hoisted_variant, const std::vector<char>* frontier) -> std::string {
+        (void)hoisted_variant; (void)frontier;
+        return ph.e.st[id].ops.empty() ? ph.e.st[id].text : "t" + std::to_string(id);
+    };
+    (void)value_name;
     const std::string zero4 = "v4<T>(bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f))";
     auto run_record = [&](const Rec& r, const std::string& value) {   // one record of the FULL program on `value`
         const uint32_t op = r.hdr & 0xffu;
-        o << "{ const Rec r = " << rec_literal(r, true, op) << "; exec_one<T, false, RegsOne<T>, " << op << ">(r, " << value
-          << ", extra, qx, qy, qz, one); }";
+        p2 << "{ const Rec r = " << rec_literal(r, true, op) << "; exec_one<T, false, RegsOne<T>, " << op << ">(r, " << value
+           << ", extra, qx, qy, qz, one); }";
     };
+    p2 << "    // ---- phase 2\n"
+       << "    const T qx = opaque(as<T>(px)), qy = opaque(as<T>(py)), qz = opaque(as<T>(pz));\n"
+       << "    V4<T> dir = " << zero4 << ";\n"
+       << "    RegsOne<T> one;\n";
     for (const Path& path : paths) {
-        o << "    {   // the primitive of record " << nodes[path.leaf].rec << " along one path to the root\n        const M m = ";
-        if (path.choices.empty()) o << "mask_of<T>::all()";
+        p2 << "    {   // the primitive of record " << nodes[path.leaf].rec << " along one path to the root\n        const M m = ";
+        if (path.choices.empty()) p2 << "mask_of<T>::all()";
         for (size_t k = 0; k < path.choices.size(); ++k)
-            o << (k ? " & " : "") << (path.choices[k].second ? "c" : "~c") << path.choices[k].first;
-        o << ";\n        if (wave_any(m)) {\n#ifndef SDF_PHASE2_ALL_LANES\n            one.act = m;\n#endif\n";
+            p2 << (k ? " & " : "") << (path.choices[k].second ? "" : "~") << "as_mask(@" << ph.choice_of_rec[path.choices[k].first] << "@, T())";
+        p2 << ";\n        if (wave_any(m)) {\n            one.act = m;\n";
         // the local coordinates of a point node: its chain of point ops from the sample point, emitted once per block
         std::vector<int> var(nodes.size(), -1);
         int next_var = 0;
         auto emit_point = [&](int node) -> std::string {
-            if (keep_pt[nodes[node].rec]) return "pt" + std::to_string(nodes[node].rec);
             std::vector<int> chain;
             for (int at = node; at >= 0 && var[at] < 0; at = nodes[at].a) chain.push_back(at);
             for (auto it = chain.rbegin(); it != chain.rend(); ++it) {
                 const Node& n = nodes[*it];
                 var[*it] = next_var++;
-                o << "            V4<T> p" << var[*it] << " = " << (n.a >= 0 ? "p" + std::to_string(var[n.a]) : zero4) << "; ";
+                p2 << "            V4<T> p" << var[*it] << " = " << (n.a >= 0 ? "p" + std::to_string(var[n.a]) : zero4) << "; ";
                 run_record(p.full[n.rec], "p" + std::to_string(var[*it]));
-                o << "\n";
+                p2 << "\n";
             }
             return "p" + std::to_string(var[node]);
         };
         const Node& leaf = nodes[path.leaf];
         const std::string at = emit_point(leaf.a);
-        o << "            V4<T> d = " << at << "; ";
+        p2 << "            V4<T> d = " << at << "; ";
         run_record(p.full[leaf.rec], "d");
-        o << "\n";
+        p2 << "\n";
         for (const Step& st : path.up) {
             if (st.node < 0) {
-                o << "            d = v4<T>(-d.x, -d.y, -d.z, d.w);\n";
+                p2 << "            d = v4<T>(-d.x, -d.y, -d.z, d.w);\n";
                 continue;
             }
             const Node& n = nodes[st.node];
             if (n.role == WITH_POINT) {
                 const std::string operand = emit_point(n.b);   // (emits the chain's statements first)
-                o << "            one.v = " << operand << ";\n";
+                p2 << "            one.v = " << operand << ";\n";
             }
-            if (reads_input_distance(n.op)) o << "            d.w = w" << n.rec << ";\n";
-            o << "            ";
+            if (reads_input_distance(n.op)) p2 << "            d.w = as<T>(@" << ph.keep_w_of_rec[n.rec] << "@);\n";
+            p2 << "            ";
             run_record(p.full[n.rec], "d");
-            o << "\n";
+            p2 << "\n";
         }
-        o << "            dir.x = sel(m, d.x, dir.x); dir.y = sel(m, d.y, dir.y); dir.z = sel(m, d.z, dir.z);\n"
-          << "        }\n    }\n";
+        p2 << "            dir.x = sel(m, d.x, dir.x); dir.y = sel(m, d.y, dir.y); dir.z = sel(m, d.z, dir.z);\n"
+           << "        }\n    }\n";
     }
-    o << "    return v4<T>(dir.x, dir.y, dir.z, w_root);\n}\n";
+    const std::string phase2 = p2.str();
+    // `@id@` in the text above: a value of phase 1 by its number; a hoisted one lives in `h`
+    auto phase2_for = [&](uint8_t walk) {
+        std::string out;
+        for (size_t i = 0; i < phase2.size(); ++i) {
+            if (phase2[i] != '@') { out += phase2[i]; continue; }
+            const size_t end = phase2.find('@', i + 1);
+            const int id = std::atoi(phase2.substr(i + 1, end - i - 1).c_str());
+            const Stmt& s = ph.e.st[id];
+            const bool hoisted = walk != 0 && !(s.deps & walk) && !s.mask && !s.ops.empty();
+            out += s.ops.empty() ? s.text : (hoisted ? "h.t" : "t") + std::to_string(id);
+            i = end;
+        }
+        return out;
+    };
+
+    const char* head = "    using namespace sdf;\n    using T = wider_t<wider_t<PX, PY>, PZ>;\n    using M = typename mask_of<T>::type;\n";
+    struct Form { const char* suffix; uint8_t walk; const char* pre_args; };
+    const Form forms[3] = {{"", 0, ""}, {"_z", DZ, "PX px, PY py"}, {"_x", DX, "PY py, PZ pz"}};
+    for (const Form& f : forms) {
+        const Variant vd = render_variant(ph, f.walk, dist_roots), ve = render_variant(ph, f.walk, eval_roots);
+        // the values handed from `pre`: the union of what the distance and the evaluation read (one struct for both)
+        const Variant& pre_of = ve;   // (eval's roots include dist's root: its frontier covers it)
+        const bool hoists = f.walk != 0 && pre_of.n_hoisted > 0;
+        if (f.walk != 0) {
+            o << "// hoisted out of walks along " << (f.walk == DZ ? "z" : "x") << ": " << pre_of.n_hoisted << " values\n"
+              << "template <class PX, class PY, class PZ> __device__ __forceinline__ auto tape_pre" << f.suffix
+              << "(PX px, PY py, PZ pz, const float* __restrict__ extra, uint32_t flags)\n{\n    using namespace sdf;\n";
+            if (hoists) o << pre_of.pre;
+            else o << "    struct Hoisted {};\n    return Hoisted{};\n";
+            o << "}\n";
+        }
+        const std::string h_param = f.walk != 0 ? ", const H& h" : "";
+        const std::string h_tmpl = f.walk != 0 ? ", class H" : "";
+        o << "template <class PX, class PY, class PZ" << h_tmpl << "> __device__ __forceinline__ auto tape_dist" << f.suffix
+          << "(PX px, PY py, PZ pz, const float* __restrict__ extra, uint32_t flags" << h_param << ")\n{\n" << head
+          << vd.main << "    return as<T>(" << (ph.e.st[ph.root].ops.empty() ? ph.e.st[ph.root].text : ((f.walk && !(ph.e.st[ph.root].deps & f.walk) ? "h.t" : "t") + std::to_string(ph.root))) << ");\n}\n";
+        o << "template <class PX, class PY, class PZ" << h_tmpl << "> __device__ __forceinline__ auto tape_eval" << f.suffix
+          << "(PX px, PY py, PZ pz, const float* __restrict__ extra, uint32_t flags" << h_param << ")\n{\n" << head
+          << ve.main << phase2_for(f.walk)
+          << "    return v4<T>(dir.x, dir.y, dir.z, as<T>(" << (ph.e.st[ph.root].ops.empty() ? ph.e.st[ph.root].text : ((f.walk && !(ph.e.st[ph.root].deps & f.walk) ? "h.t" : "t") + std::to_string(ph.root))) << "));\n}\n";
+        (void)vd;
+    }
+    o << "// deferred directions: " << paths.size() << " (primitive, path) pairs; " << ph.e.st.size() << " statements in phase 1\n";
     return true;
 }
 
 // The whole translation unit handed to hipRTC.  `deferred` (may be NULL) <- whether the deferred form was used.
 inline std::string specialised_source(const SpecProgram& p, bool allow_deferred, bool* deferred = nullptr)
 {
-    std::ostringstream o;
-    // HU_ABS_BUILTIN=1 (an experiment that lost): |x| - h written plainly in the brick kernels, so that the compiler hoists
-    // the terms in x and y out of the loop over a wavefront's bricks (interp.hpp abs_minus) -- it does, and the hoisted
-    // values cost 30 registers (85 -> 115, a wavefront less per SIMD): dense 0.83 -> 1.12 ms, leaf blocks 0.58 -> 0.92 ms
-    static const bool abs_builtin = [] { const char* e = getenv("HU_ABS_BUILTIN"); return e && e[0] == '1'; }();
-    std::ostringstream d;
-    static const bool save_points = [] { const char* e = getenv("HU_PHASE2_SAVE_POINTS"); return e && e[0] == '1'; }();
-    const bool ok = allow_deferred && emit_deferred(d, p, 40, save_points);
-    o << (ok && abs_builtin ? "#define SDF_ABS_MINUS_BUILTIN 1\n" : "") << "#include \"kernels.hpp\"\nnamespace sdfk {\nusing sdf::Rec;\n";
+    std::ostringstream o, d;
+    const bool ok = allow_deferred && emit_deferred(d, p, 40);
+    o << "#include \"kernels.hpp\"\nnamespace sdfk {\nusing sdf::Rec;\n";
     if (ok) o << d.str();
     else emit_plain(o, p);
     if (deferred) *deferred = ok;
     o << "struct JitEval {\n    static constexpr bool kBricks = " << (ok ? "true" : "false") << ";\n"
       << "    const float* extra;\n"
-      << "    template <class T> __device__ __forceinline__ sdf::V4<T> operator()(T px, T py, T pz, void*) const\n"
-      << "    { return tape_eval<T, 0>(px, py, pz, extra, nullptr); }\n"
-      << "    template <class T> __device__ __forceinline__ T dist(T px, T py, T pz, void*) const\n"
-      << "    { return tape_dist<T, 0>(px, py, pz, extra, nullptr); }\n"
-      // what does not change along z, for kernels that walk bricks along z with x and y fixed (kernels.hpp)
-      << "    template <class T> struct Hoisted { T v[kHoisted > 0 ? kHoisted : 1]; };\n"
-      << "    template <class T> __device__ __forceinline__ Hoisted<T> hoist(T px, T py) const\n"
-      << "    { Hoisted<T> h; if constexpr (kHoisted > 0) tape_dist<T, 1, 4u>(px, py, sdf::bc<T>(0.0f), extra, h.v); return h; }\n"
-      << "    template <class T> __device__ __forceinline__ sdf::V4<T> eval_hoisted(T px, T py, T pz, Hoisted<T>& h) const\n"
-      << "    { return tape_eval<T, (kHoisted > 0 ? 2 : 0), 4u>(px, py, pz, extra, h.v); }\n"
-      << "    template <class T> __device__ __forceinline__ T dist_hoisted(T px, T py, T pz, Hoisted<T>& h) const\n"
-      << "    { return tape_dist<T, (kHoisted > 0 ? 2 : 0), 4u>(px, py, pz, extra, h.v); }\n"
-      // ... and the same for a walk along x with y and z fixed (k_grid_eval_blocks)
-      << "    template <class T> __device__ __forceinline__ Hoisted<T> hoist_x(T py, T pz) const\n"
-      << "    { Hoisted<T> h; if constexpr (kHoisted > 0) tape_dist<T, 1, 1u>(sdf::bc<T>(0.0f), py, pz, extra, h.v); return h; }\n"
-      << "    template <class T> __device__ __forceinline__ sdf::V4<T> eval_hoisted_x(T px, T py, T pz, Hoisted<T>& h) const\n"
-      << "    { return tape_eval<T, (kHoisted > 0 ? 2 : 0), 1u>(px, py, pz, extra, h.v); }\n"
-      << "    template <class T> __device__ __forceinline__ T dist_hoisted_x(T px, T py, T pz, Hoisted<T>& h) const\n"
-      << "    { return tape_dist<T, (kHoisted > 0 ? 2 : 0), 1u>(px, py, pz, extra, h.v); }\n"
-      << "};\n}  // namespace sdfk\n";
+      << "    uint32_t flags;   // sdf::kFlagInRange: the launch's coordinates cannot leave the fast range of sqrt_cr\n";
+    if (ok) {
+        o << "    template <class T> __device__ __forceinline__ sdf::V4<T> operator()(T px, T py, T pz, void*) const\n"
+          << "    { return tape_eval(px, py, pz, extra, flags); }\n"
+          << "    template <class T> __device__ __forceinline__ T dist(T px, T py, T pz, void*) const\n"
+          << "    { return tape_dist(px, py, pz, extra, flags); }\n"
+          // what does not change along z, for kernels that walk bricks along z with x and y fixed (kernels.hpp) ...
+          << "    template <class PX, class PY> __device__ __forceinline__ auto hoist(PX px, PY py) const\n"
+          << "    { return tape_pre_z(px, py, 0.0f, extra, flags); }\n"
+          << "    template <class PX, class PY, class PZ, class H> __device__ __forceinline__ auto eval_hoisted(PX px, PY py, PZ pz, const H& h) const\n"
+          << "    { return tape_eval_z(px, py, pz, extra, flags, h); }\n"
+          << "    template <class PX, class PY, class PZ, class H> __device__ __forceinline__ auto dist_hoisted(PX px, PY py, PZ pz, const H& h) const\n"
+          << "    { return tape_dist_z(px, py, pz, extra, flags, h); }\n"
+          // ... and the same for a walk along x with y and z fixed (k_grid_eval_blocks)
+          << "    template <class PY, class PZ> __device__ __forceinline__ auto hoist_x(PY py, PZ pz) const\n"
+          << "    { return tape_pre_x(0.0f, py, pz, extra, flags); }\n"
+          << "    template <class PX, class PY, class PZ, class H> __device__ __forceinline__ auto eval_hoisted_x(PX px, PY py, PZ pz, const H& h) const\n"
+          << "    { return tape_eval_x(px, py, pz, extra, flags, h); }\n"
+          << "    template <class PX, class PY, class PZ, class H> __device__ __forceinline__ auto dist_hoisted_x(PX px, PY py, PZ pz, const H& h) const\n"
+          << "    { return tape_dist_x(px, py, pz, extra, flags, h); }\n";
+    } else {
+        o << "    template <class T> __device__ __forceinline__ sdf::V4<T> operator()(T px, T py, T pz, void*) const\n"
+          << "    { return tape_eval<T>(px, py, pz, extra); }\n"
+          << "    template <class T> __device__ __forceinline__ T dist(T px, T py, T pz, void*) const\n"
+          << "    { return tape_dist<T>(px, py, pz, extra); }\n";
+    }
+    o << "};\n}  // namespace sdfk\n";
     return o.str();
 }
 
