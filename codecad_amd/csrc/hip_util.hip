@@ -234,12 +234,36 @@ struct SpecKernels {
     hipFunction_t classify[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [MASS][BATCH]
     hipFunction_t ray_caster = nullptr, bitmap = nullptr;
     bool deferred = false;   // the module was generated with deferred directions (specialise.hpp): dense launches use bricks
+    double coord_limit = 0.0;   // a launch whose sample coordinates all stay below this sets sdf::kFlagInRange (specialise.hpp)
 };
 
 namespace {
 
 constexpr int kSpecVoxelsPerLane = 2;
 constexpr uint32_t kSpecBlock = 256;
+
+// The flags a per-tape kernel is launched with: kFlagInRange when no sample coordinate of the launch can exceed the
+// tape's limit (HU_INRANGE=0 never sets it: measurements)
+uint32_t spec_flags(const hu_tape_s* t, double max_abs_coordinate)
+{
+    static const bool off = [] { const char* e = getenv("HU_INRANGE"); return e && e[0] == '0'; }();
+    return (!off && t->spec && max_abs_coordinate < t->spec->coord_limit) ? sdf::kFlagInRange : 0u;
+}
+// |coordinate| of any sample of a grid: corner + step * [0, n)
+double grid_reach(const float corner[3], float step, const uint32_t dims[3])
+{
+    double m = 0.0;
+    for (int c = 0; c < 3; ++c) {
+        const double a = std::fabs((double)corner[c]), b = std::fabs((double)corner[c] + (double)step * (double)dims[c]);
+        m = std::max(m, std::max(a, b));
+    }
+    return m;
+}
+// ... of any sample of blocks whose integer corners (32-bit) come from a device list: |int| * resolution + origin + the block
+double list_reach(double resolution, double ox, double oy, double oz, double block_extent)
+{
+    return 2147483648.0 * std::fabs(resolution) + std::max(std::fabs(ox), std::max(std::fabs(oy), std::fabs(oz))) + std::fabs(block_extent);
+}
 
 // HU_DEFER_DIRECTIONS=0 keeps the plain straight-line form of every tape (measurements, bisecting)
 bool defer_directions()
@@ -248,9 +272,9 @@ bool defer_directions()
     return !off;
 }
 
-std::string generate_source(const hu_tape_s* t, bool* deferred = nullptr)
+std::string generate_source(const hu_tape_s* t, bool* deferred = nullptr, double* coord_limit = nullptr)
 {
-    return sdf::specialised_source(t->program, defer_directions(), deferred);
+    return sdf::specialised_source(t->program, defer_directions(), deferred, coord_limit);
 }
 
 void keep_programs(hu_tape_s* t, const sdf::DecodedTape& d)
@@ -503,7 +527,7 @@ int hu_grid_eval_slab(hu_tape t, const float corner[4], float step, const uint32
     if (plane >= (1ull << 30)) return fail(HU_ERR_BAD_ARG, "dims[1]*dims[2] must be below 2^30");
     if (t->spec) {
         const uint32_t max_x = (uint32_t)((1ull << 30) / plane);
-        SpecEval ev{t->extra_dev, 0u};
+        SpecEval ev{t->extra_dev, spec_flags(t, grid_reach(corner, step, dims))};
         float cx = corner[0], cy = corner[1], cz = corner[2];
         uint32_t sx = dims[0];
         Dim sy = make_dim(dims[1]), sz = make_dim(dims[2]);
@@ -599,7 +623,8 @@ static int grid_eval_blocks_impl(hu_tape t, const int32_t* blocks_dev, uint32_t 
         // (a wavefront per (y, z) column of 4 x 4 x 8 bricks, walking along x)
         uint32_t bricks = t->spec->deferred && brick_tiles(dims[0], dims[1], 32u) && dims[2] % 8u == 0u && dims[0] <= 64u ? dims[0] / 4u : 0u;
         if (bricks) chunks = ((dims[1] / 4u) * (dims[2] / 8u) + 3u) / 4u;
-        SpecEval ev{t->extra_dev, 0u};
+        const double extent = (double)step * (double)std::max(dims[0], std::max(dims[1], dims[2]));
+        SpecEval ev{t->extra_dev, spec_flags(t, list_reach(resolution, origin[0], origin[1], origin[2], extent))};
         const int4* b = (const int4*)blocks_dev;
         double res = resolution, ox = origin[0], oy = origin[1], oz = origin[2];
         uint32_t sx = dims[0];
@@ -678,7 +703,13 @@ int launch_classify(hu_tape t, ClassifyArgs& a, uint32_t n_parents, const uint32
         a.dy = make_dim(dims[1]); a.dz = make_dim(dims[2]);
         a.chunks = (uint32_t)((cells + per_block - 1) / per_block);
         a.scratch_offset = 0;
-        SpecEval ev{t->extra_dev, 0u};
+        // (mass-property parents are fp64 corners on the device: their magnitude is not the host's to know)
+        const double extent = (double)a.step * (double)std::max(dims[0], std::max(dims[1], dims[2]));
+        const float c3[3] = {a.cx, a.cy, a.cz};
+        const double reach = !BATCH ? grid_reach(c3, a.step, dims)
+                             : MASS ? HUGE_VAL
+                                    : list_reach(a.res, a.ox, a.oy, a.oz, extent + std::fabs((double)a.int_step * a.res));
+        SpecEval ev{t->extra_dev, spec_flags(t, reach)};
         const uint32_t piece = units_per_launch(a.chunks, kSpecBlock);
         for (uint32_t p0 = 0; p0 < n_parents; p0 += piece) {
             a.parent_base = p0;
@@ -1161,7 +1192,8 @@ int hu_tape_specialize_cached(hu_tape t, const char* include_dir, const char* ca
     if (!t || !include_dir) return fail(HU_ERR_BAD_ARG, "NULL argument");
     if (t->spec) return HU_OK;
     bool deferred = false;
-    const std::string src = generate_source(t, &deferred);
+    double coord_limit = 0.0;
+    const std::string src = generate_source(t, &deferred, &coord_limit);
     int cached = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         SpecImage img;
@@ -1178,6 +1210,7 @@ int hu_tape_specialize_cached(hu_tape t, const char* include_dir, const char* ca
             e = hipModuleGetFunction(slots[i], k->module, img.lowered[i].c_str());
         if (e == hipSuccess) {
             k->deferred = deferred;
+            k->coord_limit = coord_limit;
             t->spec = k;
             if (from_cache) *from_cache = cached;
             return HU_OK;

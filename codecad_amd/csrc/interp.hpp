@@ -394,16 +394,17 @@ template <class A, class B> __device__ __forceinline__ wider_t<A, B> perp_w_x(A 
     if (any_lane(corner)) r = sel(corner, sqrt_cr(fma_(as<R>(b), as<R>(b), as<R>(a * a)), corner, flags), r);
     return r;
 }
-template <class A, class B> __device__ __forceinline__ wider_t<A, B> len2_x(A x, B y, uint32_t flags)
+// (a length can be exactly zero -- a sample on the axis --, so these keep the range test whatever the launch knows)
+template <class A, class B> __device__ __forceinline__ wider_t<A, B> len2_x(A x, B y)
 {
     using R = wider_t<A, B>;
-    return sqrt_cr(fma_(as<R>(y), as<R>(y), as<R>(x * x)), mask_of<R>::all(), flags);
+    return sqrt_cr(fma_(as<R>(y), as<R>(y), as<R>(x * x)), mask_of<R>::all());
 }
-template <class A, class B, class C> __device__ __forceinline__ wider_t<wider_t<A, B>, C> len3_x(A x, B y, C z, uint32_t flags)
+template <class A, class B, class C> __device__ __forceinline__ wider_t<wider_t<A, B>, C> len3_x(A x, B y, C z)
 {
     using R = wider_t<wider_t<A, B>, C>;
     using RXY = wider_t<A, B>;
-    return sqrt_cr(fma_(as<R>(z), as<R>(z), as<R>(fma_(as<RXY>(y), as<RXY>(y), as<RXY>(x * x)))), mask_of<R>::all(), flags);
+    return sqrt_cr(fma_(as<R>(z), as<R>(z), as<R>(fma_(as<RXY>(y), as<RXY>(y), as<RXY>(x * x)))), mask_of<R>::all());
 }
 
 // reference shapes/simple3d.cl:18-21 = perpendicular_intersection(slab_z(h, coords), in)

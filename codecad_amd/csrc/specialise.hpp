@@ -24,6 +24,7 @@
 //    results are identical; only operations whose results were going to be discarded are gone.
 #pragma once
 
+#include <algorithm>
 #include <array>
 #include <cmath>
 #include <cstdio>
@@ -246,6 +247,10 @@ struct Stmt {
     std::vector<int> ops;
     uint8_t deps = 0;        // DX | DY | DZ: the sample coordinates the value depends on
     bool mask = false;       // a predicate (wavefront masks live in scalar registers: never handed from `pre`)
+    // |value| <= g * B + o when every sample coordinate is within [-B, B] (coordinate_limit below); !bounded: unknown
+    double g = 0.0, o = 0.0;
+    bool bounded = true;
+    float abs_h = -1.0f;     // the value is |x| - abs_h
 };
 enum : uint8_t { DX = 1, DY = 2, DZ = 4 };
 
@@ -294,6 +299,7 @@ inline std::string render(const Stmt& s, const std::function<std::string(int)>& 
 
 struct Phase1 {
     Emitter e;
+    std::vector<std::pair<int, int>> perp;    // the operands of every perp_w_x statement (coordinate_limit)
     std::vector<int> dist_of;                 // node -> value id of its distance (RESULT nodes)
     std::vector<int> choice_of_rec;           // record -> value id of its choice mask, or -1
     std::vector<int> keep_w_of_rec;           // record -> value id of the distance that entered it, or -1
@@ -315,14 +321,45 @@ inline bool symbolic_phase1(const SpecProgram& p, const std::vector<Node>& nodes
     out.py = e.add("py", {}, DY);
     out.pz = e.add("pz", {}, DZ);
     const int zero = e.add("0.0f", {});
-    auto fma_c = [&](int v, float a, float b) { return e.add("fma_x($0, " + flit(a) + ", " + flit(b) + ")", {v}); };
-    auto fma_v = [&](int v, float a, int acc) { return e.add("fma_x($0, " + flit(a) + ", $1)", {v, acc}); };
+    // magnitude bounds (Stmt::g, o): set right after a statement is made; anything not set below is "unknown"
+    auto bound = [&](int id, double g, double o, bool ok = true) {
+        Stmt& s = e.st[id];
+        s.g = g; s.o = o; s.bounded = ok && std::isfinite(g) && std::isfinite(o);
+        return id;
+    };
+    auto G = [&](int v) { return e.st[v].g; };
+    auto O = [&](int v) { return e.st[v].o; };
+    auto OK = [&](int v) { return e.st[v].bounded; };
+    auto A = [](float v) { return std::fabs((double)v); };
+    for (int v : {out.px, out.py, out.pz}) bound(v, 1.0, 0.0);
+    bound(zero, 0.0, 0.0);
+    auto fma_c = [&](int v, float a, float b) { return bound(e.add("fma_x($0, " + flit(a) + ", " + flit(b) + ")", {v}), A(a) * G(v), A(a) * O(v) + A(b), OK(v)); };
+    auto fma_v = [&](int v, float a, int acc) {
+        return bound(e.add("fma_x($0, " + flit(a) + ", $1)", {v, acc}), A(a) * G(v) + G(acc), A(a) * O(v) + O(acc), OK(v) && OK(acc));
+    };
+    auto neg = [&](int v) { return bound(e.neg(v), G(v), O(v), OK(v)); };
+    auto abs_minus = [&](int v, float h) {
+        const int r = bound(e.abs_minus(v, h), G(v), O(v) + A(h), OK(v));
+        e.st[r].abs_h = h;
+        return r;
+    };
+    auto perp = [&](int a, int b) {
+        const int r = bound(e.add("perp_w_x($0, $1, flags)", {a, b}), G(a) + G(b), O(a) + O(b), OK(a) && OK(b));
+        out.perp.emplace_back(a, b);
+        return r;
+    };
+    auto row = [&](const int (&c)[3], const float* q) {   // fma_x(x, q0, fma_x(y, q1, fma_x(z, q2, q3)))
+        return bound(e.add("fma_x($0, " + flit(q[0]) + ", fma_x($1, " + flit(q[1]) + ", fma_x($2, " + flit(q[2]) + ", " + flit(q[3]) + ")))", {c[0], c[1], c[2]}),
+                     A(q[0]) * G(c[0]) + A(q[1]) * G(c[1]) + A(q[2]) * G(c[2]), A(q[0]) * O(c[0]) + A(q[1]) * O(c[1]) + A(q[2]) * O(c[2]) + A(q[3]),
+                     OK(c[0]) && OK(c[1]) && OK(c[2]));
+    };
+    auto unknown = [&](int id) { return bound(id, 0.0, 0.0, false); };
     // a record of the library run on widened values (ops that are rare in CAD tapes and branchy inside: polygons, gears,
     // twists, circular repetitions): last = ($0, $1, $2, $3), its register operand = ($4, $5, $6, $7)
     auto run_record = [&](const Rec& r, const int (&last)[4], const int (&operand)[4]) {
         const uint32_t op = r.hdr & 0xffu;
-        return e.add("run_record<" + std::to_string(op) + ">(" + rec_literal(r, true, op) + ", extra, v4x($0, $1, $2, $3), v4x($4, $5, $6, $7))",
-                     {last[0], last[1], last[2], last[3], operand[0], operand[1], operand[2], operand[3]});
+        return unknown(e.add("run_record<" + std::to_string(op) + ">(" + rec_literal(r, true, op) + ", extra, v4x($0, $1, $2, $3), v4x($4, $5, $6, $7))",
+                             {last[0], last[1], last[2], last[3], operand[0], operand[1], operand[2], operand[3]}));
     };
     for (int n = 0; n < (int)nodes.size(); ++n) {
         const Node& nd = nodes[n];
@@ -343,7 +380,7 @@ inline bool symbolic_phase1(const SpecProgram& p, const std::vector<Node>& nodes
                 // interp.hpp axis_rotate: (along, u, v) = the axis and the other two in cyclic order
                 const int ax = op == OPX_TO_AXIS_X ? 0 : op == OPX_TO_AXIS_Y ? 1 : 2, u = (ax + 1) % 3, v = (ax + 2) % 3;
                 o.c[ax] = fma_c(in.c[ax], q[0], q[4 + ax]);
-                int ru = fma_c(e.neg(in.c[v]), q[2], q[4 + u]);
+                int ru = fma_c(neg(in.c[v]), q[2], q[4 + u]);
                 int rv = fma_c(in.c[u], q[2], q[4 + v]);
                 if (q[1] != 0.0f) {
                     ru = fma_v(in.c[u], q[1], ru);
@@ -356,35 +393,33 @@ inline bool symbolic_phase1(const SpecProgram& p, const std::vector<Node>& nodes
             case OPX_TO_ROW_X: case OPX_INIT_ROW_X: {
                 const Pt src = op == OPX_INIT_ROW_X ? Pt{{out.px, out.py, out.pz}, -1} : in;
                 o = src;
-                o.w = e.add("fma_x($0, " + flit(q[0]) + ", fma_x($1, " + flit(q[1]) + ", fma_x($2, " + flit(q[2]) + ", " + flit(q[3]) + ")))",
-                            {src.c[0], src.c[1], src.c[2]});
+                o.w = row(src.c, q);
                 break;
             }
             case OPX_TO_ROWS_YZ: case OPX_INIT_ROWS_YZ: {
                 if (in.w < 0) return false;
                 const Pt src = op == OPX_INIT_ROWS_YZ ? Pt{{out.px, out.py, out.pz}, -1} : in;
                 o.c[0] = in.w;
-                o.c[1] = e.add("fma_x($0, " + flit(q[0]) + ", fma_x($1, " + flit(q[1]) + ", fma_x($2, " + flit(q[2]) + ", " + flit(q[3]) + ")))",
-                               {src.c[0], src.c[1], src.c[2]});
-                o.c[2] = e.add("fma_x($0, " + flit(q[4]) + ", fma_x($1, " + flit(q[5]) + ", fma_x($2, " + flit(q[6]) + ", " + flit(q[7]) + ")))",
-                               {src.c[0], src.c[1], src.c[2]});
+                o.c[1] = row(src.c, q);
+                o.c[2] = row(src.c, q + 4);
                 break;
             }
             case OP_REPETITION:
                 for (int c = 0; c < 3; ++c)   // remainder_t: inv == 0 (an infinite spacing) returns the coordinate itself
-                    o.c[c] = q[3 + c] == 0.0f ? in.c[c] : e.add("remainder_t($0, " + flit(q[c]) + ", " + flit(q[3 + c]) + ")", {in.c[c]});
+                    o.c[c] = q[3 + c] == 0.0f ? in.c[c] : bound(e.add("remainder_t($0, " + flit(q[c]) + ", " + flit(q[3 + c]) + ")", {in.c[c]}),
+                                                                G(in.c[c]), O(in.c[c]), OK(in.c[c]));   // (|x - n y| <= |x|: safe for huge x too)
                 break;
-            case OP_MIRROR: o = in; o.c[0] = e.neg(in.c[0]); break;
-            case OP_SYMMETRICAL_TO: o = in; o.c[0] = e.add("abs_($0)", {in.c[0]}); break;
+            case OP_MIRROR: o = in; o.c[0] = neg(in.c[0]); break;
+            case OP_SYMMETRICAL_TO: o = in; o.c[0] = bound(e.add("abs_($0)", {in.c[0]}), G(in.c[0]), O(in.c[0]), OK(in.c[0])); break;
             case OP_REVOLUTION_TO:
-                o.c[0] = e.add("len2_x($0, $1, flags)", {in.c[0], in.c[2]});
+                o.c[0] = bound(e.add("len2_x($0, $1)", {in.c[0], in.c[2]}), G(in.c[0]) + G(in.c[2]), O(in.c[0]) + O(in.c[2]), OK(in.c[0]) && OK(in.c[2]));
                 o.c[1] = in.c[1];
                 o.c[2] = zero;
                 break;
             case OP_CIRCULAR_REPETITION_TO: case OP_TWIST_REVOLUTION_TO: {
                 const int last[4] = {in.c[0], in.c[1], in.c[2], zero};
                 const int v = run_record(r, last, none4);
-                o.c[0] = e.add("$0.x", {v}); o.c[1] = e.add("$0.y", {v}); o.c[2] = e.add("$0.z", {v});
+                o.c[0] = unknown(e.add("$0.x", {v})); o.c[1] = unknown(e.add("$0.y", {v})); o.c[2] = unknown(e.add("$0.z", {v}));
                 break;
             }
             default: return false;
@@ -398,13 +433,16 @@ inline bool symbolic_phase1(const SpecProgram& p, const std::vector<Node>& nodes
         switch (nd.role) {
         case LEAF: {
             const Pt& c = pt[a];
-            if (op == OP_RECTANGLE) w = e.add("perp_w_x($0, $1, flags)", {e.abs_minus(c.c[0], q[0]), e.abs_minus(c.c[1], q[1])});
-            else if (op == OP_CIRCLE) w = e.add("len2_x($0, $1, flags) - " + flit(q[0]), {c.c[0], c.c[1]});
-            else if (op == OP_SPHERE) w = e.add("len3_x($0, $1, $2, flags) - " + flit(q[0]), {c.c[0], c.c[1], c.c[2]});
-            else if (op == OP_HALF_SPACE) w = e.neg(c.c[1]);
+            if (op == OP_RECTANGLE) w = perp(abs_minus(c.c[0], q[0]), abs_minus(c.c[1], q[1]));
+            else if (op == OP_CIRCLE)
+                w = bound(e.add("len2_x($0, $1) - " + flit(q[0]), {c.c[0], c.c[1]}), G(c.c[0]) + G(c.c[1]), O(c.c[0]) + O(c.c[1]) + A(q[0]), OK(c.c[0]) && OK(c.c[1]));
+            else if (op == OP_SPHERE)
+                w = bound(e.add("len3_x($0, $1, $2) - " + flit(q[0]), {c.c[0], c.c[1], c.c[2]}), G(c.c[0]) + G(c.c[1]) + G(c.c[2]),
+                          O(c.c[0]) + O(c.c[1]) + O(c.c[2]) + A(q[0]), OK(c.c[0]) && OK(c.c[1]) && OK(c.c[2]));
+            else if (op == OP_HALF_SPACE) w = neg(c.c[1]);
             else {   // polygons, the gear
                 const int last[4] = {c.c[0], c.c[1], c.c[2], zero};
-                w = e.add("$0.w", {run_record(r, last, none4)});
+                w = unknown(e.add("$0.w", {run_record(r, last, none4)}));
             }
             break;
         }
@@ -413,11 +451,11 @@ inline bool symbolic_phase1(const SpecProgram& p, const std::vector<Node>& nodes
             if (keep_w[nd.rec]) out.keep_w_of_rec[nd.rec] = in;
             switch (op) {
             case OP_TRANSFORMATION_FROM: case OPX_FROM_SCALE: case OPX_FROM_AXIS_X: case OPX_FROM_AXIS_Y: case OPX_FROM_AXIS_Z:
-                w = e.add("$0 * " + flit(q[5]), {in});
+                w = bound(e.add("$0 * " + flit(q[5]), {in}), A(q[5]) * G(in), A(q[5]) * O(in), OK(in));
                 break;
-            case OPX_FROM_MATRIX: w = e.add("$0 * " + flit(q[9]), {in}); break;
-            case OP_OFFSET: w = e.add("$0 - " + flit(q[0]), {in}); break;
-            case OP_SHELL: w = e.add("sel(ge($0, 0.0f), $0, -$0) - " + flit(q[0]), {in}); break;
+            case OPX_FROM_MATRIX: w = bound(e.add("$0 * " + flit(q[9]), {in}), A(q[9]) * G(in), A(q[9]) * O(in), OK(in)); break;
+            case OP_OFFSET: w = bound(e.add("$0 - " + flit(q[0]), {in}), G(in), O(in) + A(q[0]), OK(in)); break;
+            case OP_SHELL: w = bound(e.add("sel(ge($0, 0.0f), $0, -$0) - " + flit(q[0]), {in}), G(in), O(in) + A(q[0]), OK(in)); break;
             case OP_MIRROR: w = in; break;      // (flips the direction's x: the distance stays)
             default: return false;
             }
@@ -427,11 +465,11 @@ inline bool symbolic_phase1(const SpecProgram& p, const std::vector<Node>& nodes
             const int in = out.dist_of[a];
             const Pt& c = pt[nd.b];
             if (keep_w[nd.rec]) out.keep_w_of_rec[nd.rec] = in;
-            if (op == OP_EXTRUSION) w = e.add("perp_w_x($0, $1, flags)", {e.abs_minus(c.c[2], q[0]), in});
+            if (op == OP_EXTRUSION) w = perp(abs_minus(c.c[2], q[0]), in);
             else if (op == OP_SYMMETRICAL_FROM || op == OP_CIRCULAR_REPETITION_FROM || op == OP_REVOLUTION_FROM) w = in;   // directions only
             else if (op == OP_TWIST_REVOLUTION_FROM) {
                 const int last[4] = {zero, zero, zero, in}, operand[4] = {c.c[0], c.c[1], c.c[2], zero};
-                w = e.add("$0.w", {run_record(r, last, operand)});
+                w = unknown(e.add("$0.w", {run_record(r, last, operand)}));
             } else return false;
             break;
         }
@@ -440,10 +478,11 @@ inline bool symbolic_phase1(const SpecProgram& p, const std::vector<Node>& nodes
             if (is_choice[nd.rec]) {
                 // the comparison of rounded_union(r < 0) for this op, on the operands it would have seen (union: a, b;
                 // intersection: -a, -b; subtraction: -a, b)
-                const int ca = op == OP_UNION ? x : e.neg(x), cb = op == OP_INTERSECTION ? e.neg(y) : y;
+                const int ca = op == OP_UNION ? x : neg(x), cb = op == OP_INTERSECTION ? neg(y) : y;
                 out.choice_of_rec[nd.rec] = e.add("lt_x($0, $1)", {ca, cb}, 0, true);
             }
-            w = e.add(std::string(op == OP_UNION ? "min_x" : op == OP_INTERSECTION ? "max_x" : "max_neg_x") + "($0, $1)", {x, y});
+            w = bound(e.add(std::string(op == OP_UNION ? "min_x" : op == OP_INTERSECTION ? "max_x" : "max_neg_x") + "($0, $1)", {x, y}),
+                      std::max(G(x), G(y)), std::max(O(x), O(y)), OK(x) && OK(y));
             break;
         }
         default: return false;
@@ -454,6 +493,28 @@ inline bool symbolic_phase1(const SpecProgram& p, const std::vector<Node>& nodes
     return out.root >= 0;
 }
 
+// The largest |sample coordinate| B up to which every perp_w_x of the tape stays inside the fast range of sqrt_cr
+// (interp.hpp kFlagInRange) in the lanes where its result is used -- both operands positive there:
+//   below: one operand is |x| - h with h >= 2^-25; a positive difference of two binary32 numbers is at least half an ulp
+//          of the smaller, so that operand is >= 2^-50 and the sum of squares >= 2^-100;
+//   above: both operands stay below 2^49 (the bounds g * B + o of symbolic_phase1), so the sum stays below 2^100.
+// 0: no such B (an op outside the analysis feeds a rectangle or an extrusion); +inf: the tape has no perp_w_x at all.
+inline double coordinate_limit(const Phase1& ph)
+{
+    double limit = HUGE_VAL;
+    const double top = std::ldexp(1.0, 49);
+    for (const auto& ab : ph.perp) {
+        const Stmt& a = ph.e.st[ab.first];
+        const Stmt& b = ph.e.st[ab.second];
+        if (!(a.abs_h >= 0x1p-25f) && !(b.abs_h >= 0x1p-25f)) return 0.0;
+        for (const Stmt* s : {&a, &b}) {
+            if (!s->bounded || !(s->o < top)) return 0.0;
+            if (s->g > 0.0) limit = std::min(limit, (top - s->o) / s->g);
+        }
+    }
+    return limit;
+}
+
 // One variant of phase 1 as text.  walk = 0: everything in place; walk = DX / DZ: the statements that do not read the
 // walk's coordinate go to `pre` (returned in a struct, one member per value the walk-dependent part reads).
 struct Variant {
@@ -461,11 +522,34 @@ struct Variant {
     std::string main;     // body of the evaluation up to the root distance
     int n_hoisted = 0;
 };
-inline Variant render_variant(const Phase1& ph, uint8_t walk, const std::vector<int>& roots)
+// Which statements are handed from `pre` when the walk is along `walk`: those that do not read its coordinate -- unless
+// they are cheaper to compute again in every brick than to keep in a register for the whole walk (a value costs one or
+// two VGPRs for the walk's duration, and registers decide how many wavefronts a SIMD holds): `min_cost` = the number
+// of instructions (roughly) a value must save per brick to be kept.
+inline std::vector<char> hoistable_set(const Phase1& ph, uint8_t walk, int min_cost)
 {
     const std::vector<Stmt>& st = ph.e.st;
     const int n = (int)st.size();
-    auto invariant = [&](int i) { return walk != 0 && !(st[i].deps & walk) && !st[i].mask && !st[i].ops.empty(); };
+    std::vector<char> out(n, 0);
+    if (walk == 0) return out;
+    std::vector<int> cost(n, 0);
+    for (int i = 0; i < n; ++i) {
+        if (st[i].ops.empty() || st[i].mask || (st[i].deps & walk)) continue;
+        const std::string& t = st[i].text;
+        int c = t.compare(0, 11, "remainder_t") == 0 ? 3 : t.compare(0, 8, "perp_w_x") == 0 ? 8 : t.compare(0, 4, "len2") == 0 ? 10 :
+                t.compare(0, 4, "len3") == 0 ? 12 : t.compare(0, 10, "run_record") == 0 ? 100 : t.compare(0, 2, "$0") == 0 && t.size() == 4 ? 0 : 1;
+        for (int o : st[i].ops) c += cost[o];     // (a tree's cost: shared subexpressions count once per use -- an upper bound)
+        cost[i] = c;
+        out[i] = c >= min_cost;
+    }
+    return out;
+}
+
+inline Variant render_variant(const Phase1& ph, const std::vector<char>& hoistable, const std::vector<int>& roots)
+{
+    const std::vector<Stmt>& st = ph.e.st;
+    const int n = (int)st.size();
+    auto invariant = [&](int i) { return hoistable[i] != 0; };
     // (statements without operands -- the sample coordinates, constants -- are names, not work: never handed on)
     std::vector<char> in_main(n, 0), frontier(n, 0), in_pre(n, 0);
     std::vector<int> stack(roots.begin(), roots.end());
@@ -516,7 +600,7 @@ inline Variant render_variant(const Phase1& ph, uint8_t walk, const std::vector<
 }  // namespace spec_detail
 
 // true: the deferred form was emitted; false: nothing was written (use emit_plain)
-inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t max_paths = 40)
+inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t max_paths = 40, double* coord_limit = nullptr)
 {
     using namespace spec_detail;
     if (p.dist.empty() || p.dist.size() != p.full.size()) return false;
@@ -537,6 +621,7 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
     }
     Phase1 ph;
     if (!symbolic_phase1(p, nodes, root, is_choice, keep_w, ph)) return false;
+    if (coord_limit) *coord_limit = coordinate_limit(ph);
     std::vector<int> dist_roots{ph.root}, eval_roots{ph.root};
     for (int v : ph.choice_of_rec) if (v >= 0) eval_roots.push_back(v);
     for (int v : ph.keep_w_of_rec) if (v >= 0) eval_roots.push_back(v);
@@ -605,15 +690,14 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
     }
     const std::string phase2 = p2.str();
     // `@id@` in the text above: a value of phase 1 by its number; a hoisted one lives in `h`
-    auto phase2_for = [&](uint8_t walk) {
+    auto phase2_for = [&](const std::vector<char>& hoistable) {
         std::string out;
         for (size_t i = 0; i < phase2.size(); ++i) {
             if (phase2[i] != '@') { out += phase2[i]; continue; }
             const size_t end = phase2.find('@', i + 1);
             const int id = std::atoi(phase2.substr(i + 1, end - i - 1).c_str());
             const Stmt& s = ph.e.st[id];
-            const bool hoisted = walk != 0 && !(s.deps & walk) && !s.mask && !s.ops.empty();
-            out += s.ops.empty() ? s.text : (hoisted ? "h.t" : "t") + std::to_string(id);
+            out += s.ops.empty() ? s.text : (hoistable[id] ? "h.t" : "t") + std::to_string(id);
             i = end;
         }
         return out;
@@ -622,8 +706,10 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
     const char* head = "    using namespace sdf;\n    using T = wider_t<wider_t<PX, PY>, PZ>;\n    using M = typename mask_of<T>::type;\n";
     struct Form { const char* suffix; uint8_t walk; const char* pre_args; };
     const Form forms[3] = {{"", 0, ""}, {"_z", DZ, "PX px, PY py"}, {"_x", DX, "PY py, PZ pz"}};
+    auto knob = [](const char* name, int fallback) { const char* e = std::getenv(name); return e && *e ? std::atoi(e) : fallback; };
     for (const Form& f : forms) {
-        const Variant vd = render_variant(ph, f.walk, dist_roots), ve = render_variant(ph, f.walk, eval_roots);
+        const std::vector<char> hoistable = hoistable_set(ph, f.walk, f.walk == DZ ? knob("HU_HOIST_MIN_Z", 1) : knob("HU_HOIST_MIN_X", 1));
+        const Variant vd = render_variant(ph, hoistable, dist_roots), ve = render_variant(ph, hoistable, eval_roots);
         // the values handed from `pre`: the union of what the distance and the evaluation read (one struct for both)
         const Variant& pre_of = ve;   // (eval's roots include dist's root: its frontier covers it)
         const bool hoists = f.walk != 0 && pre_of.n_hoisted > 0;
@@ -639,11 +725,11 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
         const std::string h_tmpl = f.walk != 0 ? ", class H" : "";
         o << "template <class PX, class PY, class PZ" << h_tmpl << "> __device__ __forceinline__ auto tape_dist" << f.suffix
           << "(PX px, PY py, PZ pz, const float* __restrict__ extra, uint32_t flags" << h_param << ")\n{\n" << head
-          << vd.main << "    return as<T>(" << (ph.e.st[ph.root].ops.empty() ? ph.e.st[ph.root].text : ((f.walk && !(ph.e.st[ph.root].deps & f.walk) ? "h.t" : "t") + std::to_string(ph.root))) << ");\n}\n";
+          << vd.main << "    return as<T>(" << (ph.e.st[ph.root].ops.empty() ? ph.e.st[ph.root].text : ((hoistable[ph.root] ? "h.t" : "t") + std::to_string(ph.root))) << ");\n}\n";
         o << "template <class PX, class PY, class PZ" << h_tmpl << "> __device__ __forceinline__ auto tape_eval" << f.suffix
           << "(PX px, PY py, PZ pz, const float* __restrict__ extra, uint32_t flags" << h_param << ")\n{\n" << head
-          << ve.main << phase2_for(f.walk)
-          << "    return v4<T>(dir.x, dir.y, dir.z, as<T>(" << (ph.e.st[ph.root].ops.empty() ? ph.e.st[ph.root].text : ((f.walk && !(ph.e.st[ph.root].deps & f.walk) ? "h.t" : "t") + std::to_string(ph.root))) << "));\n}\n";
+          << ve.main << phase2_for(hoistable)
+          << "    return v4<T>(dir.x, dir.y, dir.z, as<T>(" << (ph.e.st[ph.root].ops.empty() ? ph.e.st[ph.root].text : ((hoistable[ph.root] ? "h.t" : "t") + std::to_string(ph.root))) << "));\n}\n";
         (void)vd;
     }
     o << "// deferred directions: " << paths.size() << " (primitive, path) pairs; " << ph.e.st.size() << " statements in phase 1\n";
@@ -651,10 +737,13 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
 }
 
 // The whole translation unit handed to hipRTC.  `deferred` (may be NULL) <- whether the deferred form was used.
-inline std::string specialised_source(const SpecProgram& p, bool allow_deferred, bool* deferred = nullptr)
+// `coord_limit` (may be NULL) <- the largest |sample coordinate| for which a launch may set sdf::kFlagInRange (0: never).
+inline std::string specialised_source(const SpecProgram& p, bool allow_deferred, bool* deferred = nullptr, double* coord_limit = nullptr)
 {
     std::ostringstream o, d;
-    const bool ok = allow_deferred && emit_deferred(d, p, 40);
+    if (coord_limit) *coord_limit = 0.0;
+    const bool ok = allow_deferred && emit_deferred(d, p, 40, coord_limit);
+    if (!ok && coord_limit) *coord_limit = 0.0;
     o << "#include \"kernels.hpp\"\nnamespace sdfk {\nusing sdf::Rec;\n";
     if (ok) o << d.str();
     else emit_plain(o, p);

@@ -141,11 +141,15 @@ def test_specialised_source_builds_under_hiprtc_without_a_device():
     buf = ctypes.create_string_buffer(needed.value)
     assert lib.hu_tape_source(p, t.size, buf, needed.value, ctypes.byref(needed)) == 0
     src = buf.value.decode()
-    # sponge(2): the deferred-directions form (specialise.hpp): the distance-only program, then one block per
-    # (primitive, path to the root) -- 6 bars + the box
+    # sponge(2): the deferred-directions form (specialise.hpp): phase 1 as typed single-assignment statements -- in
+    # place, hoisted out of walks along z, and along x --, then one block per (primitive, path to the root): 6 bars +
+    # the box, in each of the three evaluation functions
     assert "struct JitEval" in src and "tape_dist" in src and "deferred directions: 7 " in src
-    assert 0 < src.count("exec_one<T, true, decltype(regs), ") <= 2 * 52      # the decoder may fold records
-    assert src.count("// the primitive of record") == 7
+    for name in ("tape_dist(", "tape_eval(", "tape_pre_z(", "tape_dist_z(", "tape_eval_z(", "tape_pre_x(", "tape_dist_x(", "tape_eval_x("):
+        assert src.count("auto " + name) == 1, name
+    assert src.count("const auto t") > 100 and "struct Hoisted {" in src and "h.t" in src
+    assert "exec_one<T, true" not in src       # no record of the distance-only program is run through the library here
+    assert src.count("// the primitive of record") == 3 * 7
     size = ctypes.c_size_t(0)
     rc = lib.hu_tape_compile_check(p, t.size, include_dir, ctypes.byref(size))
     assert rc == 0, lib.hu_last_error().decode()
