@@ -407,6 +407,115 @@ template <class A, class B, class C> __device__ __forceinline__ wider_t<wider_t<
     return sqrt_cr(fma_(as<R>(z), as<R>(z), as<R>(fma_(as<RXY>(y), as<RXY>(y), as<RXY>(x * x)))), mask_of<R>::all());
 }
 
+// ---- directions of mixed width (the second phase of per-tape code, specialise.hpp) -------------------------------
+// The direction parts of rectangle_op / circle_op / sphere_op / extrusion_op above, operation for operation, on
+// coordinates of different widths; `act` = the lanes (voxels) of the path being evaluated, as `wanted` above.
+__device__ __forceinline__ m1 narrow_mask(m1 a, float) { return a; }
+__device__ __forceinline__ m2 narrow_mask(m2 a, f2) { return a; }
+__device__ __forceinline__ m1 narrow_mask(m2 a, float) { return m1{a.x || a.y, a.wx | a.wy}; }   // "either voxel of the lane"
+template <class M, class A, class B> __device__ __forceinline__ auto sel_x(M m, A a, B b)
+{
+    using R = typename lanes_type<M>::type;
+    return sel(m, as<R>(a), as<R>(b));
+}
+template <class T, class M> __device__ __forceinline__ void sqrt_inv_cr(T x, M used, T& s, T& r, uint32_t flags)
+{
+#if SDF_FAST_CR_MATH
+    const T y = rsq_hw(x);
+    const T s0 = x * y, h = 0.5f * y;
+    s = fma_(fma_(-s0, s0, x), h, s0);
+    const T r0 = rcp_hw(s);
+    r = fma_(fma_(-s, r0, bc<T>(1.0f)), r0, r0);
+    if (!(flags & kFlagInRange)) {
+        SDF_KEEP_BRANCH("range test of the fast sqrt and reciprocal");
+        if (wave_any(used & outside_fast_range(x))) {
+            SDF_KEEP_BRANCH("IEEE sqrt and divide for out-of-range input");
+            s = sqrt_(x);
+            r = 1.0f / s;
+        }
+    }
+#else
+    s = sqrt_(x);
+    r = 1.0f / s;
+#endif
+}
+// shell (a component of the direction, the distance that entered) and symmetrical_from (x of the direction, x of the point)
+template <class C, class W> __device__ __forceinline__ wider_t<C, W> shell_dir_x(C c, W w)
+{
+    using R = wider_t<C, W>;
+    return sel(as_mask(ge(w, 0.0f), R()), as<R>(c), -as<R>(c));
+}
+template <class C, class P> __device__ __forceinline__ wider_t<C, P> symm_dir_x(C c, P ptx)
+{
+    using R = wider_t<C, P>;
+    return sel(as_mask(lt(ptx, 0.0f), R()), -as<R>(c), as<R>(c));
+}
+template <class R> struct D2 { R x, y; };
+template <class R> struct D3 { R x, y, z; };
+template <class X, class Y, class M>
+__device__ __forceinline__ D2<wider_t<X, Y>> rect_dir_x(X cx, Y cy, float hw, float hh, M act, uint32_t flags)
+{
+    using R = wider_t<X, Y>;
+    const R zero = bc<R>(0.0f);
+    const R sx = as<R>(copysign_(bc<X>(1.0f), cx)), sy = as<R>(copysign_(bc<Y>(1.0f), cy));
+    const X wx0 = abs_minus(cx, hw);
+    const Y wy0 = abs_minus(cy, hh);
+    const R wx = as<R>(wx0), wy = as<R>(wy0);
+    const auto corner = as_mask(gt(wx0, 0.0f), R()) & as_mask(gt(wy0, 0.0f), R());
+    const auto xs = gt(wx, wy);
+    D2<R> r{sel(xs, sx, zero), sel(xs, zero, sy)};
+    const auto wanted = narrow_mask(act, R());
+    if (any_lane(corner & wanted)) {
+        R dist, inv;
+        sqrt_inv_cr(fma_(wy, wy, wx * wx), corner & wanted, dist, inv, flags);
+        r.x = sel(corner, sx * (wx * inv), r.x);
+        r.y = sel(corner, sy * (wy * inv), r.y);
+    }
+    return r;
+}
+template <class X, class Y, class M> __device__ __forceinline__ D2<wider_t<X, Y>> circle_dir_x(X cx, Y cy, M act)
+{
+    using R = wider_t<X, Y>;
+    R a, inv;
+    sqrt_inv_cr(fma_(as<R>(cy), as<R>(cy), as<R>(cx * cx)), narrow_mask(act, R()), a, inv);
+    const auto zero = eq(a, 0.0f);
+    return D2<R>{sel(zero, bc<R>(1.0f), as<R>(cx) * inv), sel(zero, bc<R>(0.0f), as<R>(cy) * inv)};
+}
+template <class X, class Y, class Z, class M>
+__device__ __forceinline__ D3<wider_t<wider_t<X, Y>, Z>> sphere_dir_x(X cx, Y cy, Z cz, M act)
+{
+    using R = wider_t<wider_t<X, Y>, Z>;
+    using RXY = wider_t<X, Y>;
+    R a, inv;
+    sqrt_inv_cr(fma_(as<R>(cz), as<R>(cz), as<R>(fma_(as<RXY>(cy), as<RXY>(cy), as<RXY>(cx * cx)))), narrow_mask(act, R()), a, inv);
+    const auto zero = eq(a, 0.0f);
+    return D3<R>{sel(zero, bc<R>(1.0f), as<R>(cx) * inv), sel(zero, bc<R>(0.0f), as<R>(cy) * inv), sel(zero, bc<R>(0.0f), as<R>(cz) * inv)};
+}
+// extrusion_op: (ix, iy, iz) = the direction that entered, iw its distance, cz = the z of the extruded point
+template <class IX, class IY, class IZ, class IW, class CZ, class M>
+__device__ __forceinline__ auto extrusion_dir_x(IX ix, IY iy, IZ iz, IW iw, CZ cz, float hh, M act, uint32_t flags)
+{
+    using R = wider_t<wider_t<wider_t<IX, IY>, wider_t<IZ, IW>>, CZ>;
+    const R zero = bc<R>(0.0f);
+    const R inx = as<R>(ix), iny = as<R>(iy), inz = as<R>(iz), inw = as<R>(iw);
+    const R sz = as<R>(copysign_(bc<CZ>(1.0f), cz));
+    const CZ wz0 = abs_minus(cz, hh);
+    const R wz = as<R>(wz0);
+    const auto corner = as_mask(gt(wz0, 0.0f), R()) & as_mask(gt(iw, 0.0f), R());
+    const auto cap = gt(wz, inw);
+    D3<R> r{sel(cap, zero, inx), sel(cap, zero, iny), sel(cap, sz, inz)};
+    const auto wanted = narrow_mask(act, R());
+    if (any_lane(corner & wanted)) {
+        R dist, inv;
+        sqrt_inv_cr(fma_(inw, inw, wz * wz), corner & wanted, dist, inv, flags);
+        const R m1_ = wz * inv, m2_ = inw * inv;
+        r.x = sel(corner, inx * m2_ + 0.0f, r.x);      // (+ 0: extrusion_op tells why)
+        r.y = sel(corner, iny * m2_ + 0.0f, r.y);
+        r.z = sel(corner, fma_(inz, m2_, sz * m1_), r.z);
+    }
+    return r;
+}
+
 // reference shapes/simple3d.cl:18-21 = perpendicular_intersection(slab_z(h, coords), in)
 template <class T, class M = typename mask_of<T>::type>
 __device__ __forceinline__ V4<T> extrusion_op(float hh, V4<T> in, V4<T> coords, M wanted = mask_of<T>::all())
@@ -1136,6 +1245,20 @@ __device__ __forceinline__ V4<T> run_tape(const Rec* __restrict__ prog, const fl
         for (int k = 0; k < kFetchGroup; ++k)
             if (exec_one<T, DISTANCE_ONLY, R>(group[k], last, extra, px, py, pz, regs)) return last;
     }
+}
+
+// The FULL form of a record on a widened value (the second phase of per-tape code, for the ops it does not restate):
+// `act` = the lanes of the path, the record's register operand in `operand`
+template <int OP, class TA, class TB, class M>
+__device__ __forceinline__ auto run_record_full(const Rec& r, const float* __restrict__ extra, V4<TA> last, V4<TB> operand, M act)
+{
+    using R = wider_t<wider_t<TA, TB>, typename lanes_type<M>::type>;
+    V4<R> v = widen4<R>(last);
+    RegsOne<R> one;
+    one.v = widen4<R>(operand);
+    one.act = act;
+    exec_one<R, false, RegsOne<R>, OP>(r, v, extra, bc<R>(0.0f), bc<R>(0.0f), bc<R>(0.0f), one);
+    return v;
 }
 
 // One record of the library on values of mixed width (per-tape code, specialise.hpp: the ops its phase 1 does not

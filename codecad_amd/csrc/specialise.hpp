@@ -274,7 +274,7 @@ struct Emitter {
     int neg(int v)
     {
         if (neg_of[v] >= 0) return neg_of[v];
-        const int r = add("-$0", {v});
+        const int r = add("-($0)", {v});
         neg_of[r] = v;
         return r;
     }
@@ -305,11 +305,12 @@ struct Phase1 {
     std::vector<int> keep_w_of_rec;           // record -> value id of the distance that entered it, or -1
     int root = -1;
     int px = -1, py = -1, pz = -1;
+    int n_phase1 = 0;                         // statements [0, n_phase1) are phase 1's; the rest are directions (phase 2)
 };
 
 // false: an op this generator does not restate (the plain form is used instead)
 inline bool symbolic_phase1(const SpecProgram& p, const std::vector<Node>& nodes, int root, const std::vector<char>& is_choice,
-                            const std::vector<char>& keep_w, Phase1& out)
+                            const std::vector<char>& keep_w, Phase1& out, std::vector<std::array<int, 3>>* points = nullptr)
 {
     Emitter& e = out.e;
     struct Pt { int c[3] = {-1, -1, -1}; int w = -1; };
@@ -425,6 +426,7 @@ inline bool symbolic_phase1(const SpecProgram& p, const std::vector<Node>& nodes
             default: return false;
             }
             pt[n] = o;
+            if (points) (*points)[n] = {{o.c[0], o.c[1], o.c[2]}};
             continue;
         }
         // ---- results: the distance alone
@@ -455,7 +457,7 @@ inline bool symbolic_phase1(const SpecProgram& p, const std::vector<Node>& nodes
                 break;
             case OPX_FROM_MATRIX: w = bound(e.add("$0 * " + flit(q[9]), {in}), A(q[9]) * G(in), A(q[9]) * O(in), OK(in)); break;
             case OP_OFFSET: w = bound(e.add("$0 - " + flit(q[0]), {in}), G(in), O(in) + A(q[0]), OK(in)); break;
-            case OP_SHELL: w = bound(e.add("sel(ge($0, 0.0f), $0, -$0) - " + flit(q[0]), {in}), G(in), O(in) + A(q[0]), OK(in)); break;
+            case OP_SHELL: w = bound(e.add("sel(ge($0, 0.0f), $0, -($0)) - " + flit(q[0]), {in}), G(in), O(in) + A(q[0]), OK(in)); break;
             case OP_MIRROR: w = in; break;      // (flips the direction's x: the distance stays)
             default: return false;
             }
@@ -521,6 +523,7 @@ struct Variant {
     std::string pre;      // body of the hoisting function ("" when nothing is hoisted)
     std::string main;     // body of the evaluation up to the root distance
     int n_hoisted = 0;
+    std::vector<char> handed;   // per statement: is it a member of the struct `pre` returns
 };
 // Which statements are handed from `pre` when the walk is along `walk`: those that do not read its coordinate -- unless
 // they are cheaper to compute again in every brick than to keep in a register for the whole walk (a value costs one or
@@ -533,7 +536,7 @@ inline std::vector<char> hoistable_set(const Phase1& ph, uint8_t walk, int min_c
     std::vector<char> out(n, 0);
     if (walk == 0) return out;
     std::vector<int> cost(n, 0);
-    for (int i = 0; i < n; ++i) {
+    for (int i = 0; i < ph.n_phase1; ++i) {   // (a direction is computed where its path's mask is known: never in `pre`)
         if (st[i].ops.empty() || st[i].mask || (st[i].deps & walk)) continue;
         const std::string& t = st[i].text;
         int c = t.compare(0, 11, "remainder_t") == 0 ? 3 : t.compare(0, 8, "perp_w_x") == 0 ? 8 : t.compare(0, 4, "len2") == 0 ? 10 :
@@ -594,6 +597,7 @@ inline Variant render_variant(const Phase1& ph, const std::vector<char>& hoistab
         main << "    const auto t" << i << " = " << render(st[i], in_walk) << ";\n";
     }
     v.main = main.str();
+    v.handed = frontier;
     return v;
 }
 
@@ -620,95 +624,168 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
             if (s.node >= 0 && reads_input_distance(nodes[s.node].op)) keep_w[nodes[s.node].rec] = 1;
     }
     Phase1 ph;
-    if (!symbolic_phase1(p, nodes, root, is_choice, keep_w, ph)) return false;
+    std::vector<std::array<int, 3>> pt(nodes.size(), {{-1, -1, -1}});   // local coordinates by (point) node
+    if (!symbolic_phase1(p, nodes, root, is_choice, keep_w, ph, &pt)) return false;
     if (coord_limit) *coord_limit = coordinate_limit(ph);
+    ph.n_phase1 = (int)ph.e.st.size();
     std::vector<int> dist_roots{ph.root}, eval_roots{ph.root};
     for (int v : ph.choice_of_rec) if (v >= 0) eval_roots.push_back(v);
     for (int v : ph.keep_w_of_rec) if (v >= 0) eval_roots.push_back(v);
 
-    // ---- phase 2, as text (the same for every variant): the directions of the primitives that win somewhere in the
-    // wavefront, each through the library's full ops on its path (exec_one)
-    std::ostringstream p2;
-    auto value_name = [&](int id, bool hoisted_variant, const std::vector<char>* frontier) -> std::string {
-        (void)hoisted_variant; (void)frontier;
-        return ph.e.st[id].ops.empty() ? ph.e.st[id].text : "t" + std::to_string(id);
-    };
-    (void)value_name;
-    const std::string zero4 = "v4<T>(bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f))";
-    auto run_record = [&](const Rec& r, const std::string& value) {   // one record of the FULL program on `value`
-        const uint32_t op = r.hdr & 0xffu;
-        p2 << "{ const Rec r = " << rec_literal(r, true, op) << "; exec_one<T, false, RegsOne<T>, " << op << ">(r, " << value
-           << ", extra, qx, qy, qz, one); }";
-    };
-    p2 << "    // ---- phase 2\n"
-       << "    const T qx = opaque(as<T>(px)), qy = opaque(as<T>(py)), qz = opaque(as<T>(pz));\n"
-       << "    V4<T> dir = " << zero4 << ";\n"
-       << "    RegsOne<T> one;\n";
-    for (const Path& path : paths) {
-        p2 << "    {   // the primitive of record " << nodes[path.leaf].rec << " along one path to the root\n        const M m = ";
-        if (path.choices.empty()) p2 << "mask_of<T>::all()";
-        for (size_t k = 0; k < path.choices.size(); ++k)
-            p2 << (k ? " & " : "") << (path.choices[k].second ? "" : "~") << "as_mask(@" << ph.choice_of_rec[path.choices[k].first] << "@, T())";
-        p2 << ";\n        if (wave_any(m)) {\n            one.act = m;\n";
-        // the local coordinates of a point node: its chain of point ops from the sample point, emitted once per block
-        std::vector<int> var(nodes.size(), -1);
-        int next_var = 0;
-        auto emit_point = [&](int node) -> std::string {
-            std::vector<int> chain;
-            for (int at = node; at >= 0 && var[at] < 0; at = nodes[at].a) chain.push_back(at);
-            for (auto it = chain.rbegin(); it != chain.rend(); ++it) {
-                const Node& n = nodes[*it];
-                var[*it] = next_var++;
-                p2 << "            V4<T> p" << var[*it] << " = " << (n.a >= 0 ? "p" + std::to_string(var[n.a]) : zero4) << "; ";
-                run_record(p.full[n.rec], "p" + std::to_string(var[*it]));
-                p2 << "\n";
-            }
-            return "p" + std::to_string(var[node]);
+    // ---- phase 2: the directions of the primitives that win somewhere in the wavefront.  For every (primitive, path to
+    // the root) a block under a wave-uniform branch: the primitive's direction from its local coordinates, pushed through
+    // the ops on the path -- restated component by component like phase 1 (interp.hpp "directions of mixed width"), in the
+    // SAME statement list, so that a coordinate phase 1 already names is found again: one that is handed from `pre` is
+    // simply read there; anything else is computed again inside the block from opaque copies of the sample point
+    // (reusing phase 1's registers across the whole second phase would cost more than recomputing: interp.hpp opaque).
+    Emitter& e = ph.e;
+    const int zero = e.add("0.0f", {});
+    struct PathCode { std::string mask; int d[3]; };
+    std::vector<PathCode> codes;
+    {
+        auto full_record = [&](const Rec& r, const int (&last)[4], const int (&operand)[4]) {
+            const uint32_t op = r.hdr & 0xffu;
+            return e.add("run_record_full<" + std::to_string(op) + ">(" + rec_literal(r, true, op) + ", extra, v4x($0, $1, $2, $3), v4x($4, $5, $6, $7), m)",
+                         {last[0], last[1], last[2], last[3], operand[0], operand[1], operand[2], operand[3]});
         };
-        const Node& leaf = nodes[path.leaf];
-        const std::string at = emit_point(leaf.a);
-        p2 << "            V4<T> d = " << at << "; ";
-        run_record(p.full[leaf.rec], "d");
-        p2 << "\n";
-        for (const Step& st : path.up) {
-            if (st.node < 0) {
-                p2 << "            d = v4<T>(-d.x, -d.y, -d.z, d.w);\n";
-                continue;
+        auto mulc = [&](int v, float c) { return e.add("$0 * " + flit(c), {v}); };
+        for (const Path& path : paths) {
+            PathCode code;
+            for (size_t k = 0; k < path.choices.size(); ++k)
+                code.mask += std::string(k ? " & " : "") + (path.choices[k].second ? "" : "~") + "as_mask(@" + std::to_string(ph.choice_of_rec[path.choices[k].first]) + "@, T())";
+            if (path.choices.empty()) code.mask = "mask_of<T>::all()";
+            const Node& leaf = nodes[path.leaf];
+            const Rec& lr = p.full[leaf.rec];
+            const std::array<int, 3>& c = pt[leaf.a];
+            int d[3] = {zero, zero, zero};
+            if (leaf.op == OP_RECTANGLE) {
+                const int v = e.add("rect_dir_x($0, $1, " + flit(lr.p[0]) + ", " + flit(lr.p[1]) + ", m, flags)", {c[0], c[1]});
+                d[0] = e.add("$0.x", {v}); d[1] = e.add("$0.y", {v});
+            } else if (leaf.op == OP_CIRCLE) {
+                const int v = e.add("circle_dir_x($0, $1, m)", {c[0], c[1]});
+                d[0] = e.add("$0.x", {v}); d[1] = e.add("$0.y", {v});
+            } else if (leaf.op == OP_SPHERE) {
+                const int v = e.add("sphere_dir_x($0, $1, $2, m)", {c[0], c[1], c[2]});
+                d[0] = e.add("$0.x", {v}); d[1] = e.add("$0.y", {v}); d[2] = e.add("$0.z", {v});
+            } else if (leaf.op == OP_HALF_SPACE) {
+                d[1] = e.add("-1.0f", {});
+            } else {
+                const int last[4] = {c[0], c[1], c[2], zero}, none4[4] = {zero, zero, zero, zero};
+                const int v = full_record(lr, last, none4);
+                d[0] = e.add("$0.x", {v}); d[1] = e.add("$0.y", {v}); d[2] = e.add("$0.z", {v});
             }
-            const Node& n = nodes[st.node];
-            if (n.role == WITH_POINT) {
-                const std::string operand = emit_point(n.b);   // (emits the chain's statements first)
-                p2 << "            one.v = " << operand << ";\n";
+            for (const Step& stp : path.up) {
+                if (stp.node < 0) {
+                    for (int k = 0; k < 3; ++k) d[k] = e.neg(d[k]);
+                    continue;
+                }
+                const Node& n = nodes[stp.node];
+                const Rec& r = p.full[n.rec];
+                const float* q = r.p;
+                const int w_in = reads_input_distance(n.op) ? ph.keep_w_of_rec[n.rec] : zero;
+                switch (n.op) {
+                case OPX_FROM_SCALE:
+                    for (int k = 0; k < 3; ++k) d[k] = mulc(d[k], q[0]);
+                    break;
+                case OPX_FROM_AXIS_X: case OPX_FROM_AXIS_Y: case OPX_FROM_AXIS_Z: {
+                    // interp.hpp axis_rotate_dir: (along, u, v) = the axis and the other two in cyclic order
+                    const int ax = n.op == OPX_FROM_AXIS_X ? 0 : n.op == OPX_FROM_AXIS_Y ? 1 : 2, u = (ax + 1) % 3, v = (ax + 2) % 3;
+                    const int along = d[ax], du = d[u], dv = d[v];
+                    d[ax] = mulc(along, q[0]);
+                    int ru = mulc(e.neg(dv), q[2]), rv = mulc(du, q[2]);
+                    if (q[1] != 0.0f) {
+                        ru = e.add("fma_x($0, " + flit(q[1]) + ", $1)", {du, ru});
+                        rv = e.add("fma_x($0, " + flit(q[1]) + ", $1)", {dv, rv});
+                    }
+                    d[u] = ru;
+                    d[v] = rv;
+                    break;
+                }
+                case OPX_FROM_MATRIX: {
+                    const int x = d[0], y = d[1], z = d[2];
+                    for (int k = 0; k < 3; ++k)
+                        d[k] = e.add("fma_x($0, " + flit(q[3 * k]) + ", fma_x($1, " + flit(q[3 * k + 1]) + ", $2 * " + flit(q[3 * k + 2]) + "))", {x, y, z});
+                    break;
+                }
+                case OP_OFFSET: break;
+                case OP_SHELL:
+                    for (int k = 0; k < 3; ++k) d[k] = e.add("shell_dir_x($0, $1)", {d[k], w_in});
+                    break;
+                case OP_MIRROR: d[0] = e.neg(d[0]); break;
+                case OP_EXTRUSION: {
+                    const int v = e.add("extrusion_dir_x($0, $1, $2, $3, $4, " + flit(q[0]) + ", m, flags)", {d[0], d[1], d[2], w_in, pt[n.b][2]});
+                    d[0] = e.add("$0.x", {v}); d[1] = e.add("$0.y", {v}); d[2] = e.add("$0.z", {v});
+                    break;
+                }
+                case OP_SYMMETRICAL_FROM: d[0] = e.add("symm_dir_x($0, $1)", {d[0], pt[n.b][0]}); break;
+                default: {   // transformation_from with a general quaternion, circular repetition, the revolutions
+                    const int last[4] = {d[0], d[1], d[2], w_in};
+                    const int operand[4] = {n.role == WITH_POINT ? pt[n.b][0] : zero, n.role == WITH_POINT ? pt[n.b][1] : zero,
+                                            n.role == WITH_POINT ? pt[n.b][2] : zero, zero};
+                    const int v = full_record(r, last, operand);
+                    d[0] = e.add("$0.x", {v}); d[1] = e.add("$0.y", {v}); d[2] = e.add("$0.z", {v});
+                    break;
+                }
+                }
             }
-            if (reads_input_distance(n.op)) p2 << "            d.w = as<T>(@" << ph.keep_w_of_rec[n.rec] << "@);\n";
-            p2 << "            ";
-            run_record(p.full[n.rec], "d");
-            p2 << "\n";
+            code.d[0] = d[0]; code.d[1] = d[1]; code.d[2] = d[2];
+            codes.push_back(code);
         }
-        p2 << "            dir.x = sel(m, d.x, dir.x); dir.y = sel(m, d.y, dir.y); dir.z = sel(m, d.z, dir.z);\n"
-           << "        }\n    }\n";
     }
-    const std::string phase2 = p2.str();
-    // `@id@` in the text above: a value of phase 1 by its number; a hoisted one lives in `h`
+    // phase 1's values that phase 2 reads where they are (not computed again): the comparisons, the kept distances
+    std::vector<char> lives(e.st.size(), 0);
+    for (int v : ph.choice_of_rec) if (v >= 0) lives[v] = 1;
+    for (int v : ph.keep_w_of_rec) if (v >= 0) lives[v] = 1;
     auto phase2_for = [&](const std::vector<char>& hoistable) {
-        std::string out;
-        for (size_t i = 0; i < phase2.size(); ++i) {
-            if (phase2[i] != '@') { out += phase2[i]; continue; }
-            const size_t end = phase2.find('@', i + 1);
-            const int id = std::atoi(phase2.substr(i + 1, end - i - 1).c_str());
-            const Stmt& s = ph.e.st[id];
-            out += s.ops.empty() ? s.text : (hoistable[id] ? "h.t" : "t") + std::to_string(id);
-            i = end;
+        const std::vector<Stmt>& st = e.st;
+        auto outer = [&](int id) { return st[id].ops.empty() ? st[id].text : (id < (int)hoistable.size() && hoistable[id] ? "h.t" : "t") + std::to_string(id); };
+        std::ostringstream o2;
+        o2 << "    // ---- phase 2\n"
+           << "    const auto qx = opaque(px); const auto qy = opaque(py); const auto qz = opaque(pz);\n"
+           << "    V4<T> dir = v4<T>(bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f));\n";
+        for (size_t k = 0; k < paths.size(); ++k) {
+            const PathCode& code = codes[k];
+            std::string mask;
+            for (size_t i = 0; i < code.mask.size(); ++i) {
+                if (code.mask[i] != '@') { mask += code.mask[i]; continue; }
+                const size_t end = code.mask.find('@', i + 1);
+                mask += outer(std::atoi(code.mask.substr(i + 1, end - i - 1).c_str()));
+                i = end;
+            }
+            o2 << "    {   // the primitive of record " << nodes[paths[k].leaf].rec << " along one path to the root\n        const M m = " << mask
+               << ";\n        if (wave_any(m)) {\n";
+            // what the block computes: the closure of the direction's statements, up to values that live outside it
+            std::vector<char> inside(st.size(), 0);
+            std::vector<int> stack{code.d[0], code.d[1], code.d[2]};
+            while (!stack.empty()) {
+                const int i = stack.back();
+                stack.pop_back();
+                if (inside[i] || st[i].ops.empty() || lives[i] || (i < (int)hoistable.size() && hoistable[i])) continue;
+                inside[i] = 1;
+                for (int op : st[i].ops) stack.push_back(op);
+            }
+            auto name = [&](int id) -> std::string {
+                if (st[id].ops.empty()) return st[id].text == "px" ? "qx" : st[id].text == "py" ? "qy" : st[id].text == "pz" ? "qz" : st[id].text;
+                return inside[id] ? "u" + std::to_string(id) : outer(id);
+            };
+            for (int i = 0; i < (int)st.size(); ++i)
+                if (inside[i]) o2 << "            const auto u" << i << " = " << render(st[i], name) << ";\n";
+            o2 << "            dir.x = sel(m, as<T>(" << name(code.d[0]) << "), dir.x); dir.y = sel(m, as<T>(" << name(code.d[1])
+               << "), dir.y); dir.z = sel(m, as<T>(" << name(code.d[2]) << "), dir.z);\n        }\n    }\n";
         }
-        return out;
+        return o2.str();
     };
 
     const char* head = "    using namespace sdf;\n    using T = wider_t<wider_t<PX, PY>, PZ>;\n    using M = typename mask_of<T>::type;\n";
     struct Form { const char* suffix; uint8_t walk; const char* pre_args; };
     const Form forms[3] = {{"", 0, ""}, {"_z", DZ, "PX px, PY py"}, {"_x", DX, "PY py, PZ pz"}};
+    // what a value must save per brick to be kept for a whole walk (hoistable_set), measured on sponge(4) at 512^3, MI355X:
+    // dense kernel (walks of sixteen bricks along z) 0.568 ms keeping everything, 0.530 / 0.519 / 0.518 / 0.521 ms at
+    // 8 / 10 / 12 / 14 -- the |x| - h of the shallow levels are cheaper to recompute than to hold, 79 registers at stake --;
+    // leaf blocks (walks of four bricks along x) 0.363 -> 0.356 ms at 8
     auto knob = [](const char* name, int fallback) { const char* e = std::getenv(name); return e && *e ? std::atoi(e) : fallback; };
     for (const Form& f : forms) {
-        const std::vector<char> hoistable = hoistable_set(ph, f.walk, f.walk == DZ ? knob("HU_HOIST_MIN_Z", 1) : knob("HU_HOIST_MIN_X", 1));
+        const std::vector<char> hoistable = hoistable_set(ph, f.walk, f.walk == DZ ? knob("HU_HOIST_MIN_Z", 12) : knob("HU_HOIST_MIN_X", 8));
         const Variant vd = render_variant(ph, hoistable, dist_roots), ve = render_variant(ph, hoistable, eval_roots);
         // the values handed from `pre`: the union of what the distance and the evaluation read (one struct for both)
         const Variant& pre_of = ve;   // (eval's roots include dist's root: its frontier covers it)
@@ -725,11 +802,11 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
         const std::string h_tmpl = f.walk != 0 ? ", class H" : "";
         o << "template <class PX, class PY, class PZ" << h_tmpl << "> __device__ __forceinline__ auto tape_dist" << f.suffix
           << "(PX px, PY py, PZ pz, const float* __restrict__ extra, uint32_t flags" << h_param << ")\n{\n" << head
-          << vd.main << "    return as<T>(" << (ph.e.st[ph.root].ops.empty() ? ph.e.st[ph.root].text : ((hoistable[ph.root] ? "h.t" : "t") + std::to_string(ph.root))) << ");\n}\n";
+          << vd.main << "    return as<T>(" << (ph.e.st[ph.root].ops.empty() ? ph.e.st[ph.root].text : ((ve.handed[ph.root] ? "h.t" : "t") + std::to_string(ph.root))) << ");\n}\n";
         o << "template <class PX, class PY, class PZ" << h_tmpl << "> __device__ __forceinline__ auto tape_eval" << f.suffix
           << "(PX px, PY py, PZ pz, const float* __restrict__ extra, uint32_t flags" << h_param << ")\n{\n" << head
-          << ve.main << phase2_for(hoistable)
-          << "    return v4<T>(dir.x, dir.y, dir.z, as<T>(" << (ph.e.st[ph.root].ops.empty() ? ph.e.st[ph.root].text : ((hoistable[ph.root] ? "h.t" : "t") + std::to_string(ph.root))) << "));\n}\n";
+          << ve.main << phase2_for(ve.handed)
+          << "    return v4<T>(dir.x, dir.y, dir.z, as<T>(" << (ph.e.st[ph.root].ops.empty() ? ph.e.st[ph.root].text : ((ve.handed[ph.root] ? "h.t" : "t") + std::to_string(ph.root))) << "));\n}\n";
         (void)vd;
     }
     o << "// deferred directions: " << paths.size() << " (primitive, path) pairs; " << ph.e.st.size() << " statements in phase 1\n";
