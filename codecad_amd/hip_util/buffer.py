@@ -230,6 +230,60 @@ def cache_dir():
     return path
 
 
+class _BackgroundCompiler:
+    """ONE worker thread that turns tapes into per-tape code objects with hipRTC while the interpreter serves their
+    launches (hu_tape_compile_cached: host only, no device call, the GIL is released for its duration).  A finished
+    build sits in the on-disk cache -- or, when that is switched off, in a private directory of this process -- where
+    the tape's next launch finds it in milliseconds.  The thread's first job also pays hipRTC's one-off start (loading
+    the compiler: ~1.5 s in a fresh process), so no launch ever waits for that either."""
+
+    def __init__(self):
+        self.queue, self.thread, self.private_dir = None, None, None
+
+    def directory(self):
+        d = cache_dir()
+        if d:
+            return d
+        if self.private_dir is None:
+            import atexit
+            import shutil
+            import tempfile
+            self.private_dir = tempfile.mkdtemp(prefix="codecad_amd_jit_")
+            atexit.register(shutil.rmtree, self.private_dir, True)
+        return self.private_dir
+
+    def submit(self, lib, host_tape, include_dir):
+        """-> a job: {"done": threading.Event, "error": None or str, "directory": where the image is}"""
+        import queue
+        import threading
+        if self.thread is None:
+            self.queue = queue.Queue()
+            self.thread = threading.Thread(target=self._run, name="codecad_amd-hiprtc", daemon=True)
+            self.thread.start()
+        job = {"done": threading.Event(), "error": None, "directory": self.directory(), "lib": lib,
+               "tape": numpy.array(host_tape, dtype=numpy.float32, copy=True), "include": include_dir}
+        self.queue.put(job)
+        return job
+
+    def _run(self):
+        while True:
+            job = self.queue.get()
+            try:
+                t = job["tape"]
+                size, hit = ctypes.c_size_t(0), ctypes.c_int(0)
+                rc = job["lib"].hu_tape_compile_cached(t.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), t.size, job["include"].encode(),
+                                                       job["directory"].encode(), ctypes.byref(size), ctypes.byref(hit))
+                if rc != 0:
+                    msg = job["lib"].hu_last_error()
+                    job["error"] = msg.decode() if msg else "hipRTC failed (%d)" % rc
+            except Exception as e:      # (never let the worker die: the tape just stays interpreted)
+                job["error"] = "%s: %s" % (type(e).__name__, e)
+            job["done"].set()
+
+
+_background = _BackgroundCompiler()
+
+
 class Tape:
     """A decoded instruction tape resident in HBM (replaces the reference's program buffer,
     nodes/program.py:79-84).  Accepted as the `scene` argument of every kernel."""
@@ -248,48 +302,72 @@ class Tape:
         check(m.lib.hu_tape_info(h, ctypes.byref(n), ctypes.byref(r), ctypes.byref(f)), "hu_tape_info")
         self.n_instructions, self.n_registers, self.flags = n.value, r.value, f.value
         self.specialized = False
-        # CODECAD_AMD_SPECIALIZE: "1" = compile per-tape kernels at upload, "0" = never on its own,
-        # otherwise (default "auto") = when the interpreter has spent on this tape about what the
-        # compilation costs (note_samples): a tape evaluated a few times never pays for hipRTC, a tape
-        # evaluated for seconds runs 2-3x faster from then on -- and a program found in the on-disk cache
-        # (cache_dir) is taken at upload.  Results are the same bytes either way.
+        # CODECAD_AMD_SPECIALIZE: "1" = compile per-tape kernels at upload (and wait for them), "0" = never on its
+        # own, otherwise (default "auto"): the interpreter serves every launch at once, and as soon as it has done a
+        # little work on this tape -- a tape evaluated once on a small grid never costs a compilation -- hipRTC
+        # builds the per-tape kernels IN THE BACKGROUND (_BackgroundCompiler); the first launch after the build has
+        # finished loads them (milliseconds) and runs 3-5x faster from then on.  No launch ever waits for the
+        # compiler.  A program found in the on-disk cache (cache_dir) is taken at upload.  Same bytes either way.
         self._policy = policy if policy is not None else os.environ.get("CODECAD_AMD_SPECIALIZE", "auto")
         self._work = 0.0
+        self._job = None
         self.from_cache = False
         if self._policy == "1":
             self.specialize()
         elif self._policy == "auto":
             self._specialize(only_if_cached=True)   # a program compiled before costs milliseconds: take it now
 
-    # measured on MI355X: the interpreter retires ~2.5e12 (tape instruction x sample) per second whatever the
-    # tape (sponge(4): 85 x 29e9; planetary: 467 x 6.2e9); hipRTC takes ~0.7 s + 8 ms per instruction (round 2's brick
-    # kernels and their hoisted forms: csg_example 1.0 s, sponge(4) 1.7 s, planetary 3.1 s; round 1: 0.3 s + 4.5 ms)
+    # The interpreter retires ~2.5e12 (tape instruction x sample) per second whatever the tape (measured on MI355X:
+    # sponge(4): 85 x 29e9; planetary: 467 x 6.2e9).  A background build starts once the interpreter has spent
+    # _START_SECONDS on the tape: enough that the tape is clearly not a one-off on a small grid, little against the
+    # seconds of interpretation that the build then saves.
     _INTERPRETER_RATE = 2.5e12
-    _JIT_SECONDS = (0.7, 0.008)
+    _START_SECONDS = 0.0005
 
     def note_samples(self, n):
         """Called by the launch wrappers with the number of samples about to be evaluated with this tape."""
         if self.specialized or self._policy != "auto":
             return
+        if self._job is not None:
+            if self._job["done"].is_set():
+                self._take_background_build()
+            return
         self._work += float(n) * self.n_instructions
-        if self._work / self._INTERPRETER_RATE >= self._JIT_SECONDS[0] + self._JIT_SECONDS[1] * self.n_instructions:
-            try:
-                self.specialize()
-            except RuntimeError:
-                self._policy = "0"   # hipRTC cannot build this tape: stay with the interpreter
+        if self._work / self._INTERPRETER_RATE >= self._START_SECONDS:
+            from . import builder
+            self._job = _background.submit(self.manager.lib, self.host_tape, builder.CSRC)
+
+    def _take_background_build(self):
+        job, self._job = self._job, None
+        if job["error"] is not None:
+            self._policy = "0"      # hipRTC cannot build this tape: stay with the interpreter
+            self.build_error = job["error"]
+            return
+        self._specialize(only_if_cached=True, directory=job["directory"])
+        if not self.specialized:
+            self._policy = "0"      # (the image vanished or does not load: do not try again and again)
+
+    def wait_specialized(self, timeout=None):
+        """Wait for a background build in flight (if any) and switch to it; returns self.specialized.  Launches never
+        need this -- they use whatever is ready --; measurements and tests do."""
+        if self._job is not None and self._job["done"].wait(timeout):
+            self._take_background_build()
+        return self.specialized
 
     def specialize(self):
-        """Compile straight-line kernels for this tape with hipRTC (seconds, once); afterwards
+        """Compile straight-line kernels for this tape with hipRTC (seconds, once) and wait for them; afterwards
         every launch with this tape uses them.  Same results as the interpreter.  Raises
         RuntimeError (with the compiler log) if hipRTC cannot build it."""
+        self._job = None
         self._specialize(only_if_cached=False)
         return self
 
-    def _specialize(self, only_if_cached):
+    def _specialize(self, only_if_cached, directory=None):
         if self.specialized:
             return
         from . import builder
-        directory = cache_dir()
+        if directory is None:
+            directory = cache_dir()
         hit, flag = ctypes.c_int(0), ctypes.c_int(0)
         check(self.manager.lib.hu_tape_specialize_cached(self.device_ptr, builder.CSRC.encode(),
                                                          directory.encode() if directory else None,

@@ -17,7 +17,8 @@ _lib = None
 _literal = {}
 
 __all__ = ["build", "lib", "evaluate_points", "grid_eval", "grid_eval_pymcubes", "ray_caster", "bitmap", "process_polygon", "marching_cubes", "stl_records", "STL_RECORD",
-           "subdivision_step", "mass_properties", "det_math", "evaluate_points_literal", "grid_distance_literal"]
+           "subdivision_step", "mass_properties", "det_math", "evaluate_points_literal", "grid_distance_literal",
+           "literal_scene", "mass_properties_literal"]
 
 _f32p = ctypes.POINTER(ctypes.c_float)
 _u32p = ctypes.POINTER(ctypes.c_uint32)
@@ -180,6 +181,49 @@ def det_math(op, a, b=None):
                                  b.ctypes.data_as(_f32p), ctypes.c_int(a.size),
                                  out.ctypes.data_as(_f32p), out2.ctypes.data_as(_f32p)), "det_math")
     return (out, out2) if op == "sincos" else out
+
+
+class literal_scene:
+    """with literal_scene(tape): the renderers below run over the frozen literal-formula evaluate() of sdf_literal.c
+    instead of the canonical one (oracle_set_scene_evaluator); binary32.  Not re-entrant."""
+
+    def __init__(self, tape):
+        self.tape = np.ascontiguousarray(tape, dtype=np.float32)
+
+    def __enter__(self):
+        lit = literal_lib()
+        lit.oracle_literal_open.restype = ctypes.c_void_p
+        lit.oracle_literal_open.argtypes = [_f32p, ctypes.c_int]
+        lit.oracle_literal_close.argtypes = [ctypes.c_void_p]
+        self.handle = lit.oracle_literal_open(self.tape.ctypes.data_as(_f32p), ctypes.c_int(self.tape.size))
+        if not self.handle:
+            raise MemoryError("oracle_literal_open")
+        lib().oracle_set_scene_evaluator.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        lib().oracle_set_scene_evaluator.restype = None
+        lib().oracle_set_scene_evaluator(ctypes.cast(lit.oracle_literal_eval, ctypes.c_void_p), ctypes.c_void_p(self.handle))
+        return self
+
+    def __exit__(self, *exc):
+        lib().oracle_set_scene_evaluator(None, None)
+        literal_lib().oracle_literal_close(ctypes.c_void_p(self.handle))
+
+
+def mass_properties_literal(tape, corner, step, thr, dims):
+    """The reference kernel mass_properties (mass_properties.cl:7-56) over the LITERAL evaluate(): distances from
+    sdf_literal.c (grid_distance_literal, binary32), classification and the integer moment sums in numpy.  Same
+    return value as mass_properties(); the list in (x, y, z) scan order."""
+    dims = tuple(int(v) for v in dims)
+    w = grid_distance_literal(tape, corner, step, dims).astype(np.float32).reshape(dims)
+    thr = np.float32(thr)
+    inside = w <= -thr                                    # mass_properties.cl:31
+    ambiguous = ~inside & (w < thr)                       # :43
+    x, y, z = np.nonzero(inside)
+    x, y, z = x.astype(np.uint64), y.astype(np.uint64), z.astype(np.uint64)
+    sums = np.array([(x * x).sum(), (x * y).sum(), (x * z).sum(), x.sum(), (y * y).sum(), (y * z).sum(), y.sum(),
+                     (z * z).sum(), z.sum(), len(x)], dtype=np.uint64)
+    assert (sums < 2 ** 32).all()
+    cells = np.stack(np.nonzero(ambiguous) + (np.zeros(int(ambiguous.sum()), dtype=np.int64),), axis=1).astype(np.uint8)
+    return sums.astype(np.uint32), len(cells), cells
 
 
 def ray_caster(tape, origin, forward, up, right, pixel_tolerance, box_radius, min_distance, max_distance, floor_z,

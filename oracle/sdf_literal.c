@@ -446,3 +446,35 @@ int oracle_grid_distance_literal(const float *tape, int n_tape, const float *cor
     free(t);
     return err;
 }
+
+/* ---- round 3: entry points for the renderers of sdf_oracle.c (no formula above is touched) ---------------------
+ * The canonical oracle's ray caster / bitmap renderer call evaluate() through a hook (oracle_set_scene_evaluator);
+ * with these three the reference's 32 baseline images are also rendered over THIS evaluate(), so that the literal
+ * formulas are pinned by reference-held fixtures directly (tests/test_render_baselines.py), not only through the
+ * canonical arithmetic.  A handle is the tape widened to `real`, read-only afterwards (any number of threads). */
+typedef struct { real *tape; int n; } literal_scene;
+
+void *oracle_literal_open(const float *tape, int n_tape)
+{
+    literal_scene *s = (literal_scene *)malloc(sizeof(literal_scene));
+    if (!s) return 0;
+    s->tape = widen(tape, n_tape);
+    s->n = n_tape;
+    if (!s->tape) { free(s); return 0; }
+    return s;
+}
+
+int oracle_literal_eval(void *handle, const float *p, float *out)
+{
+    const literal_scene *s = (const literal_scene *)handle;
+    l4 r = v4(0, 0, 0, 0);
+    const int rc = evaluate_literal(s->tape, s->tape + s->n, v3(p[0], p[1], p[2]), &r);
+    out[0] = (float)r.x; out[1] = (float)r.y; out[2] = (float)r.z; out[3] = (float)r.w;
+    return rc;
+}
+
+void oracle_literal_close(void *handle)
+{
+    literal_scene *s = (literal_scene *)handle;
+    if (s) { free(s->tape); free(s); }
+}

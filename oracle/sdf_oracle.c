@@ -722,9 +722,23 @@ static inline float smoothstepf(float e0, float e1, float x)
 
 typedef struct { const float *tape, *end; } scene_t;
 
+/* The renderers below normally run over evaluate() above.  A test may put another evaluator in its place -- the
+ * frozen literal-formula one of sdf_literal.c -- to render the reference's baseline images over it as well
+ * (tests/test_render_baselines.py): fn(handle, point[3], out[4]).  NULL: evaluate().  Set before a render, not during. */
+typedef int (*scene_hook_t)(void *handle, const float *p, float *out);
+static scene_hook_t g_scene_hook;
+static void *g_scene_handle;
+void oracle_set_scene_evaluator(scene_hook_t fn, void *handle) { g_scene_hook = fn; g_scene_handle = handle; }
+
 static inline f4 scene_eval(const scene_t *s, f3 p)
 {
     f4 r = mk4(0, 0, 0, 0);
+    if (g_scene_hook) {
+        const float q[3] = { p.x, p.y, p.z };
+        float o[4] = { 0, 0, 0, 0 };
+        g_scene_hook(g_scene_handle, q, o);
+        return mk4(o[0], o[1], o[2], o[3]);
+    }
     evaluate(s->tape, s->end, mk4(p.x, p.y, p.z, 0), &r);
     return r;
 }

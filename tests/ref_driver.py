@@ -49,8 +49,10 @@ def subdivision(tape, bbox, dimension, resolution, overlap=True, grid_size=128):
     return levels[-1][1], final
 
 
-def mass_properties(tape, bbox, resolution, grid_size=64):
-    """The reference's per-block traversal with Kahan-summed integrals -> (volume, centroid, inertia)."""
+def mass_properties(tape, bbox, resolution, grid_size=64, kernel=None):
+    """The reference's per-block traversal with Kahan-summed integrals -> (volume, centroid, inertia).
+    `kernel`: the block kernel, oracle.mass_properties (canonical arithmetic) unless given."""
+    kernel = kernel or oracle.mass_properties
     assert grid_size ** 5 <= 2 ** 32
     levels = [(resolution * c, d) for c, d in calculate_block_sizes(bbox, 3, resolution, grid_size, False)]
     acc = {k: util.KahanSummation() for k in ("1", "x", "y", "z", "xx", "yy", "zz", "xy", "xz", "yz")}
@@ -63,7 +65,7 @@ def mass_properties(tape, bbox, resolution, grid_size=64):
         leaf = level == len(levels) - 1
         thr = 0.0 if leaf else s * math.sqrt(3) / 2
         shifted = corner + util.Vector.splat(s / 2)
-        sums, n, cells = oracle.mass_properties(tape, f32_corner(shifted), np.float32(s), np.float32(thr), dims)
+        sums, n, cells = kernel(tape, f32_corner(shifted), np.float32(s), np.float32(thr), dims)
         evaluations += dims[0] * dims[1] * dims[2]
         sxx, sxy, sxz, sx, syy, syz, sy, szz, sz, cnt = (float(v) for v in sums)
         s2, s3 = s * s, s * s * s

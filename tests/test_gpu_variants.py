@@ -96,7 +96,10 @@ def test_specialised_tape_is_bit_identical_to_the_interpreter(hip, name):
 
 @pytest.mark.gpu
 def test_tiered_specialisation_policy(hip, monkeypatch):
-    """Default policy: a tape is compiled once the interpreter has spent on it about what hipRTC costs."""
+    """Default policy: the interpreter serves every launch at once; once it has done a little work on a tape, hipRTC
+    builds the per-tape kernels in the background, and the first launch after the build switches to them.  No launch
+    waits for the compiler; the bytes are the same before and after."""
+    import time
     import numpy as np
     from codecad_amd import hip_util, examples, nodes, grid_eval
     tape = nodes.make_program(examples.sponge(2))
@@ -105,20 +108,32 @@ def test_tiered_specialisation_policy(hip, monkeypatch):
     out = hip_util.Buffer(grid_eval.FLOAT4, (24, 24, 24))
 
     t = hip_util.Tape(tape)
-    assert t._policy == "auto" and not t.specialized
+    assert t._policy == "auto" and not t.specialized and t._job is None
     hip.k.grid_eval((24, 24, 24), None, t, c, np.float32(1 / 24), out).wait()
-    assert not t.specialized and t._work == 24 ** 3 * t.n_instructions      # far below the break-even point
+    assert not t.specialized and t._job is None and t._work == 24 ** 3 * t.n_instructions      # too little work to bother
     interpreted = out.read().copy()
-    t._JIT_SECONDS = (0.0, 0.0)                                              # pretend hipRTC is free
+    t._START_SECONDS = 0.0                                                   # "enough work" from now on
+    t0 = time.perf_counter()
     hip.k.grid_eval((24, 24, 24), None, t, c, np.float32(1 / 24), out).wait()
-    assert t.specialized                                                     # compiled before this launch
+    assert time.perf_counter() - t0 < 0.5 and t._job is not None and not t.specialized       # interpreted, the build is under way
     assert np.array_equal(out.read().view(np.uint32), interpreted.view(np.uint32))
+    assert t.wait_specialized(timeout=120) and t.specialized
+    hip.k.grid_eval((24, 24, 24), None, t, c, np.float32(1 / 24), out).wait()
+    assert np.array_equal(out.read().view(np.uint32), interpreted.view(np.uint32))
+    # a second tape: its launches pick the finished build up by themselves
+    u = hip_util.Tape(nodes.make_program(examples.sponge(1)))
+    u._START_SECONDS = 0.0
+    deadline = time.perf_counter() + 120
+    while not u.specialized and time.perf_counter() < deadline:
+        hip.k.grid_eval((24, 24, 24), None, u, c, np.float32(1 / 24), out).wait()
+        time.sleep(0.05)
+    assert u.specialized
 
     monkeypatch.setenv("CODECAD_AMD_SPECIALIZE", "0")
     never = hip_util.Tape(tape)
-    never._JIT_SECONDS = (0.0, 0.0)
+    never._START_SECONDS = 0.0
     hip.k.grid_eval((24, 24, 24), None, never, c, np.float32(1 / 24), out).wait()
-    assert not never.specialized
+    assert not never.specialized and never._job is None
     out.release()
 
 

@@ -83,8 +83,16 @@ def compare(tape, pts, scale, max_ill_share=0.01, directions=slice(None)):
     # the origin in binary fractions sits ON repetition boundaries and symmetry planes by construction
     n = int(keep.sum())
     assert (~ok_w & keep).sum() <= max_ill_share * n, "%d of %d points ill-conditioned" % ((~ok_w & keep).sum(), n)
-    return {"max_rel_w": float(np.max(dw[ok_w] / np.maximum(np.abs(exact[ok_w, 3]), scale))) if ok_w.any() else 0.0,
-            "max_dir": float(np.max(dd[ok_d])) if ok_d.any() else 0.0, "ill_w": int((~ok_w).sum())}
+    stats = {"max_rel_w": float(np.max(dw[ok_w] / np.maximum(np.abs(exact[ok_w, 3]), scale))) if ok_w.any() else 0.0,
+             "max_dir": float(np.max(dd[ok_d])) if ok_d.any() else 0.0, "ill_w": int((~ok_w).sum()),
+             # what the assertions above allow, REPORTED (pytest -rP shows it; tools/literal_shares.py sums it up):
+             "points": n, "skipped": int((~ok_w & keep).sum()), "directions_compared": int(ok_d.sum()),
+             "directions_over_1e-5": int((dd[ok_d] > TOL).sum()) if ok_d.any() else 0}
+    print("literal-oracle shares: %d of %d points skipped as ill-conditioned (%.3f %%), %d of %d directions beyond 1e-5 (%.3f %%), "
+          "largest %.2e; distances within %.2e of the scale" %
+          (stats["skipped"], n, 100.0 * stats["skipped"] / max(n, 1), stats["directions_over_1e-5"], stats["directions_compared"],
+           100.0 * stats["directions_over_1e-5"] / max(stats["directions_compared"], 1), stats["max_dir"], stats["max_rel_w"]))
+    return stats
 
 
 @pytest.mark.parametrize("name", sorted(GOLDEN))

@@ -41,6 +41,24 @@ def test_mass_properties_analytic(name):
         assert np.allclose(result.inertia_tensor, inertia, rtol=precision)
 
 
+@pytest.mark.parametrize("name", sorted(shapes_zoo.mass_property_cases))
+def test_mass_properties_analytic_over_the_literal_formulas(name):
+    """The same known answers with the block kernel running over the frozen literal-formula evaluate()
+    (oracle/sdf_literal.c): the reference's formulas themselves, not only the canonical arithmetic, are held to the
+    reference's analytic fixtures (reference tests/test_mass_properties.py:16-108)."""
+    _, volume, centroid, inertia = shapes_zoo.mass_property_cases[name]
+    ref = GOLDEN["mp_" + name]
+    precision = 2e-3
+    result, _ = ref_driver.mass_properties(ref["tape"], _bbox(ref), 10 * precision, kernel=oracle.mass_properties_literal)
+    assert result.volume == pytest.approx(volume, abs=1e-4, rel=precision)
+    assert tuple(result.centroid) == pytest.approx(centroid, abs=1e-4, rel=precision)
+    if inertia is not None:
+        assert np.allclose(result.inertia_tensor, inertia, rtol=precision)
+    # ... and the two arithmetics agree far inside the fixture's tolerance
+    canonical, _ = ref_driver.mass_properties(ref["tape"], _bbox(ref), 10 * precision)
+    assert result.volume == pytest.approx(canonical.volume, rel=1e-6, abs=1e-9)
+
+
 def test_block_corners_cube():
     ref = GOLDEN["kat_box10"]
     dims, blocks = ref_driver.subdivision(ref["tape"], _bbox(ref), 3, 1, overlap=True, grid_size=4)

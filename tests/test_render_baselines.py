@@ -35,9 +35,13 @@ def mse(pixels, name):
     return float(np.mean(err * err))
 
 
-def oracle_render(name, size=SIZE, threads=None):
+def oracle_render(name, size=SIZE, threads=None, literal=False):
+    """literal=True: the same renderers over the frozen literal-formula evaluate() (oracle/sdf_literal.c)."""
     shape = {**shapes_zoo.shapes_2d, **shapes_zoo.shapes_3d}[name]
     tape = nodes.make_program(shape)
+    if literal:
+        with oracle.literal_scene(tape):
+            return oracle_render(name, size, threads)
     if shape.dimension() == 2:
         origin, step = pictures.bitmap_arguments(shape, size)
         out = oracle.bitmap(tape, list(origin), np.float32(step), size)
@@ -58,6 +62,19 @@ def test_all_baselines_present():
 @pytest.mark.parametrize("name", CPU_SUBSET)
 def test_oracle_render_matches_reference_baseline(name):
     assert mse(oracle_render(name), name) <= 1e-3
+
+
+@pytest.mark.parametrize("name", CPU_SUBSET)
+def test_literal_formulas_render_the_reference_baseline(name):
+    """The chain closed from the other side: the reference's formulas taken literally (the frozen oracle/sdf_literal.c,
+    which the canonical arithmetic is held to within 1e-5 by tests/test_literal_oracle.py) render the reference's own
+    images within the reference's tolerance too -- so the literal restatement is pinned by a reference-held fixture
+    itself, not only through the canonical oracle."""
+    pixels = oracle_render(name, literal=True)
+    assert mse(pixels, name) <= 1e-3
+    # ... and the two arithmetics give the same picture within that tolerance as well (a bitmap pixel on the contour may flip)
+    canonical = oracle_render(name)
+    assert float(np.mean((pixels.astype(np.float32) - canonical.astype(np.float32)) ** 2)) / 255 ** 2 <= 1e-3
 
 
 @pytest.mark.gpu
