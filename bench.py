@@ -378,7 +378,7 @@ def main():
             k_ms, k_voxels, k_bytes = avg(c_ms), my_leaves * leaf_cells, my_leaves * (leaf_cells * 4.0 + 16.0)
             k_note = "4 B stored per sample (float) + 16 B read per leaf block"
         achieved = k_bytes / (k_ms * 1e-3) / 1e9
-        prof = profile_summary(n, evaluator, args.config)
+        prof = profile_summary(kernel, k_voxels, args.config) if world == 1 and (args.n is None or args.n == n_default) else None
         roofline = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel_ms": round(k_ms, 4),
                     "algorithmic_bytes": k_bytes, "algorithmic_bytes_note": k_note,
@@ -512,28 +512,27 @@ _PARAMS = {0: 0, 1: 0, 2: 0, 3: 2, 4: 1, 5: 2, 7: 1, 8: 0, 9: 0, 10: 2, 11: 7, 1
            16: 1, 17: 1, 18: 3, 19: 1, 20: 1, 21: 2, 22: 1, 23: 0, 24: 3, 25: 0, 26: 1, 27: 1, 28: 1}
 
 
-def profile_summary(n, evaluator, config):
-    """The committed rocprofv3 PMC summary (profiles/*summary.json, tools/collect_profiles.sh) of the dominant
-    kernel for this grid, evaluator and config -- only if it was taken on THIS device code (csrc hash); else None."""
+def profile_summary(kernel, samples_per_launch, config):
+    """The committed rocprofv3 PMC summary (profiles/*kernels_summary.json: tools/collect_kernels.sh +
+    tools/summarize_kernels.py, counters per kernel per launch) of `kernel` in `config` -- only if it was taken on THIS
+    device code (csrc hash); else None.  `samples_per_launch`: what one launch of the kernel evaluates in this config."""
     import glob
     want = csrc_hash()
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*summary.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*kernels_summary.json"))):
         try:
             d = json.load(open(f))
-            c = d["dense_kernel_counters_per_launch"]
-            if (d.get("csrc_hash") == want and d.get("grid_edge", 512) == n and d.get("evaluator", "interpreter") == evaluator
-                    and d.get("config", "c3") == config):
-                waves = c["SQ_WAVES"]
-                best = {"file": os.path.basename(f), "csrc_hash": want,
-                        "valu_insts_per_wave": round(c["SQ_INSTS_VALU"] / waves, 2),
-                        # (a wavefront of the per-tape kernel takes up to 16 bricks of 128 voxels: per 128 voxels is the
-                        # figure that compares across rounds -- round 1: 721.3, the verdict's bar: 550)
-                        "valu_insts_per_128_voxels": round(c["SQ_INSTS_VALU"] / (n ** 3 / 128.0), 2),
-                        "hbm_traffic_bytes_per_launch": d.get("hbm_traffic_bytes_per_launch"),
-                        # share of the VALU issue slots used while the kernel ran: busy cycles of the vector ALUs over
-                        # the kernel's cycles (GRBM_GUI_ACTIVE counts per XCD; SQ_BUSY_CYCLES would count per SE)
-                        "valu_issue_busy": d.get("valu_issue_busy")}
+            if d.get("csrc_hash") != want:
+                continue
+            entry = d[config][kernel]
+            c = entry["counters_per_launch"]
+            best = {"file": os.path.basename(f), "csrc_hash": want,
+                    "valu_insts_per_wave": round(c["SQ_INSTS_VALU"] / c["SQ_WAVES"], 2),
+                    # per 128 samples (a wavefront-instruction's worth of two-voxel lanes): the figure that compares across
+                    # kernels and rounds -- round 1 dense: 721.3, round 2: 366.7
+                    "valu_insts_per_128_voxels": round(c["SQ_INSTS_VALU"] / (samples_per_launch / 128.0), 2),
+                    "hbm_traffic_bytes_per_launch": entry.get("hbm_traffic_bytes_per_launch"),
+                    "valu_issue_busy": entry.get("valu_issue_busy"), "profiled_avg_ms": round(entry["avg_ns"] / 1e6, 4)}
         except (ValueError, KeyError, ZeroDivisionError, TypeError):
             continue
     return best

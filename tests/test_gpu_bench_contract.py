@@ -51,22 +51,24 @@ def test_bench_line(hip, evaluator):
 
 def test_bench_profile_fields_need_a_profile_of_this_code():
     """roofline.traffic and the VALU-issue fraction come from a committed rocprofv3 counter summary -- only if it
-    was taken on the device code that is running (hash of csrc/)."""
+    was taken on the device code that is running (hash of csrc/) -- for the dense kernel (c3) and for the leaf-block
+    kernel (c5) alike."""
     import bench
     import glob
-    tagged = [json.load(open(f)).get("csrc_hash") for f in glob.glob(os.path.join(ROOT, "profiles", "*summary.json"))]
-    got = bench.profile_summary(512, "specialised", "c3")
+    tagged = [json.load(open(f)).get("csrc_hash") for f in glob.glob(os.path.join(ROOT, "profiles", "*kernels_summary.json"))]
+    dense = bench.profile_summary("k_grid_eval<JitEval, 0, 2>", 512 ** 3, "c3")
     if bench.csrc_hash() in tagged:
-        assert got is not None and got["csrc_hash"] == bench.csrc_hash() and got["valu_insts_per_wave"] > 0
+        assert dense is not None and dense["csrc_hash"] == bench.csrc_hash() and dense["valu_insts_per_wave"] > 0
         # what the roofline is computed from: per 128 voxels (a wavefront may take many bricks), and with it the issue
         # fraction of the profiled launches themselves stays below 1
-        assert 100 < got["valu_insts_per_128_voxels"] < 1000
-        summary = json.load(open(os.path.join(ROOT, "profiles", got["file"])))
-        dense = [k for k in summary["kernel_stats"] if k["name"].startswith("k_grid_eval<JitEval, 0, 2>")][0]
-        rate = got["valu_insts_per_128_voxels"] * (512 ** 3 / 128) / (dense["avg_ns"] * 1e-9) / 1e9
-        assert 0.3 * bench.VALU_ISSUE_PEAK < rate < bench.VALU_ISSUE_PEAK
+        assert 100 < dense["valu_insts_per_128_voxels"] < 1000
+        rate = dense["valu_insts_per_128_voxels"] * (512 ** 3 / 128) / (dense["profiled_avg_ms"] * 1e-3) / 1e9
+        assert 0.3 * bench.VALU_ISSUE_PEAK < rate < 1.1 * bench.VALU_ISSUE_PEAK
+        assert dense["hbm_traffic_bytes_per_launch"] == pytest.approx(512 ** 3 * 16, rel=0.02)
+        summary = json.load(open(os.path.join(ROOT, "profiles", dense["file"])))
+        assert any(k.startswith("k_grid_eval_blocks<JitEval, 1, 2>") for k in summary["c5"]) and any(k.startswith("k_classify") for k in summary["c3"])
     else:
-        assert got is None
+        assert dense is None
 
 
 def test_bench_config_c5_reduced(hip):

@@ -41,4 +41,6 @@ for seed in range(count):
         bad = np.count_nonzero(np.any(got != want, axis=-1))
         assert bad == 0, (seed, options, bad)
     done += 1
+    if done % 10 == 0:
+        print("...", done, "trees", flush=True)
 print("soak ok:", done, "rendered trees of", count)
