@@ -457,7 +457,7 @@ def main():
         torch.distributed.destroy_process_group()
 
 
-def hbm_regime(lib, check, hip_util, cc, torch, np, dev, stream, n, evaluator):
+def hbm_regime(lib, check, hip_util, cc, torch, np, dev, stream, n, evaluator, tapes=None):
     """The HBM-bound regime, measured in this run: the SAME dense kernels on tapes whose arithmetic fits under the
     store stream (box: 5 instructions; sphere: 3; sphere + box: 9; csg_example: 28), float4 (16 B/voxel) and float (4 B/voxel),
     with the tape interpreter and with per-tape code.  Each entry: algorithmic bytes / average kernel time (HIP
@@ -470,8 +470,8 @@ def hbm_regime(lib, check, hip_util, cc, torch, np, dev, stream, n, evaluator):
     buf = torch.empty((n, n, n, 4), dtype=torch.float32, device=dev)
     dims = (ctypes.c_uint32 * 3)(n, n, n)
     reps = 10
-    for name, shape in (("box", cc.shapes.box(100)), ("sphere", cc.shapes.sphere(130)), ("sphere_plus_box", cc.examples.sphere_plus_box()),
-                        ("csg_example", cc.examples.csg_example())):
+    for name, shape in tapes or (("box", cc.shapes.box(100)), ("sphere", cc.shapes.sphere(130)), ("sphere_plus_box", cc.examples.sphere_plus_box()),
+                                 ("csg_example", cc.examples.csg_example())):
         host_tape = cc.nodes.make_program(shape)
         bb = shape.bounding_box()
         extent = max(bb.b.x - bb.a.x, bb.b.y - bb.a.y, bb.b.z - bb.a.z)

@@ -511,9 +511,9 @@ def subdivision(shape, resolution, overlap_edge_samples=True, grid_size=None):
             break
         except Overflow as e:
             capacities = [sub.checked_capacity(max(int(v * 1.125) + 16, c)) for v, c in zip(e.needed, capacities)]
-    # tighten: the lists of a traversal that is repeated (bench.py does) need not stay at their first guesses
     if len(levels) > 1:
-        share = mine[1:1 + int(mine[0, 0])]
+        # (a copy: the pipeline's buffers are sized for their capacities -- a first guess may be tens of MB -- and go with it)
+        share = mine[1:1 + int(mine[0, 0])].clone()
         leaves = allgather_rows(share)
     else:
         # the whole shape is one leaf block: it is rank 0's, the other ranks' shares are empty
