@@ -1,16 +1,24 @@
 #!/bin/bash
-# Run ON THE GPU BOX (through gpurun): everything profiles/ holds for a round, in one go -- the PMC / kernel-stats
-# profiles of both evaluators (collect_profiles.sh), the consumers' kernel stats (collect_consumer_profiles.sh), the
-# HBM-regime sweep, the free-running bench lines (c3 and c5) and the BASELINE configs.  tools/publish_profiles.py and
-# a few copies (profiles/README.md) then move the judged pieces into profiles/.
+# Run ON THE GPU BOX (through gpurun): everything profiles/ holds for a round, in one call.
+#   collect_kernels.sh      rocprofv3 --kernel-trace --stats + separate --pmc passes over whole bench steps (c3 and c5),
+#                           summarised per kernel (dense, leaf-block, classification; both evaluators' dense kernels)
+#   collect_consumer_profiles.sh   kernel stats of the mesh pipeline, the renderers, contouring
+#   the free-running bench lines: c3, c3 with forced collectives under torchrun, c5, c5 forced; the interpreter's line
+#   prof_hbm.py (HBM-bound regime), run_configs.py (BASELINE configs through the library), prof_jit.py (compile cost, policy)
+# tools/publish_round.py then copies the judged pieces into profiles/<tag>_*.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd "$GRAFT_REPO_ROOT"
-bash tools/collect_profiles.sh $TAG > gpurun_out/collect_$TAG.log 2>&1; echo "spec rc=$?"
-CODECAD_AMD_SPECIALIZE=0 bash tools/collect_profiles.sh ${TAG}_interpreter > gpurun_out/collect_${TAG}_interpreter.log 2>&1; echo "interp rc=$?"
+mkdir -p gpurun_out
+bash tools/collect_kernels.sh $TAG > gpurun_out/collect_${TAG}_kernels.log 2>&1; echo "kernels rc=$?"
 bash tools/collect_consumer_profiles.sh ${TAG}_consumers > gpurun_out/collect_${TAG}_consumers.log 2>&1; echo "consumers rc=$?"
-python3 tools/prof_hbm.py > gpurun_out/${TAG}_hbm_sweep.jsonl 2> gpurun_out/${TAG}_hbm_sweep.err; echo "hbm rc=$?"
 python3 bench.py --steps 20 --warmup 3 > gpurun_out/${TAG}_bench_line.json 2> gpurun_out/${TAG}_bench_line.err; echo "bench rc=$?"
-python3 bench.py --config c5 --steps 5 --warmup 2 > gpurun_out/${TAG}_bench_line_c5.json 2> gpurun_out/${TAG}_bench_line_c5.err; echo "bench c5 rc=$?"
+CODECAD_AMD_FORCE_COLLECTIVES=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 \
+  bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline --no-hbm-leg > gpurun_out/${TAG}_bench_line_forced_collectives.json 2> gpurun_out/${TAG}_bench_line_forced_collectives.err; echo "bench forced rc=$?"
+python3 bench.py --config c5 --steps 5 --warmup 2 --no-cpu-baseline --no-hbm-leg > gpurun_out/${TAG}_bench_line_c5.json 2> gpurun_out/${TAG}_bench_line_c5.err; echo "bench c5 rc=$?"
+CODECAD_AMD_FORCE_COLLECTIVES=1 python3 bench.py --config c5 --steps 5 --warmup 2 --no-cpu-baseline --no-hbm-leg > gpurun_out/${TAG}_bench_line_c5_forced_collectives.json 2> gpurun_out/${TAG}_bench_line_c5_forced_collectives.err; echo "bench c5 forced rc=$?"
+python3 bench.py --evaluator interpreter --steps 10 --warmup 2 --no-cpu-baseline --no-hbm-leg > gpurun_out/${TAG}_bench_line_interpreter.json 2> gpurun_out/${TAG}_bench_line_interpreter.err; echo "bench interpreter rc=$?"
+python3 tools/prof_hbm.py > gpurun_out/${TAG}_hbm_sweep.jsonl 2> gpurun_out/${TAG}_hbm_sweep.err; echo "hbm rc=$?"
 python3 tools/run_configs.py > gpurun_out/${TAG}_configs.txt 2>&1; echo "configs rc=$?"
-tail -1 gpurun_out/${TAG}_bench_line.json | cut -c1-400
+python3 tools/prof_jit.py > gpurun_out/${TAG}_jit.txt 2>&1; echo "jit rc=$?"
+cut -c1-300 gpurun_out/${TAG}_bench_line.json

@@ -38,3 +38,36 @@ for name in ("sponge4", "csg_example", "planetary"):
     print("%-12s %4d instructions: specialize (compile, ten kernels) %.2f s, first float4 launch %.3f s, first float launch %.3f s; "
           "upload + load from the cache %.1f ms (from_cache=%s), first launch %.1f ms; cache now %.2f MB"
           % (name, t.n_instructions, t1 - t0, t2 - t1, t3 - t2, (t5 - t4) * 1e3, again.from_cache, (t6 - t5) * 1e3, size / 1e6), flush=True)
+
+# ---- the default policy as a library user meets it (round 3): a NEW tape in a fresh cache, launched over and over: no
+# launch waits for the compiler; how long until the launches run per-tape code, and what each kind of launch costs
+os.environ["CODECAD_AMD_CACHE"] = tempfile.mkdtemp(prefix="codecad_amd_cache2_")
+n = 256
+for name in ("sponge4", "planetary"):
+    tape = np.array(shapes[name]["tape_u32"], dtype=np.uint32).view(np.float32)
+    t_start = time.perf_counter()
+    t = hip_util.Tape(tape)                      # policy "auto"
+    out = hip_util.Buffer(cc.grid_eval.FLOAT4, (n, n, n))
+    c = np.array([-0.5, -0.5, -0.5, 0], np.float32)
+    launches, first_ms, switched_at, slowest = 0, None, None, 0.0
+    interpreted_ms, fast_ms = [], []
+    while time.perf_counter() - t_start < 60:
+        a = time.perf_counter()
+        ev = hip_util.manager.k.grid_eval((n, n, n), None, t, c, np.float32(1.0 / n), out)
+        ev.wait()
+        b = time.perf_counter()
+        launches += 1
+        slowest = max(slowest, b - a)
+        if first_ms is None:
+            first_ms = (b - t_start) * 1e3
+        (fast_ms if t.specialized else interpreted_ms).append(ev.elapsed_ms())
+        if t.specialized and switched_at is None:
+            switched_at = b - t_start
+        if switched_at is not None and len(fast_ms) >= 5:
+            break
+    print("%-12s default policy, %d^3 float4 grids back to back: first result after %.1f ms; per-tape code from launch %d on, %.2f s after "
+          "upload; kernel %.3f ms interpreted -> %.3f ms; the slowest call of the run took %.1f ms (the one that loads the finished build)"
+          % (name, n, first_ms, len(interpreted_ms) + 1, switched_at if switched_at is not None else float("nan"),
+             sorted(interpreted_ms)[len(interpreted_ms) // 2] if interpreted_ms else float("nan"),
+             sorted(fast_ms)[len(fast_ms) // 2] if fast_ms else float("nan"), slowest * 1e3), flush=True)
+    out.release()
