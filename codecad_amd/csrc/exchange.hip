@@ -29,8 +29,10 @@ constexpr uint32_t kMaxWorld = 64;
 // stats[0] = rows over all ranks, stats[1] != 0: a piece or the share was truncated
 __global__ void __launch_bounds__(256)
 k_slice_rows(const uint4* __restrict__ gathered, uint32_t world, uint32_t piece_rows, uint32_t row_u4, uint32_t rank,
-             uint4* __restrict__ out, uint32_t out_capacity, uint32_t* __restrict__ stats)
+             uint32_t sharers, uint4* __restrict__ out, uint32_t out_capacity, uint32_t* __restrict__ stats)
 {
+    // `world` pieces are concatenated; the concatenation is shared out among `sharers` ranks (hu_slice_rows: the same
+    // number; hu_slice_rows_of: ONE piece that every rank computed for itself, shared out among all ranks)
     __shared__ uint32_t first[kMaxWorld + 1];   // exclusive prefix of the (clamped) counts
     __shared__ uint32_t truncated;
     if (threadIdx.x == 0) {
@@ -46,7 +48,7 @@ k_slice_rows(const uint4* __restrict__ gathered, uint32_t world, uint32_t piece_
     }
     __syncthreads();
     const uint32_t total = first[world];
-    const uint32_t base = total / world, extra = total - base * world;
+    const uint32_t base = total / sharers, extra = total - base * sharers;
     const uint32_t begin = rank * base + (rank < extra ? rank : extra);
     uint32_t count = base + (rank < extra ? 1u : 0u);
     const bool over = truncated != 0u || count > out_capacity;
@@ -71,18 +73,30 @@ k_slice_rows(const uint4* __restrict__ gathered, uint32_t world, uint32_t piece_
 
 }  // namespace
 
-extern "C" int hu_slice_rows(const void* gathered_dev, uint32_t world, uint32_t piece_rows, uint32_t row_bytes, uint32_t rank,
-                             void* out_dev, uint32_t out_capacity, uint32_t* stats_dev, void* stream)
+static int slice_rows(const void* gathered_dev, uint32_t pieces, uint32_t piece_rows, uint32_t row_bytes, uint32_t rank, uint32_t sharers,
+                      void* out_dev, uint32_t out_capacity, uint32_t* stats_dev, void* stream)
 {
     if (!gathered_dev || !out_dev || !stats_dev) return hu_fail_external(HU_ERR_BAD_ARG, "NULL argument");
-    if (world == 0 || world > kMaxWorld || rank >= world)
+    if (pieces == 0 || pieces > kMaxWorld || sharers == 0 || sharers > kMaxWorld || rank >= sharers)
         return hu_fail_external(HU_ERR_BAD_ARG, "world must be in 1..64 and rank below it");
     if (row_bytes == 0 || row_bytes % 16 != 0) return hu_fail_external(HU_ERR_BAD_ARG, "row_bytes must be a multiple of 16");
     if (piece_rows == 0) return hu_fail_external(HU_ERR_BAD_ARG, "a piece has at least its header row");
     const uint32_t blocks = out_capacity / 256u + 1u;
-    hipLaunchKernelGGL(k_slice_rows, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)gathered_dev, world,
-                       piece_rows, row_bytes / 16u, rank, (uint4*)out_dev, out_capacity, stats_dev);
+    hipLaunchKernelGGL(k_slice_rows, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)gathered_dev, pieces,
+                       piece_rows, row_bytes / 16u, rank, sharers, (uint4*)out_dev, out_capacity, stats_dev);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hu_fail_external(HU_ERR_HIP, (std::string("k_slice_rows: ") + hipGetErrorString(e)).c_str());
     return HU_OK;
+}
+
+extern "C" int hu_slice_rows(const void* gathered_dev, uint32_t world, uint32_t piece_rows, uint32_t row_bytes, uint32_t rank,
+                             void* out_dev, uint32_t out_capacity, uint32_t* stats_dev, void* stream)
+{
+    return slice_rows(gathered_dev, world, piece_rows, row_bytes, rank, world, out_dev, out_capacity, stats_dev, stream);
+}
+
+extern "C" int hu_slice_rows_of(const void* piece_dev, uint32_t piece_rows, uint32_t row_bytes, uint32_t rank, uint32_t world,
+                                void* out_dev, uint32_t out_capacity, uint32_t* stats_dev, void* stream)
+{
+    return slice_rows(piece_dev, 1u, piece_rows, row_bytes, rank, world, out_dev, out_capacity, stats_dev, stream);
 }

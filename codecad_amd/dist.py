@@ -204,16 +204,19 @@ class Overflow(RuntimeError):
         self.needed = needed    # per level: the largest per-rank survivor count (and share) seen
 
 
-def slice_rows_reference(gathered, rank, out, stats):
+def slice_rows_reference(gathered, rank, out, stats, sharers=None):
     """What `hu_slice_rows` computes on the device, in torch ops (CPU tensors: the gloo tests and nothing else).
     gathered: (world, piece_rows, k) integer tensor, row 0 of a piece = header (element 0 = rows that follow);
-    out: (capacity + 1, k) <- [header | this rank's balanced share of the concatenated rows]; stats: (2,)."""
-    world, piece_rows = int(gathered.shape[0]), int(gathered.shape[1])
+    out: (capacity + 1, k) <- [header | this rank's balanced share of the concatenated rows]; stats: (2,).
+    sharers: among how many ranks the concatenation is shared out (default: as many as there are pieces;
+    hu_slice_rows_of: ONE piece, all ranks)."""
+    piece_rows = int(gathered.shape[1])
+    world = int(sharers) if sharers is not None else int(gathered.shape[0])
     counts = [int(c) for c in gathered[:, 0, 0].tolist()]
     over = any(c > piece_rows - 1 for c in counts)
     counts = [min(c, piece_rows - 1) for c in counts]
     rows = torch.cat([gathered[r, 1:1 + c] for r, c in enumerate(counts)], dim=0)
-    begin, end = balanced_slice(int(rows.shape[0]), rank, world)
+    begin, end = balanced_slice(int(rows.shape[0]), rank, world)   # (world = the sharers)
     capacity = int(out.shape[0]) - 1
     if end - begin > capacity:
         over, end = True, begin + capacity
@@ -250,10 +253,17 @@ class LevelPipeline:
     n_parents = the 1-element view of the header holding their count, out = the (capacity + 1, k) buffer to
     count into / append to (header already zeroed).  For the HIP path see `subdivision_pipeline`, `mass_pipeline`."""
 
-    def __init__(self, top_rows, capacities, classify, slice_rows=None, device=None, stream=None):
+    def __init__(self, top_rows, capacities, classify, slice_rows=None, device=None, stream=None, replicate_first=False):
+        """replicate_first: every rank classifies the WHOLE top list itself and takes its share of the result without
+        a collective (slice_rows(..., sharers=world) on its own piece).  Only valid where all ranks compute the identical
+        list in the identical order: ONE top row whose cells fit one workgroup of every kernel variant (<= 256 cells) --
+        the compaction order of a single workgroup is the lane order (kernels.hpp wg_compact_slots).  That is the top
+        level of a hierarchy like the bench's (3 x 3 x 3 cells): one all-gather less in a latency-bound step."""
         assert top_rows.dtype == torch.int32, "rows are int32 words (view 32-byte double rows as (n, 8) int32)"
         self.rank, self.world = rank_world()
         self.exchange = exchanging()
+        self.replicate_first = bool(replicate_first) and self.exchange and bool(capacities)
+        assert not self.replicate_first or int(top_rows.shape[0]) == 1
         self.classify = classify
         self.slice_rows = slice_rows or slice_rows_reference
         self.capacities = [int(c) for c in capacities]
@@ -261,6 +271,8 @@ class LevelPipeline:
         self.device, self.stream = device, stream
         k = int(top_rows.shape[1])
         begin, end = balanced_slice(int(top_rows.shape[0]), self.rank, self.world)   # the top list is host knowledge
+        if self.replicate_first:
+            begin, end = 0, int(top_rows.shape[0])
         self.top = torch.zeros((max(end - begin, 1) + 1, k), dtype=torch.int32, device=device)
         self.top[0, 0] = end - begin
         self.top[1:1 + end - begin] = top_rows[begin:end]
@@ -286,6 +298,10 @@ class LevelPipeline:
             self.classify(level, parents[1:], parents[0, :1], max_parents, out)
             if not self.exchange:
                 parents = out
+            elif level == 0 and self.replicate_first:
+                # every rank holds the whole (identical) list: its share, no collective
+                self.slice_rows(out.unsqueeze(0), self.rank, self.mine[level], self.stats[level], sharers=self.world)
+                parents = self.mine[level]
             else:
                 g = self.gathered[level]
                 if g.device.type != "cpu" and _host_staged():     # several ranks on one GPU through gloo: rehearsal only
@@ -315,6 +331,7 @@ class LevelPipeline:
             totals = [int(row[0]) for row in st]
             biggest = allreduce_max(torch.tensor(own, dtype=torch.int64, device=self.send[0].device)).tolist()
             needed = [max(int(b), -(-t // self.world)) for b, t in zip(biggest, totals)]
+            # (a replicated first level: `own` is the whole list on every rank, and that is what its buffer must hold)
         self.needed = needed      # per level: the largest list any rank held (what the capacities must cover)
         if any(n > c for n, c in zip(needed, self.capacities)):
             raise Overflow(needed)
@@ -322,10 +339,15 @@ class LevelPipeline:
 
 
 def _hip_slice_rows(lib, check, stream):
-    def slice_rows(gathered, rank, out, stats):
-        check(lib.hu_slice_rows(gathered.data_ptr(), int(gathered.shape[0]), int(gathered.shape[1]),
-                                int(gathered.shape[2]) * gathered.element_size(), rank, out.data_ptr(), int(out.shape[0]) - 1,
-                                stats.data_ptr(), stream), "hu_slice_rows")
+    def slice_rows(gathered, rank, out, stats, sharers=None):
+        row_bytes = int(gathered.shape[2]) * gathered.element_size()
+        if sharers is None:
+            check(lib.hu_slice_rows(gathered.data_ptr(), int(gathered.shape[0]), int(gathered.shape[1]), row_bytes, rank, out.data_ptr(),
+                                    int(out.shape[0]) - 1, stats.data_ptr(), stream), "hu_slice_rows")
+        else:
+            assert int(gathered.shape[0]) == 1
+            check(lib.hu_slice_rows_of(gathered.data_ptr(), int(gathered.shape[1]), row_bytes, rank, int(sharers), out.data_ptr(),
+                                       int(out.shape[0]) - 1, stats.data_ptr(), stream), "hu_slice_rows_of")
     return slice_rows
 
 
@@ -354,7 +376,10 @@ def subdivision_pipeline(tape, levels, resolution, origin, dimension, capacities
 
     if top_rows is None:
         top_rows = torch.zeros((1, 4), dtype=torch.int32, device=device)
-    return LevelPipeline(top_rows, capacities, classify, _hip_slice_rows(lib, check, stream), device, stream)
+    # one top block of at most 256 cells (one workgroup of every kernel variant): all ranks classify it themselves
+    top_cells = int(levels[0][1][0]) * int(levels[0][1][1]) * int(levels[0][1][2])
+    return LevelPipeline(top_rows, capacities, classify, _hip_slice_rows(lib, check, stream), device, stream,
+                         replicate_first=int(top_rows.shape[0]) == 1 and top_cells <= 256)
 
 
 class MassPipeline:

@@ -50,6 +50,7 @@ PROTOTYPES = {
     "hu_subdivision_level_indirect": [_vp, _vp, _vp, _u32, _c.c_int32, _u3, _i, _d, _d3, _f, _f, _vp, _vp, _u32, _vp],
     "hu_grid_eval_blocks_indirect": [_vp, _vp, _vp, _u32, _d, _d3, _f, _u3, _i, _vp, _vp],
     "hu_slice_rows": [_vp, _u32, _u32, _u32, _u32, _vp, _u32, _vp, _vp],
+    "hu_slice_rows_of": [_vp, _u32, _u32, _u32, _u32, _vp, _u32, _vp, _vp],
     "hu_mass_properties_level": [_vp, _vp, _u32, _d, _u3, _f, _f, _vp, _vp, _vp, _u32, _vp],
     "hu_mass_integrals": [_vp, _vp, _u32, _d, _vp, _u32, _vp],
     "hu_mass_properties_level_indirect": [_vp, _vp, _vp, _u32, _d, _u3, _f, _f, _vp, _vp, _vp, _u32, _vp],

@@ -144,6 +144,11 @@ int hu_grid_eval_blocks_indirect(hu_tape t, const int32_t* blocks_dev, const uin
  * ranks, 1 if a piece or the share was truncated}.  Asynchronous, no host involvement. */
 int hu_slice_rows(const void* gathered_dev, uint32_t world, uint32_t piece_rows, uint32_t row_bytes,
                   uint32_t rank, void* out_dev, uint32_t out_capacity, uint32_t* stats_dev, void* stream);
+/* The same for ONE piece that every rank holds identically -- a level small enough that each rank classified ALL of it
+ * itself, in one workgroup per parent, whose compaction order is the lane order and hence the same everywhere (the top
+ * level of a hierarchy: one parent, a few cells) -- shared out among `world` ranks without any collective. */
+int hu_slice_rows_of(const void* piece_dev, uint32_t piece_rows, uint32_t row_bytes, uint32_t rank, uint32_t world,
+                     void* out_dev, uint32_t out_capacity, uint32_t* stats_dev, void* stream);
 
 /* One level of mass_properties() for ALL parents (mass_properties.py:69-157).
  * parents_dev: double[4]*n_parents box corners; sample corner = corner + s/2 (fp64), cast

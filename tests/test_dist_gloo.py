@@ -46,7 +46,7 @@ def _traverse(tape, levels, resolution, origin, n_objects, hints=None):
     return dist.run_levels(top, len(levels) - 1, classify, hints=hints)
 
 
-def _pipeline(tape, levels, resolution, origin, n_objects, capacities):
+def _pipeline(tape, levels, resolution, origin, n_objects, capacities, replicate_first=False):
     """The traversal through dist.LevelPipeline (lists with their lengths in header rows, one fixed-size
     all-gather per level, the balanced share taken without the host looking at any count), classification by
     the CPU oracle.  -> (this rank's share of the leaves, global survivors per level)"""
@@ -74,7 +74,7 @@ def _pipeline(tape, levels, resolution, origin, n_objects, capacities):
 
     top = torch.zeros((n_objects, 4), dtype=torch.int32)
     top[:, 3] = torch.arange(n_objects, dtype=torch.int32)
-    pipe = dist.LevelPipeline(top, capacities, classify)
+    pipe = dist.LevelPipeline(top, capacities, classify, replicate_first=replicate_first)
     mine = pipe.enqueue()
     totals = pipe.check()
     return mine[1:1 + int(mine[0, 0])], totals
@@ -211,6 +211,12 @@ def _worker(rank, world, port, queue):
     assert e - b == share.shape[0]
     shares = dist.allgather_rows(share)
     assert sorted(map(tuple, shares.tolist())) == sorted(map(tuple, one.tolist()))
+    # the same with the first level REPLICATED: every rank classifies the one top block itself and takes its share of the
+    # (identical) result without a collective (hu_slice_rows_of) -- same totals, the shares still tile the leaf list
+    share_r, totals_r = _pipeline(tape, levels, res, origin, 1, [max(one_counts) + 3] * len(one_counts), replicate_first=True)
+    assert totals_r == one_counts and share_r.shape[0] == e - b
+    shares_r = dist.allgather_rows(share_r)
+    assert sorted(map(tuple, shares_r.tolist())) == sorted(map(tuple, one.tolist()))
     # a list that outgrows its capacity is reported with the sizes that would have sufficed -- on every rank
     try:
         _pipeline(tape, levels, res, origin, 1, [2] * len(one_counts))

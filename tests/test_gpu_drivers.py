@@ -591,3 +591,48 @@ def test_library_forms_over_a_process_group(hip, forced):
     proc = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rehearse_dist.py")], capture_output=True, text=True,
                           timeout=600, cwd=ROOT, env=env)
     assert proc.returncode == 0 and "rehearsal ok" in proc.stdout, proc.stdout[-2000:] + proc.stderr[-3000:]
+
+
+def test_a_single_workgroup_compacts_in_lane_order(hip):
+    """What replicating the first level of a multi-rank traversal rests on (dist.LevelPipeline replicate_first): a
+    level with ONE parent whose cells fit one workgroup leaves its survivors in the same order every time, on every
+    rank -- one workgroup's compaction order is the lane order -- and hu_slice_rows_of shares that one piece out like
+    hu_slice_rows shares a gathered set."""
+    import torch
+    import codecad_amd as cc
+    from codecad_amd import subdivision, dist
+    from codecad_amd.hip_util import check
+    shape = cc.examples.sponge(4)
+    tape = cc.nodes.make_program_buffer(shape)
+    res = 1 / 512
+    box = shape.bounding_box().expanded_additive(res / 2)
+    levels = subdivision.calculate_block_sizes(box, 3, res, 16, True)
+    assert int(levels[0][1][0]) * int(levels[0][1][1]) * int(levels[0][1][2]) <= 256
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    lists = []
+    for evaluator in ("interpreter", "specialised"):
+        if evaluator == "specialised":
+            tape.specialize()
+        for _ in range(4):
+            pipe = dist.subdivision_pipeline(tape, levels[:2], res, tuple(box.a), 3, [64], dev, stream)
+            mine = pipe.enqueue()
+            assert pipe.check() == [27]
+            lists.append(mine[1:28].cpu().numpy().copy())
+    for other in lists[1:]:
+        assert np.array_equal(lists[0], other)
+    # the share rule on one replicated piece: the shares of 1..8 ranks tile it in order
+    piece = torch.zeros((33, 4), dtype=torch.int32, device=dev)
+    piece[0, 0] = 27
+    piece[1:28] = torch.from_numpy(lists[0]).to(dev)
+    for world in (1, 2, 3, 8):
+        got = []
+        for rank in range(world):
+            out = torch.full((30, 4), -1, dtype=torch.int32, device=dev)
+            stats = torch.zeros(2, dtype=torch.int32, device=dev)
+            check(hip.lib.hu_slice_rows_of(piece.data_ptr(), 33, 16, rank, world, out.data_ptr(), 29, stats.data_ptr(), stream), "slice")
+            n = int(out[0, 0])
+            b, e = dist.balanced_slice(27, rank, world)
+            assert n == e - b and stats.cpu().tolist() == [27, 0]
+            got.append(out[1:1 + n].cpu().numpy())
+        assert np.array_equal(np.concatenate(got), lists[0])
