@@ -228,7 +228,8 @@ int check_dims(const uint32_t dims[3], uint64_t& cells)
 // shared straight-line tape function, not per kernel (sponge(4): 0.9 s for eight kernels, 0.56 s for one;
 // planetary: 18 s either way), so compiling lazily, kernel by kernel, costs more whenever two are used.
 struct SpecKernels {
-    hipModule_t module = nullptr;
+    std::vector<hipModule_t> modules;   // one per hu_tape_specialize_groups call that built something
+    uint32_t groups = 0;                // HU_SPEC_* bits: the kernel families that are loaded
     hipFunction_t dense[2] = {nullptr, nullptr};
     hipFunction_t blocks[2] = {nullptr, nullptr};
     hipFunction_t classify[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [MASS][BATCH]
@@ -289,6 +290,9 @@ void keep_programs(hu_tape_s* t, const sdf::DecodedTape& d)
 struct SpecEval { const float* extra; uint32_t flags; };  // same layout as the generated sdfk::JitEval
 
 constexpr int kSpecKernelCount = 10;
+// the family (include/hip_util.h HU_SPEC_*) of each kernel below: a build may hold any subset of the families
+constexpr uint32_t kSpecGroupOf[kSpecKernelCount] = {HU_SPEC_DENSE, HU_SPEC_DENSE, HU_SPEC_BLOCKS, HU_SPEC_BLOCKS, HU_SPEC_CLASSIFY, HU_SPEC_CLASSIFY,
+                                                      HU_SPEC_CLASSIFY, HU_SPEC_CLASSIFY, HU_SPEC_RENDER, HU_SPEC_RENDER};
 const char* const kSpecKernelNames[kSpecKernelCount] = {
     "sdfk::k_grid_eval<sdfk::JitEval, 0, 2>",           "sdfk::k_grid_eval<sdfk::JitEval, 1, 2>",
     "sdfk::k_grid_eval_blocks<sdfk::JitEval, 0, 2>",    "sdfk::k_grid_eval_blocks<sdfk::JitEval, 1, 2>",
@@ -495,7 +499,7 @@ int hu_tape_destroy(hu_tape t)
 {
     if (!t) return HU_OK;
     if (t->spec) {
-        if (t->spec->module) (void)hipModuleUnload(t->spec->module);
+        for (hipModule_t m : t->spec->modules) (void)hipModuleUnload(m);
         delete t->spec;
     }
     (void)hipFree(t->recs_dev);
@@ -525,7 +529,7 @@ int hu_grid_eval_slab(hu_tape t, const float corner[4], float step, const uint32
     if ((uint64_t)x0 + x_count > dims[0]) return fail(HU_ERR_BAD_ARG, "slab exceeds the grid's x extent");
     const uint64_t plane = (uint64_t)dims[1] * dims[2];
     if (plane >= (1ull << 30)) return fail(HU_ERR_BAD_ARG, "dims[1]*dims[2] must be below 2^30");
-    if (t->spec) {
+    if (t->spec && t->spec->dense[layout]) {
         const uint32_t max_x = (uint32_t)((1ull << 30) / plane);
         SpecEval ev{t->extra_dev, spec_flags(t, grid_reach(corner, step, dims))};
         float cx = corner[0], cy = corner[1], cz = corner[2];
@@ -616,7 +620,7 @@ static int grid_eval_blocks_impl(hu_tape t, const int32_t* blocks_dev, uint32_t 
     if ((rc = check_dims(dims, cells))) return rc;
     if (cells > (1ull << 24)) return fail(HU_ERR_BAD_ARG, "a block may have at most 2^24 cells (256^3)");
     if (n_blocks == 0) return HU_OK;
-    if (t->spec) {
+    if (t->spec && t->spec->blocks[layout]) {
         const uint32_t per_block = kSpecBlock * kSpecVoxelsPerLane;
         uint32_t chunks = (uint32_t)((cells + per_block - 1) / per_block);
         // deferred-direction code over compact bricks (kernels.hpp): a wavefront per (x, y) column of 4 x 4 x 8 bricks
@@ -697,7 +701,7 @@ int launch_classify(hu_tape t, ClassifyArgs& a, uint32_t n_parents, const uint32
     if (dims[0] > 256 || dims[1] > 256 || dims[2] > 256)
         return fail(HU_ERR_BAD_ARG, "grid size > 256 would overflow the uchar4 cell index (reference subdivision.py:206-208)");
     if (n_parents == 0) return HU_OK;
-    if (t->spec) {
+    if (t->spec && t->spec->classify[MASS ? 1 : 0][BATCH ? 1 : 0]) {
         const uint32_t per_block = kSpecBlock * kSpecVoxelsPerLane;
         a.sx = dims[0]; a.sy = dims[1]; a.sz = dims[2];
         a.dy = make_dim(dims[1]); a.dz = make_dim(dims[2]);
@@ -900,7 +904,7 @@ int hu_ray_caster(hu_tape t, const float origin[4], const float forward[4], cons
     a.w = width;
     a.h = height;
     a.out = static_cast<uint8_t*>(out_dev);
-    if (t->spec) {
+    if (t->spec && t->spec->ray_caster) {
         SpecEval ev{t->extra_dev, 0u};
         void* args[] = {&ev, &a};
         const uint64_t spec_blocks = (tiles + kSpecBlock / 64u - 1) / (kSpecBlock / 64u);
@@ -920,7 +924,7 @@ int hu_bitmap(hu_tape t, const float origin[4], float step_size, uint32_t width,
     const uint64_t pixels = (uint64_t)width * height;
     if (pixels > 0x7fffffffull) return fail(HU_ERR_BAD_ARG, "image too large for one launch");
     uint8_t* out = static_cast<uint8_t*>(out_dev);
-    if (t->spec) {
+    if (t->spec && t->spec->bitmap) {
         SpecEval ev{t->extra_dev, 0u};
         float ox = origin[0], oy = origin[1], oz = origin[2];
         void* args[] = {&ev, &ox, &oy, &oz, &step_size, &width, &height, &out};
@@ -987,7 +991,7 @@ static std::vector<std::string> spec_options(const char* include_dir)
 
 // Two independent 64-bit hashes over everything the build depends on; false if a header cannot be read
 // (then nothing is cached).
-static bool spec_cache_key(const std::string& src, const char* include_dir, const std::vector<std::string>& opts,
+static bool spec_cache_key(const std::string& src, const char* include_dir, const std::vector<std::string>& opts, uint32_t groups,
                            uint64_t key[2])
 {
     uint64_t h[2] = {0xcbf29ce484222325ull, 0x84222325cbf29ce4ull};
@@ -1004,7 +1008,8 @@ static bool spec_cache_key(const std::string& src, const char* include_dir, cons
     mix(src.data(), src.size());
     for (size_t i = 0; i < opts.size(); ++i)  // the include path itself does not matter, the headers' bytes do
         if (opts[i].compare(0, 2, "-I") != 0) mix(opts[i].data(), opts[i].size());
-    for (const char* name : kSpecKernelNames) mix(name, std::strlen(name));
+    for (int i = 0; i < kSpecKernelCount; ++i)   // the kernels of this build: a build of other families is another file
+        if (kSpecGroupOf[i] & groups) mix(kSpecKernelNames[i], std::strlen(kSpecKernelNames[i]));
     std::string text;
     for (const char* name : kSpecHeaders) {
         if (!read_file(std::string(include_dir) + "/" + name, text)) return false;
@@ -1022,7 +1027,14 @@ static std::string spec_cache_path(const char* cache_dir, const uint64_t key[2])
     return std::string(cache_dir) + name;
 }
 
-static bool spec_cache_load(const std::string& path, const uint64_t key[2], SpecImage& img)
+static uint32_t spec_kernels_in(uint32_t groups)
+{
+    uint32_t n = 0;
+    for (int i = 0; i < kSpecKernelCount; ++i) n += (kSpecGroupOf[i] & groups) ? 1u : 0u;
+    return n;
+}
+
+static bool spec_cache_load(const std::string& path, const uint64_t key[2], uint32_t groups, SpecImage& img)
 {
     std::string blob;
     if (!read_file(path, blob)) return false;
@@ -1037,7 +1049,7 @@ static bool spec_cache_load(const std::string& path, const uint64_t key[2], Spec
     uint64_t k[2], code_size, sum;
     uint32_t names;
     if (!take(magic, 8) || std::memcmp(magic, kSpecMagic, 8) != 0 || !take(k, 16) || k[0] != key[0] || k[1] != key[1] ||
-        !take(&names, 4) || names != (uint32_t)kSpecKernelCount)
+        !take(&names, 4) || names != spec_kernels_in(groups))
         return false;
     img.lowered.clear();
     for (uint32_t i = 0; i < names; ++i) {
@@ -1099,12 +1111,13 @@ static void spec_cache_prune(const char* cache_dir)
 }
 
 // Compile `src` with hipRTC (needs no device) into an image.
-static int compile_specialised(const std::string& src, const std::vector<std::string>& options, SpecImage& img)
+static int compile_specialised(const std::string& src, const std::vector<std::string>& options, uint32_t groups, SpecImage& img)
 {
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "tape_specialised.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
         return fail(HU_ERR_UNSUPPORTED, "hiprtcCreateProgram failed");
-    for (const char* n : kSpecKernelNames) (void)hiprtcAddNameExpression(prog, n);
+    for (int i = 0; i < kSpecKernelCount; ++i)
+        if (kSpecGroupOf[i] & groups) (void)hiprtcAddNameExpression(prog, kSpecKernelNames[i]);
     std::vector<const char*> opts;
     for (const std::string& w : options) opts.push_back(w.c_str());
     const hiprtcResult rc = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
@@ -1123,7 +1136,9 @@ static int compile_specialised(const std::string& src, const std::vector<std::st
     img.code.resize(size);
     (void)hiprtcGetCode(prog, img.code.data());
     img.lowered.clear();
-    for (const char* name : kSpecKernelNames) {
+    for (int i = 0; i < kSpecKernelCount; ++i) {
+        if (!(kSpecGroupOf[i] & groups)) continue;
+        const char* name = kSpecKernelNames[i];
         const char* lowered = nullptr;
         if (hiprtcGetLoweredName(prog, name, &lowered) != HIPRTC_SUCCESS || !lowered) {
             (void)hiprtcDestroyProgram(&prog);
@@ -1137,7 +1152,7 @@ static int compile_specialised(const std::string& src, const std::vector<std::st
 
 // The image of `src`: from the cache when it is there, else built (and stored).  With only_if_cached a miss
 // leaves img.code empty and is not an error.
-static int specialised_image(const std::string& src, const char* include_dir, const char* cache_dir, bool only_if_cached,
+static int specialised_image(const std::string& src, const char* include_dir, const char* cache_dir, bool only_if_cached, uint32_t groups,
                              SpecImage& img, int* from_cache, bool replace_cached = false)
 {
     if (from_cache) *from_cache = 0;
@@ -1145,10 +1160,10 @@ static int specialised_image(const std::string& src, const char* include_dir, co
     const std::vector<std::string> options = spec_options(include_dir);
     uint64_t key[2];
     std::string path;
-    const bool cached = cache_dir && *cache_dir && spec_cache_key(src, include_dir, options, key);
+    const bool cached = cache_dir && *cache_dir && spec_cache_key(src, include_dir, options, groups, key);
     if (cached) {
         path = spec_cache_path(cache_dir, key);
-        if (!replace_cached && spec_cache_load(path, key, img)) {
+        if (!replace_cached && spec_cache_load(path, key, groups, img)) {
             if (from_cache) *from_cache = 1;
             return HU_OK;
         }
@@ -1156,7 +1171,7 @@ static int specialised_image(const std::string& src, const char* include_dir, co
     }
     if (only_if_cached) return HU_OK;
     int rc;
-    if ((rc = compile_specialised(src, options, img))) return rc;
+    if ((rc = compile_specialised(src, options, groups, img))) return rc;
     if (cached) {
         spec_cache_store(cache_dir, path, key, img);
         spec_cache_prune(cache_dir);
@@ -1167,7 +1182,14 @@ static int specialised_image(const std::string& src, const char* include_dir, co
 int hu_tape_compile_cached(const float* tape, size_t n, const char* include_dir, const char* cache_dir, size_t* code_bytes,
                            int* from_cache)
 {
+    return hu_tape_compile_groups(tape, n, include_dir, cache_dir, HU_SPEC_ALL, code_bytes, from_cache);
+}
+
+int hu_tape_compile_groups(const float* tape, size_t n, const char* include_dir, const char* cache_dir, uint32_t groups,
+                           size_t* code_bytes, int* from_cache)
+{
     if (!tape || !include_dir) return fail(HU_ERR_BAD_ARG, "NULL argument");
+    if (groups == 0 || (groups & ~(uint32_t)HU_SPEC_ALL)) return fail(HU_ERR_BAD_ARG, "groups must be a non-empty set of HU_SPEC_* bits");
     sdf::DecodedTape d;
     const std::string err = sdf::decode_tape(tape, n, d);
     if (!err.empty()) return fail(HU_ERR_BAD_TAPE, "malformed tape: " + err);
@@ -1176,7 +1198,7 @@ int hu_tape_compile_cached(const float* tape, size_t n, const char* include_dir,
     keep_programs(&t, d);
     SpecImage img;
     int rc;
-    if ((rc = specialised_image(generate_source(&t), include_dir, cache_dir, false, img, from_cache))) return rc;
+    if ((rc = specialised_image(generate_source(&t), include_dir, cache_dir, false, groups, img, from_cache))) return rc;
     if (code_bytes) *code_bytes = img.code.size();
     return HU_OK;
 }
@@ -1188,9 +1210,18 @@ int hu_tape_compile_check(const float* tape, size_t n, const char* include_dir, 
 
 int hu_tape_specialize_cached(hu_tape t, const char* include_dir, const char* cache_dir, int only_if_cached, int* from_cache)
 {
+    return hu_tape_specialize_groups(t, include_dir, cache_dir, only_if_cached, HU_SPEC_ALL, from_cache);
+}
+
+int hu_tape_specialize_groups(hu_tape t, const char* include_dir, const char* cache_dir, int only_if_cached, uint32_t groups, int* from_cache)
+{
     if (from_cache) *from_cache = 0;
     if (!t || !include_dir) return fail(HU_ERR_BAD_ARG, "NULL argument");
-    if (t->spec) return HU_OK;
+    if (groups & ~(uint32_t)HU_SPEC_ALL) return fail(HU_ERR_BAD_ARG, "groups must be a set of HU_SPEC_* bits");
+    // families that are loaded already stay as they are; the image is the one of the REQUESTED set (so that a build of
+    // all ten kernels, made while one family was already running, is found under its own name)
+    const uint32_t missing = t->spec ? (groups & ~t->spec->groups) : groups;
+    if (missing == 0) return HU_OK;
     bool deferred = false;
     double coord_limit = 0.0;
     const std::string src = generate_source(t, &deferred, &coord_limit);
@@ -1199,24 +1230,30 @@ int hu_tape_specialize_cached(hu_tape t, const char* include_dir, const char* ca
         SpecImage img;
         int crc;
         // second attempt: the cached image did not load (e.g. written by an incompatible runtime): build and replace it
-        if ((crc = specialised_image(src, include_dir, cache_dir, only_if_cached != 0, img, &cached, attempt != 0))) return crc;
+        if ((crc = specialised_image(src, include_dir, cache_dir, only_if_cached != 0, groups, img, &cached, attempt != 0))) return crc;
         if (img.code.empty()) return HU_OK;  // only_if_cached and not there: still interpreted
-        SpecKernels* k = new SpecKernels();
-        hipError_t e = hipModuleLoadData(&k->module, img.code.data());
-        hipFunction_t* slots[kSpecKernelCount] = {&k->dense[0], &k->dense[1], &k->blocks[0], &k->blocks[1],
-                                                  &k->classify[0][0], &k->classify[0][1], &k->classify[1][0], &k->classify[1][1],
-                                                  &k->ray_caster, &k->bitmap};
+        hipModule_t module = nullptr;
+        hipFunction_t loaded[kSpecKernelCount] = {};
+        hipError_t e = hipModuleLoadData(&module, img.code.data());
+        size_t next = 0;
         for (int i = 0; i < kSpecKernelCount && e == hipSuccess; ++i)
-            e = hipModuleGetFunction(slots[i], k->module, img.lowered[i].c_str());
+            if (kSpecGroupOf[i] & groups) e = hipModuleGetFunction(&loaded[i], module, img.lowered[next++].c_str());
         if (e == hipSuccess) {
+            if (!t->spec) t->spec = new SpecKernels();
+            SpecKernels* k = t->spec;
+            hipFunction_t* slots[kSpecKernelCount] = {&k->dense[0], &k->dense[1], &k->blocks[0], &k->blocks[1],
+                                                      &k->classify[0][0], &k->classify[0][1], &k->classify[1][0], &k->classify[1][1],
+                                                      &k->ray_caster, &k->bitmap};
+            for (int i = 0; i < kSpecKernelCount; ++i)
+                if (kSpecGroupOf[i] & missing) *slots[i] = loaded[i];
+            k->modules.push_back(module);
+            k->groups |= missing;
             k->deferred = deferred;
             k->coord_limit = coord_limit;
-            t->spec = k;
             if (from_cache) *from_cache = cached;
             return HU_OK;
         }
-        if (k->module) (void)hipModuleUnload(k->module);
-        delete k;
+        if (module) (void)hipModuleUnload(module);
         (void)hipGetLastError();  // the failed load must not surface at the next launch's error check
         if (cached && only_if_cached) return HU_OK;  // an unusable cached image is not the caller's problem: still interpreted
         if (!cached) return fail(HU_ERR_HIP, std::string("loading the specialised module: ") + hipGetErrorString(e));
@@ -1361,7 +1398,7 @@ int hu_tape_listing(const float* tape, size_t n, int which, char* buf, size_t ca
 int hu_tape_specialized(hu_tape t, int* out)
 {
     if (!t || !out) return fail(HU_ERR_BAD_ARG, "NULL argument");
-    *out = t->spec ? 1 : 0;
+    *out = t->spec ? (int)t->spec->groups : 0;   // the HU_SPEC_* families that are loaded (0: interpreted)
     return HU_OK;
 }
 

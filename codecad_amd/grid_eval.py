@@ -48,7 +48,7 @@ def grid_eval_blocks(leaves, pymcubes=False, out=None, queue=None):
     d = (ctypes.c_uint32 * 3)(*dims)
     o = (ctypes.c_double * 3)(leaves.origin.x, leaves.origin.y, leaves.origin.z)
     ev = hip_util.Event(hip_manager, queue)
-    leaves.tape.note_samples(leaves.count * dims[0] * dims[1] * dims[2])
+    leaves.tape.note_samples(leaves.count * dims[0] * dims[1] * dims[2], hip_util.SPEC_BLOCKS)
     check(hip_manager.lib.hu_grid_eval_blocks(leaves.tape.device_ptr, leaves.blocks.device_ptr, leaves.count,
                                               float(leaves.resolution), o, numpy.float32(leaves.step), d,
                                               1 if pymcubes else 0, out.device_ptr, queue.handle),

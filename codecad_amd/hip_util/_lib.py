@@ -66,13 +66,18 @@ PROTOTYPES = {
     "hu_sort_blocks": [_vp, _u32, _vp, _sz, _c.POINTER(_sz), _vp],
     "hu_tape_specialize": [_vp, _c.c_char_p],
     "hu_tape_specialize_cached": [_vp, _c.c_char_p, _c.c_char_p, _i, _c.POINTER(_i)],
+    "hu_tape_specialize_groups": [_vp, _c.c_char_p, _c.c_char_p, _i, _u32, _c.POINTER(_i)],
     "hu_tape_specialized": [_vp, _c.POINTER(_i)],
     "hu_tape_compile_check": [_f4, _sz, _c.c_char_p, _c.POINTER(_sz)],
     "hu_tape_compile_cached": [_f4, _sz, _c.c_char_p, _c.c_char_p, _c.POINTER(_sz), _c.POINTER(_i)],
+    "hu_tape_compile_groups": [_f4, _sz, _c.c_char_p, _c.c_char_p, _u32, _c.POINTER(_sz), _c.POINTER(_i)],
     "hu_selftest_math": [_c.POINTER(_c.c_uint64)],
     "hu_tape_source": [_f4, _sz, _c.c_char_p, _sz, _c.POINTER(_sz)],
     "hu_tape_listing": [_f4, _sz, _i, _c.c_char_p, _sz, _c.POINTER(_sz)],
 }
+
+# hu_spec_group (include/hip_util.h): the kernel families of per-tape code
+SPEC_DENSE, SPEC_BLOCKS, SPEC_CLASSIFY, SPEC_RENDER, SPEC_ALL = 1, 2, 4, 8, 15
 
 HEADER = os.path.normpath(os.path.join(os.path.dirname(__file__), "..", "..", "include", "hip_util.h"))
 

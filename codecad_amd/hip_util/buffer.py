@@ -232,13 +232,15 @@ def cache_dir():
 
 class _BackgroundCompiler:
     """ONE worker thread that turns tapes into per-tape code objects with hipRTC while the interpreter serves their
-    launches (hu_tape_compile_cached: host only, no device call, the GIL is released for its duration).  A finished
-    build sits in the on-disk cache -- or, when that is switched off, in a private directory of this process -- where
-    the tape's next launch finds it in milliseconds.  The thread's first job also pays hipRTC's one-off start (loading
-    the compiler: ~1.5 s in a fresh process), so no launch ever waits for that either."""
+    launches.  The builds themselves run in a PROCESS of their own (_compile_server.py, started at the first request,
+    host only): the HIP runtime and hipRTC share a lock, so a build on a thread of this process would stall a module
+    load or a kernel's first launch for its whole duration.  A finished build sits in the on-disk cache -- or, when that
+    is switched off, in a private directory of this process -- where the tape's next launch finds it in milliseconds.
+    The server's first build also pays hipRTC's one-off start (~1.5 s in a fresh process), so no launch ever waits for
+    that either.  CODECAD_AMD_RTC_SERVER=0 (or a server that cannot be started) builds on the worker thread instead."""
 
     def __init__(self):
-        self.queue, self.thread, self.private_dir = None, None, None
+        self.queue, self.thread, self.private_dir, self.server = None, None, None, None
 
     def directory(self):
         d = cache_dir()
@@ -252,30 +254,80 @@ class _BackgroundCompiler:
             atexit.register(shutil.rmtree, self.private_dir, True)
         return self.private_dir
 
-    def submit(self, lib, host_tape, include_dir):
-        """-> a job: {"done": threading.Event, "error": None or str, "directory": where the image is}"""
+    def submit(self, lib, host_tape, include_dir, groups):
+        """-> a job: {"done": threading.Event, "error": None or str, "directory": where the image is, "groups": the
+        kernel families it builds (hu_spec_group bits)}"""
         import queue
         import threading
         if self.thread is None:
             self.queue = queue.Queue()
             self.thread = threading.Thread(target=self._run, name="codecad_amd-hiprtc", daemon=True)
             self.thread.start()
-        job = {"done": threading.Event(), "error": None, "directory": self.directory(), "lib": lib,
+        job = {"done": threading.Event(), "error": None, "directory": self.directory(), "lib": lib, "groups": int(groups),
                "tape": numpy.array(host_tape, dtype=numpy.float32, copy=True), "include": include_dir}
         self.queue.put(job)
         return job
+
+    def _start_server(self, lib):
+        import atexit
+        import subprocess
+        import sys
+        if os.environ.get("CODECAD_AMD_RTC_SERVER", "1") == "0":
+            return None
+        try:
+            path = getattr(lib, "_name", None) or ""
+            script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_compile_server.py")
+            server = subprocess.Popen([sys.executable, script, path], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                                      stderr=subprocess.DEVNULL, text=True, bufsize=1)
+        except OSError:
+            return None
+
+        def stop(p=server):
+            try:
+                p.stdin.close()
+                p.terminate()
+            except Exception:
+                pass
+        atexit.register(stop)
+        return server
+
+    def _build_remote(self, job):
+        """-> None (done) / an error string / False (the server is not there: build here)"""
+        import base64
+        import json
+        if self.server is None:
+            self.server = self._start_server(job["lib"]) or False
+        if not self.server:
+            return False
+        try:
+            req = {"tape": base64.b64encode(job["tape"].tobytes()).decode(), "include": job["include"], "dir": job["directory"],
+                   "groups": job["groups"]}
+            self.server.stdin.write(json.dumps(req) + "\n")
+            self.server.stdin.flush()
+            line = self.server.stdout.readline()
+            if not line:
+                raise OSError("the compile server ended")
+            reply = json.loads(line)
+            return None if reply.get("rc") == 0 else str(reply.get("error") or "hipRTC failed (%s)" % reply.get("rc"))
+        except (OSError, ValueError):
+            self.server = False          # gone: from now on build on this thread
+            return False
 
     def _run(self):
         while True:
             job = self.queue.get()
             try:
-                t = job["tape"]
-                size, hit = ctypes.c_size_t(0), ctypes.c_int(0)
-                rc = job["lib"].hu_tape_compile_cached(t.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), t.size, job["include"].encode(),
-                                                       job["directory"].encode(), ctypes.byref(size), ctypes.byref(hit))
-                if rc != 0:
-                    msg = job["lib"].hu_last_error()
-                    job["error"] = msg.decode() if msg else "hipRTC failed (%d)" % rc
+                result = self._build_remote(job)
+                if result is False:
+                    t = job["tape"]
+                    size, hit = ctypes.c_size_t(0), ctypes.c_int(0)
+                    rc = job["lib"].hu_tape_compile_groups(t.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), t.size, job["include"].encode(),
+                                                           job["directory"].encode(), job["groups"], ctypes.byref(size), ctypes.byref(hit))
+                    if rc != 0:
+                        msg = job["lib"].hu_last_error()
+                        job["error"] = msg.decode() if msg else "hipRTC failed (%d)" % rc
+                else:
+                    job["error"] = result
             except Exception as e:      # (never let the worker die: the tape just stays interpreted)
                 job["error"] = "%s: %s" % (type(e).__name__, e)
             job["done"].set()
@@ -310,7 +362,8 @@ class Tape:
         # compiler.  A program found in the on-disk cache (cache_dir) is taken at upload.  Same bytes either way.
         self._policy = policy if policy is not None else os.environ.get("CODECAD_AMD_SPECIALIZE", "auto")
         self._work = 0.0
-        self._job = None
+        self._jobs = []          # background builds in flight, in the order they were asked for
+        self.groups = 0          # the kernel families whose per-tape code is loaded (hu_spec_group bits)
         self.from_cache = False
         if self._policy == "1":
             self.specialize()
@@ -324,56 +377,70 @@ class Tape:
     _INTERPRETER_RATE = 2.5e12
     _START_SECONDS = 0.0005
 
-    def note_samples(self, n):
-        """Called by the launch wrappers with the number of samples about to be evaluated with this tape."""
-        if self.specialized or self._policy != "auto":
+    def note_samples(self, n, group=1):
+        """Called by the launch wrappers with the number of samples about to be evaluated with this tape and the kernel
+        family (hu_spec_group bit) that is about to run."""
+        if self._policy != "auto" or self.groups == 15:
             return
-        if self._job is not None:
-            if self._job["done"].is_set():
-                self._take_background_build()
+        if self._jobs:
+            if self._jobs[0]["done"].is_set():
+                self._take_background_builds()
             return
+        if self.groups:
+            return      # (what was asked for is loaded; the other families follow when they are used)
         self._work += float(n) * self.n_instructions
         if self._work / self._INTERPRETER_RATE >= self._START_SECONDS:
+            # the family in use first (a fraction of the time of all ten kernels), then all of them (that image is
+            # also what a later process finds in the on-disk cache at upload)
             from . import builder
-            self._job = _background.submit(self.manager.lib, self.host_tape, builder.CSRC)
+            self._jobs = [_background.submit(self.manager.lib, self.host_tape, builder.CSRC, group),
+                          _background.submit(self.manager.lib, self.host_tape, builder.CSRC, 15)]
 
-    def _take_background_build(self):
-        job, self._job = self._job, None
-        if job["error"] is not None:
-            self._policy = "0"      # hipRTC cannot build this tape: stay with the interpreter
-            self.build_error = job["error"]
-            return
-        self._specialize(only_if_cached=True, directory=job["directory"])
-        if not self.specialized:
-            self._policy = "0"      # (the image vanished or does not load: do not try again and again)
+    def _take_background_builds(self):
+        while self._jobs and self._jobs[0]["done"].is_set():
+            job = self._jobs.pop(0)
+            if job["error"] is not None:
+                self._policy = "0"      # hipRTC cannot build this tape: stay with the interpreter
+                self.build_error = job["error"]
+                self._jobs = []
+                return
+            before = self.groups
+            self._specialize(only_if_cached=True, directory=job["directory"], groups=job["groups"])
+            if self.groups == before:
+                self._policy = "0"      # (the image vanished or does not load: do not try again and again)
+                self._jobs = []
+                return
 
     def wait_specialized(self, timeout=None):
-        """Wait for a background build in flight (if any) and switch to it; returns self.specialized.  Launches never
+        """Wait for the background builds in flight (if any) and switch to them; returns self.specialized.  Launches never
         need this -- they use whatever is ready --; measurements and tests do."""
-        if self._job is not None and self._job["done"].wait(timeout):
-            self._take_background_build()
+        for job in list(self._jobs):
+            if not job["done"].wait(timeout):
+                break
+        self._take_background_builds()
         return self.specialized
 
     def specialize(self):
         """Compile straight-line kernels for this tape with hipRTC (seconds, once) and wait for them; afterwards
         every launch with this tape uses them.  Same results as the interpreter.  Raises
         RuntimeError (with the compiler log) if hipRTC cannot build it."""
-        self._job = None
+        self._jobs = []
         self._specialize(only_if_cached=False)
         return self
 
-    def _specialize(self, only_if_cached, directory=None):
-        if self.specialized:
+    def _specialize(self, only_if_cached, directory=None, groups=15):
+        if self.groups & groups == groups:
             return
         from . import builder
         if directory is None:
             directory = cache_dir()
         hit, flag = ctypes.c_int(0), ctypes.c_int(0)
-        check(self.manager.lib.hu_tape_specialize_cached(self.device_ptr, builder.CSRC.encode(),
+        check(self.manager.lib.hu_tape_specialize_groups(self.device_ptr, builder.CSRC.encode(),
                                                          directory.encode() if directory else None,
-                                                         1 if only_if_cached else 0, ctypes.byref(hit)), "hu_tape_specialize_cached")
+                                                         1 if only_if_cached else 0, int(groups), ctypes.byref(hit)), "hu_tape_specialize_groups")
         check(self.manager.lib.hu_tape_specialized(self.device_ptr, ctypes.byref(flag)), "hu_tape_specialized")
-        self.specialized = bool(flag.value)
+        self.groups = int(flag.value)
+        self.specialized = self.groups != 0     # some family runs per-tape code (all of them: groups == 15)
         self.from_cache = bool(hit.value)
 
     @property

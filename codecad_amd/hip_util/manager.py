@@ -29,14 +29,19 @@ def check(rc, what=""):
         raise HipError("%s failed (%d): %s" % (what or "hip_util call", rc, msg.decode() if msg else "?"))
 
 
-def _note(scene, global_size, factor=1):
-    """Tell a Tape how many samples a launch is about to evaluate (Tape.note_samples: tiered specialisation)."""
+# kernel families of per-tape code (include/hip_util.h hu_spec_group)
+from ._lib import SPEC_DENSE, SPEC_BLOCKS, SPEC_CLASSIFY, SPEC_RENDER, SPEC_ALL  # noqa: E402,F401
+
+
+def _note(scene, global_size, factor=1, group=SPEC_DENSE):
+    """Tell a Tape how many samples a launch is about to evaluate, and with which kernel family (Tape.note_samples:
+    tiered specialisation builds the family in use first)."""
     note = getattr(scene, "note_samples", None)
     if note is not None:
         n = factor
         for v in global_size:
             n *= int(v)
-        note(n)
+        note(n, group)
 
 
 def _ptr(obj):
@@ -179,7 +184,7 @@ class _Kernels:
 
     def subdivision_step(self, global_size, local_size, scene, box_corner, box_step, distance_threshold,
                          intersecting_counter, list_buffer, wait_for=None, queue=None):
-        _note(scene, global_size)
+        _note(scene, global_size, group=SPEC_CLASSIFY)
         c, d = _float4(box_corner), _dims3(global_size)
         return self._launch(wait_for, queue, lambda s: check(self._m.lib.hu_subdivision_step(
             _ptr(scene), c.ctypes.data_as(_lib._f4), float(box_step), float(distance_threshold), d,
@@ -187,7 +192,7 @@ class _Kernels:
 
     def mass_properties(self, global_size, local_size, shape, box_corner, box_step, distance_threshold,
                         sums, intersecting_counter, list_buffer, wait_for=None, queue=None):
-        _note(shape, global_size)
+        _note(shape, global_size, group=SPEC_CLASSIFY)
         c, d = _float4(box_corner), _dims3(global_size)
         return self._launch(wait_for, queue, lambda s: check(self._m.lib.hu_mass_properties(
             _ptr(shape), c.ctypes.data_as(_lib._f4), float(box_step), float(distance_threshold), d,
@@ -196,7 +201,7 @@ class _Kernels:
     def ray_caster(self, global_size, local_size, scene, origin, forward, up, right, pixel_tolerance, box_radius,
                    min_distance, max_distance, floor_z, render_options, output, wait_for=None, queue=None):
         """rendering/ray_caster.cl:146-159; global_size = (width, height)."""
-        _note(scene, global_size, 50)   # a march is tens of evaluations per pixel
+        _note(scene, global_size, 50, SPEC_RENDER)   # a march is tens of evaluations per pixel
         v = [_float4(x) for x in (origin, forward, up, right)]
         return self._launch(wait_for, queue, lambda s: check(self._m.lib.hu_ray_caster(
             _ptr(scene), *[x.ctypes.data_as(_lib._f4) for x in v], float(pixel_tolerance), float(box_radius),
@@ -205,7 +210,7 @@ class _Kernels:
 
     def bitmap(self, global_size, local_size, scene, origin, step_size, output, wait_for=None, queue=None):
         """rendering/bitmap.cl:1-4; global_size = (width, height)."""
-        _note(scene, global_size)
+        _note(scene, global_size, group=SPEC_RENDER)
         o = _float4(origin)
         return self._launch(wait_for, queue, lambda s: check(self._m.lib.hu_bitmap(
             _ptr(scene), o.ctypes.data_as(_lib._f4), float(step_size), int(global_size[0]), int(global_size[1]),

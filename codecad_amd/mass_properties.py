@@ -167,7 +167,7 @@ def mass_properties(shape, resolution, grid_size=None):
     for i, part in enumerate(partials):
         stats["kernel_invocations"] += 1
         stats["function_evaluations"] += parents_n * cells[i]
-        tape.note_samples(parents_n * cells[i])
+        tape.note_samples(parents_n * cells[i], hip_util.SPEC_CLASSIFY)
         for k, column in zip(_KEYS, part.T.tolist()):   # the rows of a level are added in order: deterministic
             total[k] += math.fsum(column)
         parents_n = counts[i] if i < len(counts) else 0

@@ -159,7 +159,7 @@ def _level_launch(tape, parents, n_parents, int_step, dims, dimension, resolutio
     while True:
         children = hip_util.Buffer(numpy.int32, (max(capacity, 1), 4), queue=queue)
         counter.enqueue_fill(0)
-        tape.note_samples(n_parents * int(dims[0]) * int(dims[1]) * int(dims[2]))
+        tape.note_samples(n_parents * int(dims[0]) * int(dims[1]) * int(dims[2]), hip_util.SPEC_CLASSIFY)
         check(lib.hu_subdivision_level(tape.device_ptr, parents.device_ptr, n_parents, int(int_step), d,
                                        dimension, float(resolution), o, numpy.float32(box_step),
                                        numpy.float32(thr), counter.device_ptr, children.device_ptr,
@@ -238,7 +238,7 @@ def subdivision_device(shape, resolution, overlap_edge_samples=True, grid_size=N
     level_counts, samples, parents_n = [], 0, 1
     for n, c in zip(counts, cells[:-1]):
         samples += parents_n * c
-        tape.note_samples(parents_n * c)
+        tape.note_samples(parents_n * c, hip_util.SPEC_CLASSIFY)
         level_counts.append(n)
         parents_n = n
         if n == 0:

@@ -274,6 +274,19 @@ int hu_tape_specialize(hu_tape t, const char* include_dir);
  * `*from_cache` (may be NULL) <- 1 if the kernels came from the cache. */
 int hu_tape_specialize_cached(hu_tape t, const char* include_dir, const char* cache_dir,
                               int only_if_cached, int* from_cache);
+/* The same for a subset of the kernel families (any combination of the bits below): compiling only what is about to be
+ * used takes a fraction of the time of all ten kernels, and a tape's families may be built one after the other (families
+ * that are loaded already are skipped).  A launch of a kernel whose family is not loaded runs the interpreter. */
+enum hu_spec_group {
+    HU_SPEC_DENSE = 1,     /* hu_grid_eval, hu_grid_eval_pymcubes, hu_grid_eval_slab */
+    HU_SPEC_BLOCKS = 2,    /* hu_grid_eval_blocks[_indirect] */
+    HU_SPEC_CLASSIFY = 4,  /* hu_subdivision_step / _level[_indirect], hu_mass_properties / _level[_indirect] */
+    HU_SPEC_RENDER = 8,    /* hu_ray_caster, hu_bitmap */
+    HU_SPEC_ALL = 15
+};
+int hu_tape_specialize_groups(hu_tape t, const char* include_dir, const char* cache_dir, int only_if_cached,
+                              uint32_t groups, int* from_cache);
+/* *out_flag <- the HU_SPEC_* families whose per-tape kernels are loaded (0: everything is interpreted) */
 int hu_tape_specialized(hu_tape t, int* out_flag);
 /* The HIP source hu_tape_specialize would compile for this tape (host only, no device needed):
  * `*needed` receives its size including the terminator; it is copied when `capacity` suffices. */
@@ -290,6 +303,9 @@ int hu_tape_compile_check(const float* tape, size_t n_floats, const char* includ
  * only reads.  `*from_cache` (may be NULL) <- 1 on a hit. */
 int hu_tape_compile_cached(const float* tape, size_t n_floats, const char* include_dir,
                            const char* cache_dir, size_t* code_bytes, int* from_cache);
+/* ... for a subset of the kernel families (hu_spec_group bits) */
+int hu_tape_compile_groups(const float* tape, size_t n_floats, const char* include_dir, const char* cache_dir,
+                           uint32_t groups, size_t* code_bytes, int* from_cache);
 
 /* Device self-test of the arithmetic contract: the kernels compute sqrt(x) and 1/sqrt(x) with a
  * short hardware-seeded sequence instead of the compiler's IEEE expansion (csrc/interp.hpp

@@ -102,3 +102,24 @@ def test_the_zoo_through_the_brick_kernels(hip, name):
     res = size / 48
     blocks = [([(-24, -24, -24), (-8, -8, -8), (8, -8, 0)], res, tuple(mid))]
     run(hip, ref["tape"], grids, blocks)
+
+
+@pytest.mark.parametrize("scale,offset", [(1.0, 0.0), (1e-9, 0.0), (1e-30, 0.0), (3e13, 0.0), (1e20, 0.0), (1.0, 7e14), (1.0, 3e37)])
+def test_the_in_range_flag_at_its_edges(hip, scale, offset):
+    """Per-tape code skips the range test of its fast sqrt when a launch's coordinates stay below the tape's
+    `coordinate_limit` (specialise.hpp; kernels read sdf::kFlagInRange).  Both sides of that decision against the oracle:
+    tiny shapes (half extents below 2^-25: the tape allows no skipping at all), huge shapes and grids far from the origin
+    (coordinates beyond the limit: the launch keeps the test; sums of squares beyond 2^100 take the IEEE path), and the
+    ordinary case.  Every float must still be the oracle's."""
+    import codecad_amd as cc
+    from codecad_amd import nodes
+    shape = cc.examples.sponge(2).scaled(scale)
+    if offset:
+        shape = shape.translated(offset, 0, -offset / 3)
+    tape = nodes.make_program(shape)
+    step = np.float32(scale / 24)
+    centre = np.array([offset, 0.0, -offset / 3])
+    grids = [(centre - float(step) * np.array([8, 8, 16]) + float(step) / 2, step, (16, 16, 32))]
+    res = float(scale) / 40
+    blocks = [([(-16, -16, -16), (0, -8, 3)], res, tuple(centre))]
+    run(hip, tape, grids, blocks)

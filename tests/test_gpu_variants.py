@@ -69,7 +69,7 @@ def test_specialised_tape_is_bit_identical_to_the_interpreter(hip, name):
             tape.specialize()
             flag = ctypes.c_int()
             check(hip.lib.hu_tape_specialized(tape.device_ptr, ctypes.byref(flag)), "hu_tape_specialized")
-            assert flag.value == 1
+            assert flag.value == hip_util.SPEC_ALL      # every kernel family runs per-tape code
         got = []
         g4 = hip_util.Buffer(hip_util.Buffer.quad_dtype(np.float32), dims)
         hip.k.grid_eval(dims, None, tape, c4, step, g4).wait()
@@ -108,32 +108,34 @@ def test_tiered_specialisation_policy(hip, monkeypatch):
     out = hip_util.Buffer(grid_eval.FLOAT4, (24, 24, 24))
 
     t = hip_util.Tape(tape)
-    assert t._policy == "auto" and not t.specialized and t._job is None
+    assert t._policy == "auto" and not t.specialized and not t._jobs
     hip.k.grid_eval((24, 24, 24), None, t, c, np.float32(1 / 24), out).wait()
-    assert not t.specialized and t._job is None and t._work == 24 ** 3 * t.n_instructions      # too little work to bother
+    assert not t.specialized and not t._jobs and t._work == 24 ** 3 * t.n_instructions      # too little work to bother
     interpreted = out.read().copy()
     t._START_SECONDS = 0.0                                                   # "enough work" from now on
     t0 = time.perf_counter()
     hip.k.grid_eval((24, 24, 24), None, t, c, np.float32(1 / 24), out).wait()
-    assert time.perf_counter() - t0 < 0.5 and t._job is not None and not t.specialized       # interpreted, the build is under way
+    assert time.perf_counter() - t0 < 0.5 and len(t._jobs) == 2 and not t.specialized       # interpreted, the builds are under way
     assert np.array_equal(out.read().view(np.uint32), interpreted.view(np.uint32))
-    assert t.wait_specialized(timeout=120) and t.specialized
+    assert t.wait_specialized(timeout=120) and t.specialized and t.groups == 15 and not t._jobs
     hip.k.grid_eval((24, 24, 24), None, t, c, np.float32(1 / 24), out).wait()
     assert np.array_equal(out.read().view(np.uint32), interpreted.view(np.uint32))
     # a second tape: its launches pick the finished build up by themselves
     u = hip_util.Tape(nodes.make_program(examples.sponge(1)))
     u._START_SECONDS = 0.0
     deadline = time.perf_counter() + 120
-    while not u.specialized and time.perf_counter() < deadline:
+    first_groups = 0
+    while u.groups != 15 and time.perf_counter() < deadline:
         hip.k.grid_eval((24, 24, 24), None, u, c, np.float32(1 / 24), out).wait()
-        time.sleep(0.05)
-    assert u.specialized
+        first_groups = first_groups or u.groups
+        time.sleep(0.02)
+    assert u.groups == 15 and first_groups in (1, 15)     # the family in use (dense grids) came first
 
     monkeypatch.setenv("CODECAD_AMD_SPECIALIZE", "0")
     never = hip_util.Tape(tape)
     never._START_SECONDS = 0.0
     hip.k.grid_eval((24, 24, 24), None, never, c, np.float32(1 / 24), out).wait()
-    assert not never.specialized and never._job is None
+    assert not never.specialized and not never._jobs
     out.release()
 
 
@@ -307,3 +309,61 @@ def test_external_tape_ending_in_load_return(hip):
         assert same_bits(w.read().reshape(-1), oracle.grid_eval_pymcubes(tape, corner, step, (n, n, n)).reshape(-1)), specialise
         out.release()
         w.release()
+
+
+@pytest.mark.gpu
+def test_kernel_families_are_built_and_loaded_separately(hip, tmp_path):
+    """hu_tape_specialize_groups: per-tape code for one kernel family at a time -- a launch of a family that is not
+    loaded yet runs the interpreter, one that is loaded runs per-tape code, the bytes are the oracle's either way -- and
+    hu_tape_compile_groups builds a family on the host alone (what the background thread does)."""
+    import ctypes
+    import numpy as np
+    import oracle
+    from conftest import same_bits
+    from codecad_amd import hip_util, examples, nodes, grid_eval
+    from codecad_amd.hip_util import builder
+    tape = nodes.make_program(examples.sponge(2))
+    corner = np.array([-0.52, -0.49, -0.5], np.float32)
+    step, dims = np.float32(1 / 32), (16, 16, 32)
+    c4 = np.zeros(4, np.float32)
+    c4[:3] = corner
+    want = oracle.grid_eval(tape, corner, step, dims)
+    count_want, cells_want = oracle.subdivision_step(tape, corner, step, np.float32(step * 0.87), dims)
+
+    def check_both(t):
+        out = hip_util.Buffer(grid_eval.FLOAT4, dims)
+        hip.k.grid_eval(dims, None, t, c4, step, out).wait()
+        assert same_bits(out.read().view(np.float32).reshape(dims + (4,)), want)
+        counter, lst = hip_util.Buffer(np.uint32, 1), hip_util.Buffer(np.uint8, (dims[0] * dims[1] * dims[2], 4))
+        counter.enqueue_fill(0)
+        hip.k.subdivision_step(dims, None, t, c4, step, np.float32(step * 0.87), counter, lst).wait()
+        n = int(counter.read()[0])
+        assert n == count_want and sorted(map(tuple, lst.read()[:n].tolist())) == sorted(map(tuple, cells_want.tolist()))
+        for b in (out, counter, lst):
+            b.release()
+
+    t = hip_util.Tape(tape, policy="0")
+    check_both(t)
+    assert t.groups == 0
+    t._specialize(only_if_cached=False, groups=1)          # the dense kernels only
+    assert t.groups == 1 and t.specialized
+    check_both(t)                                          # grid_eval: per-tape code; subdivision_step: interpreter
+    t._specialize(only_if_cached=False, groups=4)
+    assert t.groups == 5
+    check_both(t)
+    t.specialize()
+    assert t.groups == 15
+    check_both(t)
+    # the host-only build of one family, and its image found again by the load
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    size, hit = ctypes.c_size_t(0), ctypes.c_int(-1)
+    ptr = t.host_tape.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+    assert hip.lib.hu_tape_compile_groups(ptr, t.host_tape.size, builder.CSRC.encode(), str(cache).encode(), 2, ctypes.byref(size), ctypes.byref(hit)) == 0
+    assert hit.value == 0 and size.value > 5000
+    u = hip_util.Tape(tape, policy="0")
+    u._specialize(only_if_cached=True, directory=str(cache), groups=2)
+    assert u.groups == 2 and u.from_cache
+    u._specialize(only_if_cached=True, directory=str(cache), groups=1)      # nothing cached for that family: stays as it is
+    assert u.groups == 2
+    assert hip.lib.hu_tape_compile_groups(ptr, t.host_tape.size, builder.CSRC.encode(), str(cache).encode(), 16, None, None) != 0

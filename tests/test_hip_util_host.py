@@ -4,6 +4,7 @@ reference's semantics (reference tests/test_clutil.py:188-248)."""
 import ctypes
 import os
 
+import numpy
 import pytest
 
 from codecad_amd import hip_util
@@ -435,3 +436,61 @@ def _check_flagged_unit(text):
                 assert not other_exits, "%s: a divergent loop with a second exit under -structurizecfg-skip-uniform-regions" % m.group(1)
                 checked += 1
     assert checked >= 1    # (the gear's bisection, the rounded blend: the check has something to look at)
+
+
+def test_background_builds_run_in_a_process_of_their_own(tmp_path, monkeypatch):
+    """The worker thread hands a tape's kernel family to the compile server (codecad_amd/hip_util/_compile_server.py:
+    host only, no torch) and finds the image in the directory it named; a failed build is reported on the job, the
+    server survives a malformed request, and with CODECAD_AMD_RTC_SERVER=0 -- or a server that is gone -- the same job is
+    built on the worker thread."""
+    import ctypes
+    import json
+    import os
+    import subprocess
+    import sys
+    import codecad_amd as cc
+    from codecad_amd.hip_util import _lib, buffer, builder
+    lib = _lib.load()
+    monkeypatch.setenv("CODECAD_AMD_CACHE", str(tmp_path / "cache"))
+    tape = cc.nodes.make_program(cc.shapes.sphere(2) - cc.shapes.box(1.5))
+
+    def is_hit(t, groups):
+        t = numpy.ascontiguousarray(t, dtype=numpy.float32)
+        size, hit = ctypes.c_size_t(0), ctypes.c_int(-1)
+        rc = lib.hu_tape_compile_groups(t.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), t.size, builder.CSRC.encode(),
+                                        str(tmp_path / "cache").encode(), groups, ctypes.byref(size), ctypes.byref(hit))
+        assert rc == 0
+        return hit.value == 1
+
+    worker = buffer._BackgroundCompiler()
+    job = worker.submit(lib, tape, builder.CSRC, _lib.SPEC_CLASSIFY)
+    assert job["done"].wait(120) and job["error"] is None and job["directory"] == str(tmp_path / "cache")
+    assert worker.server and worker.server.poll() is None          # a live child process built it
+    assert is_hit(tape, _lib.SPEC_CLASSIFY)
+    # a tape hipRTC cannot build (malformed) -> the error is on the job, the server goes on
+    bad = worker.submit(lib, [99 * 512.0], builder.CSRC, _lib.SPEC_DENSE)
+    assert bad["done"].wait(120) and bad["error"] and "malformed" in bad["error"]
+    assert worker.server.poll() is None
+    # the server gone -> the worker builds the next job itself
+    worker.server.kill()
+    worker.server.wait(10)
+    tape2 = cc.nodes.make_program(cc.shapes.sphere(2) - cc.shapes.box(1.25))
+    job = worker.submit(lib, tape2, builder.CSRC, _lib.SPEC_CLASSIFY)
+    assert job["done"].wait(120) and job["error"] is None and worker.server is False
+    assert is_hit(tape2, _lib.SPEC_CLASSIFY)
+    # switched off -> never started
+    monkeypatch.setenv("CODECAD_AMD_RTC_SERVER", "0")
+    worker = buffer._BackgroundCompiler()
+    tape3 = cc.nodes.make_program(cc.shapes.sphere(2) - cc.shapes.box(1.125))
+    job = worker.submit(lib, tape3, builder.CSRC, _lib.SPEC_DENSE)
+    assert job["done"].wait(120) and job["error"] is None and worker.server is False and is_hit(tape3, _lib.SPEC_DENSE)
+    # the protocol itself: one JSON line in, one out; garbage is answered, not fatal; stdin closing ends it
+    script = os.path.join(os.path.dirname(buffer.__file__), "_compile_server.py")
+    text = open(script).read()
+    assert "import torch" not in text and "import numpy" not in text and "codecad_amd" not in text.split('"""')[2]
+    p = subprocess.Popen([sys.executable, script, lib._name], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, bufsize=1)
+    p.stdin.write("not json\n")
+    p.stdin.flush()
+    assert json.loads(p.stdout.readline())["rc"] != 0
+    p.stdin.close()
+    assert p.wait(30) == 0
