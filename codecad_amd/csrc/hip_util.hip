@@ -236,6 +236,7 @@ struct SpecKernels {
     hipFunction_t ray_caster = nullptr, bitmap = nullptr;
     bool deferred = false;   // the module was generated with deferred directions (specialise.hpp): dense launches use bricks
     double coord_limit = 0.0;   // a launch whose sample coordinates all stay below this sets sdf::kFlagInRange (specialise.hpp)
+    int tabs[2][3] = {{0, 0, 0}, {0, 0, 0}};   // columns of the axis tables [walk along z, along x][x, y, z] (specialise.hpp)
 };
 
 namespace {
@@ -273,10 +274,14 @@ bool defer_directions()
     return !off;
 }
 
-std::string generate_source(const hu_tape_s* t, bool* deferred = nullptr, double* coord_limit = nullptr)
+std::string generate_source(const hu_tape_s* t, sdf::SpecMeta* meta = nullptr)
 {
-    return sdf::specialised_source(t->program, defer_directions(), deferred, coord_limit);
+    return sdf::specialised_source(t->program, defer_directions(), meta);
 }
+// LDS bytes of the axis tables a brick launch needs (kernels.hpp: the dense kernel's tables hold 4 / 16 / 128 entries
+// per column, a leaf block's 64 each)
+uint32_t dense_table_bytes(const SpecKernels* k) { return (uint32_t)(k->tabs[0][0] * 4 + k->tabs[0][1] * 16 + k->tabs[0][2] * 128) * 4u; }
+uint32_t block_table_bytes(const SpecKernels* k) { return (uint32_t)(k->tabs[1][0] + k->tabs[1][1] + k->tabs[1][2]) * 64u * 4u; }
 
 void keep_programs(hu_tape_s* t, const sdf::DecodedTape& d)
 {
@@ -554,11 +559,12 @@ int hu_grid_eval_slab(hu_tape t, const float corner[4], float step, const uint32
                 // 0.129 ms with 16 -- 8 192 wavefronts are 1.3 rounds of the chip -- and 0.128 ms with 4)
                 for (uint32_t g = 16u; g > 4u; g >>= 1)
                     if (nbz % g == 0u && bricks / g >= 16384u) { tiles = g; break; }
-                grid = (uint32_t)((bricks / tiles + 3u) / 4u);
+                // a workgroup: four rows of bricks that are neighbours along y (they share the axis tables of their box)
+                grid = (nx / 4u) * ((dims[1] / 4u + 3u) / 4u) * (nbz / tiles);
             }
             void* args[] = {&ev, &cx, &cy, &cz, &step, &sx, &sy, &sz, &xs, &n_cells, &tiles, &o};
             HU_HIP(hipModuleLaunchKernel(t->spec->dense[layout], grid, 1, 1, kSpecBlock, 1, 1,
-                                         0, (hipStream_t)stream, args, nullptr));
+                                         tiles ? dense_table_bytes(t->spec) : 0u, (hipStream_t)stream, args, nullptr));
             done += nx;
         }
         return HU_OK;
@@ -625,7 +631,9 @@ static int grid_eval_blocks_impl(hu_tape t, const int32_t* blocks_dev, uint32_t 
         uint32_t chunks = (uint32_t)((cells + per_block - 1) / per_block);
         // deferred-direction code over compact bricks (kernels.hpp): a wavefront per (x, y) column of 4 x 4 x 8 bricks
         // (a wavefront per (y, z) column of 4 x 4 x 8 bricks, walking along x)
-        uint32_t bricks = t->spec->deferred && brick_tiles(dims[0], dims[1], 32u) && dims[2] % 8u == 0u && dims[0] <= 64u ? dims[0] / 4u : 0u;
+        // (extents up to 64: the block's axis tables hold 64 entries per column)
+        uint32_t bricks = t->spec->deferred && brick_tiles(dims[0], dims[1], 32u) && dims[2] % 8u == 0u && dims[0] <= 64u && dims[1] <= 64u && dims[2] <= 64u
+                              ? dims[0] / 4u : 0u;
         if (bricks) chunks = ((dims[1] / 4u) * (dims[2] / 8u) + 3u) / 4u;
         const double extent = (double)step * (double)std::max(dims[0], std::max(dims[1], dims[2]));
         SpecEval ev{t->extra_dev, spec_flags(t, list_reach(resolution, origin[0], origin[1], origin[2], extent))};
@@ -638,8 +646,8 @@ static int grid_eval_blocks_impl(hu_tape t, const int32_t* blocks_dev, uint32_t 
             uint32_t first = b0;
             const uint32_t count = n_blocks - b0 < piece ? n_blocks - b0 : piece;
             void* args[] = {&ev, &b, &n_dev, &first, &chunks, &bricks, &res, &ox, &oy, &oz, &step, &sx, &sy, &sz, &out_dev};
-            HU_HIP(hipModuleLaunchKernel(t->spec->blocks[layout], chunks * count, 1, 1, kSpecBlock, 1, 1, 0, (hipStream_t)stream,
-                                         args, nullptr));
+            HU_HIP(hipModuleLaunchKernel(t->spec->blocks[layout], chunks * count, 1, 1, kSpecBlock, 1, 1,
+                                         bricks ? block_table_bytes(t->spec) : 0u, (hipStream_t)stream, args, nullptr));
         }
         return HU_OK;
     }
@@ -1222,9 +1230,8 @@ int hu_tape_specialize_groups(hu_tape t, const char* include_dir, const char* ca
     // all ten kernels, made while one family was already running, is found under its own name)
     const uint32_t missing = t->spec ? (groups & ~t->spec->groups) : groups;
     if (missing == 0) return HU_OK;
-    bool deferred = false;
-    double coord_limit = 0.0;
-    const std::string src = generate_source(t, &deferred, &coord_limit);
+    sdf::SpecMeta meta;
+    const std::string src = generate_source(t, &meta);
     int cached = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         SpecImage img;
@@ -1248,8 +1255,9 @@ int hu_tape_specialize_groups(hu_tape t, const char* include_dir, const char* ca
                 if (kSpecGroupOf[i] & missing) *slots[i] = loaded[i];
             k->modules.push_back(module);
             k->groups |= missing;
-            k->deferred = deferred;
-            k->coord_limit = coord_limit;
+            k->deferred = meta.deferred;
+            k->coord_limit = meta.coord_limit;
+            std::memcpy(k->tabs, meta.tabs, sizeof k->tabs);
             if (from_cache) *from_cache = cached;
             return HU_OK;
         }

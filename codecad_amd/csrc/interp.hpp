@@ -1247,6 +1247,20 @@ __device__ __forceinline__ V4<T> run_tape(const Rec* __restrict__ prog, const fl
     }
 }
 
+// AXIS TABLES (per-tape code, specialise.hpp): what a brick kernel's walks read instead of recomputing single-axis
+// statements.  A table is [column][entry] floats in LDS, SX / SY / SZ entries per column; x, y, z point at THIS LANE's
+// entry of column 0 (a lane's two voxels are two x entries apart; its y and z are one number each).  Columns are
+// template arguments so that every read is one ds_read with an immediate offset (the pair of an x column: ds_read2).
+typedef __attribute__((address_space(3))) float lds_float;
+template <int SX, int SY, int SZ> struct AxisTabs {
+    const lds_float* x;
+    const lds_float* y;
+    const lds_float* z;
+    template <int K> __device__ __forceinline__ f2 X() const { return make_f2(x[K * SX], x[K * SX + 2]); }
+    template <int K> __device__ __forceinline__ float Y() const { return y[K * SY]; }
+    template <int K> __device__ __forceinline__ float Z() const { return z[K * SZ]; }
+};
+
 // The FULL form of a record on a widened value (the second phase of per-tape code, for the ops it does not restate):
 // `act` = the lanes of the path, the record's register operand in `operand`
 template <int OP, class TA, class TB, class M>

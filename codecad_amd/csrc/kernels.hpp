@@ -223,12 +223,35 @@ k_grid_eval(const E ev, float cx, float cy, float cz, float step, uint32_t sx, D
             // bytes (eight float4 along z) per (x, y) row of the brick
             const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
             // A wavefront takes tiles = G bricks in a row along z (the index arithmetic and the launch of a wavefront are
-            // paid once per G bricks: 512^3 sponge(4): 0.974 ms with one brick per wavefront, 0.886 with sixteen).
+            // paid once per G bricks: 512^3 sponge(4): 0.974 ms with one brick per wavefront, 0.886 with sixteen); the
+            // four wavefronts of a workgroup take four neighbouring rows along y: together a box of 4 x 16 x 8G voxels.
             const uint32_t G = tiles;
-            const uint32_t nbz = (sz >> 3) / G, nby = sy >> 2;      // groups of G bricks along z, bricks along y
-            const uint32_t wid = blockIdx.x * 4u + wave;
-            const uint32_t gz = wid % nbz, t = wid / nbz, by = t % nby, bx = t / nby;
-            if (bx * 4u >= sx_slab(n_cells, sy, sz)) return;        // wavefronts past the last group (uniform)
+            const uint32_t nbz = (sz >> 3) / G, nby = sy >> 2, nbyg = (nby + 3u) >> 2;   // groups of G bricks along z, bricks along y, workgroups along y
+            const uint32_t gz = blockIdx.x % nbz, t = blockIdx.x / nbz, byg = t % nbyg, bx = t / nbyg;
+            if (bx * 4u >= sx_slab(n_cells, sy, sz)) return;        // workgroups past the last one (uniform)
+            const uint32_t by = byg * 4u + wave;
+            // The axis tables of the box (specialise.hpp "AXIS TABLES"): every statement of the tape that reads one
+            // sample coordinate, evaluated once per sample of that axis -- 4 x, 16 y, 8G z -- by the wavefronts side by
+            // side; the walks read them back (interp.hpp AxisTabs).
+            constexpr int NX = E::kTabZX, NY = E::kTabZY, NZ = E::kTabZZ;
+            using Tabs = sdf::AxisTabs<4, 16, 128>;
+            sdf::lds_float* const tx = (sdf::lds_float*)lds;
+            sdf::lds_float* const ty = tx + NX * 4;
+            sdf::lds_float* const tz = ty + NY * 16;
+            if constexpr (NX + NY + NZ > 0) {
+                if (wave < 2u) {
+                    if constexpr (NZ > 0)
+                        for (uint32_t e = threadIdx.x; e < G * 8u; e += 128u) ev.template tab_z_z<128>(sample(cz, step, gz * G * 8u + e), tz + e);
+                } else if (wave == 2u) {
+                    if constexpr (NY > 0)
+                        if (lane < 16u) ev.template tab_z_y<16>(sample(cy, step, byg * 16u + lane), ty + lane);
+                } else {
+                    if constexpr (NX > 0)
+                        if (lane < 4u) ev.template tab_z_x<4>(sample(cx, step, x0 + bx * 4u + lane), tx + lane);
+                }
+                __syncthreads();
+            }
+            if (by >= nby) return;                                  // wavefronts past the last row (uniform per wavefront)
             const uint32_t x = bx * 4u + (lane >> 5), y = by * 4u + ((lane >> 3) & 3u);
             float xs[N];
 #pragma unroll
@@ -237,23 +260,28 @@ k_grid_eval(const E ev, float cx, float cy, float cz, float step, uint32_t sx, D
             // on them alone in scalars per lane, not in packed pairs: interp.hpp "values of mixed width")
             const T px = pack(xs);
             const float py = sample(cy, step, y);
-            // what the tape computes from x and y alone is computed once for the wavefront's bricks (specialise.hpp)
-            const auto hoisted = ev.hoist(px, py);
+            // what the tape computes from x and y together is computed once for the wavefront's bricks (specialise.hpp)
+            Tabs tb{tx + (lane >> 5), ty + (wave * 4u + ((lane >> 3) & 3u)), tz + (lane & 7u)};
+            const auto hoisted = ev.hoist(px, py, tb);
 #pragma unroll 1
             for (uint32_t j = 0; j < G; ++j) {
+                // (the table columns of x and y do not change along the walk: read again in every brick -- a ds_read is
+                // cheaper than a register held for sixteen bricks -- which the compiler would otherwise undo)
+                asm volatile("" ::: "memory");
                 const uint32_t z = (gz * G + j) * 8u + (lane & 7u);
                 const float pz = sample(cz, step, z);
                 if (LAYOUT == 0) {
-                    const sdf::V4<T> r = ev.eval_hoisted(px, py, pz, hoisted);
+                    const sdf::V4<T> r = ev.eval_hoisted(px, py, pz, hoisted, tb);
                     float4* o = static_cast<float4*>(out) + ((size_t)z + (size_t)sz * ((size_t)y + (size_t)sy * x));
 #pragma unroll
                     for (int i = 0; i < N; ++i) store_voxel(o + (size_t)i * 2u * sy * sz, sdf::voxel(r, i));
                 } else {
-                    const T w = ev.dist_hoisted(px, py, pz, hoisted);
+                    const T w = ev.dist_hoisted(px, py, pz, hoisted, tb);
                     float* o = static_cast<float*>(out) + ((size_t)z + ((size_t)(x0 + x) + (size_t)(sy - 1u - y) * sx) * sz);
 #pragma unroll
                     for (int i = 0; i < N; ++i) store_voxel(o + (size_t)i * 2u * sz, sdf::get(w, i));
                 }
+                tb.z += 8;
             }
             return;
         }
@@ -306,33 +334,55 @@ k_grid_eval_blocks(const E ev, const int4* __restrict__ blocks, const uint32_t* 
         if (bricks) {
             // As in k_grid_eval: a wavefront evaluates compact 4 x 4 x 8 bricks (lane -> z: 8, y: 4, x: 2, its two voxels
             // two x planes apart) -- here the `bricks` = sx / 4 of one (y, z) column of the block, one after the other ALONG
-            // X (a 16^3 block: four; along z it would be two): what the tape computes from y and z alone is computed once
+            // X (a 16^3 block: four; along z it would be two): what the tape computes from y and z together is computed once
             // for them (specialise.hpp: the bars of a cross that run along x).  `chunks` counts workgroups of four columns.
-            const uint32_t lane = threadIdx.x & 63u, column = chunk * 4u + (threadIdx.x >> 6);
+            const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, column = chunk * 4u + wave;
             const uint32_t nbz = sz >> 3, bz = column % nbz, by = column / nbz;
+            // the axis tables of the BLOCK (its extents are at most 64: the launcher), one wavefront per axis
+            constexpr int NX = E::kTabXX, NY = E::kTabXY, NZ = E::kTabXZ;
+            using Tabs = sdf::AxisTabs<64, 64, 64>;
+            sdf::lds_float* const tx = (sdf::lds_float*)lds;
+            sdf::lds_float* const ty = tx + NX * 64;
+            sdf::lds_float* const tz = ty + NY * 64;
+            if constexpr (NX + NY + NZ > 0) {
+                if (wave == 0u) {
+                    if constexpr (NX > 0)
+                        if (lane < sx) ev.template tab_x_x<64>(sample(cx, step, lane), tx + lane);
+                } else if (wave == 1u) {
+                    if constexpr (NY > 0)
+                        if (lane < sy) ev.template tab_x_y<64>(sample(cy, step, lane), ty + lane);
+                } else if (wave == 2u) {
+                    if constexpr (NZ > 0)
+                        if (lane < sz) ev.template tab_x_z<64>(sample(cz, step, lane), tz + lane);
+                }
+                __syncthreads();
+            }
             if (by * 4u >= sy) return;   // wavefronts past the last column (uniform)
             const uint32_t y = by * 4u + ((lane >> 3) & 3u), z = bz * 8u + (lane & 7u);
             const float py = sample(cy, step, y), pz = sample(cz, step, z);   // (one number per lane: its voxels differ in x)
             const size_t base = (size_t)b * cells;
-            const auto hoisted = ev.hoist_x(py, pz);
+            Tabs tb{tx + (lane >> 5), ty + y, tz + z};
+            const auto hoisted = ev.hoist_x(py, pz, tb);
 #pragma unroll 1
             for (uint32_t j = 0; j < bricks; ++j) {
+                asm volatile("" ::: "memory");   // (the y and z columns are read again in every brick: k_grid_eval)
                 const uint32_t x = j * 4u + (lane >> 5);
                 float xs[N];
 #pragma unroll
                 for (int i = 0; i < N; ++i) xs[i] = sample(cx, step, x + 2u * i);
                 const T px = pack(xs);
                 if (LAYOUT == 0) {
-                    const sdf::V4<T> r = ev.eval_hoisted_x(px, py, pz, hoisted);
+                    const sdf::V4<T> r = ev.eval_hoisted_x(px, py, pz, hoisted, tb);
                     float4* o = static_cast<float4*>(out) + base + ((size_t)z + (size_t)sz * ((size_t)y + (size_t)sy * x));
 #pragma unroll
                     for (int i = 0; i < N; ++i) store_voxel(o + (size_t)i * 2u * sy * sz, sdf::voxel(r, i));
                 } else {
-                    const T w = ev.dist_hoisted_x(px, py, pz, hoisted);
+                    const T w = ev.dist_hoisted_x(px, py, pz, hoisted, tb);
                     float* o = static_cast<float*>(out) + base + ((size_t)z + ((size_t)x + (size_t)(sy - 1u - y) * sx) * sz);
 #pragma unroll
                     for (int i = 0; i < N; ++i) store_voxel(o + (size_t)i * 2u * sz, sdf::get(w, i));
                 }
+                tb.x += 4;
             }
             return;
         }

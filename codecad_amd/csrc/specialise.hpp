@@ -523,8 +523,26 @@ struct Variant {
     std::string pre;      // body of the hoisting function ("" when nothing is hoisted)
     std::string main;     // body of the evaluation up to the root distance
     int n_hoisted = 0;
-    std::vector<char> handed;   // per statement: is it a member of the struct `pre` returns
+    std::vector<char> handed;     // per statement: is it a member of the struct `pre` returns
+    std::vector<char> tab_read;   // per statement: the body or `pre` reads it from its axis' table (axis tables, below)
+    std::vector<char> tab_main;   // ... the body does, in every brick
 };
+// Roughly the instructions a statement's whole tree costs (shared subexpressions count once per use: an upper bound);
+// 0 for names (sample coordinates, constants), masks and the directions of phase 2.
+inline std::vector<int> statement_costs(const Phase1& ph)
+{
+    const std::vector<Stmt>& st = ph.e.st;
+    std::vector<int> cost(st.size(), 0);
+    for (int i = 0; i < ph.n_phase1; ++i) {
+        if (st[i].ops.empty() || st[i].mask) continue;
+        const std::string& t = st[i].text;
+        int c = t.compare(0, 11, "remainder_t") == 0 ? 3 : t.compare(0, 8, "perp_w_x") == 0 ? 8 : t.compare(0, 4, "len2") == 0 ? 10 :
+                t.compare(0, 4, "len3") == 0 ? 12 : t.compare(0, 10, "run_record") == 0 ? 100 : t.compare(0, 2, "$0") == 0 && t.size() == 4 ? 0 : 1;
+        for (int o : st[i].ops) c += cost[o];
+        cost[i] = c;
+    }
+    return cost;
+}
 // Which statements are handed from `pre` when the walk is along `walk`: those that do not read its coordinate -- unless
 // they are cheaper to compute again in every brick than to keep in a register for the whole walk (a value costs one or
 // two VGPRs for the walk's duration, and registers decide how many wavefronts a SIMD holds): `min_cost` = the number
@@ -535,31 +553,64 @@ inline std::vector<char> hoistable_set(const Phase1& ph, uint8_t walk, int min_c
     const int n = (int)st.size();
     std::vector<char> out(n, 0);
     if (walk == 0) return out;
-    std::vector<int> cost(n, 0);
+    const std::vector<int> cost = statement_costs(ph);
     for (int i = 0; i < ph.n_phase1; ++i) {   // (a direction is computed where its path's mask is known: never in `pre`)
         if (st[i].ops.empty() || st[i].mask || (st[i].deps & walk)) continue;
-        const std::string& t = st[i].text;
-        int c = t.compare(0, 11, "remainder_t") == 0 ? 3 : t.compare(0, 8, "perp_w_x") == 0 ? 8 : t.compare(0, 4, "len2") == 0 ? 10 :
-                t.compare(0, 4, "len3") == 0 ? 12 : t.compare(0, 10, "run_record") == 0 ? 100 : t.compare(0, 2, "$0") == 0 && t.size() == 4 ? 0 : 1;
-        for (int o : st[i].ops) c += cost[o];     // (a tree's cost: shared subexpressions count once per use -- an upper bound)
-        cost[i] = c;
-        out[i] = c >= min_cost;
+        out[i] = cost[i] >= min_cost;
+    }
+    return out;
+}
+// AXIS TABLES (round 3).  A brick kernel's workgroup covers a box of the grid -- 4 x 16 x (8 G) voxels in the dense
+// kernel, a whole leaf block in k_grid_eval_blocks -- and a statement that reads ONE sample coordinate takes as many
+// distinct values in it as that axis has samples: 4 / 16 / 128, not 8 192.  Such statements are evaluated once per
+// sample of their axis into a table in LDS (`tape_tab_*`, called by the kernel before its walks) and the walks read
+// them there (one ds_read where a chain of remainder / fma / |x| - h was recomputed in every brick by every lane).
+// The arithmetic is the same statement on the same coordinate value, so the bits are the same.  Candidates: phase 1's
+// single-axis values worth at least `min_cost` instructions; which of them become table columns is decided by the
+// walk-dependent code that reads them (render_walk below).
+inline std::vector<char> table_candidates(const Phase1& ph, int min_cost)
+{
+    const std::vector<Stmt>& st = ph.e.st;
+    std::vector<char> out(st.size(), 0);
+    const std::vector<int> cost = statement_costs(ph);
+    for (int i = 0; i < ph.n_phase1; ++i) {
+        if (st[i].ops.empty() || st[i].mask) continue;
+        const uint8_t d = st[i].deps;
+        out[i] = (d == DX || d == DY || d == DZ) && cost[i] >= min_cost;
     }
     return out;
 }
 
-inline Variant render_variant(const Phase1& ph, const std::vector<char>& hoistable, const std::vector<int>& roots)
+// the expression that reads column `column` of a single-axis statement's table (interp.hpp AxisTabs)
+inline std::string table_load(const Stmt& s, int column)
+{
+    return std::string("tb.template ") + (s.deps == DX ? "X" : s.deps == DY ? "Y" : "Z") + "<" + std::to_string(column) + ">()";
+}
+
+// `tabc`: the table candidates the walk may read (empty: none); `tab_index` (may be NULL while the columns are still
+// being counted): statement -> its column; `held` (may be empty): the columns that do not change along the walk and are
+// read ONCE, in `pre`, and kept in registers (a table read is not free: the data returning from LDS takes the register
+// file's write port for about one vector instruction per dword -- measured: 220 vector instructions + 34 dwords read per
+// brick ran like 264 --, so a column the walk reads in every brick is worth a register or two once registers are there).
+inline Variant render_variant(const Phase1& ph, const std::vector<char>& hoistable, const std::vector<int>& roots,
+                              const std::vector<char>& tabc = std::vector<char>(), const std::vector<int>* tab_index = nullptr,
+                              const std::vector<char>& held = std::vector<char>())
 {
     const std::vector<Stmt>& st = ph.e.st;
     const int n = (int)st.size();
     auto invariant = [&](int i) { return hoistable[i] != 0; };
+    auto tabled = [&](int i) { return i < (int)tabc.size() && tabc[i] != 0; };
+    auto is_held = [&](int i) { return i < (int)held.size() && held[i] != 0; };
+    auto column = [&](int i) { return table_load(st[i], tab_index ? (*tab_index)[i] : 0); };
     // (statements without operands -- the sample coordinates, constants -- are names, not work: never handed on)
-    std::vector<char> in_main(n, 0), frontier(n, 0), in_pre(n, 0);
+    std::vector<char> in_main(n, 0), frontier(n, 0), in_pre(n, 0), tab_read(n, 0), pre_load(n, 0);
     std::vector<int> stack(roots.begin(), roots.end());
     while (!stack.empty()) {
         const int i = stack.back();
         stack.pop_back();
         if (i < 0) continue;
+        if (is_held(i)) { frontier[i] = 1; continue; }
+        if (tabled(i)) { tab_read[i] = 1; continue; }      // (a table column costs no register for the walk: before `pre`)
         if (invariant(i)) { frontier[i] = 1; continue; }
         if (in_main[i]) continue;
         in_main[i] = 1;
@@ -569,7 +620,8 @@ inline Variant render_variant(const Phase1& ph, const std::vector<char>& hoistab
     while (!stack.empty()) {
         const int i = stack.back();
         stack.pop_back();
-        if (in_pre[i]) continue;
+        if (in_pre[i] || pre_load[i]) continue;
+        if (tabled(i)) { pre_load[i] = 1; continue; }      // (`pre` runs after the tables are built: it reads them too)
         in_pre[i] = 1;
         for (int o : st[i].ops) stack.push_back(o);
     }
@@ -578,7 +630,8 @@ inline Variant render_variant(const Phase1& ph, const std::vector<char>& hoistab
     std::ostringstream pre, main;
     for (int i = 0; i < n; ++i) {
         if (st[i].ops.empty()) continue;
-        if (in_pre[i]) pre << "    const auto t" << i << " = " << render(st[i], plain) << ";\n";
+        if (pre_load[i]) pre << "    const auto t" << i << " = " << column(i) << ";\n";
+        else if (in_pre[i]) pre << "    const auto t" << i << " = " << render(st[i], plain) << ";\n";
     }
     std::ostringstream members, values;
     for (int i = 0; i < n; ++i)
@@ -593,18 +646,56 @@ inline Variant render_variant(const Phase1& ph, const std::vector<char>& hoistab
     }
     auto in_walk = [&](int i) { return st[i].ops.empty() ? st[i].text : (frontier[i] ? "h.t" : "t") + std::to_string(i); };
     for (int i = 0; i < n; ++i) {
-        if (st[i].ops.empty() || !in_main[i]) continue;
-        main << "    const auto t" << i << " = " << render(st[i], in_walk) << ";\n";
+        if (st[i].ops.empty()) continue;
+        if (tab_read[i]) main << "    const auto t" << i << " = " << column(i) << ";\n";
+        else if (in_main[i]) main << "    const auto t" << i << " = " << render(st[i], in_walk) << ";\n";
     }
     v.main = main.str();
     v.handed = frontier;
+    v.tab_read = tab_read;
+    v.tab_main = tab_read;
+    for (int i = 0; i < n; ++i) if (pre_load[i]) v.tab_read[i] = 1;   // (what needs a column, whoever reads it)
     return v;
+}
+
+// The function that fills one axis' table for one sample of that axis: the columns' statements (and what they are
+// computed from: all of it reads this one coordinate), each column stored at out[column * S].
+inline std::string render_table_builder(const Phase1& ph, uint8_t axis, const std::vector<int>& tab_index)
+{
+    const std::vector<Stmt>& st = ph.e.st;
+    const int n = (int)st.size();
+    std::vector<char> in(n, 0);
+    std::vector<int> stack;
+    for (int i = 0; i < n; ++i) if (tab_index[i] >= 0 && st[i].deps == axis) stack.push_back(i);
+    while (!stack.empty()) {
+        const int i = stack.back();
+        stack.pop_back();
+        if (in[i]) continue;
+        in[i] = 1;
+        for (int o : st[i].ops) stack.push_back(o);
+    }
+    auto plain = [&](int i) { return st[i].ops.empty() ? st[i].text : "t" + std::to_string(i); };
+    std::ostringstream o;
+    for (int i = 0; i < n; ++i) {
+        if (!in[i] || st[i].ops.empty()) continue;
+        o << "    const auto t" << i << " = " << render(st[i], plain) << ";\n";
+        if (tab_index[i] >= 0 && st[i].deps == axis) o << "    out[" << tab_index[i] << " * S] = t" << i << ";\n";
+    }
+    return o.str();
 }
 
 }  // namespace spec_detail
 
 // true: the deferred form was emitted; false: nothing was written (use emit_plain)
-inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t max_paths = 40, double* coord_limit = nullptr)
+// What the host needs to know about the generated code (hip_util.hip SpecKernels).
+struct SpecMeta {
+    bool deferred = false;
+    double coord_limit = 0.0;    // the largest |sample coordinate| for which a launch may set sdf::kFlagInRange (0: never)
+    int tabs[2][3] = {{0, 0, 0}, {0, 0, 0}};   // [walk along z, walk along x][x, y, z]: columns of the axis tables
+};
+constexpr int kMaxTableColumns = 48;   // per axis (a 128-entry column of the dense kernel's z table is 512 B of LDS)
+
+inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t max_paths = 40, SpecMeta* meta = nullptr)
 {
     using namespace spec_detail;
     if (p.dist.empty() || p.dist.size() != p.full.size()) return false;
@@ -626,7 +717,7 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
     Phase1 ph;
     std::vector<std::array<int, 3>> pt(nodes.size(), {{-1, -1, -1}});   // local coordinates by (point) node
     if (!symbolic_phase1(p, nodes, root, is_choice, keep_w, ph, &pt)) return false;
-    if (coord_limit) *coord_limit = coordinate_limit(ph);
+    if (meta) meta->coord_limit = coordinate_limit(ph);
     ph.n_phase1 = (int)ph.e.st.size();
     std::vector<int> dist_roots{ph.root}, eval_roots{ph.root};
     for (int v : ph.choice_of_rec) if (v >= 0) eval_roots.push_back(v);
@@ -736,13 +827,19 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
     std::vector<char> lives(e.st.size(), 0);
     for (int v : ph.choice_of_rec) if (v >= 0) lives[v] = 1;
     for (int v : ph.keep_w_of_rec) if (v >= 0) lives[v] = 1;
-    auto phase2_for = [&](const std::vector<char>& hoistable) {
+    // `tabc` / `tab_index` / `tab_used`: the axis tables (render_variant): a block reads a table column where it would
+    // have recomputed the statement; `tab_used` (may be NULL) collects which candidates the blocks read
+    auto phase2_for = [&](const std::vector<char>& hoistable, const std::vector<char>& tabc, const std::vector<int>* tab_index,
+                          std::vector<char>* tab_used) {
         const std::vector<Stmt>& st = e.st;
         auto outer = [&](int id) { return st[id].ops.empty() ? st[id].text : (id < (int)hoistable.size() && hoistable[id] ? "h.t" : "t") + std::to_string(id); };
+        auto tabled = [&](int id) { return id < (int)tabc.size() && tabc[id] != 0; };
         std::ostringstream o2;
         o2 << "    // ---- phase 2\n"
-           << "    const auto qx = opaque(px); const auto qy = opaque(py); const auto qz = opaque(pz);\n"
-           << "    V4<T> dir = v4<T>(bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f));\n";
+           << "    const auto qx = opaque(px); const auto qy = opaque(py); const auto qz = opaque(pz);\n";
+        // (table columns are read again where a block wants them: without this the compiler keeps phase 1's copies alive)
+        if (!tabc.empty()) o2 << "    asm volatile(\"\" ::: \"memory\");\n";
+        o2 << "    V4<T> dir = v4<T>(bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f));\n";
         for (size_t k = 0; k < paths.size(); ++k) {
             const PathCode& code = codes[k];
             std::string mask;
@@ -755,21 +852,24 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
             o2 << "    {   // the primitive of record " << nodes[paths[k].leaf].rec << " along one path to the root\n        const M m = " << mask
                << ";\n        if (wave_any(m)) {\n";
             // what the block computes: the closure of the direction's statements, up to values that live outside it
-            std::vector<char> inside(st.size(), 0);
+            std::vector<char> inside(st.size(), 0), loads(st.size(), 0);
             std::vector<int> stack{code.d[0], code.d[1], code.d[2]};
             while (!stack.empty()) {
                 const int i = stack.back();
                 stack.pop_back();
-                if (inside[i] || st[i].ops.empty() || lives[i] || (i < (int)hoistable.size() && hoistable[i])) continue;
+                if (inside[i] || loads[i] || st[i].ops.empty() || lives[i] || (i < (int)hoistable.size() && hoistable[i])) continue;
+                if (tabled(i)) { loads[i] = 1; if (tab_used) (*tab_used)[i] = 1; continue; }
                 inside[i] = 1;
                 for (int op : st[i].ops) stack.push_back(op);
             }
             auto name = [&](int id) -> std::string {
                 if (st[id].ops.empty()) return st[id].text == "px" ? "qx" : st[id].text == "py" ? "qy" : st[id].text == "pz" ? "qz" : st[id].text;
-                return inside[id] ? "u" + std::to_string(id) : outer(id);
+                return inside[id] || loads[id] ? "u" + std::to_string(id) : outer(id);
             };
-            for (int i = 0; i < (int)st.size(); ++i)
-                if (inside[i]) o2 << "            const auto u" << i << " = " << render(st[i], name) << ";\n";
+            for (int i = 0; i < (int)st.size(); ++i) {
+                if (loads[i]) o2 << "            const auto u" << i << " = " << table_load(st[i], tab_index ? (*tab_index)[i] : 0) << ";\n";
+                else if (inside[i]) o2 << "            const auto u" << i << " = " << render(st[i], name) << ";\n";
+            }
             o2 << "            dir.x = sel(m, as<T>(" << name(code.d[0]) << "), dir.x); dir.y = sel(m, as<T>(" << name(code.d[1])
                << "), dir.y); dir.z = sel(m, as<T>(" << name(code.d[2]) << "), dir.z);\n        }\n    }\n";
         }
@@ -784,47 +884,97 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
     // 8 / 10 / 12 / 14 -- the |x| - h of the shallow levels are cheaper to recompute than to hold, 79 registers at stake --;
     // leaf blocks (walks of four bricks along x) 0.363 -> 0.356 ms at 8
     auto knob = [](const char* name, int fallback) { const char* e = std::getenv(name); return e && *e ? std::atoi(e) : fallback; };
+    const int tab_min = knob("HU_TAB_MIN", 2);      // what a single-axis value must cost to become a table column (0: no tables)
     for (const Form& f : forms) {
         const std::vector<char> hoistable = hoistable_set(ph, f.walk, f.walk == DZ ? knob("HU_HOIST_MIN_Z", 12) : knob("HU_HOIST_MIN_X", 8));
-        const Variant vd = render_variant(ph, hoistable, dist_roots), ve = render_variant(ph, hoistable, eval_roots);
+        // ---- axis tables: the candidates this form's walk-dependent code and its direction blocks read become columns
+        std::vector<char> tabc;
+        std::vector<int> tab_index(ph.e.st.size(), -1);
+        int n_tab[3] = {0, 0, 0};
+        std::vector<char> held;
+        if (f.walk != 0 && tab_min > 0) {
+            tabc = table_candidates(ph, tab_min);
+            for (;;) {
+                // the columns the DISTANCES read in every brick and the walk does not change are kept in registers instead
+                // (`held`), lowest statements first, while the budget lasts: a column of x costs two registers, others one
+                const Variant probe = render_variant(ph, hoistable, dist_roots, tabc);
+                held.assign(ph.e.st.size(), 0);
+                // (measured, sponge(4), MI355X: the dense kernel's walks along z 0.497 / 0.508 / 0.532 / 0.553 ms holding
+                // 0 / 6 / 9 / 16 registers' worth -- registers are dearer there than reads --, the leaf blocks' walks along x
+                // 0.327 / 0.325 / 0.319 / 0.325 ms at 0 / 6 / 12 / 24)
+                int budget = f.walk == DZ ? knob("HU_TAB_HOLD_Z", 0) : knob("HU_TAB_HOLD_X", 12);
+                for (int i = 0; i < (int)probe.tab_main.size(); ++i) {
+                    if (!probe.tab_main[i] || !tabc[i] || (ph.e.st[i].deps & f.walk)) continue;
+                    const int regs = ph.e.st[i].deps == DX ? 2 : 1;
+                    if (budget >= regs) { held[i] = 1; budget -= regs; }
+                }
+                const Variant all = render_variant(ph, hoistable, eval_roots, tabc, nullptr, held);
+                std::vector<char> used = all.tab_read;
+                for (int i = 0; i < (int)held.size(); ++i) if (held[i]) used[i] = 1;
+                (void)phase2_for(all.handed, tabc, nullptr, &used);
+                std::fill(tab_index.begin(), tab_index.end(), -1);
+                n_tab[0] = n_tab[1] = n_tab[2] = 0;
+                bool over = false;
+                for (int i = 0; i < (int)used.size(); ++i) {
+                    if (!used[i]) continue;
+                    const int axis = ph.e.st[i].deps == DX ? 0 : ph.e.st[i].deps == DY ? 1 : 2;
+                    if (n_tab[axis] < kMaxTableColumns) tab_index[i] = n_tab[axis]++;
+                    else over = true;
+                }
+                if (!over) break;
+                // what did not fit is computed by the walk itself, which may then reach further candidates: only the
+                // columns that were given out stay candidates, and the walk is looked at again
+                for (int i = 0; i < (int)tabc.size(); ++i) tabc[i] = tab_index[i] >= 0;
+            }
+            if (n_tab[0] + n_tab[1] + n_tab[2] == 0) { tabc.clear(); held.clear(); }
+        }
+        if (meta && f.walk != 0) for (int a = 0; a < 3; ++a) meta->tabs[f.walk == DZ ? 0 : 1][a] = n_tab[a];
+        const Variant vd = render_variant(ph, hoistable, dist_roots, tabc, &tab_index, held), ve = render_variant(ph, hoistable, eval_roots, tabc, &tab_index, held);
         // the values handed from `pre`: the union of what the distance and the evaluation read (one struct for both)
         const Variant& pre_of = ve;   // (eval's roots include dist's root: its frontier covers it)
         const bool hoists = f.walk != 0 && pre_of.n_hoisted > 0;
         if (f.walk != 0) {
-            o << "// hoisted out of walks along " << (f.walk == DZ ? "z" : "x") << ": " << pre_of.n_hoisted << " values\n"
-              << "template <class PX, class PY, class PZ> __device__ __forceinline__ auto tape_pre" << f.suffix
-              << "(PX px, PY py, PZ pz, const float* __restrict__ extra, uint32_t flags)\n{\n    using namespace sdf;\n";
+            o << "// hoisted out of walks along " << (f.walk == DZ ? "z" : "x") << ": " << pre_of.n_hoisted << " values; axis tables: "
+              << n_tab[0] << " / " << n_tab[1] << " / " << n_tab[2] << " columns (x / y / z)\n"
+              << "template <class PX, class PY, class PZ, class TB> __device__ __forceinline__ auto tape_pre" << f.suffix
+              << "(PX px, PY py, PZ pz, const float* __restrict__ extra, uint32_t flags, const TB& tb)\n{\n    using namespace sdf;\n";
             if (hoists) o << pre_of.pre;
             else o << "    struct Hoisted {};\n    return Hoisted{};\n";
             o << "}\n";
+            const char* axis_name[3] = {"x", "y", "z"};
+            const uint8_t axis_bit[3] = {DX, DY, DZ};
+            for (int a = 0; a < 3; ++a)
+                o << "template <int S, class L> __device__ __forceinline__ void tape_tab" << f.suffix << "_" << axis_name[a] << "(float p"
+                  << axis_name[a] << ", const float* __restrict__ extra, uint32_t flags, L out)\n{\n    using namespace sdf;\n"
+                  << (n_tab[a] ? render_table_builder(ph, axis_bit[a], tab_index) : std::string()) << "}\n";
         }
-        const std::string h_param = f.walk != 0 ? ", const H& h" : "";
-        const std::string h_tmpl = f.walk != 0 ? ", class H" : "";
+        const std::string h_param = f.walk != 0 ? ", const H& h, const TB& tb" : "";
+        const std::string h_tmpl = f.walk != 0 ? ", class H, class TB" : "";
+        const std::string root_name = ph.e.st[ph.root].ops.empty() ? ph.e.st[ph.root].text : ((ve.handed[ph.root] ? "h.t" : "t") + std::to_string(ph.root));
         o << "template <class PX, class PY, class PZ" << h_tmpl << "> __device__ __forceinline__ auto tape_dist" << f.suffix
           << "(PX px, PY py, PZ pz, const float* __restrict__ extra, uint32_t flags" << h_param << ")\n{\n" << head
-          << vd.main << "    return as<T>(" << (ph.e.st[ph.root].ops.empty() ? ph.e.st[ph.root].text : ((ve.handed[ph.root] ? "h.t" : "t") + std::to_string(ph.root))) << ");\n}\n";
+          << vd.main << "    return as<T>(" << root_name << ");\n}\n";
         o << "template <class PX, class PY, class PZ" << h_tmpl << "> __device__ __forceinline__ auto tape_eval" << f.suffix
           << "(PX px, PY py, PZ pz, const float* __restrict__ extra, uint32_t flags" << h_param << ")\n{\n" << head
-          << ve.main << phase2_for(ve.handed)
-          << "    return v4<T>(dir.x, dir.y, dir.z, as<T>(" << (ph.e.st[ph.root].ops.empty() ? ph.e.st[ph.root].text : ((ve.handed[ph.root] ? "h.t" : "t") + std::to_string(ph.root))) << "));\n}\n";
-        (void)vd;
+          << ve.main << phase2_for(ve.handed, tabc, &tab_index, nullptr)
+          << "    return v4<T>(dir.x, dir.y, dir.z, as<T>(" << root_name << "));\n}\n";
     }
     o << "// deferred directions: " << paths.size() << " (primitive, path) pairs; " << ph.e.st.size() << " statements in phase 1\n";
     return true;
 }
 
-// The whole translation unit handed to hipRTC.  `deferred` (may be NULL) <- whether the deferred form was used.
-// `coord_limit` (may be NULL) <- the largest |sample coordinate| for which a launch may set sdf::kFlagInRange (0: never).
-inline std::string specialised_source(const SpecProgram& p, bool allow_deferred, bool* deferred = nullptr, double* coord_limit = nullptr)
+// The whole translation unit handed to hipRTC.  `meta` (may be NULL) <- what the host needs to know about it.
+inline std::string specialised_source(const SpecProgram& p, bool allow_deferred, SpecMeta* meta = nullptr)
 {
     std::ostringstream o, d;
-    if (coord_limit) *coord_limit = 0.0;
-    const bool ok = allow_deferred && emit_deferred(d, p, 40, coord_limit);
-    if (!ok && coord_limit) *coord_limit = 0.0;
+    SpecMeta m;
+    const bool ok = allow_deferred && emit_deferred(d, p, 40, &m);
+    if (!ok) m = SpecMeta();
+    m.deferred = ok;
+    if (meta) *meta = m;
     o << "#include \"kernels.hpp\"\nnamespace sdfk {\nusing sdf::Rec;\n";
     if (ok) o << d.str();
     else emit_plain(o, p);
-    if (deferred) *deferred = ok;
     o << "struct JitEval {\n    static constexpr bool kBricks = " << (ok ? "true" : "false") << ";\n"
       << "    const float* extra;\n"
       << "    uint32_t flags;   // sdf::kFlagInRange: the launch's coordinates cannot leave the fast range of sqrt_cr\n";
@@ -833,20 +983,27 @@ inline std::string specialised_source(const SpecProgram& p, bool allow_deferred,
           << "    { return tape_eval(px, py, pz, extra, flags); }\n"
           << "    template <class T> __device__ __forceinline__ T dist(T px, T py, T pz, void*) const\n"
           << "    { return tape_dist(px, py, pz, extra, flags); }\n"
-          // what does not change along z, for kernels that walk bricks along z with x and y fixed (kernels.hpp) ...
-          << "    template <class PX, class PY> __device__ __forceinline__ auto hoist(PX px, PY py) const\n"
-          << "    { return tape_pre_z(px, py, 0.0f, extra, flags); }\n"
-          << "    template <class PX, class PY, class PZ, class H> __device__ __forceinline__ auto eval_hoisted(PX px, PY py, PZ pz, const H& h) const\n"
-          << "    { return tape_eval_z(px, py, pz, extra, flags, h); }\n"
-          << "    template <class PX, class PY, class PZ, class H> __device__ __forceinline__ auto dist_hoisted(PX px, PY py, PZ pz, const H& h) const\n"
-          << "    { return tape_dist_z(px, py, pz, extra, flags, h); }\n"
+          // the axis tables of the two walks: columns per axis, and the functions that fill one entry of each table
+          << "    static constexpr int kTabZX = " << m.tabs[0][0] << ", kTabZY = " << m.tabs[0][1] << ", kTabZZ = " << m.tabs[0][2]
+          << ", kTabXX = " << m.tabs[1][0] << ", kTabXY = " << m.tabs[1][1] << ", kTabXZ = " << m.tabs[1][2] << ";\n";
+        for (const char* walk : {"z", "x"})
+            for (const char* axis : {"x", "y", "z"})
+                o << "    template <int S, class L> __device__ __forceinline__ void tab_" << walk << "_" << axis << "(float p, L out) const\n"
+                  << "    { tape_tab_" << walk << "_" << axis << "<S>(p, extra, flags, out); }\n";
+        // what does not change along z, for kernels that walk bricks along z with x and y fixed (kernels.hpp) ...
+        o << "    template <class PX, class PY, class TB> __device__ __forceinline__ auto hoist(PX px, PY py, const TB& tb) const\n"
+          << "    { return tape_pre_z(px, py, 0.0f, extra, flags, tb); }\n"
+          << "    template <class PX, class PY, class PZ, class H, class TB> __device__ __forceinline__ auto eval_hoisted(PX px, PY py, PZ pz, const H& h, const TB& tb) const\n"
+          << "    { return tape_eval_z(px, py, pz, extra, flags, h, tb); }\n"
+          << "    template <class PX, class PY, class PZ, class H, class TB> __device__ __forceinline__ auto dist_hoisted(PX px, PY py, PZ pz, const H& h, const TB& tb) const\n"
+          << "    { return tape_dist_z(px, py, pz, extra, flags, h, tb); }\n"
           // ... and the same for a walk along x with y and z fixed (k_grid_eval_blocks)
-          << "    template <class PY, class PZ> __device__ __forceinline__ auto hoist_x(PY py, PZ pz) const\n"
-          << "    { return tape_pre_x(0.0f, py, pz, extra, flags); }\n"
-          << "    template <class PX, class PY, class PZ, class H> __device__ __forceinline__ auto eval_hoisted_x(PX px, PY py, PZ pz, const H& h) const\n"
-          << "    { return tape_eval_x(px, py, pz, extra, flags, h); }\n"
-          << "    template <class PX, class PY, class PZ, class H> __device__ __forceinline__ auto dist_hoisted_x(PX px, PY py, PZ pz, const H& h) const\n"
-          << "    { return tape_dist_x(px, py, pz, extra, flags, h); }\n";
+          << "    template <class PY, class PZ, class TB> __device__ __forceinline__ auto hoist_x(PY py, PZ pz, const TB& tb) const\n"
+          << "    { return tape_pre_x(0.0f, py, pz, extra, flags, tb); }\n"
+          << "    template <class PX, class PY, class PZ, class H, class TB> __device__ __forceinline__ auto eval_hoisted_x(PX px, PY py, PZ pz, const H& h, const TB& tb) const\n"
+          << "    { return tape_eval_x(px, py, pz, extra, flags, h, tb); }\n"
+          << "    template <class PX, class PY, class PZ, class H, class TB> __device__ __forceinline__ auto dist_hoisted_x(PX px, PY py, PZ pz, const H& h, const TB& tb) const\n"
+          << "    { return tape_dist_x(px, py, pz, extra, flags, h, tb); }\n";
     } else {
         o << "    template <class T> __device__ __forceinline__ sdf::V4<T> operator()(T px, T py, T pz, void*) const\n"
           << "    { return tape_eval<T>(px, py, pz, extra); }\n"
