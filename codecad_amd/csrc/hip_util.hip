@@ -236,7 +236,7 @@ struct SpecKernels {
     hipFunction_t ray_caster = nullptr, bitmap = nullptr;
     bool deferred = false;   // the module was generated with deferred directions (specialise.hpp): dense launches use bricks
     double coord_limit = 0.0;   // a launch whose sample coordinates all stay below this sets sdf::kFlagInRange (specialise.hpp)
-    int tabs[2][3] = {{0, 0, 0}, {0, 0, 0}};   // columns of the axis tables [walk along z, along x][x, y, z] (specialise.hpp)
+    int tabs[2][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};   // table columns [walk along z, along x][x, y, z, xy, xz, yz] (specialise.hpp)
 };
 
 namespace {
@@ -281,7 +281,10 @@ std::string generate_source(const hu_tape_s* t, sdf::SpecMeta* meta = nullptr)
 // LDS bytes of the axis tables a brick launch needs (kernels.hpp: the dense kernel's tables hold 4 / 16 / 128 entries
 // per column, a leaf block's 64 each)
 uint32_t dense_table_bytes(const SpecKernels* k) { return (uint32_t)(k->tabs[0][0] * 4 + k->tabs[0][1] * 16 + k->tabs[0][2] * 128) * 4u; }
-uint32_t block_table_bytes(const SpecKernels* k) { return (uint32_t)(k->tabs[1][0] + k->tabs[1][1] + k->tabs[1][2]) * 64u * 4u; }
+uint32_t block_table_bytes(const SpecKernels* k)   // (sdf::BoxTabs: 16 entries per single-axis column, 256 per pair column)
+{
+    return (uint32_t)((k->tabs[1][0] + k->tabs[1][1] + k->tabs[1][2]) * 16 + (k->tabs[1][3] + k->tabs[1][4] + k->tabs[1][5]) * 256) * 4u;
+}
 
 void keep_programs(hu_tape_s* t, const sdf::DecodedTape& d)
 {
@@ -629,12 +632,14 @@ static int grid_eval_blocks_impl(hu_tape t, const int32_t* blocks_dev, uint32_t 
     if (t->spec && t->spec->blocks[layout]) {
         const uint32_t per_block = kSpecBlock * kSpecVoxelsPerLane;
         uint32_t chunks = (uint32_t)((cells + per_block - 1) / per_block);
-        // deferred-direction code over compact bricks (kernels.hpp): a wavefront per (x, y) column of 4 x 4 x 8 bricks
-        // (a wavefront per (y, z) column of 4 x 4 x 8 bricks, walking along x)
-        // (extents up to 64: the block's axis tables hold 64 entries per column)
-        uint32_t bricks = t->spec->deferred && brick_tiles(dims[0], dims[1], 32u) && dims[2] % 8u == 0u && dims[0] <= 64u && dims[1] <= 64u && dims[2] <= 64u
-                              ? dims[0] / 4u : 0u;
-        if (bricks) chunks = ((dims[1] / 4u) * (dims[2] / 8u) + 3u) / 4u;
+        // deferred-direction code over compact bricks (kernels.hpp): a workgroup per box of up to 16^3 voxels of the block,
+        // its wavefronts walking 4 x 4 x 8 bricks along x; `bricks` carries the boxes along y and z
+        uint32_t bricks = 0u;
+        if (t->spec->deferred && brick_tiles(dims[0], dims[1], 32u) && dims[2] % 8u == 0u) {
+            const uint32_t bxn = (dims[0] + 15u) / 16u, byn = (dims[1] + 15u) / 16u, bzn = (dims[2] + 15u) / 16u;
+            bricks = (byn << 16) | bzn;
+            chunks = bxn * byn * bzn;
+        }
         const double extent = (double)step * (double)std::max(dims[0], std::max(dims[1], dims[2]));
         SpecEval ev{t->extra_dev, spec_flags(t, list_reach(resolution, origin[0], origin[1], origin[2], extent))};
         const int4* b = (const int4*)blocks_dev;

@@ -1260,6 +1260,26 @@ template <int SX, int SY, int SZ> struct AxisTabs {
     template <int K> __device__ __forceinline__ float Y() const { return y[K * SY]; }
     template <int K> __device__ __forceinline__ float Z() const { return z[K * SZ]; }
 };
+// The tables of a 16^3 BOX (k_grid_eval_blocks): single-axis tables of 16 entries per column, and PAIR tables of 16 x 16
+// entries per column -- what the tape computes from two coordinates, evaluated once per pair of samples (specialise.hpp
+// "PAIR TABLES").  xy and xz are [y or z][x], yz is [y][z]; every pointer is this lane's entry of column 0.  X1 / XY1 /
+// XZ1: one entry (the builders of the pair tables fill one entry per lane) where the walks read a lane's two voxels.
+struct BoxTabs {
+    static constexpr int kAxis = 16, kPair = 256;
+    const lds_float* x;
+    const lds_float* y;
+    const lds_float* z;
+    const lds_float* xy;
+    const lds_float* xz;
+    const lds_float* yz;
+    template <int K> __device__ __forceinline__ f2 X() const { return make_f2(x[K * kAxis], x[K * kAxis + 2]); }
+    template <int K> __device__ __forceinline__ float X1() const { return x[K * kAxis]; }
+    template <int K> __device__ __forceinline__ float Y() const { return y[K * kAxis]; }
+    template <int K> __device__ __forceinline__ float Z() const { return z[K * kAxis]; }
+    template <int K> __device__ __forceinline__ f2 XY() const { return make_f2(xy[K * kPair], xy[K * kPair + 2]); }
+    template <int K> __device__ __forceinline__ f2 XZ() const { return make_f2(xz[K * kPair], xz[K * kPair + 2]); }
+    template <int K> __device__ __forceinline__ float YZ() const { return yz[K * kPair]; }
+};
 
 // The FULL form of a record on a widened value (the second phase of per-tape code, for the ops it does not restate):
 // `act` = the lanes of the path, the record's register operand in `operand`

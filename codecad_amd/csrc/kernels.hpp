@@ -332,57 +332,83 @@ k_grid_eval_blocks(const E ev, const int4* __restrict__ blocks, const uint32_t* 
     const float cz = (float)((double)ic.z * res + oz);
     if constexpr (E::kBricks && N == 2) {
         if (bricks) {
-            // As in k_grid_eval: a wavefront evaluates compact 4 x 4 x 8 bricks (lane -> z: 8, y: 4, x: 2, its two voxels
-            // two x planes apart) -- here the `bricks` = sx / 4 of one (y, z) column of the block, one after the other ALONG
-            // X (a 16^3 block: four; along z it would be two): what the tape computes from y and z together is computed once
-            // for them (specialise.hpp: the bars of a cross that run along x).  `chunks` counts workgroups of four columns.
-            const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, column = chunk * 4u + wave;
-            const uint32_t nbz = sz >> 3, bz = column % nbz, by = column / nbz;
-            // the axis tables of the BLOCK (its extents are at most 64: the launcher), one wavefront per axis
-            constexpr int NX = E::kTabXX, NY = E::kTabXY, NZ = E::kTabXZ;
-            using Tabs = sdf::AxisTabs<64, 64, 64>;
+            // A workgroup takes one BOX of the block: up to 16 x 16 x 16 voxels (a 16^3 block is one box; `chunks` = boxes
+            // per block, `bricks` = boxes along y and z packed as (boxes_y << 16 | boxes_z)).  As in k_grid_eval a wavefront
+            // evaluates compact 4 x 4 x 8 bricks (lane -> z: 8, y: 4, x: 2, its two voxels two x planes apart), here the
+            // bricks of one (y, z) column of the box one after the other ALONG X.  Before the walks the workgroup fills the
+            // box's tables (specialise.hpp "AXIS TABLES", "PAIR TABLES"): what the tape computes from one coordinate, once per
+            // sample of that axis; then what it computes from two, once per PAIR of samples (16 x 16 evaluations where the
+            // walks would make 4096) -- the bars of a cross, any extruded profile.  The walks read, combine and store.
+            const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+            const uint32_t boxes_z = bricks & 0xffffu, boxes_y = bricks >> 16;
+            const uint32_t qz = chunk % boxes_z, qt = chunk / boxes_z, qy = qt % boxes_y, qx = qt / boxes_y;
+            const uint32_t x0 = qx * 16u, y0 = qy * 16u, z0 = qz * 16u;                       // the box's corner in the block
+            const uint32_t nx = min(16u, sx - x0), ny = min(16u, sy - y0), nz = min(16u, sz - z0);   // and its extents
+            constexpr int NX = E::kTabXX, NY = E::kTabXY, NZ = E::kTabXZ, NXY = E::kPairXY, NXZ = E::kPairXZ, NYZ = E::kPairYZ;
+            using Tabs = sdf::BoxTabs;
             sdf::lds_float* const tx = (sdf::lds_float*)lds;
-            sdf::lds_float* const ty = tx + NX * 64;
-            sdf::lds_float* const tz = ty + NY * 64;
+            sdf::lds_float* const ty = tx + NX * Tabs::kAxis;
+            sdf::lds_float* const tz = ty + NY * Tabs::kAxis;
+            sdf::lds_float* const txy = tz + NZ * Tabs::kAxis;
+            sdf::lds_float* const txz = txy + NXY * Tabs::kPair;
+            sdf::lds_float* const tyz = txz + NXZ * Tabs::kPair;
             if constexpr (NX + NY + NZ > 0) {
                 if (wave == 0u) {
                     if constexpr (NX > 0)
-                        if (lane < sx) ev.template tab_x_x<64>(sample(cx, step, lane), tx + lane);
+                        if (lane < nx) ev.template tab_x_x<Tabs::kAxis>(sample(cx, step, x0 + lane), tx + lane);
                 } else if (wave == 1u) {
                     if constexpr (NY > 0)
-                        if (lane < sy) ev.template tab_x_y<64>(sample(cy, step, lane), ty + lane);
+                        if (lane < ny) ev.template tab_x_y<Tabs::kAxis>(sample(cy, step, y0 + lane), ty + lane);
                 } else if (wave == 2u) {
                     if constexpr (NZ > 0)
-                        if (lane < sz) ev.template tab_x_z<64>(sample(cz, step, lane), tz + lane);
+                        if (lane < nz) ev.template tab_x_z<Tabs::kAxis>(sample(cz, step, z0 + lane), tz + lane);
                 }
                 __syncthreads();
             }
-            if (by * 4u >= sy) return;   // wavefronts past the last column (uniform)
-            const uint32_t y = by * 4u + ((lane >> 3) & 3u), z = bz * 8u + (lane & 7u);
-            const float py = sample(cy, step, y), pz = sample(cz, step, z);   // (one number per lane: its voxels differ in x)
+            if constexpr (NXY + NXZ + NYZ > 0) {
+                // one entry per lane: (row, column) = (thread / 16, thread % 16); the column is the table's fastest index
+                const uint32_t r = threadIdx.x >> 4, c = threadIdx.x & 15u;
+                if constexpr (NXY > 0)
+                    if (r < ny && c < nx)
+                        ev.template tab_x_xy<Tabs::kPair>(sample(cx, step, x0 + c), sample(cy, step, y0 + r), Tabs{tx + c, ty + r, tz, txy, txz, tyz}, txy + threadIdx.x);
+                if constexpr (NXZ > 0)
+                    if (r < nz && c < nx)
+                        ev.template tab_x_xz<Tabs::kPair>(sample(cx, step, x0 + c), sample(cz, step, z0 + r), Tabs{tx + c, ty, tz + r, txy, txz, tyz}, txz + threadIdx.x);
+                if constexpr (NYZ > 0)
+                    if (r < ny && c < nz)
+                        ev.template tab_x_yz<Tabs::kPair>(sample(cy, step, y0 + r), sample(cz, step, z0 + c), Tabs{tx, ty + r, tz + c, txy, txz, tyz}, tyz + threadIdx.x);
+                __syncthreads();
+            }
+            const uint32_t nbz = nz >> 3, columns = (ny >> 2) * nbz;     // the box's (y, z) columns of bricks: at most eight
             const size_t base = (size_t)b * cells;
-            Tabs tb{tx + (lane >> 5), ty + y, tz + z};
-            const auto hoisted = ev.hoist_x(py, pz, tb);
+            for (uint32_t column = wave; column < columns; column += 4u) {
+                const uint32_t bz = column % nbz, by = column / nbz;
+                const uint32_t yl = by * 4u + ((lane >> 3) & 3u), zl = bz * 8u + (lane & 7u);   // in the box
+                const uint32_t y = y0 + yl, z = z0 + zl;
+                const float py = sample(cy, step, y), pz = sample(cz, step, z);   // (one number per lane: its voxels differ in x)
+                Tabs tb{tx + (lane >> 5), ty + yl, tz + zl, txy + (yl * 16u + (lane >> 5)), txz + (zl * 16u + (lane >> 5)), tyz + (yl * 16u + zl)};
+                const auto hoisted = ev.hoist_x(py, pz, tb);
 #pragma unroll 1
-            for (uint32_t j = 0; j < bricks; ++j) {
-                asm volatile("" ::: "memory");   // (the y and z columns are read again in every brick: k_grid_eval)
-                const uint32_t x = j * 4u + (lane >> 5);
-                float xs[N];
+                for (uint32_t j = 0; j < (nx >> 2); ++j) {
+                    asm volatile("" ::: "memory");   // (the columns of y and z are read again in every brick: k_grid_eval)
+                    const uint32_t x = x0 + j * 4u + (lane >> 5);
+                    float xs[N];
 #pragma unroll
-                for (int i = 0; i < N; ++i) xs[i] = sample(cx, step, x + 2u * i);
-                const T px = pack(xs);
-                if (LAYOUT == 0) {
-                    const sdf::V4<T> r = ev.eval_hoisted_x(px, py, pz, hoisted, tb);
-                    float4* o = static_cast<float4*>(out) + base + ((size_t)z + (size_t)sz * ((size_t)y + (size_t)sy * x));
+                    for (int i = 0; i < N; ++i) xs[i] = sample(cx, step, x + 2u * i);
+                    const T px = pack(xs);
+                    if (LAYOUT == 0) {
+                        const sdf::V4<T> r = ev.eval_hoisted_x(px, py, pz, hoisted, tb);
+                        float4* o = static_cast<float4*>(out) + base + ((size_t)z + (size_t)sz * ((size_t)y + (size_t)sy * x));
 #pragma unroll
-                    for (int i = 0; i < N; ++i) store_voxel(o + (size_t)i * 2u * sy * sz, sdf::voxel(r, i));
-                } else {
-                    const T w = ev.dist_hoisted_x(px, py, pz, hoisted, tb);
-                    float* o = static_cast<float*>(out) + base + ((size_t)z + ((size_t)x + (size_t)(sy - 1u - y) * sx) * sz);
+                        for (int i = 0; i < N; ++i) store_voxel(o + (size_t)i * 2u * sy * sz, sdf::voxel(r, i));
+                    } else {
+                        const T w = ev.dist_hoisted_x(px, py, pz, hoisted, tb);
+                        float* o = static_cast<float*>(out) + base + ((size_t)z + ((size_t)x + (size_t)(sy - 1u - y) * sx) * sz);
 #pragma unroll
-                    for (int i = 0; i < N; ++i) store_voxel(o + (size_t)i * 2u * sz, sdf::get(w, i));
+                        for (int i = 0; i < N; ++i) store_voxel(o + (size_t)i * 2u * sz, sdf::get(w, i));
+                    }
+                    tb.x += 4; tb.xy += 4; tb.xz += 4;
                 }
-                tb.x += 4;
             }
             return;
         }

@@ -31,6 +31,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <numeric>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -568,7 +569,11 @@ inline std::vector<char> hoistable_set(const Phase1& ph, uint8_t walk, int min_c
 // The arithmetic is the same statement on the same coordinate value, so the bits are the same.  Candidates: phase 1's
 // single-axis values worth at least `min_cost` instructions; which of them become table columns is decided by the
 // walk-dependent code that reads them (render_walk below).
-inline std::vector<char> table_candidates(const Phase1& ph, int min_cost)
+// PAIR TABLES: the same for statements that read TWO coordinates -- a bar of a cross, any extruded profile: its distance
+// takes nx * ny distinct values in a box of nx * ny * nz voxels.  In a 16^3 box (k_grid_eval_blocks) such a statement is
+// evaluated 256 times into a 2D table, from the single-axis columns, instead of 4096 times by the walks.
+// -> per statement: 0 not a candidate, 1 a single-axis column, 2 a pair column (`min_pair` = 0: no pair tables)
+inline std::vector<char> table_candidates(const Phase1& ph, int min_cost, int min_pair = 0)
 {
     const std::vector<Stmt>& st = ph.e.st;
     std::vector<char> out(st.size(), 0);
@@ -576,15 +581,23 @@ inline std::vector<char> table_candidates(const Phase1& ph, int min_cost)
     for (int i = 0; i < ph.n_phase1; ++i) {
         if (st[i].ops.empty() || st[i].mask) continue;
         const uint8_t d = st[i].deps;
-        out[i] = (d == DX || d == DY || d == DZ) && cost[i] >= min_cost;
+        if ((d == DX || d == DY || d == DZ) && cost[i] >= min_cost) out[i] = 1;
+        else if ((d == (DX | DY) || d == (DX | DZ) || d == (DY | DZ)) && min_pair > 0 && cost[i] >= min_pair) out[i] = 2;
     }
     return out;
 }
-
-// the expression that reads column `column` of a single-axis statement's table (interp.hpp AxisTabs)
-inline std::string table_load(const Stmt& s, int column)
+// the table a statement's column lives in, by the coordinates it reads: x, y, z, xy, xz, yz
+inline int table_slot(uint8_t deps)
 {
-    return std::string("tb.template ") + (s.deps == DX ? "X" : s.deps == DY ? "Y" : "Z") + "<" + std::to_string(column) + ">()";
+    switch (deps) { case DX: return 0; case DY: return 1; case DZ: return 2; case DX | DY: return 3; case DX | DZ: return 4; default: return 5; }
+}
+constexpr const char* kTableName[6] = {"X", "Y", "Z", "XY", "XZ", "YZ"};
+
+// the expression that reads column `column` of a statement's table (interp.hpp AxisTabs / BoxTabs); `single`: one entry
+// (the table builders: a lane fills one entry) where the walks read the pair of a lane's two voxels
+inline std::string table_load(const Stmt& s, int column, bool single = false)
+{
+    return std::string("tb.template ") + kTableName[table_slot(s.deps)] + (single && (s.deps & DX) ? "1" : "") + "<" + std::to_string(column) + ">()";
 }
 
 // `tabc`: the table candidates the walk may read (empty: none); `tab_index` (may be NULL while the columns are still
@@ -658,28 +671,34 @@ inline Variant render_variant(const Phase1& ph, const std::vector<char>& hoistab
     return v;
 }
 
-// The function that fills one axis' table for one sample of that axis: the columns' statements (and what they are
-// computed from: all of it reads this one coordinate), each column stored at out[column * S].
-inline std::string render_table_builder(const Phase1& ph, uint8_t axis, const std::vector<int>& tab_index)
+// The function that fills one table for one entry: the statements of its columns and what they are computed from, each
+// column stored at out[column * S].  A single-axis table computes everything from its coordinate; a pair table reads the
+// single-axis columns (`tabc`, may be empty; `reads`, may be NULL, collects them) and computes the rest.
+inline std::string render_table_builder(const Phase1& ph, uint8_t deps, const std::vector<int>& tab_index, const std::vector<char>& tabc,
+                                        const std::vector<char>& used, std::vector<char>* reads = nullptr)
 {
     const std::vector<Stmt>& st = ph.e.st;
     const int n = (int)st.size();
-    std::vector<char> in(n, 0);
+    const bool pair = (deps & (deps - 1)) != 0;
+    std::vector<char> in(n, 0), loads(n, 0);
     std::vector<int> stack;
-    for (int i = 0; i < n; ++i) if (tab_index[i] >= 0 && st[i].deps == axis) stack.push_back(i);
+    for (int i = 0; i < n; ++i) if (used[i] && st[i].deps == deps && !st[i].ops.empty()) stack.push_back(i);
     while (!stack.empty()) {
         const int i = stack.back();
         stack.pop_back();
-        if (in[i]) continue;
+        if (in[i] || loads[i]) continue;
+        if (pair && i < (int)tabc.size() && tabc[i] == 1) { loads[i] = 1; if (reads) (*reads)[i] = 1; continue; }
         in[i] = 1;
         for (int o : st[i].ops) stack.push_back(o);
     }
     auto plain = [&](int i) { return st[i].ops.empty() ? st[i].text : "t" + std::to_string(i); };
     std::ostringstream o;
     for (int i = 0; i < n; ++i) {
-        if (!in[i] || st[i].ops.empty()) continue;
+        if (st[i].ops.empty()) continue;
+        if (loads[i]) o << "    const auto t" << i << " = " << table_load(st[i], tab_index[i], true) << ";\n";
+        if (!in[i]) continue;
         o << "    const auto t" << i << " = " << render(st[i], plain) << ";\n";
-        if (tab_index[i] >= 0 && st[i].deps == axis) o << "    out[" << tab_index[i] << " * S] = t" << i << ";\n";
+        if (used[i] && st[i].deps == deps) o << "    out[" << tab_index[i] << " * S] = t" << i << ";\n";
     }
     return o.str();
 }
@@ -691,9 +710,10 @@ inline std::string render_table_builder(const Phase1& ph, uint8_t axis, const st
 struct SpecMeta {
     bool deferred = false;
     double coord_limit = 0.0;    // the largest |sample coordinate| for which a launch may set sdf::kFlagInRange (0: never)
-    int tabs[2][3] = {{0, 0, 0}, {0, 0, 0}};   // [walk along z, walk along x][x, y, z]: columns of the axis tables
+    int tabs[2][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};   // [walk along z, along x][x, y, z, xy, xz, yz]: columns of the tables
 };
 constexpr int kMaxTableColumns = 48;   // per axis (a 128-entry column of the dense kernel's z table is 512 B of LDS)
+constexpr int kMaxPairColumns = 16;    // per pair of axes (a column of a 16^3 box is 1 KiB)
 
 inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t max_paths = 40, SpecMeta* meta = nullptr)
 {
@@ -887,16 +907,17 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
     const int tab_min = knob("HU_TAB_MIN", 2);      // what a single-axis value must cost to become a table column (0: no tables)
     for (const Form& f : forms) {
         const std::vector<char> hoistable = hoistable_set(ph, f.walk, f.walk == DZ ? knob("HU_HOIST_MIN_Z", 12) : knob("HU_HOIST_MIN_X", 8));
-        // ---- axis tables: the candidates this form's walk-dependent code and its direction blocks read become columns
+        // ---- axis and pair tables: the candidates this form's walk-dependent code and its direction blocks read become
+        // columns; the pair tables (walks along x only: the 16^3 boxes of k_grid_eval_blocks) are filled from single-axis columns
         std::vector<char> tabc;
         std::vector<int> tab_index(ph.e.st.size(), -1);
-        int n_tab[3] = {0, 0, 0};
-        std::vector<char> held;
+        int n_tab[6] = {0, 0, 0, 0, 0, 0};
+        std::vector<char> held, used;
         if (f.walk != 0 && tab_min > 0) {
-            tabc = table_candidates(ph, tab_min);
+            tabc = table_candidates(ph, tab_min, f.walk == DX ? knob("HU_TAB_PAIR_MIN", 3) : 0);
             for (;;) {
                 // the columns the DISTANCES read in every brick and the walk does not change are kept in registers instead
-                // (`held`), lowest statements first, while the budget lasts: a column of x costs two registers, others one
+                // (`held`), lowest statements first, while the budget lasts: a column with x in it costs two registers, others one
                 const Variant probe = render_variant(ph, hoistable, dist_roots, tabc);
                 held.assign(ph.e.st.size(), 0);
                 // (measured, sponge(4), MI355X: the dense kernel's walks along z 0.497 / 0.508 / 0.532 / 0.553 ms holding
@@ -905,48 +926,56 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
                 int budget = f.walk == DZ ? knob("HU_TAB_HOLD_Z", 0) : knob("HU_TAB_HOLD_X", 12);
                 for (int i = 0; i < (int)probe.tab_main.size(); ++i) {
                     if (!probe.tab_main[i] || !tabc[i] || (ph.e.st[i].deps & f.walk)) continue;
-                    const int regs = ph.e.st[i].deps == DX ? 2 : 1;
+                    const int regs = (ph.e.st[i].deps & DX) ? 2 : 1;
                     if (budget >= regs) { held[i] = 1; budget -= regs; }
                 }
                 const Variant all = render_variant(ph, hoistable, eval_roots, tabc, nullptr, held);
-                std::vector<char> used = all.tab_read;
+                used = all.tab_read;
                 for (int i = 0; i < (int)held.size(); ++i) if (held[i]) used[i] = 1;
                 (void)phase2_for(all.handed, tabc, nullptr, &used);
+                // what the builders of the pair tables read of the single-axis tables
+                for (uint8_t pair : {(uint8_t)(DX | DY), (uint8_t)(DX | DZ), (uint8_t)(DY | DZ)})
+                    (void)render_table_builder(ph, pair, tab_index, tabc, std::vector<char>(used), &used);
                 std::fill(tab_index.begin(), tab_index.end(), -1);
-                n_tab[0] = n_tab[1] = n_tab[2] = 0;
+                std::fill(n_tab, n_tab + 6, 0);
                 bool over = false;
                 for (int i = 0; i < (int)used.size(); ++i) {
                     if (!used[i]) continue;
-                    const int axis = ph.e.st[i].deps == DX ? 0 : ph.e.st[i].deps == DY ? 1 : 2;
-                    if (n_tab[axis] < kMaxTableColumns) tab_index[i] = n_tab[axis]++;
-                    else over = true;
+                    const int slot = table_slot(ph.e.st[i].deps);
+                    if (n_tab[slot] < (slot < 3 ? kMaxTableColumns : kMaxPairColumns)) tab_index[i] = n_tab[slot]++;
+                    else { over = true; used[i] = 0; }
                 }
                 if (!over) break;
                 // what did not fit is computed by the walk itself, which may then reach further candidates: only the
                 // columns that were given out stay candidates, and the walk is looked at again
-                for (int i = 0; i < (int)tabc.size(); ++i) tabc[i] = tab_index[i] >= 0;
+                for (int i = 0; i < (int)tabc.size(); ++i) if (tab_index[i] < 0) tabc[i] = 0;
             }
-            if (n_tab[0] + n_tab[1] + n_tab[2] == 0) { tabc.clear(); held.clear(); }
+            if (std::accumulate(n_tab, n_tab + 6, 0) == 0) { tabc.clear(); held.clear(); }
         }
-        if (meta && f.walk != 0) for (int a = 0; a < 3; ++a) meta->tabs[f.walk == DZ ? 0 : 1][a] = n_tab[a];
+        if (meta && f.walk != 0) for (int a = 0; a < 6; ++a) meta->tabs[f.walk == DZ ? 0 : 1][a] = n_tab[a];
         const Variant vd = render_variant(ph, hoistable, dist_roots, tabc, &tab_index, held), ve = render_variant(ph, hoistable, eval_roots, tabc, &tab_index, held);
         // the values handed from `pre`: the union of what the distance and the evaluation read (one struct for both)
         const Variant& pre_of = ve;   // (eval's roots include dist's root: its frontier covers it)
         const bool hoists = f.walk != 0 && pre_of.n_hoisted > 0;
         if (f.walk != 0) {
-            o << "// hoisted out of walks along " << (f.walk == DZ ? "z" : "x") << ": " << pre_of.n_hoisted << " values; axis tables: "
-              << n_tab[0] << " / " << n_tab[1] << " / " << n_tab[2] << " columns (x / y / z)\n"
+            o << "// hoisted out of walks along " << (f.walk == DZ ? "z" : "x") << ": " << pre_of.n_hoisted << " values; table columns: "
+              << n_tab[0] << " / " << n_tab[1] << " / " << n_tab[2] << " (x / y / z), " << n_tab[3] << " / " << n_tab[4] << " / " << n_tab[5] << " (xy / xz / yz)\n"
               << "template <class PX, class PY, class PZ, class TB> __device__ __forceinline__ auto tape_pre" << f.suffix
               << "(PX px, PY py, PZ pz, const float* __restrict__ extra, uint32_t flags, const TB& tb)\n{\n    using namespace sdf;\n";
             if (hoists) o << pre_of.pre;
             else o << "    struct Hoisted {};\n    return Hoisted{};\n";
             o << "}\n";
-            const char* axis_name[3] = {"x", "y", "z"};
-            const uint8_t axis_bit[3] = {DX, DY, DZ};
+            const char* slot_name[6] = {"x", "y", "z", "xy", "xz", "yz"};
+            const uint8_t slot_deps[6] = {DX, DY, DZ, DX | DY, DX | DZ, DY | DZ};
             for (int a = 0; a < 3; ++a)
-                o << "template <int S, class L> __device__ __forceinline__ void tape_tab" << f.suffix << "_" << axis_name[a] << "(float p"
-                  << axis_name[a] << ", const float* __restrict__ extra, uint32_t flags, L out)\n{\n    using namespace sdf;\n"
-                  << (n_tab[a] ? render_table_builder(ph, axis_bit[a], tab_index) : std::string()) << "}\n";
+                o << "template <int S, class L> __device__ __forceinline__ void tape_tab" << f.suffix << "_" << slot_name[a] << "(float p"
+                  << slot_name[a] << ", const float* __restrict__ extra, uint32_t flags, L out)\n{\n    using namespace sdf;\n"
+                  << (n_tab[a] ? render_table_builder(ph, slot_deps[a], tab_index, tabc, used) : std::string()) << "}\n";
+            if (f.walk == DX)   // (a pair table's entry: the two coordinates, and the single-axis tables positioned at it)
+                for (int a = 3; a < 6; ++a)
+                    o << "template <int S, class TB, class L> __device__ __forceinline__ void tape_tab" << f.suffix << "_" << slot_name[a]
+                      << "(float px, float py, float pz, const float* __restrict__ extra, uint32_t flags, const TB& tb, L out)\n{\n    using namespace sdf;\n"
+                      << (n_tab[a] ? render_table_builder(ph, slot_deps[a], tab_index, tabc, used) : std::string()) << "}\n";
         }
         const std::string h_param = f.walk != 0 ? ", const H& h, const TB& tb" : "";
         const std::string h_tmpl = f.walk != 0 ? ", class H, class TB" : "";
@@ -985,11 +1014,19 @@ inline std::string specialised_source(const SpecProgram& p, bool allow_deferred,
           << "    { return tape_dist(px, py, pz, extra, flags); }\n"
           // the axis tables of the two walks: columns per axis, and the functions that fill one entry of each table
           << "    static constexpr int kTabZX = " << m.tabs[0][0] << ", kTabZY = " << m.tabs[0][1] << ", kTabZZ = " << m.tabs[0][2]
-          << ", kTabXX = " << m.tabs[1][0] << ", kTabXY = " << m.tabs[1][1] << ", kTabXZ = " << m.tabs[1][2] << ";\n";
+          << ", kTabXX = " << m.tabs[1][0] << ", kTabXY = " << m.tabs[1][1] << ", kTabXZ = " << m.tabs[1][2]
+          << ", kPairXY = " << m.tabs[1][3] << ", kPairXZ = " << m.tabs[1][4] << ", kPairYZ = " << m.tabs[1][5] << ";\n";
         for (const char* walk : {"z", "x"})
             for (const char* axis : {"x", "y", "z"})
                 o << "    template <int S, class L> __device__ __forceinline__ void tab_" << walk << "_" << axis << "(float p, L out) const\n"
                   << "    { tape_tab_" << walk << "_" << axis << "<S>(p, extra, flags, out); }\n";
+        // one entry (a, b) of a pair table of the walks along x
+        o << "    template <int S, class TB, class L> __device__ __forceinline__ void tab_x_xy(float a, float b, const TB& tb, L out) const\n"
+          << "    { tape_tab_x_xy<S>(a, b, 0.0f, extra, flags, tb, out); }\n"
+          << "    template <int S, class TB, class L> __device__ __forceinline__ void tab_x_xz(float a, float b, const TB& tb, L out) const\n"
+          << "    { tape_tab_x_xz<S>(a, 0.0f, b, extra, flags, tb, out); }\n"
+          << "    template <int S, class TB, class L> __device__ __forceinline__ void tab_x_yz(float a, float b, const TB& tb, L out) const\n"
+          << "    { tape_tab_x_yz<S>(0.0f, a, b, extra, flags, tb, out); }\n";
         // what does not change along z, for kernels that walk bricks along z with x and y fixed (kernels.hpp) ...
         o << "    template <class PX, class PY, class TB> __device__ __forceinline__ auto hoist(PX px, PY py, const TB& tb) const\n"
           << "    { return tape_pre_z(px, py, 0.0f, extra, flags, tb); }\n"
