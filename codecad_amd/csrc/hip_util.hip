@@ -187,12 +187,12 @@ int ensure_attrs()
     return HU_OK;
 }
 
-// Dense launches over compact 4 x 4 x 8 bricks per wavefront (kernels.hpp k_grid_eval) when the slab's extents
-// allow it without ragged bricks; the same number of workgroups either way.  HU_BRICKS=0: always runs along z.
+// Launches of per-tape code go over 16^3 boxes of compact 4 x 4 x 8 bricks (kernels.hpp box_eval) when the slab's or the
+// block's extents allow it without ragged bricks.  HU_BRICKS=0: always runs of cells along z.
 uint32_t brick_tiles(uint32_t nx, uint32_t sy, uint32_t sz)
 {
     static const bool off = [] { const char* e = getenv("HU_BRICKS"); return e && e[0] == '0'; }();
-    return (!off && nx % 4u == 0u && sy % 4u == 0u && sz % 32u == 0u) ? 1u : 0u;
+    return (!off && nx % 4u == 0u && sy % 4u == 0u && sz % 8u == 0u) ? 1u : 0u;
 }
 
 // How many units (blocks / parents) of `chunks` workgroups of `threads` lanes go into one launch: a grid may
@@ -236,7 +236,7 @@ struct SpecKernels {
     hipFunction_t ray_caster = nullptr, bitmap = nullptr;
     bool deferred = false;   // the module was generated with deferred directions (specialise.hpp): dense launches use bricks
     double coord_limit = 0.0;   // a launch whose sample coordinates all stay below this sets sdf::kFlagInRange (specialise.hpp)
-    int tabs[2][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};   // table columns [walk along z, along x][x, y, z, xy, xz, yz] (specialise.hpp)
+    int tabs[6] = {0, 0, 0, 0, 0, 0};   // columns of a box's tables: x, y, z, xy, xz, yz (specialise.hpp)
 };
 
 namespace {
@@ -278,12 +278,10 @@ std::string generate_source(const hu_tape_s* t, sdf::SpecMeta* meta = nullptr)
 {
     return sdf::specialised_source(t->program, defer_directions(), meta);
 }
-// LDS bytes of the axis tables a brick launch needs (kernels.hpp: the dense kernel's tables hold 4 / 16 / 128 entries
-// per column, a leaf block's 64 each)
-uint32_t dense_table_bytes(const SpecKernels* k) { return (uint32_t)(k->tabs[0][0] * 4 + k->tabs[0][1] * 16 + k->tabs[0][2] * 128) * 4u; }
-uint32_t block_table_bytes(const SpecKernels* k)   // (sdf::BoxTabs: 16 entries per single-axis column, 256 per pair column)
+// LDS bytes of a box's tables (sdf::BoxTabs: 16 entries per single-axis column, 256 per pair column)
+uint32_t box_table_bytes(const SpecKernels* k)
 {
-    return (uint32_t)((k->tabs[1][0] + k->tabs[1][1] + k->tabs[1][2]) * 16 + (k->tabs[1][3] + k->tabs[1][4] + k->tabs[1][5]) * 256) * 4u;
+    return (uint32_t)((k->tabs[0] + k->tabs[1] + k->tabs[2]) * 16 + (k->tabs[3] + k->tabs[4] + k->tabs[5]) * 256) * 4u;
 }
 
 void keep_programs(hu_tape_s* t, const sdf::DecodedTape& d)
@@ -547,27 +545,16 @@ int hu_grid_eval_slab(hu_tape t, const float corner[4], float step, const uint32
             const uint32_t nx = (x_count - done < max_x) ? (x_count - done) : max_x;
             uint32_t n_cells = (uint32_t)(nx * plane), xs = x0 + done;
             void* o = (layout == 0) ? (void*)(static_cast<float4*>(out_dev) + (size_t)done * plane) : out_dev;
-            // bricks pay where a wavefront's work depends on how many primitives win in it (deferred directions);
-            // a tape that is bound by its store stream keeps the runs along z (2 KiB contiguous per wavefront:
-            // sphere, 512^3 float4: 0.34 ms in runs, 0.42 ms in bricks)
-            uint32_t tiles = t->spec->deferred ? brick_tiles(nx, dims[1], dims[2]) : 0u;
+            // boxes of compact bricks pay where a wavefront's work depends on how many primitives win in it (deferred
+            // directions) and where the tape has tables to fill; a tape that is bound by its store stream keeps the runs
+            // along z (2 KiB contiguous per wavefront: sphere, 512^3 float4: 0.34 ms in runs, 0.42 ms in bricks)
+            uint32_t boxes = t->spec->deferred ? brick_tiles(nx, dims[1], dims[2]) : 0u;
             const uint32_t per_block = kSpecBlock * kSpecVoxelsPerLane;
             uint32_t grid = (n_cells + per_block - 1) / per_block;
-            if (tiles) {
-                // a wavefront takes G bricks in a row along z: up to 16 while the launch still has a few thousand wavefronts
-                const uint32_t nbz = dims[2] / 8u;   // a multiple of four (sz % 32 == 0)
-                const uint64_t bricks = (uint64_t)(nx / 4u) * (dims[1] / 4u) * nbz;
-                tiles = 4u;
-                // (16 384: a rank's 64-plane slab of a 512^3 grid on eight GPUs takes 0.1225 ms with 8 bricks per wavefront,
-                // 0.129 ms with 16 -- 8 192 wavefronts are 1.3 rounds of the chip -- and 0.128 ms with 4)
-                for (uint32_t g = 16u; g > 4u; g >>= 1)
-                    if (nbz % g == 0u && bricks / g >= 16384u) { tiles = g; break; }
-                // a workgroup: four rows of bricks that are neighbours along y (they share the axis tables of their box)
-                grid = (nx / 4u) * ((dims[1] / 4u + 3u) / 4u) * (nbz / tiles);
-            }
-            void* args[] = {&ev, &cx, &cy, &cz, &step, &sx, &sy, &sz, &xs, &n_cells, &tiles, &o};
-            HU_HIP(hipModuleLaunchKernel(t->spec->dense[layout], grid, 1, 1, kSpecBlock, 1, 1,
-                                         tiles ? dense_table_bytes(t->spec) : 0u, (hipStream_t)stream, args, nullptr));
+            if (boxes) grid = ((nx + 15u) / 16u) * ((dims[1] + 15u) / 16u) * ((dims[2] + 15u) / 16u);   // a workgroup per 16^3 box
+            void* args[] = {&ev, &cx, &cy, &cz, &step, &sx, &sy, &sz, &xs, &n_cells, &boxes, &o};
+            HU_HIP(hipModuleLaunchKernel(t->spec->dense[layout], grid, 1, 1, kSpecBlock, 1, 1, boxes ? box_table_bytes(t->spec) : 0u,
+                                         (hipStream_t)stream, args, nullptr));
             done += nx;
         }
         return HU_OK;
@@ -635,7 +622,7 @@ static int grid_eval_blocks_impl(hu_tape t, const int32_t* blocks_dev, uint32_t 
         // deferred-direction code over compact bricks (kernels.hpp): a workgroup per box of up to 16^3 voxels of the block,
         // its wavefronts walking 4 x 4 x 8 bricks along x; `bricks` carries the boxes along y and z
         uint32_t bricks = 0u;
-        if (t->spec->deferred && brick_tiles(dims[0], dims[1], 32u) && dims[2] % 8u == 0u) {
+        if (t->spec->deferred && brick_tiles(dims[0], dims[1], dims[2])) {
             const uint32_t bxn = (dims[0] + 15u) / 16u, byn = (dims[1] + 15u) / 16u, bzn = (dims[2] + 15u) / 16u;
             bricks = (byn << 16) | bzn;
             chunks = bxn * byn * bzn;
@@ -652,7 +639,7 @@ static int grid_eval_blocks_impl(hu_tape t, const int32_t* blocks_dev, uint32_t 
             const uint32_t count = n_blocks - b0 < piece ? n_blocks - b0 : piece;
             void* args[] = {&ev, &b, &n_dev, &first, &chunks, &bricks, &res, &ox, &oy, &oz, &step, &sx, &sy, &sz, &out_dev};
             HU_HIP(hipModuleLaunchKernel(t->spec->blocks[layout], chunks * count, 1, 1, kSpecBlock, 1, 1,
-                                         bricks ? block_table_bytes(t->spec) : 0u, (hipStream_t)stream, args, nullptr));
+                                         bricks ? box_table_bytes(t->spec) : 0u, (hipStream_t)stream, args, nullptr));
         }
         return HU_OK;
     }

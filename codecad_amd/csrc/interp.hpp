@@ -1247,20 +1247,11 @@ __device__ __forceinline__ V4<T> run_tape(const Rec* __restrict__ prog, const fl
     }
 }
 
-// AXIS TABLES (per-tape code, specialise.hpp): what a brick kernel's walks read instead of recomputing single-axis
-// statements.  A table is [column][entry] floats in LDS, SX / SY / SZ entries per column; x, y, z point at THIS LANE's
-// entry of column 0 (a lane's two voxels are two x entries apart; its y and z are one number each).  Columns are
-// template arguments so that every read is one ds_read with an immediate offset (the pair of an x column: ds_read2).
+// TABLES (per-tape code, specialise.hpp): what the walks of a box read instead of recomputing statements that read one or
+// two sample coordinates.  Columns are template arguments so that every read is one ds_read with an immediate offset (the
+// pair of a lane's two voxels, two x entries apart: one ds_read2).
 typedef __attribute__((address_space(3))) float lds_float;
-template <int SX, int SY, int SZ> struct AxisTabs {
-    const lds_float* x;
-    const lds_float* y;
-    const lds_float* z;
-    template <int K> __device__ __forceinline__ f2 X() const { return make_f2(x[K * SX], x[K * SX + 2]); }
-    template <int K> __device__ __forceinline__ float Y() const { return y[K * SY]; }
-    template <int K> __device__ __forceinline__ float Z() const { return z[K * SZ]; }
-};
-// The tables of a 16^3 BOX (k_grid_eval_blocks): single-axis tables of 16 entries per column, and PAIR tables of 16 x 16
+// The tables of a 16^3 BOX (kernels.hpp box_eval): single-axis tables of 16 entries per column, and PAIR tables of 16 x 16
 // entries per column -- what the tape computes from two coordinates, evaluated once per pair of samples (specialise.hpp
 // "PAIR TABLES").  xy and xz are [y or z][x], yz is [y][z]; every pointer is this lane's entry of column 0.  X1 / XY1 /
 // XZ1: one entry (the builders of the pair tables fill one entry per lane) where the walks read a lane's two voxels.

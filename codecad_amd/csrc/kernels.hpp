@@ -200,89 +200,124 @@ __device__ __forceinline__ uint32_t wave_sum_to_last_lane(uint32_t v)
 }
 
 // ------------------------------------------------------------------------------------------
+// boxes: per-tape code over compact bricks with the box's tables in LDS
+// ------------------------------------------------------------------------------------------
+// Where a box's voxels go: LAYOUT 0 float4[x][y][z] (z fastest) of a slab or block with extents (., sy, sz), LAYOUT 1 the
+// PyMCubes order float[sy - 1 - y][xa + x][z] of a grid that is `sxa` wide (grid_eval.cl:18); `base` = elements before it.
+struct BoxOut {
+    void* out;
+    size_t base;
+    uint32_t sxa, sy, sz, xa;
+    uint32_t nx;   // the slab's or block's extent along x (the boxes tile nx * sy * sz)
+};
+// One workgroup, one BOX: up to 16 x 16 x 16 voxels at (x0, y0, z0) of a slab or block whose corner sample is (cx, cy, cz)
+// [sample index of x: xs0 + x].  A wavefront evaluates compact 4 x 4 x 8 bricks (lane -> z: 8, y: 4, x: 2, its two voxels
+// two x planes apart: a store instruction writes eight voxels along z per (x, y) row), the bricks of one (y, z) column of
+// the box one after the other ALONG X.  Before the walks the workgroup fills the box's tables (specialise.hpp "AXIS
+// TABLES", "PAIR TABLES"): what the tape computes from one coordinate, once per sample of that axis; then what it computes
+// from two, once per PAIR of samples (16 x 16 evaluations where the walks would make 4096) -- the bars of a cross, any
+// extruded profile.  The walks read, combine and store.  Extents: multiples of 4, 4 and 8 (the launchers).
+template <class E, int LAYOUT, int N>
+__device__ __forceinline__ void box_eval(const E& ev, float4* lds, float cx, float cy, float cz, float step, uint32_t xs0,
+                                         uint32_t x0, uint32_t y0, uint32_t z0, const BoxOut& o)
+{
+    using T = typename Pack<N>::T;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t sx = o.sxa, sy = o.sy, sz = o.sz;
+    const uint32_t nx = min(16u, o.nx - x0), ny = min(16u, sy - y0), nz = min(16u, sz - z0);
+    constexpr int NX = E::kTabXX, NY = E::kTabXY, NZ = E::kTabXZ, NXY = E::kPairXY, NXZ = E::kPairXZ, NYZ = E::kPairYZ;
+    using Tabs = sdf::BoxTabs;
+    sdf::lds_float* const tx = (sdf::lds_float*)lds;
+    sdf::lds_float* const ty = tx + NX * Tabs::kAxis;
+    sdf::lds_float* const tz = ty + NY * Tabs::kAxis;
+    sdf::lds_float* const txy = tz + NZ * Tabs::kAxis;
+    sdf::lds_float* const txz = txy + NXY * Tabs::kPair;
+    sdf::lds_float* const tyz = txz + NXZ * Tabs::kPair;
+    if constexpr (NX + NY + NZ > 0) {
+        if (wave == 0u) {
+            if constexpr (NX > 0)
+                if (lane < nx) ev.template tab_x_x<Tabs::kAxis>(sample(cx, step, xs0 + x0 + lane), tx + lane);
+        } else if (wave == 1u) {
+            if constexpr (NY > 0)
+                if (lane < ny) ev.template tab_x_y<Tabs::kAxis>(sample(cy, step, y0 + lane), ty + lane);
+        } else if (wave == 2u) {
+            if constexpr (NZ > 0)
+                if (lane < nz) ev.template tab_x_z<Tabs::kAxis>(sample(cz, step, z0 + lane), tz + lane);
+        }
+        __syncthreads();
+    }
+    if constexpr (NXY + NXZ + NYZ > 0) {
+        // one entry per lane: (row, column) = (thread / 16, thread % 16); the column is the table's fastest index
+        const uint32_t r = threadIdx.x >> 4, c = threadIdx.x & 15u;
+        if constexpr (NXY > 0)
+            if (r < ny && c < nx)
+                ev.template tab_x_xy<Tabs::kPair>(sample(cx, step, xs0 + x0 + c), sample(cy, step, y0 + r), Tabs{tx + c, ty + r, tz, txy, txz, tyz}, txy + threadIdx.x);
+        if constexpr (NXZ > 0)
+            if (r < nz && c < nx)
+                ev.template tab_x_xz<Tabs::kPair>(sample(cx, step, xs0 + x0 + c), sample(cz, step, z0 + r), Tabs{tx + c, ty, tz + r, txy, txz, tyz}, txz + threadIdx.x);
+        if constexpr (NYZ > 0)
+            if (r < ny && c < nz)
+                ev.template tab_x_yz<Tabs::kPair>(sample(cy, step, y0 + r), sample(cz, step, z0 + c), Tabs{tx, ty + r, tz + c, txy, txz, tyz}, tyz + threadIdx.x);
+        __syncthreads();
+    }
+    const uint32_t nbz = nz >> 3, columns = (ny >> 2) * nbz;     // the box's (y, z) columns of bricks: at most eight
+    for (uint32_t column = wave; column < columns; column += 4u) {
+        const uint32_t bz = column % nbz, by = column / nbz;
+        const uint32_t yl = by * 4u + ((lane >> 3) & 3u), zl = bz * 8u + (lane & 7u);   // in the box
+        const uint32_t y = y0 + yl, z = z0 + zl;
+        const float py = sample(cy, step, y), pz = sample(cz, step, z);   // (one number per lane: its voxels differ in x)
+        Tabs tb{tx + (lane >> 5), ty + yl, tz + zl, txy + (yl * 16u + (lane >> 5)), txz + (zl * 16u + (lane >> 5)), tyz + (yl * 16u + zl)};
+        const auto hoisted = ev.hoist_x(py, pz, tb);
+#pragma unroll 1
+        for (uint32_t j = 0; j < (nx >> 2); ++j) {
+            // (the columns of y and z do not change along the walk: read again in every brick -- a ds_read is cheaper than a
+            // register held for the walk -- which the compiler would otherwise undo)
+            asm volatile("" ::: "memory");
+            const uint32_t x = x0 + j * 4u + (lane >> 5);
+            float xs[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) xs[i] = sample(cx, step, xs0 + x + 2u * i);
+            const T px = pack(xs);
+            if (LAYOUT == 0) {
+                const sdf::V4<T> r = ev.eval_hoisted_x(px, py, pz, hoisted, tb);
+                float4* p = static_cast<float4*>(o.out) + o.base + ((size_t)z + (size_t)sz * ((size_t)y + (size_t)sy * x));
+#pragma unroll
+                for (int i = 0; i < N; ++i) store_voxel(p + (size_t)i * 2u * sy * sz, sdf::voxel(r, i));
+            } else {
+                const T w = ev.dist_hoisted_x(px, py, pz, hoisted, tb);
+                float* p = static_cast<float*>(o.out) + o.base + ((size_t)z + ((size_t)(o.xa + x) + (size_t)(sy - 1u - y) * sx) * sz);
+#pragma unroll
+                for (int i = 0; i < N; ++i) store_voxel(p + (size_t)i * 2u * sz, sdf::get(w, i));
+            }
+            tb.x += 4; tb.xy += 4; tb.xz += 4;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // dense grid evaluation
 // ------------------------------------------------------------------------------------------
-// `tiles` != 0 (the launcher sets it when the slab's extents allow: sx % 4 == 0, sy % 4 == 0, sz % 32 == 0, two voxels
-// per lane): a wavefront covers a compact 4 x 4 x 8 brick of voxels (a lane: two voxels two x planes apart) and a workgroup
-// four bricks along z, instead of a run of 128 (512) cells along z.  What that buys: values that are uniform over a
-// wavefront stay uniform far more often -- which primitive of a CSG tree is nearest (sponge(4) at 512^3: 1.8
-// distinct winners per brick against 3.1 per run; per-tape code computes the direction once per DISTINCT winner,
-// hip_util.hip generate_source), and whether any lane is in the corner region of a rectangle.  Stores: a
-// workgroup writes 512 contiguous bytes per (x, y) row of its bricks.
+// `boxes` != 0 (the launcher sets it for per-tape code with deferred directions when the slab's extents are multiples of
+// 4, 4 and 8): a workgroup takes a 16^3 box of the slab (box_eval above) instead of runs of cells along z.  What compact
+// bricks buy besides the tables: values that are uniform over a wavefront stay uniform far more often -- which primitive
+// of a CSG tree is nearest (sponge(4) at 512^3: 1.8 distinct winners per brick against 3.1 per run; per-tape code
+// computes the direction once per DISTINCT winner), and whether any lane is in the corner region of a rectangle.
 template <class E, int LAYOUT, int N>
 __global__ void __launch_bounds__(256) SDF_KERNEL_ATTRS
 k_grid_eval(const E ev, float cx, float cy, float cz, float step, uint32_t sx, Dim dy, Dim dz, uint32_t x0,
-            uint32_t n_cells, uint32_t tiles, void* __restrict__ out)
+            uint32_t n_cells, uint32_t boxes, void* __restrict__ out)
 {
     const uint32_t sy = dy.n, sz = dz.n;
     using T = typename Pack<N>::T;
     extern __shared__ float4 lds[];
     if constexpr (E::kBricks && N == 2) {
-        if (tiles) {
-            // lane -> (z: 8, y: 4, x: 2), its two voxels two x planes apart: a store instruction writes 128 contiguous
-            // bytes (eight float4 along z) per (x, y) row of the brick
-            const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-            // A wavefront takes tiles = G bricks in a row along z (the index arithmetic and the launch of a wavefront are
-            // paid once per G bricks: 512^3 sponge(4): 0.974 ms with one brick per wavefront, 0.886 with sixteen); the
-            // four wavefronts of a workgroup take four neighbouring rows along y: together a box of 4 x 16 x 8G voxels.
-            const uint32_t G = tiles;
-            const uint32_t nbz = (sz >> 3) / G, nby = sy >> 2, nbyg = (nby + 3u) >> 2;   // groups of G bricks along z, bricks along y, workgroups along y
-            const uint32_t gz = blockIdx.x % nbz, t = blockIdx.x / nbz, byg = t % nbyg, bx = t / nbyg;
-            if (bx * 4u >= sx_slab(n_cells, sy, sz)) return;        // workgroups past the last one (uniform)
-            const uint32_t by = byg * 4u + wave;
-            // The axis tables of the box (specialise.hpp "AXIS TABLES"): every statement of the tape that reads one
-            // sample coordinate, evaluated once per sample of that axis -- 4 x, 16 y, 8G z -- by the wavefronts side by
-            // side; the walks read them back (interp.hpp AxisTabs).
-            constexpr int NX = E::kTabZX, NY = E::kTabZY, NZ = E::kTabZZ;
-            using Tabs = sdf::AxisTabs<4, 16, 128>;
-            sdf::lds_float* const tx = (sdf::lds_float*)lds;
-            sdf::lds_float* const ty = tx + NX * 4;
-            sdf::lds_float* const tz = ty + NY * 16;
-            if constexpr (NX + NY + NZ > 0) {
-                if (wave < 2u) {
-                    if constexpr (NZ > 0)
-                        for (uint32_t e = threadIdx.x; e < G * 8u; e += 128u) ev.template tab_z_z<128>(sample(cz, step, gz * G * 8u + e), tz + e);
-                } else if (wave == 2u) {
-                    if constexpr (NY > 0)
-                        if (lane < 16u) ev.template tab_z_y<16>(sample(cy, step, byg * 16u + lane), ty + lane);
-                } else {
-                    if constexpr (NX > 0)
-                        if (lane < 4u) ev.template tab_z_x<4>(sample(cx, step, x0 + bx * 4u + lane), tx + lane);
-                }
-                __syncthreads();
-            }
-            if (by >= nby) return;                                  // wavefronts past the last row (uniform per wavefront)
-            const uint32_t x = bx * 4u + (lane >> 5), y = by * 4u + ((lane >> 3) & 3u);
-            float xs[N];
-#pragma unroll
-            for (int i = 0; i < N; ++i) xs[i] = sample(cx, step, x0 + x + 2u * i);
-            // a lane's two voxels differ in x only: y and z are ONE number per lane (per-tape code computes what depends
-            // on them alone in scalars per lane, not in packed pairs: interp.hpp "values of mixed width")
-            const T px = pack(xs);
-            const float py = sample(cy, step, y);
-            // what the tape computes from x and y together is computed once for the wavefront's bricks (specialise.hpp)
-            Tabs tb{tx + (lane >> 5), ty + (wave * 4u + ((lane >> 3) & 3u)), tz + (lane & 7u)};
-            const auto hoisted = ev.hoist(px, py, tb);
-#pragma unroll 1
-            for (uint32_t j = 0; j < G; ++j) {
-                // (the table columns of x and y do not change along the walk: read again in every brick -- a ds_read is
-                // cheaper than a register held for sixteen bricks -- which the compiler would otherwise undo)
-                asm volatile("" ::: "memory");
-                const uint32_t z = (gz * G + j) * 8u + (lane & 7u);
-                const float pz = sample(cz, step, z);
-                if (LAYOUT == 0) {
-                    const sdf::V4<T> r = ev.eval_hoisted(px, py, pz, hoisted, tb);
-                    float4* o = static_cast<float4*>(out) + ((size_t)z + (size_t)sz * ((size_t)y + (size_t)sy * x));
-#pragma unroll
-                    for (int i = 0; i < N; ++i) store_voxel(o + (size_t)i * 2u * sy * sz, sdf::voxel(r, i));
-                } else {
-                    const T w = ev.dist_hoisted(px, py, pz, hoisted, tb);
-                    float* o = static_cast<float*>(out) + ((size_t)z + ((size_t)(x0 + x) + (size_t)(sy - 1u - y) * sx) * sz);
-#pragma unroll
-                    for (int i = 0; i < N; ++i) store_voxel(o + (size_t)i * 2u * sz, sdf::get(w, i));
-                }
-                tb.z += 8;
-            }
+        if (boxes) {
+            // boxes along z fastest
+            const uint32_t nx_slab = sx_slab(n_cells, sy, sz);
+            const uint32_t boxes_z = (sz + 15u) >> 4, boxes_y = (sy + 15u) >> 4;
+            const uint32_t qz = blockIdx.x % boxes_z, qt = blockIdx.x / boxes_z, qy = qt % boxes_y, qx = qt / boxes_y;
+            const BoxOut o{out, 0, sx, sy, sz, LAYOUT == 0 ? 0u : x0, nx_slab};
+            box_eval<E, LAYOUT, N>(ev, lds, cx, cy, cz, step, x0, qx * 16u, qy * 16u, qz * 16u, o);
             return;
         }
     }
@@ -332,84 +367,12 @@ k_grid_eval_blocks(const E ev, const int4* __restrict__ blocks, const uint32_t* 
     const float cz = (float)((double)ic.z * res + oz);
     if constexpr (E::kBricks && N == 2) {
         if (bricks) {
-            // A workgroup takes one BOX of the block: up to 16 x 16 x 16 voxels (a 16^3 block is one box; `chunks` = boxes
-            // per block, `bricks` = boxes along y and z packed as (boxes_y << 16 | boxes_z)).  As in k_grid_eval a wavefront
-            // evaluates compact 4 x 4 x 8 bricks (lane -> z: 8, y: 4, x: 2, its two voxels two x planes apart), here the
-            // bricks of one (y, z) column of the box one after the other ALONG X.  Before the walks the workgroup fills the
-            // box's tables (specialise.hpp "AXIS TABLES", "PAIR TABLES"): what the tape computes from one coordinate, once per
-            // sample of that axis; then what it computes from two, once per PAIR of samples (16 x 16 evaluations where the
-            // walks would make 4096) -- the bars of a cross, any extruded profile.  The walks read, combine and store.
-            const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+            // a workgroup takes one BOX of the block (box_eval): `chunks` = boxes per block, `bricks` = the boxes along y
+            // and z packed as (boxes_y << 16 | boxes_z); a 16^3 block is one box
             const uint32_t boxes_z = bricks & 0xffffu, boxes_y = bricks >> 16;
             const uint32_t qz = chunk % boxes_z, qt = chunk / boxes_z, qy = qt % boxes_y, qx = qt / boxes_y;
-            const uint32_t x0 = qx * 16u, y0 = qy * 16u, z0 = qz * 16u;                       // the box's corner in the block
-            const uint32_t nx = min(16u, sx - x0), ny = min(16u, sy - y0), nz = min(16u, sz - z0);   // and its extents
-            constexpr int NX = E::kTabXX, NY = E::kTabXY, NZ = E::kTabXZ, NXY = E::kPairXY, NXZ = E::kPairXZ, NYZ = E::kPairYZ;
-            using Tabs = sdf::BoxTabs;
-            sdf::lds_float* const tx = (sdf::lds_float*)lds;
-            sdf::lds_float* const ty = tx + NX * Tabs::kAxis;
-            sdf::lds_float* const tz = ty + NY * Tabs::kAxis;
-            sdf::lds_float* const txy = tz + NZ * Tabs::kAxis;
-            sdf::lds_float* const txz = txy + NXY * Tabs::kPair;
-            sdf::lds_float* const tyz = txz + NXZ * Tabs::kPair;
-            if constexpr (NX + NY + NZ > 0) {
-                if (wave == 0u) {
-                    if constexpr (NX > 0)
-                        if (lane < nx) ev.template tab_x_x<Tabs::kAxis>(sample(cx, step, x0 + lane), tx + lane);
-                } else if (wave == 1u) {
-                    if constexpr (NY > 0)
-                        if (lane < ny) ev.template tab_x_y<Tabs::kAxis>(sample(cy, step, y0 + lane), ty + lane);
-                } else if (wave == 2u) {
-                    if constexpr (NZ > 0)
-                        if (lane < nz) ev.template tab_x_z<Tabs::kAxis>(sample(cz, step, z0 + lane), tz + lane);
-                }
-                __syncthreads();
-            }
-            if constexpr (NXY + NXZ + NYZ > 0) {
-                // one entry per lane: (row, column) = (thread / 16, thread % 16); the column is the table's fastest index
-                const uint32_t r = threadIdx.x >> 4, c = threadIdx.x & 15u;
-                if constexpr (NXY > 0)
-                    if (r < ny && c < nx)
-                        ev.template tab_x_xy<Tabs::kPair>(sample(cx, step, x0 + c), sample(cy, step, y0 + r), Tabs{tx + c, ty + r, tz, txy, txz, tyz}, txy + threadIdx.x);
-                if constexpr (NXZ > 0)
-                    if (r < nz && c < nx)
-                        ev.template tab_x_xz<Tabs::kPair>(sample(cx, step, x0 + c), sample(cz, step, z0 + r), Tabs{tx + c, ty, tz + r, txy, txz, tyz}, txz + threadIdx.x);
-                if constexpr (NYZ > 0)
-                    if (r < ny && c < nz)
-                        ev.template tab_x_yz<Tabs::kPair>(sample(cy, step, y0 + r), sample(cz, step, z0 + c), Tabs{tx, ty + r, tz + c, txy, txz, tyz}, tyz + threadIdx.x);
-                __syncthreads();
-            }
-            const uint32_t nbz = nz >> 3, columns = (ny >> 2) * nbz;     // the box's (y, z) columns of bricks: at most eight
-            const size_t base = (size_t)b * cells;
-            for (uint32_t column = wave; column < columns; column += 4u) {
-                const uint32_t bz = column % nbz, by = column / nbz;
-                const uint32_t yl = by * 4u + ((lane >> 3) & 3u), zl = bz * 8u + (lane & 7u);   // in the box
-                const uint32_t y = y0 + yl, z = z0 + zl;
-                const float py = sample(cy, step, y), pz = sample(cz, step, z);   // (one number per lane: its voxels differ in x)
-                Tabs tb{tx + (lane >> 5), ty + yl, tz + zl, txy + (yl * 16u + (lane >> 5)), txz + (zl * 16u + (lane >> 5)), tyz + (yl * 16u + zl)};
-                const auto hoisted = ev.hoist_x(py, pz, tb);
-#pragma unroll 1
-                for (uint32_t j = 0; j < (nx >> 2); ++j) {
-                    asm volatile("" ::: "memory");   // (the columns of y and z are read again in every brick: k_grid_eval)
-                    const uint32_t x = x0 + j * 4u + (lane >> 5);
-                    float xs[N];
-#pragma unroll
-                    for (int i = 0; i < N; ++i) xs[i] = sample(cx, step, x + 2u * i);
-                    const T px = pack(xs);
-                    if (LAYOUT == 0) {
-                        const sdf::V4<T> r = ev.eval_hoisted_x(px, py, pz, hoisted, tb);
-                        float4* o = static_cast<float4*>(out) + base + ((size_t)z + (size_t)sz * ((size_t)y + (size_t)sy * x));
-#pragma unroll
-                        for (int i = 0; i < N; ++i) store_voxel(o + (size_t)i * 2u * sy * sz, sdf::voxel(r, i));
-                    } else {
-                        const T w = ev.dist_hoisted_x(px, py, pz, hoisted, tb);
-                        float* o = static_cast<float*>(out) + base + ((size_t)z + ((size_t)x + (size_t)(sy - 1u - y) * sx) * sz);
-#pragma unroll
-                        for (int i = 0; i < N; ++i) store_voxel(o + (size_t)i * 2u * sz, sdf::get(w, i));
-                    }
-                    tb.x += 4; tb.xy += 4; tb.xz += 4;
-                }
-            }
+            const BoxOut o{out, (size_t)b * cells, sx, sy, sz, 0u, sx};
+            box_eval<E, LAYOUT, N>(ev, lds, cx, cy, cz, step, 0u, qx * 16u, qy * 16u, qz * 16u, o);
             return;
         }
     }

@@ -710,9 +710,9 @@ inline std::string render_table_builder(const Phase1& ph, uint8_t deps, const st
 struct SpecMeta {
     bool deferred = false;
     double coord_limit = 0.0;    // the largest |sample coordinate| for which a launch may set sdf::kFlagInRange (0: never)
-    int tabs[2][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};   // [walk along z, along x][x, y, z, xy, xz, yz]: columns of the tables
+    int tabs[6] = {0, 0, 0, 0, 0, 0};   // columns of a box's tables: x, y, z, xy, xz, yz
 };
-constexpr int kMaxTableColumns = 48;   // per axis (a 128-entry column of the dense kernel's z table is 512 B of LDS)
+constexpr int kMaxTableColumns = 48;   // per axis (a column of a 16^3 box is 64 B of LDS)
 constexpr int kMaxPairColumns = 16;    // per pair of axes (a column of a 16^3 box is 1 KiB)
 
 inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t max_paths = 40, SpecMeta* meta = nullptr)
@@ -897,33 +897,34 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
     };
 
     const char* head = "    using namespace sdf;\n    using T = wider_t<wider_t<PX, PY>, PZ>;\n    using M = typename mask_of<T>::type;\n";
-    struct Form { const char* suffix; uint8_t walk; const char* pre_args; };
-    const Form forms[3] = {{"", 0, ""}, {"_z", DZ, "PX px, PY py"}, {"_x", DX, "PY py, PZ pz"}};
-    // what a value must save per brick to be kept for a whole walk (hoistable_set), measured on sponge(4) at 512^3, MI355X:
-    // dense kernel (walks of sixteen bricks along z) 0.568 ms keeping everything, 0.530 / 0.519 / 0.518 / 0.521 ms at
-    // 8 / 10 / 12 / 14 -- the |x| - h of the shallow levels are cheaper to recompute than to hold, 79 registers at stake --;
-    // leaf blocks (walks of four bricks along x) 0.363 -> 0.356 ms at 8
+    // two forms: in place (the classification kernels, the ray caster, ragged grids), and for the walks along x of a box
+    // (kernels.hpp box_eval: the dense grids and the leaf blocks)
+    struct Form { const char* suffix; uint8_t walk; };
+    const Form forms[2] = {{"", 0}, {"_x", DX}};
+    // what a value that the walk does not change must save per brick to be computed once per walk and kept in a register
+    // (hoistable_set; with the tables few statements are left to it).  Measured on sponge(4), MI355X, before the tables:
+    // walks of four bricks along x 0.363 -> 0.356 ms at 8.
     auto knob = [](const char* name, int fallback) { const char* e = std::getenv(name); return e && *e ? std::atoi(e) : fallback; };
     const int tab_min = knob("HU_TAB_MIN", 2);      // what a single-axis value must cost to become a table column (0: no tables)
     for (const Form& f : forms) {
-        const std::vector<char> hoistable = hoistable_set(ph, f.walk, f.walk == DZ ? knob("HU_HOIST_MIN_Z", 12) : knob("HU_HOIST_MIN_X", 8));
+        const std::vector<char> hoistable = hoistable_set(ph, f.walk, knob("HU_HOIST_MIN_X", 8));
         // ---- axis and pair tables: the candidates this form's walk-dependent code and its direction blocks read become
-        // columns; the pair tables (walks along x only: the 16^3 boxes of k_grid_eval_blocks) are filled from single-axis columns
+        // columns; the pair tables are filled from single-axis columns
         std::vector<char> tabc;
         std::vector<int> tab_index(ph.e.st.size(), -1);
         int n_tab[6] = {0, 0, 0, 0, 0, 0};
         std::vector<char> held, used;
         if (f.walk != 0 && tab_min > 0) {
-            tabc = table_candidates(ph, tab_min, f.walk == DX ? knob("HU_TAB_PAIR_MIN", 3) : 0);
+            tabc = table_candidates(ph, tab_min, knob("HU_TAB_PAIR_MIN", 3));
             for (;;) {
                 // the columns the DISTANCES read in every brick and the walk does not change are kept in registers instead
                 // (`held`), lowest statements first, while the budget lasts: a column with x in it costs two registers, others one
                 const Variant probe = render_variant(ph, hoistable, dist_roots, tabc);
                 held.assign(ph.e.st.size(), 0);
-                // (measured, sponge(4), MI355X: the dense kernel's walks along z 0.497 / 0.508 / 0.532 / 0.553 ms holding
-                // 0 / 6 / 9 / 16 registers' worth -- registers are dearer there than reads --, the leaf blocks' walks along x
-                // 0.327 / 0.325 / 0.319 / 0.325 ms at 0 / 6 / 12 / 24)
-                int budget = f.walk == DZ ? knob("HU_TAB_HOLD_Z", 0) : knob("HU_TAB_HOLD_X", 12);
+                // (measured, sponge(4), MI355X, single-axis tables only: leaf blocks 0.327 / 0.325 / 0.319 / 0.325 ms holding
+                // 0 / 6 / 12 / 24 registers' worth; walks of sixteen bricks along z, round 3's first form of the dense kernel,
+                // 0.497 / 0.508 / 0.532 / 0.553 ms at 0 / 6 / 9 / 16 -- registers were dearer there than reads)
+                int budget = knob("HU_TAB_HOLD_X", 12);
                 for (int i = 0; i < (int)probe.tab_main.size(); ++i) {
                     if (!probe.tab_main[i] || !tabc[i] || (ph.e.st[i].deps & f.walk)) continue;
                     const int regs = (ph.e.st[i].deps & DX) ? 2 : 1;
@@ -952,13 +953,13 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
             }
             if (std::accumulate(n_tab, n_tab + 6, 0) == 0) { tabc.clear(); held.clear(); }
         }
-        if (meta && f.walk != 0) for (int a = 0; a < 6; ++a) meta->tabs[f.walk == DZ ? 0 : 1][a] = n_tab[a];
+        if (meta && f.walk != 0) for (int a = 0; a < 6; ++a) meta->tabs[a] = n_tab[a];
         const Variant vd = render_variant(ph, hoistable, dist_roots, tabc, &tab_index, held), ve = render_variant(ph, hoistable, eval_roots, tabc, &tab_index, held);
         // the values handed from `pre`: the union of what the distance and the evaluation read (one struct for both)
         const Variant& pre_of = ve;   // (eval's roots include dist's root: its frontier covers it)
         const bool hoists = f.walk != 0 && pre_of.n_hoisted > 0;
         if (f.walk != 0) {
-            o << "// hoisted out of walks along " << (f.walk == DZ ? "z" : "x") << ": " << pre_of.n_hoisted << " values; table columns: "
+            o << "// hoisted out of walks along x: " << pre_of.n_hoisted << " values; table columns: "
               << n_tab[0] << " / " << n_tab[1] << " / " << n_tab[2] << " (x / y / z), " << n_tab[3] << " / " << n_tab[4] << " / " << n_tab[5] << " (xy / xz / yz)\n"
               << "template <class PX, class PY, class PZ, class TB> __device__ __forceinline__ auto tape_pre" << f.suffix
               << "(PX px, PY py, PZ pz, const float* __restrict__ extra, uint32_t flags, const TB& tb)\n{\n    using namespace sdf;\n";
@@ -971,11 +972,11 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
                 o << "template <int S, class L> __device__ __forceinline__ void tape_tab" << f.suffix << "_" << slot_name[a] << "(float p"
                   << slot_name[a] << ", const float* __restrict__ extra, uint32_t flags, L out)\n{\n    using namespace sdf;\n"
                   << (n_tab[a] ? render_table_builder(ph, slot_deps[a], tab_index, tabc, used) : std::string()) << "}\n";
-            if (f.walk == DX)   // (a pair table's entry: the two coordinates, and the single-axis tables positioned at it)
-                for (int a = 3; a < 6; ++a)
-                    o << "template <int S, class TB, class L> __device__ __forceinline__ void tape_tab" << f.suffix << "_" << slot_name[a]
-                      << "(float px, float py, float pz, const float* __restrict__ extra, uint32_t flags, const TB& tb, L out)\n{\n    using namespace sdf;\n"
-                      << (n_tab[a] ? render_table_builder(ph, slot_deps[a], tab_index, tabc, used) : std::string()) << "}\n";
+            // (a pair table's entry: the two coordinates, and the single-axis tables positioned at it)
+            for (int a = 3; a < 6; ++a)
+                o << "template <int S, class TB, class L> __device__ __forceinline__ void tape_tab" << f.suffix << "_" << slot_name[a]
+                  << "(float px, float py, float pz, const float* __restrict__ extra, uint32_t flags, const TB& tb, L out)\n{\n    using namespace sdf;\n"
+                  << (n_tab[a] ? render_table_builder(ph, slot_deps[a], tab_index, tabc, used) : std::string()) << "}\n";
         }
         const std::string h_param = f.walk != 0 ? ", const H& h, const TB& tb" : "";
         const std::string h_tmpl = f.walk != 0 ? ", class H, class TB" : "";
@@ -1013,28 +1014,19 @@ inline std::string specialised_source(const SpecProgram& p, bool allow_deferred,
           << "    template <class T> __device__ __forceinline__ T dist(T px, T py, T pz, void*) const\n"
           << "    { return tape_dist(px, py, pz, extra, flags); }\n"
           // the axis tables of the two walks: columns per axis, and the functions that fill one entry of each table
-          << "    static constexpr int kTabZX = " << m.tabs[0][0] << ", kTabZY = " << m.tabs[0][1] << ", kTabZZ = " << m.tabs[0][2]
-          << ", kTabXX = " << m.tabs[1][0] << ", kTabXY = " << m.tabs[1][1] << ", kTabXZ = " << m.tabs[1][2]
-          << ", kPairXY = " << m.tabs[1][3] << ", kPairXZ = " << m.tabs[1][4] << ", kPairYZ = " << m.tabs[1][5] << ";\n";
-        for (const char* walk : {"z", "x"})
-            for (const char* axis : {"x", "y", "z"})
-                o << "    template <int S, class L> __device__ __forceinline__ void tab_" << walk << "_" << axis << "(float p, L out) const\n"
-                  << "    { tape_tab_" << walk << "_" << axis << "<S>(p, extra, flags, out); }\n";
-        // one entry (a, b) of a pair table of the walks along x
+          << "    static constexpr int kTabXX = " << m.tabs[0] << ", kTabXY = " << m.tabs[1] << ", kTabXZ = " << m.tabs[2]
+          << ", kPairXY = " << m.tabs[3] << ", kPairXZ = " << m.tabs[4] << ", kPairYZ = " << m.tabs[5] << ";\n";
+        for (const char* axis : {"x", "y", "z"})
+            o << "    template <int S, class L> __device__ __forceinline__ void tab_x_" << axis << "(float p, L out) const\n"
+              << "    { tape_tab_x_" << axis << "<S>(p, extra, flags, out); }\n";
+        // one entry (a, b) of a pair table
         o << "    template <int S, class TB, class L> __device__ __forceinline__ void tab_x_xy(float a, float b, const TB& tb, L out) const\n"
           << "    { tape_tab_x_xy<S>(a, b, 0.0f, extra, flags, tb, out); }\n"
           << "    template <int S, class TB, class L> __device__ __forceinline__ void tab_x_xz(float a, float b, const TB& tb, L out) const\n"
           << "    { tape_tab_x_xz<S>(a, 0.0f, b, extra, flags, tb, out); }\n"
           << "    template <int S, class TB, class L> __device__ __forceinline__ void tab_x_yz(float a, float b, const TB& tb, L out) const\n"
-          << "    { tape_tab_x_yz<S>(0.0f, a, b, extra, flags, tb, out); }\n";
-        // what does not change along z, for kernels that walk bricks along z with x and y fixed (kernels.hpp) ...
-        o << "    template <class PX, class PY, class TB> __device__ __forceinline__ auto hoist(PX px, PY py, const TB& tb) const\n"
-          << "    { return tape_pre_z(px, py, 0.0f, extra, flags, tb); }\n"
-          << "    template <class PX, class PY, class PZ, class H, class TB> __device__ __forceinline__ auto eval_hoisted(PX px, PY py, PZ pz, const H& h, const TB& tb) const\n"
-          << "    { return tape_eval_z(px, py, pz, extra, flags, h, tb); }\n"
-          << "    template <class PX, class PY, class PZ, class H, class TB> __device__ __forceinline__ auto dist_hoisted(PX px, PY py, PZ pz, const H& h, const TB& tb) const\n"
-          << "    { return tape_dist_z(px, py, pz, extra, flags, h, tb); }\n"
-          // ... and the same for a walk along x with y and z fixed (k_grid_eval_blocks)
+          << "    { tape_tab_x_yz<S>(0.0f, a, b, extra, flags, tb, out); }\n"
+          // what does not change along x, for the walks of a box with y and z fixed (kernels.hpp box_eval)
           << "    template <class PY, class PZ, class TB> __device__ __forceinline__ auto hoist_x(PY py, PZ pz, const TB& tb) const\n"
           << "    { return tape_pre_x(0.0f, py, pz, extra, flags, tb); }\n"
           << "    template <class PX, class PY, class PZ, class H, class TB> __device__ __forceinline__ auto eval_hoisted_x(PX px, PY py, PZ pz, const H& h, const TB& tb) const\n"

@@ -143,14 +143,19 @@ def test_specialised_source_builds_under_hiprtc_without_a_device():
     assert lib.hu_tape_source(p, t.size, buf, needed.value, ctypes.byref(needed)) == 0
     src = buf.value.decode()
     # sponge(2): the deferred-directions form (specialise.hpp): phase 1 as typed single-assignment statements -- in
-    # place, hoisted out of walks along z, and along x --, then one block per (primitive, path to the root): 6 bars +
-    # the box, in each of the three evaluation functions
+    # place, and for the walks along x of a box with its tables --, then one block per (primitive, path to the root): 6
+    # bars + the box, in each of the two evaluation functions
     assert "struct JitEval" in src and "tape_dist" in src and "deferred directions: 7 " in src
-    for name in ("tape_dist(", "tape_eval(", "tape_pre_z(", "tape_dist_z(", "tape_eval_z(", "tape_pre_x(", "tape_dist_x(", "tape_eval_x("):
+    for name in ("tape_dist(", "tape_eval(", "tape_pre_x(", "tape_dist_x(", "tape_eval_x("):
         assert src.count("auto " + name) == 1, name
-    assert src.count("const auto t") > 100 and "struct Hoisted {" in src and "h.t" in src
+    for name in ("tape_tab_x_x(", "tape_tab_x_y(", "tape_tab_x_z(", "tape_tab_x_xy(", "tape_tab_x_xz(", "tape_tab_x_yz("):
+        assert src.count("void " + name) == 1, name
+    # the bars of the two crosses are pair columns (2 x 3) and so is the box's square; the walks read them
+    assert "table columns:" in src and "3 / 2 / 2 (xy / xz / yz)" in src, src[src.index("table columns:"):][:120]
+    assert "tb.template XY<" in src and "tb.template YZ<" in src and "out[0 * S] = " in src
+    assert src.count("const auto t") > 100 and "struct Hoisted {" in src
     assert "exec_one<T, true" not in src       # no record of the distance-only program is run through the library here
-    assert src.count("// the primitive of record") == 3 * 7
+    assert src.count("// the primitive of record") == 2 * 7
     size = ctypes.c_size_t(0)
     rc = lib.hu_tape_compile_check(p, t.size, include_dir, ctypes.byref(size))
     assert rc == 0, lib.hu_last_error().decode()
