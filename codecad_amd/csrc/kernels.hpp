@@ -270,8 +270,8 @@ __device__ __forceinline__ void box_eval(const E& ev, float4* lds, float cx, flo
         const auto hoisted = ev.hoist_x(py, pz, tb);
 #pragma unroll 1
         for (uint32_t j = 0; j < (nx >> 2); ++j) {
-            // (the columns of y and z do not change along the walk: read again in every brick -- a ds_read is cheaper than a
-            // register held for the walk -- which the compiler would otherwise undo)
+            // (the columns of y and z that `pre` does not hold are read again in every brick, which the compiler would
+            // otherwise undo; unrolling the walk and batching its reads were measured: no gain)
             asm volatile("" ::: "memory");
             const uint32_t x = x0 + j * 4u + (lane >> 5);
             float xs[N];
@@ -346,7 +346,7 @@ k_grid_eval(const E ev, float cx, float cy, float cz, float step, uint32_t sx, D
 }
 
 template <class E, int LAYOUT, int N>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) SDF_KERNEL_ATTRS
 k_grid_eval_blocks(const E ev, const int4* __restrict__ blocks, const uint32_t* __restrict__ n_blocks_dev, uint32_t b0,
                    uint32_t chunks, uint32_t bricks, double res, double ox, double oy, double oz, float step, uint32_t sx,
                    Dim dy, Dim dz, void* __restrict__ out)
