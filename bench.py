@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--no-hbm-leg", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph leg (steps captured once and replayed)")
     ap.add_argument("--graph", action="store_true", help="run the hipGraph leg on more than one rank too (default: one rank only)")
+    ap.add_argument("--pipelines", type=int, default=None,
+                    help="traversals in flight, each with its lists and its stream (default: 2)")
     ap.add_argument("--n", type=int, default=None, help="grid edge (default: the config's)")
     ap.add_argument("--evaluator", choices=["auto", "specialised", "interpreter"], default="auto",
                     help="auto = per-tape hipRTC specialisation when it builds, else the tape interpreter")
@@ -136,8 +138,15 @@ def main():
     main_stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(main_stream)
     stream = main_stream.cuda_stream
-    side_stream = torch.cuda.Stream(device=dev, priority=-1)
-    side = side_stream.cuda_stream
+    # One stream per traversal in flight.  A traversal is a latency chain (per level: classify, all-gather, slice); on
+    # several GPUs it is longer than a rank's share of the dense grid and the leaf blocks together, so two of them are
+    # kept in flight, each on its own stream with its own lists (the collectives of one process group still run in the
+    # order they were enqueued, the same on every rank): a step then costs max(A + C, B / 2), not max(A + C, B) as with
+    # round 2's single side stream.  More in flight was measured on one GPU with forced collectives (--pipelines 4):
+    # 0.92 ms per step against 0.70 -- four high-priority traversals get in the way of the dense kernel.
+    n_pipes = args.pipelines or 2
+    assert n_pipes >= 2
+    side_streams = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(n_pipes)]
 
     # ---- A: dense grid (this rank's x-slab of the ONE grid; --weak: a whole grid per rank) --------------
     step_f = np.float32(1.0 / n)
@@ -160,20 +169,21 @@ def main():
     leaf_cells = cells[-1]
     ld = (ctypes.c_uint32 * 3)(int(leaf_dims[0]), int(leaf_dims[1]), int(leaf_dims[2]))
 
-    def build_pipeline(capacities):
-        with torch.cuda.stream(side_stream):
-            p = dist.subdivision_pipeline(tape, levels, resolution, (box.a.x, box.a.y, box.a.z), 3, capacities, dev, side, top)
-        side_stream.synchronize()
+    def build_pipeline(capacities, i):
+        with torch.cuda.stream(side_streams[i]):
+            p = dist.subdivision_pipeline(tape, levels, resolution, (box.a.x, box.a.y, box.a.z), 3, capacities, dev,
+                                          side_streams[i].cuda_stream, top)
+        side_streams[i].synchronize()
         return p
 
     # first capacities: every cell of a level while that is small, else a surface estimate; a traversal that
     # overflows says what it needed (dist.Overflow) and the pipeline is rebuilt -- during warm-up only
     capacities = cc.subdivision.first_capacities(cells[:-1], n_top=n_objects)
-    # Two pipelines, taken in turn: the traversal of step k + 1 (latency-bound at 8 GPUs: two levels of classify +
-    # all-gather + slice) runs on its stream while step k's leaf blocks are still being evaluated from the other
-    # pipeline's list; it only waits for the leaf-block launch that last read ITS list (step k - 1).
-    pipes = [build_pipeline(capacities), build_pipeline(capacities)]
-    list_free = [torch.cuda.Event(), torch.cuda.Event()]   # recorded after the leaf-block launch that read pipes[i]'s list
+    # P pipelines, taken in turn: the traversal of step k + 1 (latency-bound at 8 GPUs: two levels of classify +
+    # all-gather + slice) runs on its stream while step k's leaf blocks are still being evaluated from another
+    # pipeline's list; it only waits for the leaf-block launch that last read ITS list (step k + 1 - P).
+    pipes = [build_pipeline(capacities, i) for i in range(n_pipes)]
+    list_free = [torch.cuda.Event() for _ in range(n_pipes)]   # recorded after the leaf-block launch that read pipes[i]'s list
     leaf_out = [None]
 
     # one set of events per step: nothing in a step waits for the host, the elapsed times are read after the timed region
@@ -200,7 +210,8 @@ def main():
 
     def one_step(evs, k):
         ev0, ev1, ev2, evb0, evb1, evc0 = evs
-        pipe = pipes[k % 2]
+        i = k % n_pipes
+        pipe, side_stream, side = pipes[i], side_streams[i], side_streams[i].cuda_stream
         # A
         if dense_leg:
             check(lib.hu_event_record(ev0, stream), "record")
@@ -208,7 +219,7 @@ def main():
             check(lib.hu_event_record(ev1, stream), "record")
         # B, concurrently with A, on the side stream
         with torch.cuda.stream(side_stream):
-            side_stream.wait_event(list_free[k % 2])   # (never recorded yet: no wait)
+            side_stream.wait_event(list_free[i])   # (never recorded yet: no wait)
             check(lib.hu_event_record(evb0, side), "record")
             mine = pipe.enqueue()                     # [header | this rank's share of the leaf blocks], all on the device
             check(lib.hu_event_record(evb1, side), "record")
@@ -217,7 +228,7 @@ def main():
         check(lib.hu_event_record(evc0, stream), "record")
         launch_c(mine)
         check(lib.hu_event_record(ev2, stream), "record")
-        list_free[k % 2].record(main_stream)          # the traversal after next may overwrite this list once C has read it
+        list_free[i].record(main_stream)              # the traversal P steps on may overwrite this list once C has read it
         return mine
 
     def capture_steps(n_steps):
@@ -229,13 +240,15 @@ def main():
         with torch.cuda.graph(g, stream=main_stream):
             fork = torch.cuda.Event()
             fork.record(main_stream)
-            side_stream.wait_event(fork)
+            for s_ in side_streams:
+                s_.wait_event(fork)
             c_done = []
             for k in range(n_steps):
+                side_stream = side_streams[k % n_pipes]
                 with torch.cuda.stream(side_stream):
-                    if k >= 2:
-                        side_stream.wait_event(c_done[k - 2])
-                    mine = pipes[k % 2].enqueue()
+                    if k >= n_pipes:
+                        side_stream.wait_event(c_done[k - n_pipes])
+                    mine = pipes[k % n_pipes].enqueue()
                     joined = torch.cuda.Event()
                     joined.record(side_stream)
                 if dense_leg:
@@ -245,7 +258,8 @@ def main():
                 done = torch.cuda.Event()
                 done.record(main_stream)
                 c_done.append(done)
-            main_stream.wait_stream(side_stream)
+            for s_ in side_streams:
+                main_stream.wait_stream(s_)
         return g
 
     def elapsed(a, b):
@@ -255,7 +269,8 @@ def main():
 
     def barrier():
         main_stream.synchronize()
-        side_stream.synchronize()
+        for s_ in side_streams:
+            s_.synchronize()
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
@@ -264,8 +279,8 @@ def main():
     # warm-up: the first traversals also settle the list capacities at what the lists need + 12 % (a launch is
     # sized for the capacity, and workgroups past the list's end cost their dispatch: 80 000 spare leaf blocks are 0.2 ms)
     totals, settled, done = None, False, 0
-    for i in range(2 * max(args.warmup, 1) + 8):
-        pipe = pipes[i % 2]
+    for i in range(n_pipes * max(args.warmup, 1) + 4 * n_pipes):
+        pipe = pipes[i % n_pipes]
         mine = one_step(warm_events, i)
         try:
             totals = pipe.check()
@@ -274,14 +289,14 @@ def main():
             totals, tight = None, [int(v * 1.125) + 16 for v in e.needed]
         if totals is None or (not settled and any(c > t for c, t in zip(pipe.capacities, tight))):
             barrier()
-            pipes[0], pipes[1] = build_pipeline(tight), build_pipeline(tight)
+            pipes[:] = [build_pipeline(tight, j) for j in range(n_pipes)]
             leaf_out[0] = None
             settled = totals is not None
             totals = None
             done = 0
             continue
         done += 1
-        if done >= max(args.warmup, 2):   # (both pipelines have run with the settled capacities)
+        if done >= max(args.warmup, n_pipes):   # (every pipeline has run with the settled capacities)
             break
     assert totals is not None, "list capacities did not settle"
     my_leaves = int(mine[0, 0].item())
@@ -311,7 +326,7 @@ def main():
     b_ms = [elapsed(e[3], e[4]) for e in step_events]   # B: the whole traversal on its stream (kernels + all-gathers)
     c_ms = [elapsed(e[5], e[2]) for e in step_events]   # C: every sample of every leaf block of this rank
     # the timed traversals were not looked at while they ran: validate now (identical work every step)
-    for used in (pipes[:1] if args.steps == 1 else pipes):
+    for used in pipes[:min(args.steps, n_pipes)]:
         assert used.check() == totals, "the timed steps did not reproduce the warm-up traversal"
 
     # ---- the same steps captured into a hipGraph and replayed (reported beside the headline, never instead of it):
@@ -418,6 +433,7 @@ def main():
                        "baseline_config": args.config,
                        "evaluator": evaluator + (" (per-tape straight-line kernels compiled with hipRTC from the same "
                                                   "op library; bit-identical to the interpreter)" if evaluator == "specialised" else ""),
+                       "traversals_in_flight": n_pipes,
                        "tape_floats": int(host_tape.size), "tape_instructions": tape.n_instructions,
                        "value_registers": tape.n_registers,
                        "parallelism": ("x-slabs of the one grid, balanced parent slices + one fixed-size RCCL all-gather of the "
