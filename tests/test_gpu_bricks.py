@@ -1,8 +1,9 @@
-"""Per-tape code on the grids where its brick kernels run (csrc/kernels.hpp): dense grids whose extents are multiples of
-(4, 4, 32) -- a wavefront walks bricks along z and what x and y alone decide is hoisted out of the walk
-(specialise.hpp emit_deferred, PRE / AXIS) -- and leaf blocks of 16^3, walked along x.  Every float must equal the
-oracle's: hoisting moves records, it does not change them.  (The other parity tests use ragged grids, which take the
-kernels without bricks.)"""
+"""Per-tape code on the grids where its box kernels run (csrc/kernels.hpp box_eval): dense grids and leaf blocks whose
+extents are multiples of (4, 4, 8) -- a workgroup takes a box of up to 16^3 voxels, fills the box's single-axis and
+pair tables in LDS (specialise.hpp "AXIS TABLES", "PAIR TABLES") and its wavefronts walk bricks along x reading them.
+Every float must equal the oracle's: the tables move statements, they do not change them.  Full boxes, boxes cut by
+the grid's edge in every direction, slabs that start inside a grid, blocks of several boxes.  (The other parity tests
+use ragged grids, which take the kernels without bricks.)"""
 import ctypes
 import random
 
@@ -37,7 +38,8 @@ def check_dense(hip, handle, tape, corner, step, dims):
 
 
 def check_blocks(hip, handle, tape, int_corners, resolution, origin, edge=16):
-    """hu_grid_eval_blocks over blocks of edge^3 samples at integer corners (subdivision.py:100: corner * resolution + origin)"""
+    """hu_grid_eval_blocks over blocks of edge^3 (or edge = (sx, sy, sz)) samples at integer corners (subdivision.py:100:
+    corner * resolution + origin)"""
     from codecad_amd import hip_util
     from codecad_amd.hip_util import check
     n = len(int_corners)
@@ -45,11 +47,12 @@ def check_blocks(hip, handle, tape, int_corners, resolution, origin, edge=16):
     blocks[:, :3] = int_corners
     blocks_dev = hip_util.Buffer(np.int32, blocks.shape)
     blocks_dev.enqueue_write(blocks).wait()
-    dims = (ctypes.c_uint32 * 3)(edge, edge, edge)
+    ext = (edge, edge, edge) if isinstance(edge, int) else tuple(edge)
+    dims = (ctypes.c_uint32 * 3)(*ext)
     o = (ctypes.c_double * 3)(*origin)
     step = np.float32(resolution)
     for layout, per_voxel in ((0, 4), (1, 1)):
-        out = hip_util.Buffer(np.float32, (n, edge, edge, edge, per_voxel) if layout == 0 else (n, edge ** 3))
+        out = hip_util.Buffer(np.float32, (n,) + ext + (per_voxel,) if layout == 0 else (n, ext[0] * ext[1] * ext[2]))
         check(hip.lib.hu_grid_eval_blocks(handle.device_ptr, blocks_dev.device_ptr, n, float(resolution), o, step, dims, layout,
                                           out.device_ptr, hip.queue.handle), "hu_grid_eval_blocks")
         hip.queue.finish()
@@ -57,10 +60,10 @@ def check_blocks(hip, handle, tape, int_corners, resolution, origin, edge=16):
         for i in range(n):
             corner = (np.array(int_corners[i], np.float64) * float(resolution) + np.array(origin, np.float64)).astype(np.float32)
             if layout == 0:
-                want = oracle.grid_eval(tape, corner, step, (edge, edge, edge))
+                want = oracle.grid_eval(tape, corner, step, ext)
                 assert same_bits(got[i], want), "block %d float4 differs" % i
             else:
-                want = oracle.grid_eval_pymcubes(tape, corner, step, (edge, edge, edge))
+                want = oracle.grid_eval_pymcubes(tape, corner, step, ext)
                 assert same_bits(got[i].reshape(-1), want.reshape(-1)), "block %d distances differ" % i
         out.release()
     blocks_dev.release()
@@ -72,9 +75,30 @@ def run(hip, tape, grids, block_sets):
     handle.specialize()
     for corner, step, dims in grids:
         check_dense(hip, handle, tape, corner, step, dims)
-    for int_corners, resolution, origin in block_sets:
-        check_blocks(hip, handle, tape, int_corners, resolution, origin)
+    for block_set in block_sets:
+        check_blocks(hip, handle, tape, *block_set)
     handle.release()
+
+
+def check_slab(hip, handle, tape, corner, step, dims, x0, count):
+    """hu_grid_eval_slab: planes [x0, x0 + count) of a grid, both layouts (what a rank of a multi-GPU job computes)"""
+    import torch
+    from codecad_amd.hip_util import check
+    c4 = np.zeros(4, np.float32)
+    c4[:3] = corner
+    d = (ctypes.c_uint32 * 3)(*dims)
+    fptr = ctypes.POINTER(ctypes.c_float)
+    slab = torch.full((count, dims[1], dims[2], 4), float("nan"), dtype=torch.float32, device="cuda")
+    check(hip.lib.hu_grid_eval_slab(handle.device_ptr, c4.ctypes.data_as(fptr), step, d, x0, count, 0, slab.data_ptr(), None), "slab")
+    flat = torch.full((dims[1], dims[0], dims[2]), float("nan"), dtype=torch.float32, device="cuda")
+    check(hip.lib.hu_grid_eval_slab(handle.device_ptr, c4.ctypes.data_as(fptr), step, d, x0, count, 1, flat.data_ptr(), None), "slab")
+    torch.cuda.synchronize()
+    want = oracle.grid_eval(tape, corner, step, dims)
+    assert same_bits(slab.cpu().numpy(), want[x0:x0 + count]), "slab differs"
+    wantw = oracle.grid_eval_pymcubes(tape, corner, step, dims).reshape(dims[1], dims[0], dims[2])
+    got = flat.cpu().numpy()
+    assert same_bits(got[:, x0:x0 + count], wantw[:, x0:x0 + count]), "slab of the distance grid differs"
+    assert np.isnan(got[:, :x0]).all() and np.isnan(got[:, x0 + count:]).all(), "a slab wrote outside its planes"
 
 
 @pytest.mark.parametrize("seed", range(40))
@@ -87,6 +111,26 @@ def test_random_trees_through_the_brick_kernels(hip, seed):
     blocks = [([(-8, -8, -8), (0, -8, -8), (-3, 1, 2), (8, 8, -24)], 0.25, (0.0, 0.0, 0.0)),
               ([(0, 0, 0), (16, 0, 0), (5, -7, 3)], 0.07, (-0.31, 0.12, -0.55))]
     run(hip, tape, grids, blocks)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_boxes_cut_by_the_edge_slabs_and_blocks_of_several_boxes(hip, seed):
+    from codecad_amd import hip_util, nodes
+    import codecad_amd as cc
+    rng = random.Random(9100 + seed)
+    tape = nodes.make_program(cc.examples.sponge(2 + seed % 3) if seed < 3 else random_3d(rng, rng.choice([2, 3, 4])))
+    scale = 1.0 if seed < 3 else 8.0
+    # 20 x 36 x 24: boxes of 16 and 4 along x, 16 / 16 / 4 along y, 16 and 8 along z
+    grids = [(np.array([-0.47, -0.51, -0.49]) * scale, np.float32(0.027 * scale), (20, 36, 24))]
+    blocks = [([(-16, -16, -16), (3, -5, 1)], 0.03 * scale, (0.01, -0.02, 0.0), 32),           # eight boxes per block
+              ([(-4, -10, -12), (0, 0, 0)], 0.05 * scale, (0.0, 0.0, 0.0), (8, 20, 24))]      # one box along x, two along y and z, cut
+    run(hip, tape, grids, blocks)
+    handle = hip_util.Tape(tape)
+    handle.specialize()
+    corner, step, dims = np.array([-0.5, -0.52, -0.48]) * scale, np.float32(0.031 * scale), (32, 16, 24)
+    for x0, count in ((8, 12), (0, 32), (20, 12), (12, 4)):
+        check_slab(hip, handle, tape, corner, step, dims, x0, count)
+    handle.release()
 
 
 @pytest.mark.parametrize("name", ZOO_3D)
