@@ -235,12 +235,14 @@ namespace spec_detail {
 // ---- phase 1 as a little compiler ---------------------------------------------------------------------------------
 // The distance-only program is executed SYMBOLICALLY, component by component: every coordinate of every point and
 // every distance becomes one statement `const auto t<id> = <expression of earlier values>;`, with the sample
-// coordinates it depends on noted beside it.  Three things fall out of that which record-by-record code (one exec_one
+// coordinates it depends on noted beside it.  Four things fall out of that which record-by-record code (one exec_one
 // call per record on a four-component value) could not give:
 //   * width: `auto` takes the narrowest type -- float where the two voxels of a lane cannot differ (in the brick kernels
 //     they differ in x only), f2 elsewhere (interp.hpp "values of mixed width");
-//   * hoisting: a statement that does not read the coordinate a wavefront walks along is computed once per walk (`pre`)
-//     and handed on (`h.t<id>`) -- whole primitives, single coordinates, |x| - h of a rectangle, whatever it is;
+//   * tables: a statement that reads one sample coordinate, or two, is evaluated once per sample (pair of samples) of a
+//     workgroup's box into a table in LDS and read from there by the walks ("AXIS TABLES", "PAIR TABLES" below);
+//   * hoisting: a statement that does not read the coordinate a wavefront walks along and is no table column is computed
+//     once per walk (`pre`) and handed on (`h.t<id>`);
 //   * sharing: equal expressions are one statement (the bars of a cross read the same |z| - h).
 // The arithmetic is exec_one's, operation for operation (the statement texts below restate its distance-only cases).
 struct Stmt {
@@ -518,8 +520,8 @@ inline double coordinate_limit(const Phase1& ph)
     return limit;
 }
 
-// One variant of phase 1 as text.  walk = 0: everything in place; walk = DX / DZ: the statements that do not read the
-// walk's coordinate go to `pre` (returned in a struct, one member per value the walk-dependent part reads).
+// One variant of phase 1 as text.  walk = 0: everything in place; walk = DX (the walks of a box, kernels.hpp box_eval):
+// the statements that do not read the walk's coordinate go to `pre` (returned in a struct, one member per value the walk-dependent part reads).
 struct Variant {
     std::string pre;      // body of the hoisting function ("" when nothing is hoisted)
     std::string main;     // body of the evaluation up to the root distance
@@ -561,16 +563,16 @@ inline std::vector<char> hoistable_set(const Phase1& ph, uint8_t walk, int min_c
     }
     return out;
 }
-// AXIS TABLES (round 3).  A brick kernel's workgroup covers a box of the grid -- 4 x 16 x (8 G) voxels in the dense
-// kernel, a whole leaf block in k_grid_eval_blocks -- and a statement that reads ONE sample coordinate takes as many
-// distinct values in it as that axis has samples: 4 / 16 / 128, not 8 192.  Such statements are evaluated once per
-// sample of their axis into a table in LDS (`tape_tab_*`, called by the kernel before its walks) and the walks read
-// them there (one ds_read where a chain of remainder / fma / |x| - h was recomputed in every brick by every lane).
-// The arithmetic is the same statement on the same coordinate value, so the bits are the same.  Candidates: phase 1's
-// single-axis values worth at least `min_cost` instructions; which of them become table columns is decided by the
-// walk-dependent code that reads them (render_walk below).
+// AXIS TABLES (round 3).  A workgroup of the grid kernels covers a BOX of up to 16 x 16 x 16 voxels (kernels.hpp
+// box_eval), and a statement that reads ONE sample coordinate takes as many distinct values in it as that axis has
+// samples: 16, not 4096.  Such statements are evaluated once per sample of their axis into a table in LDS (`tape_tab_x_*`,
+// called by the kernel before its walks) and the walks read them there (one ds_read where a chain of remainder / fma /
+// |x| - h was recomputed in every brick by every lane).  The arithmetic is the same statement on the same coordinate
+// value, so the bits are the same.  Candidates: phase 1's single-axis values worth at least `min_cost` instructions; which
+// of them become table columns is decided by the code that reads them (render_variant, the direction blocks, the
+// builders of the pair tables).
 // PAIR TABLES: the same for statements that read TWO coordinates -- a bar of a cross, any extruded profile: its distance
-// takes nx * ny distinct values in a box of nx * ny * nz voxels.  In a 16^3 box (k_grid_eval_blocks) such a statement is
+// takes nx * ny distinct values in a box of nx * ny * nz voxels.  In a 16^3 box such a statement is
 // evaluated 256 times into a 2D table, from the single-axis columns, instead of 4096 times by the walks.
 // -> per statement: 0 not a candidate, 1 a single-axis column, 2 a pair column (`min_pair` = 0: no pair tables)
 inline std::vector<char> table_candidates(const Phase1& ph, int min_cost, int min_pair = 0)

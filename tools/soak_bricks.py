@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One-off soak of the brick kernels of per-tape code (dense walk along z, leaf blocks along x, hoisted distances) on
+"""One-off soak of the box kernels of per-tape code (dense grids and leaf blocks: bricks walked along x over the tables of a box) on
 seeded random CSG trees against the oracle: `soak_bricks.py [first_seed] [count]`.  tests/test_gpu_bricks.py holds the
 cases that run every time."""
 import os
