@@ -715,7 +715,8 @@ struct SpecMeta {
     int tabs[6] = {0, 0, 0, 0, 0, 0};   // columns of a box's tables: x, y, z, xy, xz, yz
 };
 constexpr int kMaxTableColumns = 48;   // per axis (a column of a 16^3 box is 64 B of LDS)
-constexpr int kMaxPairColumns = 16;    // per pair of axes (a column of a 16^3 box is 1 KiB)
+constexpr int kMaxPairColumns = 16;    // per pair of axes (a column of a 16^3 box is 1 KiB) ...
+constexpr int kMaxPairTotal = 24;      // ... and in all: the tables of a box stay below 28 KiB, five workgroups to a CU
 
 inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t max_paths = 40, SpecMeta* meta = nullptr)
 {
@@ -945,7 +946,9 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
                 for (int i = 0; i < (int)used.size(); ++i) {
                     if (!used[i]) continue;
                     const int slot = table_slot(ph.e.st[i].deps);
-                    if (n_tab[slot] < (slot < 3 ? kMaxTableColumns : kMaxPairColumns)) tab_index[i] = n_tab[slot]++;
+                    const bool fits = slot < 3 ? n_tab[slot] < kMaxTableColumns
+                                               : n_tab[slot] < kMaxPairColumns && n_tab[3] + n_tab[4] + n_tab[5] < kMaxPairTotal;
+                    if (fits) tab_index[i] = n_tab[slot]++;
                     else { over = true; used[i] = 0; }
                 }
                 if (!over) break;

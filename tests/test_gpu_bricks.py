@@ -167,3 +167,16 @@ def test_the_in_range_flag_at_its_edges(hip, scale, offset):
     res = float(scale) / 40
     blocks = [([(-16, -16, -16), (0, -8, 3)], res, tuple(centre))]
     run(hip, tape, grids, blocks)
+
+
+def test_more_pair_statements_than_table_columns(hip):
+    """Thirty cylinders along two axes: more statements of two coordinates than a box's tables have columns (specialise.hpp
+    kMaxPairColumns, kMaxPairTotal) -- the rest is computed by the walks; every float the oracle's all the same."""
+    import codecad_amd as cc
+    from codecad_amd import nodes
+    parts = [cc.shapes.cylinder(d=0.5 + 0.01 * i, h=40).translated(i * 0.7 - 7, (i % 5) * 0.9, 0) for i in range(20)]
+    parts += [cc.shapes.cylinder(d=0.4 + 0.01 * i, h=40).rotated_x(90).translated(i * 0.7 - 3, 0, (i % 3) * 1.1) for i in range(10)]
+    tape = nodes.make_program(cc.shapes.union(parts))
+    grids = [(np.array([-7.3, -1.1, -1.6]), np.float32(0.11), (32, 16, 24))]
+    blocks = [([(-60, -8, -8), (0, 0, 0), (20, 5, -3)], 0.1, (0.0, 0.0, 0.0))]
+    run(hip, tape, grids, blocks)

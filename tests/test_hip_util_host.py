@@ -160,6 +160,16 @@ def test_specialised_source_builds_under_hiprtc_without_a_device():
     rc = lib.hu_tape_compile_check(p, t.size, include_dir, ctypes.byref(size))
     assert rc == 0, lib.hu_last_error().decode()
     assert size.value > 10000
+    # more statements of two coordinates than the tables of a box have columns: the caps hold, the rest stays with the walks
+    import re
+    parts = [cc.shapes.cylinder(d=0.5 + 0.01 * i, h=40).translated(i * 0.7 - 7, (i % 5) * 0.9, 0) for i in range(20)]
+    parts += [cc.shapes.cylinder(d=0.4 + 0.01 * i, h=40).rotated_x(90).translated(i * 0.7 - 3, 0, (i % 3) * 1.1) for i in range(10)]
+    tm, pm = _tape_ptr(cc.nodes.make_program(cc.shapes.union(parts)))
+    assert lib.hu_tape_source(pm, tm.size, None, 0, ctypes.byref(needed)) == 0
+    bufm = ctypes.create_string_buffer(needed.value)
+    assert lib.hu_tape_source(pm, tm.size, bufm, needed.value, ctypes.byref(needed)) == 0
+    cols = [int(v) for v in re.search(r"table columns: (\d+) / (\d+) / (\d+) \(x / y / z\), (\d+) / (\d+) / (\d+) \(xy / xz / yz\)", bufm.value.decode()).groups()]
+    assert max(cols[:3]) <= 48 and max(cols[3:]) <= 16 and sum(cols[3:]) == 24, cols
     # a tape with a rounded blend keeps the plain straight-line form (its distance depends on directions)
     blend = cc.nodes.make_program(cc.shapes.union([cc.shapes.sphere(2), cc.shapes.box(1).translated_x(1)], r=0.3))
     tb, pb_ = _tape_ptr(blend)
