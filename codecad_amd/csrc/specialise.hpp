@@ -1003,7 +1003,8 @@ inline std::string specialised_source(const SpecProgram& p, bool allow_deferred,
 {
     std::ostringstream o, d;
     SpecMeta m;
-    const bool ok = allow_deferred && emit_deferred(d, p, 40, &m);
+    static const size_t max_paths = [] { const char* e = std::getenv("HU_MAX_PATHS"); return e && *e ? (size_t)std::atoi(e) : (size_t)40; }();
+    const bool ok = allow_deferred && emit_deferred(d, p, max_paths, &m);
     if (!ok) m = SpecMeta();
     m.deferred = ok;
     if (meta) *meta = m;

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Offline (no GPU): generate the specialised source of a tape, compile one kernel for gfx950 with
-hipcc and print its instruction mix.  Usage: python tools/spec_isa.py [sponge4|<golden tape name>] [dense|scalar]"""
+hipcc and print its instruction mix.  Usage: python tools/spec_isa.py [sponge4|<golden tape name>] [dense|scalar|blocks]
+(dense / scalar: k_grid_eval with float4 / float output; blocks: k_grid_eval_blocks with float output)"""
 import collections
 import ctypes
 import os
@@ -28,7 +29,8 @@ def source_of(tape):
 
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "sponge4"
-    layout = 1 if (len(sys.argv) > 2 and sys.argv[2] == "scalar") else 0
+    layout = 1 if (len(sys.argv) > 2 and sys.argv[2] in ("scalar", "blocks")) else 0
+    blocks = len(sys.argv) > 2 and sys.argv[2] == "blocks"
     if name.startswith("sponge"):
         tape = cc.nodes.make_program(cc.examples.sponge(int(name[6:])))
     else:
@@ -37,7 +39,13 @@ def main():
         tape = np.array({s["name"]: s for s in shapes}[name]["tape_u32"], dtype=np.uint32).view(np.float32)
     out = "/tmp/spec_isa"
     os.makedirs(out, exist_ok=True)
-    src = source_of(tape) + "\ntemplate __global__ void sdfk::k_grid_eval<sdfk::JitEval, %d, 2>(const sdfk::JitEval, float, float, float, float, uint32_t, sdfk::Dim, sdfk::Dim, uint32_t, uint32_t, uint32_t, void*);\n" % layout
+    if blocks:
+        inst = ("template __global__ void sdfk::k_grid_eval_blocks<sdfk::JitEval, 1, 2>(const sdfk::JitEval, const int4*, const uint32_t*, uint32_t, "
+                "uint32_t, uint32_t, double, double, double, double, float, uint32_t, sdfk::Dim, sdfk::Dim, void*);\n")
+    else:
+        inst = ("template __global__ void sdfk::k_grid_eval<sdfk::JitEval, %d, 2>(const sdfk::JitEval, float, float, float, float, uint32_t, "
+                "sdfk::Dim, sdfk::Dim, uint32_t, uint32_t, uint32_t, void*);\n" % layout)
+    src = source_of(tape) + "\n" + inst
     open(out + "/spec.hip", "w").write(src)
     extra = [a for a in sys.argv[3:]]
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I", ROOT + "/codecad_amd/csrc",
