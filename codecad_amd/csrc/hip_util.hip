@@ -278,10 +278,11 @@ std::string generate_source(const hu_tape_s* t, sdf::SpecMeta* meta = nullptr)
 {
     return sdf::specialised_source(t->program, defer_directions(), meta);
 }
-// LDS bytes of a box's tables (sdf::BoxTabs: 16 entries per single-axis column, 256 per pair column)
+// LDS bytes of a box's tables (sdf::BoxTabs: 16 entries per single-axis column; pair columns of 16 rows of 17 / 24 floats)
 uint32_t box_table_bytes(const SpecKernels* k)
 {
-    return (uint32_t)((k->tabs[0] + k->tabs[1] + k->tabs[2]) * 16 + (k->tabs[3] + k->tabs[4] + k->tabs[5]) * 256) * 4u;
+    return (uint32_t)((k->tabs[0] + k->tabs[1] + k->tabs[2]) * sdf::BoxTabs::kAxis + (k->tabs[3] + k->tabs[4]) * sdf::BoxTabs::kPairX +
+                      k->tabs[5] * sdf::BoxTabs::kPairYZ) * 4u;
 }
 
 void keep_programs(hu_tape_s* t, const sdf::DecodedTape& d)

@@ -1253,10 +1253,17 @@ __device__ __forceinline__ V4<T> run_tape(const Rec* __restrict__ prog, const fl
 typedef __attribute__((address_space(3))) float lds_float;
 // The tables of a 16^3 BOX (kernels.hpp box_eval): single-axis tables of 16 entries per column, and PAIR tables of 16 x 16
 // entries per column -- what the tape computes from two coordinates, evaluated once per pair of samples (specialise.hpp
-// "PAIR TABLES").  xy and xz are [y or z][x], yz is [y][z]; every pointer is this lane's entry of column 0.  X1 / XY1 /
-// XZ1: one entry (the builders of the pair tables fill one entry per lane) where the walks read a lane's two voxels.
+// "PAIR TABLES").  xy and xz are [y or z][x], yz is [y][z]; every pointer is this lane's entry of column 0.  X1: one
+// entry (the builders of the pair tables fill one entry per lane) where the walks read a lane's two voxels.
+// ROW STRIDES.  A wavefront reads a table at (its lane's y, x), (z, x) or (y, z) with lane -> (x: 2, y: 4, z: 8): half a
+// wavefront asks xy for 4 rows, xz for 8 rows, yz for 4 rows of 8 entries.  With rows of 16 floats those rows start in
+// LDS banks 0 and 16 only -- two-, four- and two-way bank conflicts on every read, and the walks do little besides
+// reading (measured: 0.178 of the leaf blocks' 0.224 ms were the walks, at half the vector ALU's rate).  Rows of 17
+// floats put the rows of xy and xz into different banks, rows of 24 floats those of yz (y * 24 mod 32 = 0, 24, 16, 8).
 struct BoxTabs {
-    static constexpr int kAxis = 16, kPair = 256;
+    static constexpr int kAxis = 16;                   // entries per column of a single-axis table
+    static constexpr int kRowX = 17, kRowYZ = 24;      // floats per row of xy / xz, of yz
+    static constexpr int kPairX = 16 * kRowX, kPairYZ = 16 * kRowYZ;   // floats per column
     const lds_float* x;
     const lds_float* y;
     const lds_float* z;
@@ -1267,9 +1274,9 @@ struct BoxTabs {
     template <int K> __device__ __forceinline__ float X1() const { return x[K * kAxis]; }
     template <int K> __device__ __forceinline__ float Y() const { return y[K * kAxis]; }
     template <int K> __device__ __forceinline__ float Z() const { return z[K * kAxis]; }
-    template <int K> __device__ __forceinline__ f2 XY() const { return make_f2(xy[K * kPair], xy[K * kPair + 2]); }
-    template <int K> __device__ __forceinline__ f2 XZ() const { return make_f2(xz[K * kPair], xz[K * kPair + 2]); }
-    template <int K> __device__ __forceinline__ float YZ() const { return yz[K * kPair]; }
+    template <int K> __device__ __forceinline__ f2 XY() const { return make_f2(xy[K * kPairX], xy[K * kPairX + 2]); }
+    template <int K> __device__ __forceinline__ f2 XZ() const { return make_f2(xz[K * kPairX], xz[K * kPairX + 2]); }
+    template <int K> __device__ __forceinline__ float YZ() const { return yz[K * kPairYZ]; }
 };
 
 // The FULL form of a record on a widened value (the second phase of per-tape code, for the ops it does not restate):

@@ -231,8 +231,8 @@ __device__ __forceinline__ void box_eval(const E& ev, float4* lds, float cx, flo
     sdf::lds_float* const ty = tx + NX * Tabs::kAxis;
     sdf::lds_float* const tz = ty + NY * Tabs::kAxis;
     sdf::lds_float* const txy = tz + NZ * Tabs::kAxis;
-    sdf::lds_float* const txz = txy + NXY * Tabs::kPair;
-    sdf::lds_float* const tyz = txz + NXZ * Tabs::kPair;
+    sdf::lds_float* const txz = txy + NXY * Tabs::kPairX;
+    sdf::lds_float* const tyz = txz + NXZ * Tabs::kPairX;
     if constexpr (NX + NY + NZ > 0) {
         if (wave == 0u) {
             if constexpr (NX > 0)
@@ -251,13 +251,16 @@ __device__ __forceinline__ void box_eval(const E& ev, float4* lds, float cx, flo
         const uint32_t r = threadIdx.x >> 4, c = threadIdx.x & 15u;
         if constexpr (NXY > 0)
             if (r < ny && c < nx)
-                ev.template tab_x_xy<Tabs::kPair>(sample(cx, step, xs0 + x0 + c), sample(cy, step, y0 + r), Tabs{tx + c, ty + r, tz, txy, txz, tyz}, txy + threadIdx.x);
+                ev.template tab_x_xy<Tabs::kPairX>(sample(cx, step, xs0 + x0 + c), sample(cy, step, y0 + r), Tabs{tx + c, ty + r, tz, txy, txz, tyz},
+                                                   txy + (r * Tabs::kRowX + c));
         if constexpr (NXZ > 0)
             if (r < nz && c < nx)
-                ev.template tab_x_xz<Tabs::kPair>(sample(cx, step, xs0 + x0 + c), sample(cz, step, z0 + r), Tabs{tx + c, ty, tz + r, txy, txz, tyz}, txz + threadIdx.x);
+                ev.template tab_x_xz<Tabs::kPairX>(sample(cx, step, xs0 + x0 + c), sample(cz, step, z0 + r), Tabs{tx + c, ty, tz + r, txy, txz, tyz},
+                                                   txz + (r * Tabs::kRowX + c));
         if constexpr (NYZ > 0)
             if (r < ny && c < nz)
-                ev.template tab_x_yz<Tabs::kPair>(sample(cy, step, y0 + r), sample(cz, step, z0 + c), Tabs{tx, ty + r, tz + c, txy, txz, tyz}, tyz + threadIdx.x);
+                ev.template tab_x_yz<Tabs::kPairYZ>(sample(cy, step, y0 + r), sample(cz, step, z0 + c), Tabs{tx, ty + r, tz + c, txy, txz, tyz},
+                                                    tyz + (r * Tabs::kRowYZ + c));
         __syncthreads();
     }
     const uint32_t nbz = nz >> 3, columns = (ny >> 2) * nbz;     // the box's (y, z) columns of bricks: at most eight
@@ -266,7 +269,8 @@ __device__ __forceinline__ void box_eval(const E& ev, float4* lds, float cx, flo
         const uint32_t yl = by * 4u + ((lane >> 3) & 3u), zl = bz * 8u + (lane & 7u);   // in the box
         const uint32_t y = y0 + yl, z = z0 + zl;
         const float py = sample(cy, step, y), pz = sample(cz, step, z);   // (one number per lane: its voxels differ in x)
-        Tabs tb{tx + (lane >> 5), ty + yl, tz + zl, txy + (yl * 16u + (lane >> 5)), txz + (zl * 16u + (lane >> 5)), tyz + (yl * 16u + zl)};
+        Tabs tb{tx + (lane >> 5), ty + yl, tz + zl, txy + (yl * Tabs::kRowX + (lane >> 5)), txz + (zl * Tabs::kRowX + (lane >> 5)),
+                tyz + (yl * Tabs::kRowYZ + zl)};
         const auto hoisted = ev.hoist_x(py, pz, tb);
 #pragma unroll 1
         for (uint32_t j = 0; j < (nx >> 2); ++j) {
