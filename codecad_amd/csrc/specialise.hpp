@@ -863,18 +863,11 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
         // (table columns are read again where a block wants them: without this the compiler keeps phase 1's copies alive)
         if (!tabc.empty()) o2 << "    asm volatile(\"\" ::: \"memory\");\n";
         o2 << "    V4<T> dir = v4<T>(bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f), bc<T>(0.0f));\n";
-        for (size_t k = 0; k < paths.size(); ++k) {
+        // the body of path k's block (`m` = its lanes): the closure of the direction's statements, up to values that live
+        // outside it, then three selects per voxel
+        auto block_body = [&](size_t k, const std::string& pad) {
             const PathCode& code = codes[k];
-            std::string mask;
-            for (size_t i = 0; i < code.mask.size(); ++i) {
-                if (code.mask[i] != '@') { mask += code.mask[i]; continue; }
-                const size_t end = code.mask.find('@', i + 1);
-                mask += outer(std::atoi(code.mask.substr(i + 1, end - i - 1).c_str()));
-                i = end;
-            }
-            o2 << "    {   // the primitive of record " << nodes[paths[k].leaf].rec << " along one path to the root\n        const M m = " << mask
-               << ";\n        if (wave_any(m)) {\n";
-            // what the block computes: the closure of the direction's statements, up to values that live outside it
+            std::ostringstream ob;
             std::vector<char> inside(st.size(), 0), loads(st.size(), 0);
             std::vector<int> stack{code.d[0], code.d[1], code.d[2]};
             while (!stack.empty()) {
@@ -890,11 +883,51 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
                 return inside[id] || loads[id] ? "u" + std::to_string(id) : outer(id);
             };
             for (int i = 0; i < (int)st.size(); ++i) {
-                if (loads[i]) o2 << "            const auto u" << i << " = " << table_load(st[i], tab_index ? (*tab_index)[i] : 0) << ";\n";
-                else if (inside[i]) o2 << "            const auto u" << i << " = " << render(st[i], name) << ";\n";
+                if (loads[i]) ob << pad << "const auto u" << i << " = " << table_load(st[i], tab_index ? (*tab_index)[i] : 0) << ";\n";
+                else if (inside[i]) ob << pad << "const auto u" << i << " = " << render(st[i], name) << ";\n";
             }
-            o2 << "            dir.x = sel(m, as<T>(" << name(code.d[0]) << "), dir.x); dir.y = sel(m, as<T>(" << name(code.d[1])
-               << "), dir.y); dir.z = sel(m, as<T>(" << name(code.d[2]) << "), dir.z);\n        }\n    }\n";
+            ob << pad << "dir.x = sel(m, as<T>(" << name(code.d[0]) << "), dir.x); dir.y = sel(m, as<T>(" << name(code.d[1])
+               << "), dir.y); dir.z = sel(m, as<T>(" << name(code.d[2]) << "), dir.z);\n";
+            return ob.str();
+        };
+        static const bool tree = [] { const char* e = std::getenv("HU_PHASE2_TREE"); return !(e && e[0] == '0'); }();
+        if (tree) {
+            // The blocks hang in the tree of the selects: a select splits its lanes between its operands (one scalar
+            // and / and-not per voxel of the lane), and an operand nobody chose is left with everything below it -- where
+            // the flat form formed every path's product of choices and tested it, 13 paths of up to six factors for
+            // sponge(4) (150 scalar instructions per brick against 95 vector ones).  collect_paths met the leaves in
+            // this order.
+            size_t next = 0;
+            std::function<void(int, const std::string&, int)> walk = [&](int at, const std::string& lanes, int depth) {
+                const Node& n = nodes[at];
+                const std::string pad(4 + 4 * (size_t)depth, ' ');
+                if (n.role == LEAF) {
+                    o2 << pad << "{   // the primitive of record " << n.rec << "\n" << pad << "    const M m = " << (lanes.empty() ? "mask_of<T>::all()" : lanes) << ";\n"
+                       << block_body(next++, pad + "    ") << pad << "}\n";
+                } else if (n.role == SELECT) {
+                    const std::string c = "as_mask(" + outer(ph.choice_of_rec[n.rec]) + ", T())", id = std::to_string(n.rec);
+                    const std::string ma = "m" + id + "a", mb = "m" + id + "b";
+                    o2 << pad << "const M " << ma << " = " << (lanes.empty() ? "" : lanes + " & ") << c << ", " << mb << " = " << (lanes.empty() ? "" : lanes + " & ") << "~" << c << ";\n"
+                       << pad << "if (wave_any(" << ma << ")) {\n";
+                    walk(n.a, ma, depth + 1);
+                    o2 << pad << "}\n" << pad << "if (wave_any(" << mb << ")) {\n";
+                    walk(n.b, mb, depth + 1);
+                    o2 << pad << "}\n";
+                } else walk(n.a, lanes, depth);
+            };
+            walk(root, "", 0);
+        } else
+        for (size_t k = 0; k < paths.size(); ++k) {
+            const PathCode& code = codes[k];
+            std::string mask;
+            for (size_t i = 0; i < code.mask.size(); ++i) {
+                if (code.mask[i] != '@') { mask += code.mask[i]; continue; }
+                const size_t end = code.mask.find('@', i + 1);
+                mask += outer(std::atoi(code.mask.substr(i + 1, end - i - 1).c_str()));
+                i = end;
+            }
+            o2 << "    {   // the primitive of record " << nodes[paths[k].leaf].rec << " along one path to the root\n        const M m = " << mask
+               << ";\n        if (wave_any(m)) {\n" << block_body(k, "            ") << "        }\n    }\n";
         }
         return o2.str();
     };
