@@ -399,24 +399,24 @@ def main():
                     "algorithmic_bytes": k_bytes, "algorithmic_bytes_note": k_note,
                     "voxels_per_s": round(k_voxels / (k_ms * 1e-3), 0), "rank": 0}
         if prof is not None:
-            # VALU issue: what actually binds this tape.  Instructions per wavefront come from the rocprofv3 PMC pass
-            # of THIS device code (the profile carries a hash of csrc/; a stale profile is ignored); the time is this run's.
-            # (per 128 voxels, not per wavefront: how many voxels a wavefront takes differs between kernels and launches)
+            # Both roofs of this launch.  `bound` stays the memory roof the north star names (algorithmic bytes / this run's
+            # kernel time / 8 TB/s; `traffic` = what the PMC passes of THIS device code counted, a stale profile is ignored);
+            # beside it the vector ALU's issue rate from the same profile's instruction count per 128 voxels -- since round
+            # 3's tables the kernel sits between the two (its stores alone and its arithmetic alone take
+            # about the same time).
             issue_rate = prof["valu_insts_per_128_voxels"] * (k_voxels / 128.0) / (k_ms * 1e-3) / 1e9
             roofline.update({
-                "bound": "valu_issue", "achieved": round(issue_rate, 2), "peak": VALU_ISSUE_PEAK,
-                "unit": "G wavefront-instructions/s", "frac": round(issue_rate / VALU_ISSUE_PEAK, 4),
                 "traffic": prof.get("hbm_traffic_bytes_per_launch"),
+                "valu_issue": {"achieved": round(issue_rate, 2), "peak": VALU_ISSUE_PEAK, "unit": "G wavefront-instructions/s",
+                               "frac": round(issue_rate / VALU_ISSUE_PEAK, 4),
+                               "note": "VALU instructions issued per second / (1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction)"},
                 "from_profile": {"file": prof["file"], "csrc_hash": prof["csrc_hash"],
                                  "valu_insts_per_128_voxels": prof["valu_insts_per_128_voxels"],
                                  "valu_insts_per_wave": prof["valu_insts_per_wave"],
-                                 "valu_issue_busy_in_profiled_run": prof.get("valu_issue_busy")},
-                "hbm": {"achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5)},
-                "note": "VALU-issue-bound: frac = VALU instructions issued per second / (1024 SIMDs x 2.4 GHz / 4 cycles per "
-                        "wave64 instruction); the HBM fraction of the same launch is in `hbm`"})
+                                 "valu_issue_busy_in_profiled_run": prof.get("valu_issue_busy")}})
         else:
             roofline["note"] = ("no rocprofv3 counter profile of this device code (csrc hash %s) is committed: only the HBM "
-                                "fraction is reported; the sponge tapes are VALU-issue-bound (DESIGN.md section 5)" % csrc_hash())
+                                "fraction is reported (DESIGN.md section 5)" % csrc_hash())
         roofline["algorithmic_flop_per_voxel_reference_formulas"] = flop
         line = {
             "metric": "SDF Mvoxels/s (grid_eval+subdivision), 512^3 menger_sponge" if args.config == "c3" else
