@@ -1335,6 +1335,21 @@ int hu_selftest_math(uint64_t counts[4])
     return HU_OK;
 }
 
+int hu_selftest_minmax3(uint64_t counts[3])
+{
+    if (!counts) return fail(HU_ERR_BAD_ARG, "counts is NULL");
+    unsigned long long* dev = nullptr;
+    HU_HIP(hipMalloc((void**)&dev, 3 * sizeof(unsigned long long)));
+    hipError_t e = hipMemset(dev, 0, 3 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hu_render::selftest_minmax3(dev);
+    unsigned long long host[3] = {0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpy(host, dev, sizeof host, hipMemcpyDeviceToHost);
+    (void)hipFree(dev);
+    if (e != hipSuccess) return fail(HU_ERR_HIP, std::string("hu_selftest_minmax3: ") + hipGetErrorString(e));
+    for (int i = 0; i < 3; ++i) counts[i] = host[i];
+    return HU_OK;
+}
+
 int hu_tape_source(const float* tape, size_t n, char* buf, size_t capacity, size_t* needed)
 {
     if (!tape || !needed || (!buf && capacity)) return fail(HU_ERR_BAD_ARG, "NULL argument");

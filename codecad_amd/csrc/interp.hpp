@@ -64,6 +64,14 @@ __device__ __forceinline__ f2 max_neg_(f2 a, f2 b) { f2 r; r.x = max_neg_(a.x, b
 __device__ __forceinline__ f2 min_(f2 a, f2 b) { f2 r; r.x = min_(a.x, b.x); r.y = min_(a.y, b.y); return r; }
 __device__ __forceinline__ f2 max_(f2 a, f2 b) { f2 r; r.x = max_(a.x, b.x); r.y = max_(a.y, b.y); return r; }
 __device__ __forceinline__ f2 rint_(f2 x) { return __builtin_elementwise_rint(x); }
+// min(min(a, b), c) and max(max(a, b), c) in ONE instruction: the same bits as the two it replaces for every triple of
+// special values (zeros of both signs, denormals, infinities, quiet and signalling NaNs) and 2^26 random triples --
+// hu_selftest_minmax3 runs that comparison on the device (tests/test_gpu_math.py).  Per-tape code uses them where the
+// inner result has no other reader (specialise.hpp render_variant).
+__device__ __forceinline__ float min3_(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float max3_(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ f2 min3_(f2 a, f2 b, f2 c) { f2 r; r.x = min3_(a.x, b.x, c.x); r.y = min3_(a.y, b.y, c.y); return r; }
+__device__ __forceinline__ f2 max3_(f2 a, f2 b, f2 c) { f2 r; r.x = max3_(a.x, b.x, c.x); r.y = max3_(a.y, b.y, c.y); return r; }
 // Per-voxel predicates: the lane's own flag(s) PLUS the wavefront mask of each flag, built up
 // alongside (`w` = ballot of `v`).  Every flag starts as a float compare, whose result IS its
 // wavefront mask in an SGPR pair, and &, | combine the masks with scalar instructions; so
@@ -352,6 +360,8 @@ template <class A, class B, class C> __device__ __forceinline__ auto fma_x(A a, 
 }
 template <class A, class B> __device__ __forceinline__ auto min_x(A a, B b) { using R = wider_t<A, B>; return min_(as<R>(a), as<R>(b)); }
 template <class A, class B> __device__ __forceinline__ auto max_x(A a, B b) { using R = wider_t<A, B>; return max_(as<R>(a), as<R>(b)); }
+template <class A, class B, class C> __device__ __forceinline__ auto min3_x(A a, B b, C c) { using R = wider_t<wider_t<A, B>, C>; return min3_(as<R>(a), as<R>(b), as<R>(c)); }
+template <class A, class B, class C> __device__ __forceinline__ auto max3_x(A a, B b, C c) { using R = wider_t<wider_t<A, B>, C>; return max3_(as<R>(a), as<R>(b), as<R>(c)); }
 template <class A, class B> __device__ __forceinline__ auto max_neg_x(A a, B b) { using R = wider_t<A, B>; return max_neg_(as<R>(a), as<R>(b)); }
 template <class A, class B> __device__ __forceinline__ auto lt_x(A a, B b) { using R = wider_t<A, B>; return lt(as<R>(a), as<R>(b)); }
 // a point or a result whose components have different widths, widened for an op of the library (exec_one)

@@ -26,5 +26,6 @@ hipError_t process_polygon(bool batch, const sdfk::PolygonArgs& a, dim3 grid, hi
 hipError_t mass_integrals(const double4* parents, const uint32_t* sums, uint32_t n_parents, uint32_t per_row, const uint32_t* n_parents_dev,
                           double s, double* out, uint32_t rows, hipStream_t stream);
 hipError_t selftest_math(unsigned long long* counts_dev);
+hipError_t selftest_minmax3(unsigned long long* counts_dev);
 
 }  // namespace hu_render

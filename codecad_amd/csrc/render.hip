@@ -108,6 +108,47 @@ __global__ void __launch_bounds__(256) k_selftest_math(unsigned long long* count
     atomicAdd(&counts[3], fast);
 }
 
+// min3_ / max3_ (interp.hpp) against the two instructions they replace: every ordered triple of 64 special values, then
+// 2^26 triples of random bit patterns; one and two voxels per lane.  counts[0], counts[1] <- disagreements, counts[2] <- triples
+__device__ __forceinline__ float minmax3_special(uint32_t k)
+{
+    const uint32_t mags[16] = {0x00000000u, 0x00000001u, 0x007fffffu, 0x00800000u, 0x00800001u, 0x3f7fffffu, 0x3f800000u, 0x3f800001u,
+                               0x7f7fffffu, 0x7f800000u, 0x7f800001u, 0x7fbfffffu, 0x7fc00000u, 0x7fc00001u, 0x7fffffffu, 0x40490fdbu};
+    // 64 values: the sixteen magnitudes with both signs, and the same again with another mantissa bit flipped
+    return __uint_as_float((mags[k & 15u] | ((k & 16u) << 27)) ^ ((k & 32u) ? 0x00000400u : 0u));
+}
+__global__ void __launch_bounds__(256) k_selftest_minmax3(unsigned long long* counts)
+{
+    unsigned long long bad_min = 0, bad_max = 0, n = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x, first = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    auto check = [&](float a, float b, float c) {
+        bad_min += !same_bits(sdf::min3_(a, b, c), sdf::min_(sdf::min_(a, b), c));
+        bad_max += !same_bits(sdf::max3_(a, b, c), sdf::max_(sdf::max_(a, b), c));
+        const sdf::f2 a2 = sdf::make_f2(a, c), b2 = sdf::make_f2(b, a), c2 = sdf::make_f2(c, b);
+        const sdf::f2 m = sdf::min3_(a2, b2, c2), mr = sdf::min_(sdf::min_(a2, b2), c2), M = sdf::max3_(a2, b2, c2), Mr = sdf::max_(sdf::max_(a2, b2), c2);
+        bad_min += !same_bits(m.x, mr.x) + !same_bits(m.y, mr.y);
+        bad_max += !same_bits(M.x, Mr.x) + !same_bits(M.y, Mr.y);
+        ++n;
+    };
+    for (uint64_t i = first; i < 64ull * 64ull * 64ull; i += stride)
+        check(minmax3_special((uint32_t)i & 63u), minmax3_special((uint32_t)(i >> 6) & 63u), minmax3_special((uint32_t)(i >> 12) & 63u));
+    for (uint64_t i = first; i < (1ull << 26); i += stride) {
+        uint64_t h = i * 0x9e3779b97f4a7c15ull + 0x1234567ull;       // splitmix64
+        uint32_t w[3];
+        for (int k = 0; k < 3; ++k) {
+            h += 0x9e3779b97f4a7c15ull;
+            uint64_t z = h;
+            z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+            z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+            w[k] = (uint32_t)((z ^ (z >> 31)) >> 16);
+        }
+        check(__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]));
+    }
+    if (bad_min) atomicAdd(&counts[0], bad_min);
+    if (bad_max) atomicAdd(&counts[1], bad_max);
+    atomicAdd(&counts[2], n);
+}
+
 }  // namespace
 
 namespace hu_render {
@@ -156,6 +197,12 @@ hipError_t mass_integrals(const double4* parents, const uint32_t* sums, uint32_t
 hipError_t selftest_math(unsigned long long* counts_dev)
 {
     hipLaunchKernelGGL(k_selftest_math, dim3(256 * 32), dim3(256), 0, nullptr, counts_dev);
+    return hipGetLastError();
+}
+
+hipError_t selftest_minmax3(unsigned long long* counts_dev)
+{
+    hipLaunchKernelGGL(k_selftest_minmax3, dim3(256 * 8), dim3(256), 0, nullptr, counts_dev);
     return hipGetLastError();
 }
 

@@ -660,10 +660,31 @@ inline Variant render_variant(const Phase1& ph, const std::vector<char>& hoistab
         v.pre = pre.str();
     }
     auto in_walk = [&](int i) { return st[i].ops.empty() ? st[i].text : (frontier[i] ? "h.t" : "t") + std::to_string(i); };
+    // min(min(a, b), c) -> min3(a, b, c) (and max) where this body is the inner result's only reader -- the distances of a
+    // union of several shapes when no comparison of the direction phase looks at the partial minimum (interp.hpp min3_)
+    std::vector<int> readers(n, 0), fused_inner(n, -1);
+    static const bool fuse = [] { const char* e = std::getenv("HU_MINMAX3"); return !(e && e[0] == '0'); }();
+    for (int i = 0; i < n; ++i) if (in_main[i]) for (int o : st[i].ops) ++readers[o];
+    for (int r : roots) if (r >= 0) ++readers[r];
+    std::vector<char> dead(n, 0);
+    for (int i = 0; fuse && i < n; ++i) {
+        if (!in_main[i] || st[i].ops.size() != 2) continue;
+        if (st[i].text != "min_x($0, $1)" && st[i].text != "max_x($0, $1)") continue;
+        const int j = st[i].ops[0];
+        if (!in_main[j] || readers[j] != 1 || st[j].text != st[i].text || fused_inner[j] >= 0) continue;
+        fused_inner[i] = j;
+        dead[j] = 1;
+    }
     for (int i = 0; i < n; ++i) {
         if (st[i].ops.empty()) continue;
         if (tab_read[i]) main << "    const auto t" << i << " = " << column(i) << ";\n";
-        else if (in_main[i]) main << "    const auto t" << i << " = " << render(st[i], in_walk) << ";\n";
+        else if (in_main[i] && !dead[i]) {
+            if (fused_inner[i] >= 0) {
+                const Stmt& in = st[fused_inner[i]];
+                main << "    const auto t" << i << " = " << (st[i].text[1] == 'i' ? "min3_x(" : "max3_x(") << in_walk(in.ops[0]) << ", " << in_walk(in.ops[1])
+                     << ", " << in_walk(st[i].ops[1]) << ");\n";
+            } else main << "    const auto t" << i << " = " << render(st[i], in_walk) << ";\n";
+        }
     }
     v.main = main.str();
     v.handed = frontier;

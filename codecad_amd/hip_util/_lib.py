@@ -72,6 +72,7 @@ PROTOTYPES = {
     "hu_tape_compile_cached": [_f4, _sz, _c.c_char_p, _c.c_char_p, _c.POINTER(_sz), _c.POINTER(_i)],
     "hu_tape_compile_groups": [_f4, _sz, _c.c_char_p, _c.c_char_p, _u32, _c.POINTER(_sz), _c.POINTER(_i)],
     "hu_selftest_math": [_c.POINTER(_c.c_uint64)],
+    "hu_selftest_minmax3": [_c.POINTER(_c.c_uint64)],
     "hu_tape_source": [_f4, _sz, _c.c_char_p, _sz, _c.POINTER(_sz)],
     "hu_tape_listing": [_f4, _sz, _i, _c.c_char_p, _sz, _c.POINTER(_sz)],
 }

@@ -314,6 +314,12 @@ int hu_tape_compile_groups(const float* tape, size_t n_floats, const char* inclu
  * sqrt_inv_cr's root, sqrt_inv_cr's reciprocal (all must be 0); counts[3] = inputs on the fast
  * path.  Synchronous, about 0.1 s. */
 int hu_selftest_math(uint64_t counts[4]);
+/* ... and of the three-operand minimum / maximum per-tape code uses for min(min(a, b), c) / max(max(a, b), c)
+ * (csrc/interp.hpp min3_ / max3_): every ordered triple of 64 special values (zeros of both signs, denormals,
+ * infinities, quiet and signalling NaNs) and 2^26 random triples, one and two voxels per lane, against the two
+ * instructions they replace: counts[0], counts[1] = disagreements of min3, max3 (must be 0); counts[2] = triples.
+ * Synchronous. */
+int hu_selftest_minmax3(uint64_t counts[3]);
 
 #ifdef __cplusplus
 }
