@@ -263,38 +263,49 @@ __device__ __forceinline__ void box_eval(const E& ev, float4* lds, float cx, flo
                                                     tyz + (r * Tabs::kRowYZ + c));
         __syncthreads();
     }
-    const uint32_t nbz = nz >> 3, columns = (ny >> 2) * nbz;     // the box's (y, z) columns of bricks: at most eight
-    for (uint32_t column = wave; column < columns; column += 4u) {
-        const uint32_t bz = column % nbz, by = column / nbz;
-        const uint32_t yl = by * 4u + ((lane >> 3) & 3u), zl = bz * 8u + (lane & 7u);   // in the box
-        const uint32_t y = y0 + yl, z = z0 + zl;
-        const float py = sample(cy, step, y), pz = sample(cz, step, z);   // (one number per lane: its voxels differ in x)
-        Tabs tb{tx + (lane >> 5), ty + yl, tz + zl, txy + (yl * Tabs::kRowX + (lane >> 5)), txz + (zl * Tabs::kRowX + (lane >> 5)),
-                tyz + (yl * Tabs::kRowYZ + zl)};
+    // The box's (y, z) columns of bricks, at most eight: a wavefront takes column `wave` and the one four on -- the same
+    // bricks along z, two (or, in a box eight voxels deep, four) rows of bricks further along y: what changes from its
+    // first column to its second are y and a few pointers, by constants.
+    const uint32_t nbz = nz >> 3;                                  // 1 or 2
+    const uint32_t bz = nbz == 2u ? (wave & 1u) : 0u, dby = 4u / nbz;
+    const uint32_t zl = bz * 8u + (lane & 7u), z = z0 + zl, xl = lane >> 5;
+    const float pz = sample(cz, step, z);                          // (one number per lane: its voxels differ in x)
+    uint32_t yl = (nbz == 2u ? (wave >> 1) : wave) * 4u + ((lane >> 3) & 3u);
+    Tabs col{tx + xl, ty + yl, tz + zl, txy + (yl * Tabs::kRowX + xl), txz + (zl * Tabs::kRowX + xl), tyz + (yl * Tabs::kRowYZ + zl)};
+    // where the lane's first voxel of a column goes, and the steps to its second voxel, the next brick, the next column
+    const size_t plane = (size_t)sy * sz;
+    size_t at = LAYOUT == 0 ? o.base + ((size_t)z + (size_t)sz * ((size_t)(y0 + yl) + (size_t)sy * (x0 + xl)))
+                            : o.base + ((size_t)z + ((size_t)(o.xa + x0 + xl) + (size_t)(sy - 1u - (y0 + yl)) * sx) * sz);
+    const size_t second = LAYOUT == 0 ? 2u * plane : 2u * (size_t)sz, brick = 2u * second;
+    const size_t rows = (size_t)(4u * dby) * (LAYOUT == 0 ? (size_t)sz : (size_t)sx * sz);   // LAYOUT 1 runs backwards along y
+    for (; yl < ny; yl += 4u * dby) {
+        const float py = sample(cy, step, y0 + yl);
+        Tabs tb = col;
         const auto hoisted = ev.hoist_x(py, pz, tb);
+        size_t p = at;
 #pragma unroll 1
         for (uint32_t j = 0; j < (nx >> 2); ++j) {
             // (the columns of y and z that `pre` does not hold are read again in every brick, which the compiler would
             // otherwise undo; unrolling the walk and batching its reads were measured: no gain)
             asm volatile("" ::: "memory");
-            const uint32_t x = x0 + j * 4u + (lane >> 5);
             float xs[N];
 #pragma unroll
-            for (int i = 0; i < N; ++i) xs[i] = sample(cx, step, xs0 + x + 2u * i);
+            for (int i = 0; i < N; ++i) xs[i] = sample(cx, step, xs0 + x0 + j * 4u + xl + 2u * i);
             const T px = pack(xs);
             if (LAYOUT == 0) {
                 const sdf::V4<T> r = ev.eval_hoisted_x(px, py, pz, hoisted, tb);
-                float4* p = static_cast<float4*>(o.out) + o.base + ((size_t)z + (size_t)sz * ((size_t)y + (size_t)sy * x));
 #pragma unroll
-                for (int i = 0; i < N; ++i) store_voxel(p + (size_t)i * 2u * sy * sz, sdf::voxel(r, i));
+                for (int i = 0; i < N; ++i) store_voxel(static_cast<float4*>(o.out) + p + (size_t)i * second, sdf::voxel(r, i));
             } else {
                 const T w = ev.dist_hoisted_x(px, py, pz, hoisted, tb);
-                float* p = static_cast<float*>(o.out) + o.base + ((size_t)z + ((size_t)(o.xa + x) + (size_t)(sy - 1u - y) * sx) * sz);
 #pragma unroll
-                for (int i = 0; i < N; ++i) store_voxel(p + (size_t)i * 2u * sz, sdf::get(w, i));
+                for (int i = 0; i < N; ++i) store_voxel(static_cast<float*>(o.out) + p + (size_t)i * second, sdf::get(w, i));
             }
             tb.x += 4; tb.xy += 4; tb.xz += 4;
+            p += brick;
         }
+        col.y += 4u * dby; col.xy += 4u * dby * Tabs::kRowX; col.yz += 4u * dby * Tabs::kRowYZ;
+        at = LAYOUT == 0 ? at + rows : at - rows;
     }
 }
 
