@@ -195,18 +195,27 @@ def main():
     warm_events = new_events()
     step_events = [new_events() for _ in range(args.steps)]
 
+    # (the launches' arguments are fixed: pointers and converted scalars are worked out once, a launch costs the host one C call)
+    a_args = (tape.device_ptr, corner.ctypes.data_as(fptr), step_f, dims, x0, x1 - x0, 0, dense_out.data_ptr() if dense_leg else None, stream)
+
     def launch_a():
-        check(lib.hu_grid_eval_slab(tape.device_ptr, corner.ctypes.data_as(fptr), step_f, dims, x0, x1 - x0, 0,
-                                    dense_out.data_ptr(), stream), "hu_grid_eval_slab")
+        check(lib.hu_grid_eval_slab(*a_args), "hu_grid_eval_slab")
+
+    c_args = {}
+    leaf_step_f = np.float32(leaf_int_step * resolution)
 
     def launch_c(mine):
         # the launch is sized for the list's capacity, the length is read on the device
-        cap = int(mine.shape[0]) - 1
-        if leaf_out[0] is None or leaf_out[0].shape[0] < cap:
-            leaf_out[0] = torch.empty((cap, leaf_cells), dtype=torch.float32, device=dev)
-        check(lib.hu_grid_eval_blocks_indirect(tape.device_ptr, mine[1:].data_ptr(), mine.data_ptr(), cap, resolution, origin,
-                                               np.float32(leaf_int_step * resolution), ld, 1, leaf_out[0].data_ptr(), stream),
-              "hu_grid_eval_blocks_indirect")
+        args = c_args.get(id(mine))
+        if args is None or args[0] is not leaf_out[0] or args[1] is not mine:
+            cap = int(mine.shape[0]) - 1
+            if leaf_out[0] is None or leaf_out[0].shape[0] < cap:
+                leaf_out[0] = torch.empty((cap, leaf_cells), dtype=torch.float32, device=dev)
+                c_args.clear()
+            args = (leaf_out[0], mine, (tape.device_ptr, mine[1:].data_ptr(), mine.data_ptr(), cap, resolution, origin, leaf_step_f, ld, 1,
+                                        leaf_out[0].data_ptr(), stream))
+            c_args[id(mine)] = args
+        check(lib.hu_grid_eval_blocks_indirect(*args[2]), "hu_grid_eval_blocks_indirect")
 
     def one_step(evs, k):
         ev0, ev1, ev2, evb0, evb1, evc0 = evs

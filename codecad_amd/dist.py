@@ -279,6 +279,7 @@ class LevelPipeline:
         self.top_max = max(end - begin, 1)
         self.send = [torch.zeros((c + 1, k), dtype=torch.int32, device=device) for c in self.capacities]
         self.gathered = self.mine = self.stats = None
+        self._plan = self._result = None
         if self.exchange:
             self.gathered = [torch.zeros((self.world, c + 1, k), dtype=torch.int32, device=device) for c in self.capacities]
             self.mine = [torch.zeros((c + 1, k), dtype=torch.int32, device=device) for c in self.capacities]
@@ -291,31 +292,51 @@ class LevelPipeline:
             # the kernels go to a raw hipStream_t, the collectives to torch's current stream: they must be the same one
             assert self.stream == torch.cuda.current_stream(self.device).cuda_stream, \
                 "LevelPipeline.enqueue: make the pipeline's stream torch's current stream (torch.cuda.stream(...))"
+        if self._plan is None:
+            self._plan, self._result = self._make_plan()
+        for call in self._plan:
+            call()
+        return self._result
+
+    def _make_plan(self):
+        """The traversal as a list of calls without arguments.  Every buffer of a pipeline is fixed, so what a call needs --
+        views, pointers, converted scalars -- is worked out ONCE here (`classify.bind` / `slice_rows.bind` where the callee
+        offers it: the HIP ones do); enqueue() then costs the host one C call or one torch op per item.  On eight GPUs a
+        step of the bench is ~0.1 ms of device time: the ~10 us per level this saves are a tenth of it."""
+        import functools
+
+        def bound(fn, *args, **kwargs):
+            bind = getattr(fn, "bind", None)
+            return bind(*args, **kwargs) if bind is not None else functools.partial(fn, *args, **kwargs)
+
+        plan = []
         parents, max_parents = self.top, self.top_max
         for level, capacity in enumerate(self.capacities):
             out = self.send[level]
-            out[:1].zero_()
-            self.classify(level, parents[1:], parents[0, :1], max_parents, out)
+            plan.append(out[:1].zero_)
+            plan.append(bound(self.classify, level, parents[1:], parents[0, :1], max_parents, out))
             if not self.exchange:
                 parents = out
             elif level == 0 and self.replicate_first:
                 # every rank holds the whole (identical) list: its share, no collective
-                self.slice_rows(out.unsqueeze(0), self.rank, self.mine[level], self.stats[level], sharers=self.world)
+                plan.append(bound(self.slice_rows, out.unsqueeze(0), self.rank, self.mine[level], self.stats[level], sharers=self.world))
                 parents = self.mine[level]
             else:
                 g = self.gathered[level]
                 if g.device.type != "cpu" and _host_staged():     # several ranks on one GPU through gloo: rehearsal only
-                    host = [torch.empty(out.shape, dtype=out.dtype) for _ in range(self.world)]
-                    dist.all_gather(host, out.cpu())
-                    g.copy_(torch.stack(host))
+                    def staged(g=g, out=out):
+                        host = [torch.empty(out.shape, dtype=out.dtype) for _ in range(self.world)]
+                        dist.all_gather(host, out.cpu())
+                        g.copy_(torch.stack(host))
+                    plan.append(staged)
                 elif g.device.type == "cpu":
-                    dist.all_gather(list(g.unbind(0)), out)
+                    plan.append(functools.partial(dist.all_gather, list(g.unbind(0)), out))
                 else:
-                    dist.all_gather_into_tensor(g, out)
-                self.slice_rows(g, self.rank, self.mine[level], self.stats[level])
+                    plan.append(functools.partial(dist.all_gather_into_tensor, g, out))
+                plan.append(bound(self.slice_rows, g, self.rank, self.mine[level], self.stats[level]))
                 parents = self.mine[level]
             max_parents = capacity
-        return parents
+        return plan, parents
 
     def check(self):
         """Wait for the traversal and validate it.  Returns the global survivor count of every level; raises
@@ -339,15 +360,28 @@ class LevelPipeline:
 
 
 def _hip_slice_rows(lib, check, stream):
-    def slice_rows(gathered, rank, out, stats, sharers=None):
+    def bind(gathered, rank, out, stats, sharers=None):
+        """-> the call without arguments (LevelPipeline._make_plan): pointers and sizes worked out once"""
         row_bytes = int(gathered.shape[2]) * gathered.element_size()
         if sharers is None:
-            check(lib.hu_slice_rows(gathered.data_ptr(), int(gathered.shape[0]), int(gathered.shape[1]), row_bytes, rank, out.data_ptr(),
-                                    int(out.shape[0]) - 1, stats.data_ptr(), stream), "hu_slice_rows")
+            fn, name = lib.hu_slice_rows, "hu_slice_rows"
+            args = (gathered.data_ptr(), int(gathered.shape[0]), int(gathered.shape[1]), row_bytes, rank, out.data_ptr(),
+                    int(out.shape[0]) - 1, stats.data_ptr(), stream)
         else:
             assert int(gathered.shape[0]) == 1
-            check(lib.hu_slice_rows_of(gathered.data_ptr(), int(gathered.shape[1]), row_bytes, rank, int(sharers), out.data_ptr(),
-                                       int(out.shape[0]) - 1, stats.data_ptr(), stream), "hu_slice_rows_of")
+            fn, name = lib.hu_slice_rows_of, "hu_slice_rows_of"
+            args = (gathered.data_ptr(), int(gathered.shape[1]), row_bytes, rank, int(sharers), out.data_ptr(),
+                    int(out.shape[0]) - 1, stats.data_ptr(), stream)
+        keep = (gathered, out, stats)      # (the pointers stay valid as long as the call does)
+
+        def run():
+            check(fn(*args), name)
+            return keep
+        return run
+
+    def slice_rows(gathered, rank, out, stats, sharers=None):
+        bind(gathered, rank, out, stats, sharers)()
+    slice_rows.bind = bind
     return slice_rows
 
 
@@ -364,15 +398,26 @@ def subdivision_pipeline(tape, levels, resolution, origin, dimension, capacities
     lib = hip_manager.lib
     o = (ctypes.c_double * 3)(*[float(v) for v in origin])
 
-    def classify(level, parents, n_parents, max_parents, out):
+    def bind(level, parents, n_parents, max_parents, out):
+        """-> the launch without arguments (LevelPipeline._make_plan): pointers, sizes and converted scalars worked out once"""
         int_step, dims = levels[level]
         d = (ctypes.c_uint32 * 3)(int(dims[0]), int(dims[1]), int(dims[2]))
         box_step = int_step * resolution
         thr = box_step * math.sqrt(dimension) / 2
-        check(lib.hu_subdivision_level_indirect(tape.device_ptr, parents.data_ptr(), n_parents.data_ptr(), int(max_parents),
-                                                int(int_step), d, dimension, float(resolution), o, numpy.float32(box_step),
-                                                numpy.float32(thr), out.data_ptr(), out[1:].data_ptr(), int(out.shape[0]) - 1,
-                                                stream), "hu_subdivision_level_indirect")
+        args = (tape.device_ptr, parents.data_ptr(), n_parents.data_ptr(), int(max_parents), int(int_step), d, dimension,
+                float(resolution), o, numpy.float32(box_step), numpy.float32(thr), out.data_ptr(), out[1:].data_ptr(),
+                int(out.shape[0]) - 1, stream)
+        keep = (parents, n_parents, out, d)
+        fn = lib.hu_subdivision_level_indirect
+
+        def run():
+            check(fn(*args), "hu_subdivision_level_indirect")
+            return keep
+        return run
+
+    def classify(level, parents, n_parents, max_parents, out):
+        bind(level, parents, n_parents, max_parents, out)()
+    classify.bind = bind
 
     if top_rows is None:
         top_rows = torch.zeros((1, 4), dtype=torch.int32, device=device)
