@@ -708,6 +708,21 @@ int launch_classify(hu_tape t, ClassifyArgs& a, uint32_t n_parents, const uint32
         a.dy = make_dim(dims[1]); a.dz = make_dim(dims[2]);
         a.chunks = (uint32_t)((cells + per_block - 1) / per_block);
         a.scratch_offset = 0;
+        a.boxes = 0;
+        // Grids of more than one workgroup's worth of cells go over 16^3 boxes with their tables in LDS (kernels.hpp
+        // k_classify / box_eval) where the extents allow it.  (Up to 256 cells the lane-order compaction of ONE workgroup
+        // is what dist.LevelPipeline's replicate_first relies on: that path stays as it is.)
+        // And only launches that fill the chip several times over: a box is one workgroup where the path below has eight,
+        // and a level of a few hundred parents is a latency exercise (measured: C5's 704 parents of 16^3 0.21 -> 0.33 ms
+        // over boxes; C3's mass properties at grid 8, 167 000 parents in the last level, 0.94 -> 0.80 ms).
+        const uint64_t bxn = (dims[0] + 15u) / 16u, byn = (dims[1] + 15u) / 16u, bzn = (dims[2] + 15u) / 16u;
+        uint64_t enough = 8192u;
+        if (const char* e = getenv("HU_CLASSIFY_BOX_MIN")) enough = (uint64_t)atoll(e);   // (read per launch: the tests switch it)
+        if (t->spec->deferred && cells > 256u && brick_tiles(dims[0], dims[1], dims[2]) && bxn * byn * bzn * n_parents >= enough) {
+            a.boxes = ((uint32_t)byn << 16) | (uint32_t)bzn;
+            a.chunks = (uint32_t)(bxn * byn * bzn);
+            a.scratch_offset = box_table_bytes(t->spec);
+        }
         // (mass-property parents are fp64 corners on the device: their magnitude is not the host's to know)
         const double extent = (double)a.step * (double)std::max(dims[0], std::max(dims[1], dims[2]));
         const float c3[3] = {a.cx, a.cy, a.cz};
@@ -721,7 +736,7 @@ int launch_classify(hu_tape t, ClassifyArgs& a, uint32_t n_parents, const uint32
             void* args[] = {&ev, &a};
             HU_HIP(hipModuleLaunchKernel(t->spec->classify[MASS ? 1 : 0][BATCH ? 1 : 0],
                                          a.chunks * (n_parents - p0 < piece ? n_parents - p0 : piece), 1, 1, kSpecBlock, 1, 1,
-                                         (unsigned)kScratchBytes, (hipStream_t)stream, args, nullptr));
+                                         (unsigned)(a.scratch_offset + kScratchBytes), (hipStream_t)stream, args, nullptr));
         }
         return HU_OK;
     }
@@ -736,6 +751,7 @@ int launch_classify(hu_tape t, ClassifyArgs& a, uint32_t n_parents, const uint32
     const uint32_t per_block = ls.block * ls.voxels_per_lane;
     a.chunks = (uint32_t)((cells + per_block - 1) / per_block);
     a.scratch_offset = (uint32_t)ls.regfile_bytes;
+    a.boxes = 0;
     const dim3 block(ls.block);
     const bool d_only = distance_only(t);
     const uint32_t piece = units_per_launch(a.chunks, ls.block);

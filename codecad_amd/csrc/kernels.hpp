@@ -217,14 +217,15 @@ struct BoxOut {
 // TABLES", "PAIR TABLES"): what the tape computes from one coordinate, once per sample of that axis; then what it computes
 // from two, once per PAIR of samples (16 x 16 evaluations where the walks would make 4096) -- the bars of a cross, any
 // extruded profile.  The walks read, combine and store.  Extents: multiples of 4, 4 and 8 (the launchers).
-template <class E, int LAYOUT, int N>
-__device__ __forceinline__ void box_eval(const E& ev, float4* lds, float cx, float cy, float cz, float step, uint32_t xs0,
-                                         uint32_t x0, uint32_t y0, uint32_t z0, const BoxOut& o)
+// The tables of a box in LDS, filled by the whole workgroup (two barriers); -> where each table starts.
+struct BoxTables {
+    sdf::lds_float *x, *y, *z, *xy, *xz, *yz;
+};
+template <class E>
+__device__ __forceinline__ BoxTables box_tables(const E& ev, float4* lds, float cx, float cy, float cz, float step, uint32_t xs0,
+                                                uint32_t x0, uint32_t y0, uint32_t z0, uint32_t nx, uint32_t ny, uint32_t nz)
 {
-    using T = typename Pack<N>::T;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t sx = o.sxa, sy = o.sy, sz = o.sz;
-    const uint32_t nx = min(16u, o.nx - x0), ny = min(16u, sy - y0), nz = min(16u, sz - z0);
     constexpr int NX = E::kTabXX, NY = E::kTabXY, NZ = E::kTabXZ, NXY = E::kPairXY, NXZ = E::kPairXZ, NYZ = E::kPairYZ;
     using Tabs = sdf::BoxTabs;
     sdf::lds_float* const tx = (sdf::lds_float*)lds;
@@ -263,6 +264,21 @@ __device__ __forceinline__ void box_eval(const E& ev, float4* lds, float cx, flo
                                                     tyz + (r * Tabs::kRowYZ + c));
         __syncthreads();
     }
+    return BoxTables{tx, ty, tz, txy, txz, tyz};
+}
+
+template <class E, int LAYOUT, int N>
+__device__ __forceinline__ void box_eval(const E& ev, float4* lds, float cx, float cy, float cz, float step, uint32_t xs0,
+                                         uint32_t x0, uint32_t y0, uint32_t z0, const BoxOut& o)
+{
+    using T = typename Pack<N>::T;
+    using Tabs = sdf::BoxTabs;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t sx = o.sxa, sy = o.sy, sz = o.sz;
+    const uint32_t nx = min(16u, o.nx - x0), ny = min(16u, sy - y0), nz = min(16u, sz - z0);
+    const BoxTables t = box_tables(ev, lds, cx, cy, cz, step, xs0, x0, y0, z0, nx, ny, nz);
+    sdf::lds_float* const tx = t.x; sdf::lds_float* const ty = t.y; sdf::lds_float* const tz = t.z;
+    sdf::lds_float* const txy = t.xy; sdf::lds_float* const txz = t.xz; sdf::lds_float* const tyz = t.yz;
     // The box's (y, z) columns of bricks, at most eight: a wavefront takes column `wave` and the one four on -- the same
     // bricks along z, two (or, in a box eight voxels deep, four) rows of bricks further along y: what changes from its
     // first column to its second are y and a few pointers, by constants.
@@ -429,7 +445,8 @@ struct ClassifyArgs {
     void* list;            // !BATCH: uchar4[]; BATCH: int4[] / double4[] children
     uint32_t capacity;
     uint32_t* sums;        // MASS: uint32[10] per parent
-    uint32_t scratch_offset;  // bytes of LDS taken by the register file (scratch follows)
+    uint32_t scratch_offset;  // bytes of LDS taken by the register file or a box's tables (scratch follows)
+    uint32_t boxes;           // per-tape code over boxes (box_classify): boxes along y << 16 | boxes along z; chunks = boxes per parent
 };
 
 template <class E, bool MASS, bool BATCH, int N>
@@ -465,6 +482,96 @@ __global__ void __launch_bounds__(256) k_classify(const E ev, const ClassifyArgs
     }
     if (MASS) {
         if (threadIdx.x < 10) scratch[8 + threadIdx.x] = 0u;
+    }
+
+    if constexpr (E::kBricks && N == 2) {
+        if (a.boxes) {
+            // Per-tape code over a BOX of the parent's grid (box_eval: tables in LDS, bricks walked along x); what differs from
+            // the path below: cells are compacted wavefront by wavefront (one global atomic per brick that has ambiguous
+            // cells: no barrier inside the walks), the moment sums are kept per lane over a wavefront's bricks.
+            using Tabs = sdf::BoxTabs;
+            const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+            const uint32_t boxes_z = a.boxes & 0xffffu, boxes_y = a.boxes >> 16;
+            const uint32_t qz = chunk % boxes_z, qt = chunk / boxes_z, qy = qt % boxes_y, qx = qt / boxes_y;
+            const uint32_t x0 = qx * 16u, y0 = qy * 16u, z0 = qz * 16u;
+            const uint32_t nx = min(16u, a.sx - x0), ny = min(16u, a.sy - y0), nz = min(16u, a.sz - z0);
+            const BoxTables t = box_tables(ev, lds, cx, cy, cz, a.step, 0u, x0, y0, z0, nx, ny, nz);
+            if (MASS) __syncthreads();   // scratch[8..17] zeroed (a tape without tables has no barrier in box_tables)
+            const bool nothing_ambiguous = MASS && a.thr == 0.0f;
+            const uint32_t nbz = nz >> 3, bz = nbz == 2u ? (wave & 1u) : 0u, dby = 4u / nbz;
+            const uint32_t zl = bz * 8u + (lane & 7u), z = z0 + zl, xl = lane >> 5;
+            const float pz = sample(cz, a.step, z);
+            const uint64_t below = (1ull << lane) - 1ull;
+            uint32_t v[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (uint32_t yl = (nbz == 2u ? (wave >> 1) : wave) * 4u + ((lane >> 3) & 3u); yl < ny; yl += 4u * dby) {
+                const uint32_t y = y0 + yl;
+                const float py = sample(cy, a.step, y);
+                Tabs tb{t.x + xl, t.y + yl, t.z + zl, t.xy + (yl * Tabs::kRowX + xl), t.xz + (zl * Tabs::kRowX + xl), t.yz + (yl * Tabs::kRowYZ + zl)};
+                const auto hoisted = ev.hoist_x(py, pz, tb);
+#pragma unroll 1
+                for (uint32_t j = 0; j < (nx >> 2); ++j) {
+                    asm volatile("" ::: "memory");
+                    const uint32_t xv = x0 + j * 4u + xl;
+                    const T px = sdf::make_f2(sample(cx, a.step, xv), sample(cx, a.step, xv + 2u));
+                    const T w = ev.dist_hoisted_x(px, py, pz, hoisted, tb);
+                    bool amb[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const float wi = sdf::get(w, i);
+                        if (MASS) {
+                            // mass_properties.cl:31-52: inside (w <= -thr) -> moments of the integer cell index; else w < thr -> ambiguous
+                            const bool inside = wi <= -a.thr;
+                            amb[i] = !inside && (wi < a.thr);
+                            const uint32_t x = xv + 2u * (uint32_t)i, m = inside ? 1u : 0u;
+                            const uint32_t xm = inside ? x : 0u, ym = inside ? y : 0u, zm = inside ? z : 0u;
+                            v[0] += __umul24(xm, x); v[1] += __umul24(xm, y); v[2] += __umul24(xm, z); v[3] += xm;
+                            v[4] += __umul24(ym, y); v[5] += __umul24(ym, z); v[6] += ym;
+                            v[7] += __umul24(zm, z); v[8] += zm; v[9] += m;
+                        } else {
+                            amb[i] = (wi > -a.thr) && (wi < a.thr);   // subdivision.cl:25
+                        }
+                    }
+                    if (!nothing_ambiguous) {
+                        const uint64_t m0 = __ballot(amb[0]), m1 = __ballot(amb[1]);
+                        const uint32_t n0 = __popcll(m0), total = n0 + __popcll(m1);
+                        if (total) {   // wave-uniform
+                            uint32_t base = 0u;
+                            if (lane == 0u) base = atomicAdd(a.counter, total);
+                            base = __builtin_amdgcn_readfirstlane(base);
+                            const uint32_t slot[2] = {base + (uint32_t)__popcll(m0 & below), base + n0 + (uint32_t)__popcll(m1 & below)};
+#pragma unroll
+                            for (int i = 0; i < 2; ++i) {
+                                if (!(amb[i] && slot[i] < a.capacity)) continue;
+                                const uint32_t x = xv + 2u * (uint32_t)i;
+                                if (!BATCH) {
+                                    static_cast<uchar4*>(a.list)[slot[i]] = make_uchar4((unsigned char)x, (unsigned char)y, (unsigned char)z, 0);
+                                } else if (MASS) {
+                                    static_cast<double4*>(a.list)[slot[i]] =
+                                        make_double4((double)x * a.s + pcx, (double)y * a.s + pcy, (double)z * a.s + pcz, pcw);
+                                } else {
+                                    static_cast<int4*>(a.list)[slot[i]] =
+                                        make_int4(ipar.x + (int)x * a.int_step, ipar.y + (int)y * a.int_step, ipar.z + (int)z * a.int_step, ipar.w);
+                                }
+                            }
+                        }
+                    }
+                    tb.x += 4; tb.xy += 4; tb.xz += 4;
+                }
+            }
+            if (MASS) {
+#pragma unroll
+                for (int i = 0; i < 10; ++i) {
+                    const uint32_t sum = wave_sum_to_last_lane(v[i]);
+                    if (lane == 63u && sum) atomicAdd(&scratch[8 + i], sum);
+                }
+                __syncthreads();
+                if (threadIdx.x < 10) {
+                    const uint32_t total = scratch[8 + threadIdx.x];
+                    if (total) atomicAdd(&a.sums[(size_t)b * 10 + threadIdx.x], total);
+                }
+            }
+            return;
+        }
     }
 
     const uint32_t lin0 = (chunk * blockDim.x + threadIdx.x) * N;

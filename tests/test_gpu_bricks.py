@@ -180,3 +180,54 @@ def test_more_pair_statements_than_table_columns(hip):
     grids = [(np.array([-7.3, -1.1, -1.6]), np.float32(0.11), (32, 16, 24))]
     blocks = [([(-60, -8, -8), (0, 0, 0), (20, 5, -3)], 0.1, (0.0, 0.0, 0.0))]
     run(hip, tape, grids, blocks)
+
+
+def check_classify(hip, handle, tape, corner, step, dims, dimension=3):
+    """subdivision_step and mass_properties (both thresholds) of per-tape code on one grid: count, index set and the ten
+    moment sums exact (the order of the list is unspecified)."""
+    import math
+    from codecad_amd import hip_util
+    c4 = np.zeros(4, np.float32)
+    c4[:3] = corner
+    cells = dims[0] * dims[1] * dims[2]
+    counter = hip_util.Buffer(np.uint32, 1)
+    lst = hip_util.Buffer(hip_util.Buffer.quad_dtype(np.uint8), cells)
+    sums = hip_util.Buffer(np.uint32, 10)
+    thr = np.float32(float(step) * math.sqrt(dimension) / 2)
+    want_n, want = oracle.subdivision_step(tape, corner, step, thr, dims)
+    ev = counter.enqueue_fill(0)
+    hip.k.subdivision_step(dims, None, handle, c4, step, thr, counter, lst, wait_for=[ev]).wait()
+    got_n = int(counter.read()[0])
+    assert got_n == want_n
+    assert sorted(map(tuple, lst.read().view(np.uint8).reshape(-1, 4)[:got_n].tolist())) == sorted(map(tuple, want.tolist()))
+    for t in (thr, np.float32(0.0)):
+        want_sums, want_n, want = oracle.mass_properties(tape, corner, step, t, dims)
+        sums.enqueue_fill(0)
+        counter.enqueue_fill(0)
+        hip.k.mass_properties(dims, None, handle, c4, step, t, sums, counter, lst).wait()
+        assert sums.read().tolist() == want_sums.tolist()
+        got_n = int(counter.read()[0])
+        assert got_n == want_n
+        assert sorted(map(tuple, lst.read().view(np.uint8).reshape(-1, 4)[:got_n].tolist())) == sorted(map(tuple, want.tolist()))
+    for b in (counter, lst, sums):
+        b.release()
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_classification_over_boxes(hip, seed, monkeypatch):
+    """The classification kernels of per-tape code take the boxes too (kernels.hpp k_classify, grids of more than 256
+    cells with extents in multiples of (4, 4, 8)): full boxes, cut boxes, several boxes per grid."""
+    from codecad_amd import hip_util, nodes
+    import codecad_amd as cc
+    rng = random.Random(9400 + seed)
+    tape = nodes.make_program(cc.examples.sponge(2 + seed % 3) if seed < 3 else random_3d(rng, rng.choice([2, 3, 4])))
+    scale = 1.0 if seed < 3 else 8.0
+    handle = hip_util.Tape(tape)
+    handle.specialize()
+    monkeypatch.setenv("HU_CLASSIFY_BOX_MIN", "1")     # (by default only launches of thousands of boxes go over boxes)
+    for corner, step, dims in ((np.array([-0.5, -0.5, -0.5]) * scale, np.float32(scale / 16), (16, 16, 16)),
+                               (np.array([-0.47, -0.51, -0.49]) * scale, np.float32(0.033 * scale), (20, 12, 24)),
+                               (np.array([-0.52, -0.5, -0.51]) * scale, np.float32(scale / 31), (32, 32, 32)),
+                               (np.array([-0.5, -0.5, -0.25]) * scale, np.float32(scale / 8), (8, 8, 8))):
+        check_classify(hip, handle, tape, corner, step, dims)
+    handle.release()
