@@ -123,6 +123,8 @@ def test_boxes_cut_by_the_edge_slabs_and_blocks_of_several_boxes(hip, seed):
     # 20 x 36 x 24: boxes of 16 and 4 along x, 16 / 16 / 4 along y, 16 and 8 along z
     grids = [(np.array([-0.47, -0.51, -0.49]) * scale, np.float32(0.027 * scale), (20, 36, 24))]
     blocks = [([(-16, -16, -16), (3, -5, 1)], 0.03 * scale, (0.01, -0.02, 0.0), 32),           # eight boxes per block
+              ([(-24, -32, -20)], 0.02 * scale, (0.0, 0.0, 0.0), (48, 64, 40)) if seed < 4 else  # 3 x 4 x 3 boxes, cut along z
+              ([(-2, -2, -4)], 0.2 * scale, (0.0, 0.0, 0.0), (4, 4, 8)),                           # one brick
               ([(-4, -10, -12), (0, 0, 0)], 0.05 * scale, (0.0, 0.0, 0.0), (8, 20, 24))]      # one box along x, two along y and z, cut
     run(hip, tape, grids, blocks)
     handle = hip_util.Tape(tape)
