@@ -50,7 +50,10 @@ CONFIGS = {
     # name: (sponge depth, effective grid edge, dense leg?)
     "c3": (4, 512, True),
     "c5": (5, 2048, False),
+    # BASELINE config 4: mass_properties of the planetary assembly at resolution 0.25, grid 64 (run_c4 below)
+    "c4": (None, None, False),
 }
+C4_RESOLUTION, C4_GRID = 0.25, 64
 
 
 def csrc_hash():
@@ -73,6 +76,7 @@ def main():
     ap.add_argument("--weak", action="store_true", help="N objects (one per GPU) instead of one object over N GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-leg", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the comparison of the timed steps' output with the CPU oracle")
     ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph leg (steps captured once and replayed)")
     ap.add_argument("--graph", action="store_true", help="run the hipGraph leg on more than one rank too (default: one rank only)")
     ap.add_argument("--pipelines", type=int, default=None,
@@ -113,6 +117,9 @@ def main():
     m = hip_util.manager
     lib = m.lib
     dev = torch.device("cuda", local)
+    if args.config == "c4":
+        run_c4(args, real_stdout, rank, world, dev)
+        return
     depth, n_default, dense_leg = CONFIGS[args.config]
     n = args.n or n_default
     weak = args.weak and world > 1
@@ -339,8 +346,9 @@ def main():
                 interp_ms.append(elapsed(ev0, ev1))
     barrier()
     t0 = time.perf_counter()
+    last_mine = None
     for k in range(args.steps):
-        one_step(step_events.get(k), k)
+        last_mine = one_step(step_events.get(k), k)
     enqueue_s = time.perf_counter() - t0            # host time to enqueue the steps (they run behind it)
     barrier()
     wall = time.perf_counter() - t0
@@ -352,6 +360,15 @@ def main():
     # the timed traversals were not looked at while they ran: validate now (identical work every step)
     for used in pipes[:min(args.steps, n_pipes)]:
         assert used.check() == totals, "the timed steps did not reproduce the warm-up traversal"
+    # what the timed steps WROTE, against the CPU oracle, bit for bit (outside the timing; a checker, nothing measured)
+    verified = None
+    if not args.no_verify:
+        verified = verify_outputs(np, torch, host_tape, dense_out if dense_leg else None, corner, step_f, x0, n, last_mine,
+                                  leaf_out[0], resolution, (box.a.x, box.a.y, box.a.z), leaf_step_f, leaf_dims)
+        if world > 1:
+            bad = torch.tensor([0.0 if verified["ok"] else 1.0], dtype=torch.float64, device=dev)
+            verified["ranks_ok"] = bool(float(dist.allreduce_max(bad).item()) == 0.0)
+            verified["ranks"] = world
 
     # ---- the same steps captured into a hipGraph and replayed (reported beside the headline, never instead of it):
     # up to eight steps per graph + one graph for the remainder, EXACTLY --steps steps in all; what it shows is the
@@ -484,6 +501,8 @@ def main():
             line["config"]["forced_collectives"] = ("CODECAD_AMD_FORCE_COLLECTIVES=1: one rank, a real process group (backend %s): every "
                                                     "level goes through all_gather_into_tensor -> hu_slice_rows -> indirect launches"
                                                     % torch.distributed.get_backend())
+        if verified is not None:
+            line["verified"] = verified
         if interp_ms:
             line["interpreter_dense_kernel_ms"] = round(avg(interp_ms), 4)
         if hbm_leg is not None:
@@ -495,6 +514,239 @@ def main():
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         dist.barrier()
         torch.distributed.destroy_process_group()
+    if verified is not None and not (verified["ok"] and verified.get("ranks_ok", True)):
+        print("bench: the timed steps' output differs from the oracle: %s" % json.dumps(verified), file=sys.stderr)
+        sys.exit(1)
+
+
+def run_c4(args, real_stdout, rank, world, dev):
+    """`--config c4`: BASELINE config 4.  A step = ONE whole `mass_properties` integration of the planetary assembly
+    (reference examples/planetary.py:503-560 as its captured tape; driver mass_properties.py:30-229) at resolution 0.25,
+    grid 64: levels [(16, 7x7x5), (0.25, 64^3)], every level enqueued with its lists on the device (dist.MassPipeline:
+    classification -> per-level integrals; N > 1: balanced parent slices, one fixed-size all-gather per level, one final
+    all-reduce of ten doubles), nothing waits for the host inside a step.  `value` = samples classified per second, all
+    ranks.  The dominant kernel is the leaf level's launch of k_classify<., true, true, 2> (57.7 M samples); it stores
+    next to nothing (40 B of sums per parent), so its roof is the vector ALU's issue rate: `roofline.bound` says so, the
+    HBM figure beside it is there for completeness."""
+    import numpy as np
+    import torch
+    import codecad_amd as cc
+    from codecad_amd import hip_util, dist, subdivision
+    from codecad_amd.hip_util import check
+    from codecad_amd.mass_properties import finish, _KEYS
+
+    lib = hip_util.manager.lib
+    shape = cc.examples.planetary()
+    host_tape = cc.nodes.make_program(shape)
+    tape = hip_util.Tape(host_tape, policy="0")
+    evaluator = "interpreter"
+    if args.evaluator != "interpreter":
+        try:
+            tape.specialize()
+            evaluator = "specialised"
+        except RuntimeError as e:
+            if args.evaluator == "specialised":
+                raise
+            print("bench: hipRTC specialisation unavailable, using the interpreter: %s" % str(e)[:300], file=sys.stderr)
+    main_stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(main_stream)
+    stream = main_stream.cuda_stream
+    box = shape.bounding_box()
+    levels = [(C4_RESOLUTION * cell, tuple(int(v) for v in dims)) for cell, dims in
+              subdivision.calculate_block_sizes(box, 3, C4_RESOLUTION, C4_GRID, overlap=False)]
+    cells = [d[0] * d[1] * d[2] for _, d in levels]
+    capacities = subdivision.first_capacities(cells[:-1], row_bytes=32 + 40)
+
+    def barrier():
+        main_stream.synchronize()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    evs = [ctypes.c_void_p() for _ in range(2)]
+    for ev in evs:
+        check(lib.hu_event_create(ctypes.byref(ev)), "event")
+    # warm-up: settles the list capacities at what the lists need + 12 % (launches are sized for the capacity)
+    pipe, totals, partial = None, None, None
+    for _ in range(max(args.warmup, 1) + 3):
+        if pipe is None:
+            pipe = dist.MassPipeline(tape, levels, (box.a.x, box.a.y, box.a.z), capacities, dev, stream)
+            pipe.timing = {len(levels) - 1: (evs[0], evs[1])}      # HIP events around the leaf level's classification launch
+        pipe.enqueue()
+        try:
+            partial, totals = pipe.finish()
+        except dist.Overflow as e:
+            capacities, pipe = [int(v * 1.125) + 16 for v in e.needed], None
+            continue
+        tight = [int(v * 1.125) + 16 for v in pipe.pipe.needed[:-1]]
+        if any(c > t for c, t in zip(capacities, tight)):
+            capacities, pipe = tight, None
+    assert pipe is not None and totals is not None, "list capacities did not settle"
+    barrier()
+    k_ms = []
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        pipe.enqueue()
+        if args.steps <= 8 or k % max(1, args.steps // 8) == 0:      # (reading an event pair waits for that step: a sample of a long run)
+            check(lib.hu_event_synchronize(evs[1]), "sync")
+            ms = ctypes.c_float()
+            check(lib.hu_event_elapsed_ms(evs[0], evs[1], ctypes.byref(ms)), "elapsed")
+            k_ms.append(ms.value)
+    barrier()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        wall = float(dist.allreduce_max(torch.tensor([wall], dtype=torch.float64, device=dev)).item())
+    partial, totals_timed = pipe.finish()
+    assert totals_timed == totals, "the timed steps did not reproduce the warm-up traversal"
+    mp = finish(dict(zip(_KEYS, dist.allreduce_sum(partial.clone()).tolist())))
+    parents = [1] + [int(t) for t in totals]
+    samples = sum(p * c for p, c in zip(parents, cells))
+    leaf_parents_here = int((pipe.pipe.mine if pipe.pipe.exchange else pipe.pipe.send)[-2][0, 0].item())
+    verified = None
+    if not args.no_verify:
+        verified = verify_c4(np, torch, host_tape, pipe, levels, leaf_parents_here)
+        if world > 1:
+            bad = torch.tensor([0.0 if verified["ok"] else 1.0], dtype=torch.float64, device=dev)
+            verified["ranks_ok"] = bool(float(dist.allreduce_max(bad).item()) == 0.0)
+    if rank == 0:
+        kernel = "k_classify<%s, true, true, 2>" % ("JitEval" if evaluator == "specialised" else "InterpEval<true>")
+        k_avg = sum(k_ms) / len(k_ms)
+        k_samples = leaf_parents_here * cells[-1]
+        k_bytes = leaf_parents_here * (40.0 + 32.0)      # ten uint32 sums written + one 32-byte parent row read, per parent
+        prof = profile_summary(kernel, k_samples, "c4") if world == 1 else None
+        roofline = {"bound": "valu_issue", "kernel": kernel, "kernel_ms": round(k_avg, 4), "samples": k_samples,
+                    "samples_per_s": round(k_samples / (k_avg * 1e-3), 0), "unit": "G wavefront-instructions/s",
+                    "peak": VALU_ISSUE_PEAK, "achieved": None, "frac": None, "traffic": None, "rank": 0,
+                    "why": "the kernel stores 40 B per 262 144 samples: its roof is the vector ALU's issue rate (1024 SIMDs x 2.4 GHz / 4 cycles "
+                           "per wave64 instruction); the HBM figure is given for completeness",
+                    "hbm": {"algorithmic_bytes": k_bytes, "achieved_GBps": round(k_bytes / (k_avg * 1e-3) / 1e9, 3), "peak_GBps": HBM_PEAK_GBS,
+                            "frac": round(k_bytes / (k_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 7)}}
+        if prof is not None:
+            issue_rate = prof["valu_insts_per_128_voxels"] * (k_samples / 128.0) / (k_avg * 1e-3) / 1e9
+            roofline.update({"achieved": round(issue_rate, 2), "frac": round(issue_rate / VALU_ISSUE_PEAK, 4),
+                             "traffic": prof.get("hbm_traffic_bytes_per_launch"),
+                             "from_profile": {"file": prof["file"], "csrc_hash": prof["csrc_hash"],
+                                              "valu_insts_per_128_samples": prof["valu_insts_per_128_voxels"],
+                                              "vgprs": prof.get("vgprs"), "waves_per_simd_by_vgprs": prof.get("waves_per_simd"),
+                                              "valu_issue_busy_in_profiled_run": prof.get("valu_issue_busy")}})
+        else:
+            roofline["note"] = ("no rocprofv3 counter profile of this device code (csrc hash %s) is committed: the instruction count "
+                                "behind `achieved` is missing" % csrc_hash())
+        line = {"metric": "SDF Mvoxels/s (mass_properties), planetary assembly at resolution %.2f, grid %d" % (C4_RESOLUTION, C4_GRID),
+                "value": round(samples * args.steps / wall / 1e6, 1), "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "mass_properties (volume / centroid / inertia) of the planetary gearbox assembly, resolution %.2f, grid %d: "
+                                       "levels %s, ONE object over all GPUs" % (C4_RESOLUTION, C4_GRID, [(s_, list(d)) for s_, d in levels]),
+                           "baseline_config": "c4", "evaluator": evaluator, "tape_floats": int(host_tape.size),
+                           "tape_instructions": tape.n_instructions,
+                           "parallelism": "balanced parent slices + one fixed-size RCCL all-gather per level + one all-reduce of ten doubles"
+                                          if world > 1 else "single GPU"},
+                "samples_per_step": {"per_level": [p * c for p, c in zip(parents, cells)], "ambiguous_cells_per_level": totals,
+                                     "total": samples},
+                "result": {"volume": mp.volume, "centroid": [mp.centroid.x, mp.centroid.y, mp.centroid.z]},
+                "roofline": roofline}
+        if verified is not None:
+            line["verified"] = verified
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline_c4(host_tape, levels, box)
+        real_stdout.write(json.dumps(line) + "\n")
+        real_stdout.flush()
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        dist.barrier()
+        torch.distributed.destroy_process_group()
+    if verified is not None and not (verified["ok"] and verified.get("ranks_ok", True)):
+        print("bench: the timed steps' output differs from the oracle: %s" % json.dumps(verified), file=sys.stderr)
+        sys.exit(1)
+
+
+def verify_c4(np, torch, host_tape, pipe, levels, leaf_parents, blocks=6):
+    """The uint32 index sums the last timed step left for `blocks` of this rank's leaf-level parents (64^3 samples each) and
+    for the top block, against the CPU oracle's mass_properties kernel (mass_properties.cl:7-56), integer for integer."""
+    import oracle
+    rng = np.random.default_rng(20261005)
+    lp = pipe.pipe
+    out = {"ok": True, "against": "oracle/sdf_oracle.c mass_properties (CPU restatement), uint32 sums exact", "blocks": []}
+    for level in sorted({0, len(levels) - 1}):
+        s, dims = levels[level]
+        leaf = level + 1 == len(levels)
+        thr = np.float32(0.0 if leaf else s * math.sqrt(3) / 2)
+        if level == 0:
+            rows, picks = lp.top[1:2].view(torch.float64).cpu().numpy(), [0]
+        else:
+            src = lp.mine[level - 1] if lp.exchange else lp.send[level - 1]
+            rows = src[1:1 + leaf_parents].view(torch.float64).cpu().numpy()
+            picks = sorted(set(rng.integers(0, leaf_parents, blocks).tolist())) if leaf_parents else []
+        sums = pipe.sums[level].cpu().numpy().view(np.uint32)
+        for b in picks:
+            # mass_properties.py:86: shifted_corner = box_corner + splat(box_step/2), fp64, cast once
+            corner = (rows[b, :3] + s / 2).astype(np.float32)
+            want, _, _ = oracle.mass_properties(host_tape, corner, np.float32(s), thr, dims)
+            ok = bool(np.array_equal(np.asarray(want, dtype=np.uint32).reshape(-1)[:10], sums[b]))
+            out["blocks"].append({"level": level, "parent": int(b), "samples": int(dims[0] * dims[1] * dims[2]), "ok": ok})
+            out["ok"] = out["ok"] and ok
+    out["samples_checked"] = sum(b["samples"] for b in out["blocks"])
+    return out
+
+
+def cpu_baseline_c4(tape, levels, box):
+    """The CPU oracle (a port) on a bounded sample of C4: leaf-level blocks of 64^3 samples from the assembly's middle."""
+    import numpy as np
+    import oracle
+    cores = effective_cores()
+    s, dims = levels[-1]
+    mid = np.array([(box.a.x + box.b.x) / 2, (box.a.y + box.b.y) / 2, (box.a.z + box.b.z) / 2])
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < 8.0:
+        corner = (mid + np.array([(n % 3 - 1) * 16.0, ((n // 3) % 3 - 1) * 16.0, 0.0]) + s / 2).astype(np.float32)
+        oracle.mass_properties(tape, corner, np.float32(s), np.float32(0.0), dims)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(n * dims[0] * dims[1] * dims[2] / dt / 1e6, 3), "unit": "Mvoxels/s", "cores": 1, "kind": "port",
+            "sample": "oracle mass_properties (C restatement, one thread; the box has %d cores) on %d leaf-level blocks of %dx%dx%d samples of this "
+                      "tape, %.1f s wall" % (cores, n, dims[0], dims[1], dims[2], dt)}
+
+
+def verify_outputs(np, torch, host_tape, dense_out, corner, step, x0, n, mine, leaf_out, resolution, origin, leaf_step, leaf_dims,
+                   dense_samples=131072, leaf_blocks=256):
+    """Compare what the last timed step left in `dense_out` (this rank's x-slab) and `leaf_out` (this rank's leaf blocks,
+    block b of it = row b of `mine`) with the CPU oracle, bit for bit (-0 != +0, NaN == NaN): `dense_samples` voxels of
+    the slab and `leaf_blocks` whole blocks, drawn with a fixed seed.  The oracle is the checker here -- nothing of it is
+    timed or shipped (reference kernels: grid_eval.cl:2-34)."""
+    import oracle
+
+    def same(a, b):
+        a, b = np.ascontiguousarray(a, dtype=np.float32), np.ascontiguousarray(b, dtype=np.float32)
+        return bool(((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all())
+
+    rng = np.random.default_rng(20261005)
+    out = {"ok": True, "against": "oracle/sdf_oracle.c (CPU restatement), bit for bit"}
+    if dense_out is not None:
+        nx = int(dense_out.shape[0])
+        idx = np.stack([rng.integers(0, nx, dense_samples), rng.integers(0, n, dense_samples), rng.integers(0, n, dense_samples)], axis=1)
+        # sample position of grid_eval.cl:31: corner + step * (float)gid, in binary32
+        pts = corner[:3][None, :] + np.float32(step) * (idx + np.array([x0, 0, 0])).astype(np.float32)
+        ti = torch.from_numpy(idx).to(dense_out.device)
+        got = dense_out[ti[:, 0], ti[:, 1], ti[:, 2]].cpu().numpy()
+        ok = same(got, oracle.evaluate_points(host_tape, pts.astype(np.float32)))
+        out["dense_voxels"] = {"checked": int(dense_samples), "of": nx * n * n, "ok": ok}
+        out["ok"] = out["ok"] and ok
+    count = int(mine[0, 0].item())
+    if count and leaf_out is not None:
+        cells = int(leaf_dims[0]) * int(leaf_dims[1]) * int(leaf_dims[2])
+        pick = np.unique(rng.integers(0, count, min(leaf_blocks, count)))
+        rows = mine[1:1 + count][torch.from_numpy(pick).to(mine.device)].cpu().numpy()
+        got = leaf_out[torch.from_numpy(pick).to(leaf_out.device)].cpu().numpy()
+        ok = True
+        dims = tuple(int(d) for d in leaf_dims)
+        for r, g in zip(rows, got):
+            # subdivision.py:100: pos = int_pos * resolution + origin in fp64, cast once
+            c = (r[:3].astype(np.float64) * resolution + np.array(origin, dtype=np.float64)).astype(np.float32)
+            want = oracle.grid_eval_pymcubes(host_tape, c, np.float32(leaf_step), dims)
+            ok = ok and same(g.reshape(-1), np.asarray(want).reshape(-1))
+        out["leaf_blocks"] = {"checked": int(len(pick)), "of": count, "samples_checked": int(len(pick)) * cells, "ok": bool(ok)}
+        out["ok"] = out["ok"] and bool(ok)
+    return out
 
 
 def hbm_regime(lib, check, hip_util, cc, torch, np, dev, stream, n, evaluator, tapes=None):
@@ -572,7 +824,8 @@ def profile_summary(kernel, samples_per_launch, config):
                     # kernels and rounds -- round 1 dense: 721.3, round 2: 366.7
                     "valu_insts_per_128_voxels": round(c["SQ_INSTS_VALU"] / (samples_per_launch / 128.0), 2),
                     "hbm_traffic_bytes_per_launch": entry.get("hbm_traffic_bytes_per_launch"),
-                    "valu_issue_busy": entry.get("valu_issue_busy"), "profiled_avg_ms": round(entry["avg_ns"] / 1e6, 4)}
+                    "valu_issue_busy": entry.get("valu_issue_busy"), "profiled_avg_ms": round(entry["avg_ns"] / 1e6, 4),
+                    "vgprs": entry.get("vgprs"), "waves_per_simd": entry.get("waves_per_simd_by_vgprs")}
         except (ValueError, KeyError, ZeroDivisionError, TypeError):
             continue
     return best

@@ -254,8 +254,16 @@ struct Stmt {
     double g = 0.0, o = 0.0;
     bool bounded = true;
     float abs_h = -1.0f;     // the value is |x| - abs_h
+    // What box pruning knows about a DISTANCE statement ("BOX PRUNING" below): how to bound it over a box from its value at
+    // the box's centre (IV_LEAF: a function of the sample point with Lipschitz constant iv_l) or from the bounds of its
+    // operands iv_a, iv_b (the rest); IV_NONE: not a distance (a coordinate, a mask, ...)
+    uint8_t iv = 0;
+    double iv_l = 0.0;
+    float iv_c = 0.0f;
+    int iv_a = -1, iv_b = -1;
 };
 enum : uint8_t { DX = 1, DY = 2, DZ = 4 };
+enum : uint8_t { IV_NONE = 0, IV_LEAF, IV_UNKNOWN, IV_SCALE, IV_OFFSET, IV_SHELL, IV_PERP, IV_MIN, IV_MAX, IV_MAXNEG };
 
 struct Emitter {
     std::vector<Stmt> st;
@@ -316,7 +324,9 @@ inline bool symbolic_phase1(const SpecProgram& p, const std::vector<Node>& nodes
                             const std::vector<char>& keep_w, Phase1& out, std::vector<std::array<int, 3>>* points = nullptr)
 {
     Emitter& e = out.e;
-    struct Pt { int c[3] = {-1, -1, -1}; int w = -1; };
+    // lip: a Lipschitz constant of the map sample point -> this point (both in the Euclidean norm), < 0: none is known (the
+    // map jumps: repetitions, twists); rowx: the first row of a general matrix, parked until its other two rows arrive
+    struct Pt { int c[3] = {-1, -1, -1}; int w = -1; double lip = 1.0; float rowx[3] = {0.0f, 0.0f, 0.0f}; };
     std::vector<Pt> pt(nodes.size());
     out.dist_of.assign(nodes.size(), -1);
     out.choice_of_rec.assign(p.full.size(), -1);
@@ -358,6 +368,36 @@ inline bool symbolic_phase1(const SpecProgram& p, const std::vector<Node>& nodes
                      OK(c[0]) && OK(c[1]) && OK(c[2]));
     };
     auto unknown = [&](int id) { return bound(id, 0.0, 0.0, false); };
+    // interval annotations (box pruning): a leaf with the Lipschitz constant of its point, an op on bounded operands
+    auto iv_leaf = [&](int id, double lip) {
+        Stmt& s = e.st[id];
+        if (lip >= 0.0 && std::isfinite(lip) && s.bounded) { s.iv = IV_LEAF; s.iv_l = lip; }
+        else s.iv = IV_UNKNOWN;
+        return id;
+    };
+    auto iv_op = [&](int id, uint8_t kind, int a, int b = -1, float c = 0.0f) {
+        Stmt& s = e.st[id];
+        if (a >= 0 && e.st[a].iv == IV_NONE) e.st[a].iv = IV_UNKNOWN;
+        if (b >= 0 && e.st[b].iv == IV_NONE) e.st[b].iv = IV_UNKNOWN;
+        s.iv = kind; s.iv_a = a; s.iv_b = b; s.iv_c = c;
+        return id;
+    };
+    // the largest singular value of the 3 x 3 matrix with these rows (power iteration on M^T M; a hair above, never below)
+    auto matrix_norm = [](const float* r0, const float* r1, const float* r2) {
+        double m[3][3] = {{r0[0], r0[1], r0[2]}, {r1[0], r1[1], r1[2]}, {r2[0], r2[1], r2[2]}}, a[3][3];
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { a[i][j] = 0.0; for (int k = 0; k < 3; ++k) a[i][j] += m[k][i] * m[k][j]; }
+        double v[3] = {1.0, 0.7, 0.4}, lambda = 0.0;
+        for (int it = 0; it < 200; ++it) {
+            double w[3] = {0.0, 0.0, 0.0};
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) w[i] += a[i][j] * v[j];
+            const double n = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+            if (!(n > 0.0)) return 0.0;
+            lambda = n;
+            for (int i = 0; i < 3; ++i) v[i] = w[i] / n;
+        }
+        const double frob = std::sqrt(a[0][0] + a[1][1] + a[2][2]);      // (an upper bound whatever the iteration did)
+        return std::min(frob, std::sqrt(lambda) * (1.0 + 1e-6));
+    };
     // a record of the library run on widened values (ops that are rare in CAD tapes and branchy inside: polygons, gears,
     // twists, circular repetitions): last = ($0, $1, $2, $3), its register operand = ($4, $5, $6, $7)
     auto run_record = [&](const Rec& r, const int (&last)[4], const int (&operand)[4]) {
@@ -376,9 +416,10 @@ inline bool symbolic_phase1(const SpecProgram& p, const std::vector<Node>& nodes
             if (nd.a >= 0) in = pt[nd.a];
             Pt o;
             switch (op) {
-            case OPX_POINT: o.c[0] = out.px; o.c[1] = out.py; o.c[2] = out.pz; break;
+            case OPX_POINT: o.c[0] = out.px; o.c[1] = out.py; o.c[2] = out.pz; o.lip = 1.0; break;
             case OPX_TO_SCALE:
                 for (int c = 0; c < 3; ++c) o.c[c] = fma_c(in.c[c], q[0], q[4 + c]);
+                o.lip = in.lip < 0.0 ? -1.0 : in.lip * A(q[0]);
                 break;
             case OPX_TO_AXIS_X: case OPX_TO_AXIS_Y: case OPX_TO_AXIS_Z: {
                 // interp.hpp axis_rotate: (along, u, v) = the axis and the other two in cyclic order
@@ -392,26 +433,33 @@ inline bool symbolic_phase1(const SpecProgram& p, const std::vector<Node>& nodes
                 }
                 o.c[u] = ru;
                 o.c[v] = rv;
+                o.lip = in.lip < 0.0 ? -1.0 : in.lip * std::max(A(q[0]), std::hypot((double)q[1], (double)q[2]));
                 break;
             }
             case OPX_TO_ROW_X: case OPX_INIT_ROW_X: {
-                const Pt src = op == OPX_INIT_ROW_X ? Pt{{out.px, out.py, out.pz}, -1} : in;
+                Pt src = in;
+                if (op == OPX_INIT_ROW_X) { src = Pt(); src.c[0] = out.px; src.c[1] = out.py; src.c[2] = out.pz; }
                 o = src;
                 o.w = row(src.c, q);
+                for (int c = 0; c < 3; ++c) o.rowx[c] = q[c];
                 break;
             }
             case OPX_TO_ROWS_YZ: case OPX_INIT_ROWS_YZ: {
                 if (in.w < 0) return false;
-                const Pt src = op == OPX_INIT_ROWS_YZ ? Pt{{out.px, out.py, out.pz}, -1} : in;
+                Pt src = in;
+                if (op == OPX_INIT_ROWS_YZ) { src = Pt(); src.c[0] = out.px; src.c[1] = out.py; src.c[2] = out.pz; }
                 o.c[0] = in.w;
                 o.c[1] = row(src.c, q);
                 o.c[2] = row(src.c, q + 4);
+                o.lip = src.lip < 0.0 ? -1.0 : src.lip * matrix_norm(in.rowx, q, q + 4);
                 break;
             }
             case OP_REPETITION:
                 for (int c = 0; c < 3; ++c)   // remainder_t: inv == 0 (an infinite spacing) returns the coordinate itself
                     o.c[c] = q[3 + c] == 0.0f ? in.c[c] : bound(e.add("remainder_t($0, " + flit(q[c]) + ", " + flit(q[3 + c]) + ")", {in.c[c]}),
                                                                 G(in.c[c]), O(in.c[c]), OK(in.c[c]));   // (|x - n y| <= |x|: safe for huge x too)
+                // (a remainder jumps at the cell boundaries: what is computed from it is not a Lipschitz function of the sample)
+                o.lip = (q[3] == 0.0f && q[4] == 0.0f && q[5] == 0.0f) ? in.lip : -1.0;
                 break;
             case OP_MIRROR: o = in; o.c[0] = neg(in.c[0]); break;
             case OP_SYMMETRICAL_TO: o = in; o.c[0] = bound(e.add("abs_($0)", {in.c[0]}), G(in.c[0]), O(in.c[0]), OK(in.c[0])); break;
@@ -419,11 +467,13 @@ inline bool symbolic_phase1(const SpecProgram& p, const std::vector<Node>& nodes
                 o.c[0] = bound(e.add("len2_x($0, $1)", {in.c[0], in.c[2]}), G(in.c[0]) + G(in.c[2]), O(in.c[0]) + O(in.c[2]), OK(in.c[0]) && OK(in.c[2]));
                 o.c[1] = in.c[1];
                 o.c[2] = zero;
+                o.lip = in.lip;
                 break;
             case OP_CIRCULAR_REPETITION_TO: case OP_TWIST_REVOLUTION_TO: {
                 const int last[4] = {in.c[0], in.c[1], in.c[2], zero};
                 const int v = run_record(r, last, none4);
                 o.c[0] = unknown(e.add("$0.x", {v})); o.c[1] = unknown(e.add("$0.y", {v})); o.c[2] = unknown(e.add("$0.z", {v}));
+                o.lip = -1.0;
                 break;
             }
             default: return false;

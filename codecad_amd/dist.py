@@ -196,6 +196,11 @@ def run_levels(top_parents, n_levels, classify_level, hints=None):
     return parents, counts
 
 
+# The largest single top block every rank may classify for itself (LevelPipeline replicate_first): the cells one
+# workgroup of EVERY kernel variant covers -- 64 lanes x 1 voxel is the smallest launch shape there is.
+REPLICATE_FIRST_MAX_CELLS = 64
+
+
 class Overflow(RuntimeError):
     """A list of a LevelPipeline traversal was longer than its capacity (the result is incomplete)."""
 
@@ -256,7 +261,8 @@ class LevelPipeline:
     def __init__(self, top_rows, capacities, classify, slice_rows=None, device=None, stream=None, replicate_first=False):
         """replicate_first: every rank classifies the WHOLE top list itself and takes its share of the result without
         a collective (slice_rows(..., sharers=world) on its own piece).  Only valid where all ranks compute the identical
-        list in the identical order: ONE top row whose cells fit one workgroup of every kernel variant (<= 256 cells) --
+        list in the identical order: ONE top row whose cells fit one workgroup of every kernel variant
+        (<= REPLICATE_FIRST_MAX_CELLS cells) --
         the compaction order of a single workgroup is the lane order (kernels.hpp wg_compact_slots).  That is the top
         level of a hierarchy like the bench's (3 x 3 x 3 cells): one all-gather less in a latency-bound step."""
         assert top_rows.dtype == torch.int32, "rows are int32 words (view 32-byte double rows as (n, 8) int32)"
@@ -315,7 +321,8 @@ class LevelPipeline:
             out = self.send[level]
             plan.append(out[:1].zero_)
             plan.append(bound(self.classify, level, parents[1:], parents[0, :1], max_parents, out))
-            if not self.exchange:
+            if not self.exchange or (capacity == 0 and level + 1 == len(self.capacities)):
+                # (a last level that can list nothing -- the leaf level of mass properties -- has nothing to exchange)
                 parents = out
             elif level == 0 and self.replicate_first:
                 # every rank holds the whole (identical) list: its share, no collective
@@ -350,12 +357,19 @@ class LevelPipeline:
         else:
             st = self.stats.cpu().tolist()
             totals = [int(row[0]) for row in st]
+            if self.capacities[-1] == 0:        # (not exchanged, _make_plan: the count is this rank's own, and zero unless it overflowed)
+                totals[-1] = own[-1]
+            # hu_slice_rows' truncation flag: set exactly when a gathered piece or a share was cut, i.e. when the counts below
+            # say Overflow -- a flag without an overflow would be a protocol error
+            truncated = [int(row[1]) != 0 for row in st]
             biggest = allreduce_max(torch.tensor(own, dtype=torch.int64, device=self.send[0].device)).tolist()
             needed = [max(int(b), -(-t // self.world)) for b, t in zip(biggest, totals)]
             # (a replicated first level: `own` is the whole list on every rank, and that is what its buffer must hold)
         self.needed = needed      # per level: the largest list any rank held (what the capacities must cover)
         if any(n > c for n, c in zip(needed, self.capacities)):
             raise Overflow(needed)
+        if self.exchange:
+            assert not any(truncated), "hu_slice_rows reported a truncated list although no level overflowed: %s" % (st,)
         return totals
 
 
@@ -421,10 +435,12 @@ def subdivision_pipeline(tape, levels, resolution, origin, dimension, capacities
 
     if top_rows is None:
         top_rows = torch.zeros((1, 4), dtype=torch.int32, device=device)
-    # one top block of at most 256 cells (one workgroup of every kernel variant): all ranks classify it themselves
+    # one top block of at most 64 cells: ONE workgroup of every kernel variant -- the interpreter shrinks its workgroups to
+    # 128 or 64 lanes when a lane's register file is large or HU_BLOCK says so (hip_util.hip launch_shape), and with more
+    # than one workgroup the list order depends on which atomic arrives first -- so all ranks classify it themselves
     top_cells = int(levels[0][1][0]) * int(levels[0][1][1]) * int(levels[0][1][2])
     return LevelPipeline(top_rows, capacities, classify, _hip_slice_rows(lib, check, stream), device, stream,
-                         replicate_first=int(top_rows.shape[0]) == 1 and top_cells <= 256)
+                         replicate_first=int(top_rows.shape[0]) == 1 and top_cells <= REPLICATE_FIRST_MAX_CELLS)
 
 
 class MassPipeline:
@@ -444,6 +460,7 @@ class MassPipeline:
 
         lib = hip_manager.lib
         self.levels, self.device = levels, device
+        self.timing = None
         capacities = list(capacities) + [0]     # the leaf level lists nothing
         top = torch.zeros((1, 4), dtype=torch.float64, device=device)
         top[0, :3] = torch.tensor([float(v) for v in box_a], dtype=torch.float64)
@@ -463,10 +480,15 @@ class MassPipeline:
             sums, pieces = self.sums[level], self.pieces[level]
             assert int(sums.shape[0]) >= int(max_parents)
             sums.zero_()
+            events = (self.timing or {}).get(level)       # bench.py: HIP events around one level's classification launch
+            if events:
+                check(lib.hu_event_record(events[0], stream), "hu_event_record")
             check(lib.hu_mass_properties_level_indirect(tape.device_ptr, parents.data_ptr(), n_parents.data_ptr(), int(max_parents),
                                                         float(s), d, numpy.float32(s), numpy.float32(thr), sums.data_ptr(),
                                                         out.data_ptr(), out[1:].data_ptr(), int(out.shape[0]) - 1, stream),
                   "hu_mass_properties_level_indirect")
+            if events:
+                check(lib.hu_event_record(events[1], stream), "hu_event_record")
             check(lib.hu_mass_integrals_indirect(parents.data_ptr(), sums.data_ptr(), n_parents.data_ptr(), int(max_parents), float(s),
                                                  pieces.data_ptr(), int(pieces.shape[0]), stream), "hu_mass_integrals_indirect")
 

@@ -34,3 +34,21 @@ def csg_example():
 
 def sphere_plus_box():
     return shapes.sphere(130) + shapes.box(100)
+
+
+def planetary():
+    """The planetary gearbox assembly of BASELINE config C4 (reference examples/planetary.py:362-556,
+    `Planetary(...).shape()`: 560 lines of model code) as its captured instruction tape -- 1,424 floats, 467
+    instructions: 58 circles, 9 involute gears, 35 extrusions under 79 unions / intersections / subtractions --
+    with its bounding box and feature size (codecad_amd/data/planetary.json, the same data as the golden fixture
+    tests/golden/ref_tapes.json)."""
+    import json
+    import os
+    import numpy
+    from . import util
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "planetary.json")
+    with open(path) as f:
+        g = json.load(f)
+    tape = numpy.array(g["tape_u32"], dtype=numpy.uint32).view(numpy.float32)
+    box = util.BoundingBox(util.Vector(*[float(v) for v in g["bbox_a"]]), util.Vector(*[float(v) for v in g["bbox_b"]]))
+    return shapes.TapeShape(tape, box, float(g["feature_size"]))

@@ -117,15 +117,21 @@ def _dense_torch(hip, tape_obj, n, x0=0, x_count=None, layout=0):
     return out, corner, step
 
 
-def test_full_size_512_dense_properties(hip):
+@pytest.mark.parametrize("specialise", [False, True])
+def test_full_size_512_dense_properties(hip, specialise):
     """BASELINE size (512^3 sponge(4), 2 GiB of float4): slabs tile the grid exactly, a random
     sample of 200k voxels equals the oracle bit for bit, the inside fraction is the sponge's
-    volume, and the field is mirror-symmetric."""
+    volume, and the field is mirror-symmetric.  Both evaluators, each PINNED (policy "0": no background build can swap
+    the evaluator under the test; specialise=True is the launch bench.py times -- k_grid_eval<JitEval, 0, 2> over boxes)."""
     import torch
     import codecad_amd as cc
+    from codecad_amd import hip_util
     n = 512
     shape = cc.examples.sponge(4)
-    tape = cc.nodes.make_program_buffer(shape)
+    tape = hip_util.Tape(cc.nodes.make_program(shape), policy="0")
+    if specialise:
+        tape.specialize()
+    assert bool(tape.specialized) == specialise
     whole, corner, step = _dense_torch(hip, tape, n)
     # (a) x-slab sharding (what each rank of an 8-GPU job computes) reproduces the whole grid
     for x0, cnt in ((0, 64), (448, 64), (200, 37)):
@@ -607,7 +613,7 @@ def test_a_single_workgroup_compacts_in_lane_order(hip):
     res = 1 / 512
     box = shape.bounding_box().expanded_additive(res / 2)
     levels = subdivision.calculate_block_sizes(box, 3, res, 16, True)
-    assert int(levels[0][1][0]) * int(levels[0][1][1]) * int(levels[0][1][2]) <= 256
+    assert int(levels[0][1][0]) * int(levels[0][1][1]) * int(levels[0][1][2]) <= dist.REPLICATE_FIRST_MAX_CELLS
     dev = torch.device("cuda", 0)
     stream = torch.cuda.current_stream(dev).cuda_stream
     lists = []

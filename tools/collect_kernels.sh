@@ -1,15 +1,15 @@
 #!/bin/bash
 # Run ON THE GPU BOX (through gpurun): rocprofv3 PMC passes over a whole bench step, summarised PER KERNEL -- the
 # dense kernel, the leaf-block kernel (k_grid_eval_blocks) and the classification kernel (k_classify) -- for the c3
-# step and for config c5.  Counters in their own passes, only with --kernel-trace.  -> gpurun_out/prof_<tag>_kernels/
+# step and for configs c4 (planetary mass properties) and c5.  Counters in their own passes, only with --kernel-trace.  -> gpurun_out/prof_<tag>_kernels/
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_${TAG}_kernels
 rm -rf "$OUT" && mkdir -p "$OUT"
-for CFG in c3 c5; do
+for CFG in ${CFGS:-c3 c4 c5}; do
   STEPS=4; [ "$CFG" = "c5" ] && STEPS=2
-  ARGS="--config $CFG --steps $STEPS --warmup 1 --no-cpu-baseline --no-hbm-leg --no-graph"
+  ARGS="--config $CFG --steps $STEPS --warmup 1 --no-cpu-baseline --no-hbm-leg --no-graph --no-verify"
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${CFG}_stats" -- python3 bench.py $ARGS > "$OUT/${CFG}_stats.log" 2>&1
   echo "$CFG stats rc=$?"
   pass() { # name counters...
