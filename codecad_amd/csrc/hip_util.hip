@@ -234,9 +234,16 @@ struct SpecKernels {
     hipFunction_t blocks[2] = {nullptr, nullptr};
     hipFunction_t classify[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [MASS][BATCH]
     hipFunction_t ray_caster = nullptr, bitmap = nullptr;
+    hipFunction_t box_masks = nullptr;   // k_box_masks (box pruning), part of every family that launches over boxes
     bool deferred = false;   // the module was generated with deferred directions (specialise.hpp): dense launches use bricks
     double coord_limit = 0.0;   // a launch whose sample coordinates all stay below this sets sdf::kFlagInRange (specialise.hpp)
     int tabs[6] = {0, 0, 0, 0, 0, 0};   // columns of a box's tables: x, y, z, xy, xz, yz (specialise.hpp)
+    int prune_words = 0;     // 32-bit words of a box's pruning mask (0: nothing to prune in this tape)
+    int prune_bits = 0;
+    // the mask buffers of launches over boxes, one per stream that launched any (the mask kernel and the launch it prepares
+    // are neighbours on their stream, so a stream's launches can share one buffer); grown when a launch needs more
+    struct MaskBuffer { hipStream_t stream; uint32_t* ptr; size_t bytes; };
+    std::vector<MaskBuffer> mask_buffers;
 };
 
 namespace {
@@ -296,16 +303,52 @@ void keep_programs(hu_tape_s* t, const sdf::DecodedTape& d)
 
 struct SpecEval { const float* extra; uint32_t flags; };  // same layout as the generated sdfk::JitEval
 
-constexpr int kSpecKernelCount = 10;
-// the family (include/hip_util.h HU_SPEC_*) of each kernel below: a build may hold any subset of the families
+constexpr int kSpecKernelCount = 11;
+// the family (include/hip_util.h HU_SPEC_*) of each kernel below: a build may hold any subset of the families (the mask
+// kernel of box pruning belongs to every family that launches over boxes)
 constexpr uint32_t kSpecGroupOf[kSpecKernelCount] = {HU_SPEC_DENSE, HU_SPEC_DENSE, HU_SPEC_BLOCKS, HU_SPEC_BLOCKS, HU_SPEC_CLASSIFY, HU_SPEC_CLASSIFY,
-                                                      HU_SPEC_CLASSIFY, HU_SPEC_CLASSIFY, HU_SPEC_RENDER, HU_SPEC_RENDER};
+                                                      HU_SPEC_CLASSIFY, HU_SPEC_CLASSIFY, HU_SPEC_RENDER, HU_SPEC_RENDER,
+                                                      HU_SPEC_DENSE | HU_SPEC_BLOCKS | HU_SPEC_CLASSIFY};
 const char* const kSpecKernelNames[kSpecKernelCount] = {
     "sdfk::k_grid_eval<sdfk::JitEval, 0, 2>",           "sdfk::k_grid_eval<sdfk::JitEval, 1, 2>",
     "sdfk::k_grid_eval_blocks<sdfk::JitEval, 0, 2>",    "sdfk::k_grid_eval_blocks<sdfk::JitEval, 1, 2>",
     "sdfk::k_classify<sdfk::JitEval, false, false, 2>", "sdfk::k_classify<sdfk::JitEval, false, true, 2>",
     "sdfk::k_classify<sdfk::JitEval, true, false, 2>",  "sdfk::k_classify<sdfk::JitEval, true, true, 2>",
-    "sdfk::k_ray_caster<sdfk::JitEval>",                "sdfk::k_bitmap<sdfk::JitEval>"};
+    "sdfk::k_ray_caster<sdfk::JitEval>",                "sdfk::k_bitmap<sdfk::JitEval>",
+    "sdfk::k_box_masks<sdfk::JitEval>"};
+
+// Box pruning: run the tape's mask kernel for the `m.n_boxes` workgroups of the launch that follows on `stream` and hand
+// back their masks -- or NULL (nothing to prune in this tape, HU_PRUNE_RUN=0, or a buffer that would have to grow while
+// the stream is being captured into a graph): the launch then treats everything as alive.
+int prepare_masks(hu_tape_s* t, MaskArgs& m, hipStream_t stream, const uint32_t** masks)
+{
+    *masks = nullptr;
+    SpecKernels* k = t->spec;
+    if (!k || !k->box_masks || k->prune_words <= 0 || m.n_boxes == 0) return HU_OK;
+    static const bool off = [] { const char* e = getenv("HU_PRUNE_RUN"); return e && e[0] == '0'; }();
+    if (off) return HU_OK;
+    const size_t bytes = (size_t)m.n_boxes * (size_t)k->prune_words * sizeof(uint32_t);
+    SpecKernels::MaskBuffer* buf = nullptr;
+    for (auto& b : k->mask_buffers) if (b.stream == stream) buf = &b;
+    if (!buf || buf->bytes < bytes) {
+        hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+        if (stream && hipStreamIsCapturing(stream, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone) return HU_OK;
+        (void)hipGetLastError();
+        if (!buf) { k->mask_buffers.push_back(SpecKernels::MaskBuffer{stream, nullptr, 0}); buf = &k->mask_buffers.back(); }
+        // (hipFree waits for the device: a launch still reading the old buffer has finished before it goes)
+        if (buf->ptr) HU_HIP(hipFree(buf->ptr));
+        buf->ptr = nullptr; buf->bytes = 0;
+        const size_t want = bytes + bytes / 2 + 4096;
+        HU_HIP(hipMalloc((void**)&buf->ptr, want));
+        buf->bytes = want;
+    }
+    m.out = buf->ptr;
+    SpecEval ev{t->extra_dev, 0u};
+    void* args[] = {&ev, &m};
+    HU_HIP(hipModuleLaunchKernel(k->box_masks, (m.n_boxes + 63u) / 64u, 1, 1, 64, 1, 1, 0, stream, args, nullptr));
+    *masks = buf->ptr;
+    return HU_OK;
+}
 
 }  // namespace
 
@@ -506,6 +549,7 @@ int hu_tape_destroy(hu_tape t)
 {
     if (!t) return HU_OK;
     if (t->spec) {
+        for (auto& b : t->spec->mask_buffers) (void)hipFree(b.ptr);
         for (hipModule_t m : t->spec->modules) (void)hipModuleUnload(m);
         delete t->spec;
     }
@@ -552,8 +596,15 @@ int hu_grid_eval_slab(hu_tape t, const float corner[4], float step, const uint32
             uint32_t boxes = t->spec->deferred ? brick_tiles(nx, dims[1], dims[2]) : 0u;
             const uint32_t per_block = kSpecBlock * kSpecVoxelsPerLane;
             uint32_t grid = (n_cells + per_block - 1) / per_block;
-            if (boxes) grid = ((nx + 15u) / 16u) * ((dims[1] + 15u) / 16u) * ((dims[2] + 15u) / 16u);   // a workgroup per 16^3 box
-            void* args[] = {&ev, &cx, &cy, &cz, &step, &sx, &sy, &sz, &xs, &n_cells, &boxes, &o};
+            const uint32_t* masks = nullptr;
+            if (boxes) {
+                grid = ((nx + 15u) / 16u) * ((dims[1] + 15u) / 16u) * ((dims[2] + 15u) / 16u);   // a workgroup per 16^3 box
+                MaskArgs m{};
+                m.mode = 0u; m.n_boxes = grid; m.chunks = grid; m.boxes_y = (dims[1] + 15u) / 16u; m.boxes_z = (dims[2] + 15u) / 16u;
+                m.nx = nx; m.ny = dims[1]; m.nz = dims[2]; m.xs0 = xs; m.cx = cx; m.cy = cy; m.cz = cz; m.step = step;
+                if ((rc = prepare_masks(t, m, (hipStream_t)stream, &masks))) return rc;
+            }
+            void* args[] = {&ev, &cx, &cy, &cz, &step, &sx, &sy, &sz, &xs, &n_cells, &boxes, &o, &masks};
             HU_HIP(hipModuleLaunchKernel(t->spec->dense[layout], grid, 1, 1, kSpecBlock, 1, 1, boxes ? box_table_bytes(t->spec) : 0u,
                                          (hipStream_t)stream, args, nullptr));
             done += nx;
@@ -575,7 +626,7 @@ int hu_grid_eval_slab(hu_tape t, const float corner[4], float step, const uint32
     hipLaunchKernelGGL((k_grid_eval<InterpEval<D>, L, NV>), dim3(blocks), dim3(ls.block), ls.lds, (hipStream_t)stream, \
                        (InterpEval<D>{ls.prog, t->extra_dev, ls.n4}), corner[0], corner[1], corner[2], step, dims[0],  \
                        make_dim(dims[1]), make_dim(dims[2]), x0 + done, n_cells,                                       \
-                       0u /* the interpreter evaluates every primitive anyway: runs along z */, o)
+                       0u /* the interpreter evaluates every primitive anyway: runs along z */, o, (const uint32_t*)nullptr)
         const bool d_only = layout == 1 && distance_only(t);
         if (ls.voxels_per_lane == 2) {
             if (layout == 0) HU_LAUNCH_DENSE(0, false, 2);
@@ -638,7 +689,15 @@ static int grid_eval_blocks_impl(hu_tape t, const int32_t* blocks_dev, uint32_t 
         for (uint32_t b0 = 0; b0 < n_blocks; b0 += piece) {
             uint32_t first = b0;
             const uint32_t count = n_blocks - b0 < piece ? n_blocks - b0 : piece;
-            void* args[] = {&ev, &b, &n_dev, &first, &chunks, &bricks, &res, &ox, &oy, &oz, &step, &sx, &sy, &sz, &out_dev};
+            const uint32_t* masks = nullptr;
+            if (bricks) {
+                MaskArgs m{};
+                m.mode = 1u; m.n_boxes = chunks * count; m.chunks = chunks; m.boxes_y = bricks >> 16; m.boxes_z = bricks & 0xffffu;
+                m.nx = dims[0]; m.ny = dims[1]; m.nz = dims[2]; m.unit_base = b0; m.units = b; m.n_units_dev = n_dev; m.step = step;
+                m.res = res; m.ox = ox; m.oy = oy; m.oz = oz;
+                if ((rc = prepare_masks(t, m, (hipStream_t)stream, &masks))) return rc;
+            }
+            void* args[] = {&ev, &b, &n_dev, &first, &chunks, &bricks, &res, &ox, &oy, &oz, &step, &sx, &sy, &sz, &out_dev, &masks};
             HU_HIP(hipModuleLaunchKernel(t->spec->blocks[layout], chunks * count, 1, 1, kSpecBlock, 1, 1,
                                          bricks ? box_table_bytes(t->spec) : 0u, (hipStream_t)stream, args, nullptr));
         }
@@ -654,7 +713,7 @@ static int grid_eval_blocks_impl(hu_tape t, const int32_t* blocks_dev, uint32_t 
 #define HU_LAUNCH_BLOCKS(L, D, NV)                                                                                 \
     hipLaunchKernelGGL((k_grid_eval_blocks<InterpEval<D>, L, NV>), grid, block, ls.lds, (hipStream_t)stream,           \
                        (InterpEval<D>{ls.prog, t->extra_dev, ls.n4}), (const int4*)blocks_dev, n_dev, b0, chunks, 0u, resolution, \
-                       origin[0], origin[1], origin[2], step, dims[0], make_dim(dims[1]), make_dim(dims[2]), out_dev)
+                       origin[0], origin[1], origin[2], step, dims[0], make_dim(dims[1]), make_dim(dims[2]), out_dev, (const uint32_t*)nullptr)
     const bool d_only = layout == 1 && distance_only(t);
     for (uint32_t b0 = 0; b0 < n_blocks; b0 += piece) {
         const dim3 grid(chunks * (n_blocks - b0 < piece ? n_blocks - b0 : piece));
@@ -733,6 +792,16 @@ int launch_classify(hu_tape t, ClassifyArgs& a, uint32_t n_parents, const uint32
         const uint32_t piece = units_per_launch(a.chunks, kSpecBlock);
         for (uint32_t p0 = 0; p0 < n_parents; p0 += piece) {
             a.parent_base = p0;
+            a.masks = nullptr;
+            if (a.boxes) {
+                MaskArgs m{};
+                m.mode = !BATCH ? 2u : MASS ? 4u : 3u;
+                m.n_boxes = a.chunks * (n_parents - p0 < piece ? n_parents - p0 : piece); m.chunks = a.chunks;
+                m.boxes_y = a.boxes >> 16; m.boxes_z = a.boxes & 0xffffu; m.nx = dims[0]; m.ny = dims[1]; m.nz = dims[2];
+                m.unit_base = p0; m.units = a.parents; m.n_units_dev = a.n_parents_dev; m.cx = a.cx; m.cy = a.cy; m.cz = a.cz; m.step = a.step;
+                m.int_step = a.int_step; m.dimension = a.dimension; m.res = a.res; m.ox = a.ox; m.oy = a.oy; m.oz = a.oz; m.s = a.s;
+                if ((rc = prepare_masks(t, m, (hipStream_t)stream, &a.masks))) return rc;
+            }
             void* args[] = {&ev, &a};
             HU_HIP(hipModuleLaunchKernel(t->spec->classify[MASS ? 1 : 0][BATCH ? 1 : 0],
                                          a.chunks * (n_parents - p0 < piece ? n_parents - p0 : piece), 1, 1, kSpecBlock, 1, 1,
@@ -752,6 +821,7 @@ int launch_classify(hu_tape t, ClassifyArgs& a, uint32_t n_parents, const uint32
     a.chunks = (uint32_t)((cells + per_block - 1) / per_block);
     a.scratch_offset = (uint32_t)ls.regfile_bytes;
     a.boxes = 0;
+    a.masks = nullptr;
     const dim3 block(ls.block);
     const bool d_only = distance_only(t);
     const uint32_t piece = units_per_launch(a.chunks, ls.block);
@@ -1259,13 +1329,15 @@ int hu_tape_specialize_groups(hu_tape t, const char* include_dir, const char* ca
             SpecKernels* k = t->spec;
             hipFunction_t* slots[kSpecKernelCount] = {&k->dense[0], &k->dense[1], &k->blocks[0], &k->blocks[1],
                                                       &k->classify[0][0], &k->classify[0][1], &k->classify[1][0], &k->classify[1][1],
-                                                      &k->ray_caster, &k->bitmap};
+                                                      &k->ray_caster, &k->bitmap, &k->box_masks};
             for (int i = 0; i < kSpecKernelCount; ++i)
                 if (kSpecGroupOf[i] & missing) *slots[i] = loaded[i];
             k->modules.push_back(module);
             k->groups |= missing;
             k->deferred = meta.deferred;
             k->coord_limit = meta.coord_limit;
+            k->prune_words = meta.prune_words;
+            k->prune_bits = meta.prune_bits;
             std::memcpy(k->tabs, meta.tabs, sizeof k->tabs);
             if (from_cache) *from_cache = cached;
             return HU_OK;
@@ -1424,6 +1496,14 @@ int hu_tape_listing(const float* tape, size_t n, int which, char* buf, size_t ca
     const std::string text = o.str();
     *needed = text.size() + 1;
     if (capacity >= text.size() + 1) std::memcpy(buf, text.c_str(), text.size() + 1);
+    return HU_OK;
+}
+
+int hu_tape_prune_info(hu_tape t, int* bits, int* words)
+{
+    if (!t) return fail(HU_ERR_BAD_ARG, "tape is NULL");
+    if (bits) *bits = t->spec ? t->spec->prune_bits : 0;
+    if (words) *words = t->spec ? t->spec->prune_words : 0;
     return HU_OK;
 }
 

@@ -1289,6 +1289,72 @@ struct BoxTabs {
     template <int K> __device__ __forceinline__ float YZ() const { return yz[K * kPairYZ]; }
 };
 
+// ---- box pruning (per-tape code, specialise.hpp "BOX PRUNING") ------------------------------------------------------
+// A box's mask: bit k set = scope k of the generated code is alive in this box.  The words are wave-uniform (one box per
+// workgroup): they sit in scalar registers, and a test is a scalar bit test and branch.
+template <int W> struct Prune {
+    uint32_t w[W > 0 ? W : 1];
+    // (the word goes through an empty volatile asm: the test stays a scalar bit test and branch where it stands.  Left to
+    // itself the compiler evaluates every test of a kernel once, ahead of the walks, as 64-bit lane masks -- 131 of them for
+    // planetary, far beyond the scalar registers: each then lives in a lane of a vector register and costs a v_readlane,
+    // its hazard s_nop and an s_and wherever it is used.)
+    template <int K> __device__ __forceinline__ bool alive() const
+    {
+        uint32_t word = w[K >> 5];
+        asm volatile("" : "+s"(word));
+        return (word >> (K & 31)) & 1u;
+    }
+};
+// a box's mask from the launch's mask buffer (NULL: nothing was decided, everything is alive)
+template <int W> __device__ __forceinline__ Prune<W> load_prune(const uint32_t* __restrict__ masks, uint32_t box)
+{
+    Prune<W> pr;
+#pragma unroll
+    for (int i = 0; i < (W > 0 ? W : 1); ++i)
+        pr.w[i] = (W > 0 && masks) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)masks[(size_t)box * W + i]) : 0xffffffffu;
+    return pr;
+}
+// the comparison of a select one of whose operands is dead: all lanes chose the survivor
+template <class M> __device__ __forceinline__ M mask_const(bool first);
+template <> __device__ __forceinline__ m1 mask_const<m1>(bool first) { return m1{first, first ? ~0ull : 0ull}; }
+template <> __device__ __forceinline__ m2 mask_const<m2>(bool first) { return m2{first, first, first ? ~0ull : 0ull, first ? ~0ull : 0ull}; }
+
+// Bounds of a distance over a box (the mask function, one box per lane; plain float arithmetic of its own -- none of it
+// reaches an output bit).  Every derived bound is moved outwards by 2^-18 of its magnitude: an order of magnitude more
+// than the one or two roundings of the operation it mirrors.
+struct Iv { float lo, hi; };
+constexpr float kIvMargin = 64.0f * 0x1p-23f;      // a leaf's margin: 64 ulps of the largest magnitude its arithmetic sees
+__device__ __forceinline__ float iv_down(float x) { return x - __builtin_fabsf(x) * 0x1p-18f; }
+__device__ __forceinline__ float iv_up(float x) { return x + __builtin_fabsf(x) * 0x1p-18f; }
+__device__ __forceinline__ float iv_hypot(float a, float b)
+{
+    a = __builtin_fabsf(a); b = __builtin_fabsf(b);
+    const float hi = __builtin_fmaxf(a, b), lo = __builtin_fminf(a, b);
+    if (!(hi > 0.0f) || hi == __builtin_inff()) return hi;
+    const float q = lo / hi;
+    return hi * __builtin_sqrtf(1.0f + q * q);
+}
+__device__ __forceinline__ Iv iv_unknown() { return Iv{-__builtin_inff(), __builtin_inff()}; }
+__device__ __forceinline__ Iv iv_zero() { return Iv{0.0f, 0.0f}; }
+__device__ __forceinline__ Iv iv_leaf(float centre, float radius, float margin)
+{
+    const float e = iv_up(radius + margin);
+    return Iv{iv_down(centre - e), iv_up(centre + e)};
+}
+__device__ __forceinline__ Iv iv_neg(Iv a) { return Iv{-a.hi, -a.lo}; }
+__device__ __forceinline__ Iv iv_scale(Iv a, float c) { return c > 0.0f ? Iv{iv_down(a.lo * c), iv_up(a.hi * c)} : Iv{iv_down(a.hi * c), iv_up(a.lo * c)}; }
+__device__ __forceinline__ Iv iv_offset(Iv a, float c) { return Iv{iv_down(a.lo - c), iv_up(a.hi - c)}; }
+__device__ __forceinline__ Iv iv_shell(Iv a, float c)
+{
+    const float least = __builtin_fmaxf(__builtin_fmaxf(a.lo, -a.hi), 0.0f), most = __builtin_fmaxf(__builtin_fabsf(a.lo), __builtin_fabsf(a.hi));
+    return Iv{iv_down(least - c), iv_up(most - c)};
+}
+// perp_w: the maximum unless both operands are positive, then the hypotenuse -- non-decreasing in both
+__device__ __forceinline__ float iv_perp1(float a, float b) { return (a > 0.0f && b > 0.0f) ? iv_hypot(a, b) : __builtin_fmaxf(a, b); }
+__device__ __forceinline__ Iv iv_perp(Iv a, Iv b) { return Iv{iv_down(iv_perp1(a.lo, b.lo)), iv_up(iv_perp1(a.hi, b.hi))}; }
+__device__ __forceinline__ Iv iv_min(Iv a, Iv b) { return Iv{__builtin_fminf(a.lo, b.lo), __builtin_fminf(a.hi, b.hi)}; }
+__device__ __forceinline__ Iv iv_max(Iv a, Iv b) { return Iv{__builtin_fmaxf(a.lo, b.lo), __builtin_fmaxf(a.hi, b.hi)}; }
+
 // The FULL form of a record on a widened value (the second phase of per-tape code, for the ops it does not restate):
 // `act` = the lanes of the path, the record's register operand in `operand`
 template <int OP, class TA, class TB, class M>

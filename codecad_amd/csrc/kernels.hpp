@@ -210,6 +210,16 @@ struct BoxOut {
     uint32_t sxa, sy, sz, xa;
     uint32_t nx;   // the slab's or block's extent along x (the boxes tile nx * sy * sz)
 };
+// A coordinate that the compiler must take as new in every iteration of a walk.  A lane's z never changes and its y only
+// from column to column, so everything the tape computes from them alone is loop-invariant to the compiler -- and it hoists
+// ALL of it (the partial sums of every general rotation: planetary's 27 frames held ~80 registers across the whole kernel,
+// one or two wavefronts per SIMD), where the generator hoists what is worth a register (tape_pre_x) and tables the rest.
+// Only for tapes with box pruning (assemblies: many frames, few of them alive in a box); the others keep their code.
+template <class E> __device__ __forceinline__ float walk_coordinate(float v)
+{
+    if constexpr (E::kPruneWords > 0) return sdf::opaque(v);
+    else return v;
+}
 // One workgroup, one BOX: up to 16 x 16 x 16 voxels at (x0, y0, z0) of a slab or block whose corner sample is (cx, cy, cz)
 // [sample index of x: xs0 + x].  A wavefront evaluates compact 4 x 4 x 8 bricks (lane -> z: 8, y: 4, x: 2, its two voxels
 // two x planes apart: a store instruction writes eight voxels along z per (x, y) row), the bricks of one (y, z) column of
@@ -221,9 +231,9 @@ struct BoxOut {
 struct BoxTables {
     sdf::lds_float *x, *y, *z, *xy, *xz, *yz;
 };
-template <class E>
+template <class E, class PR>
 __device__ __forceinline__ BoxTables box_tables(const E& ev, float4* lds, float cx, float cy, float cz, float step, uint32_t xs0,
-                                                uint32_t x0, uint32_t y0, uint32_t z0, uint32_t nx, uint32_t ny, uint32_t nz)
+                                                uint32_t x0, uint32_t y0, uint32_t z0, uint32_t nx, uint32_t ny, uint32_t nz, const PR& pr)
 {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     constexpr int NX = E::kTabXX, NY = E::kTabXY, NZ = E::kTabXZ, NXY = E::kPairXY, NXZ = E::kPairXZ, NYZ = E::kPairYZ;
@@ -252,15 +262,15 @@ __device__ __forceinline__ BoxTables box_tables(const E& ev, float4* lds, float 
         const uint32_t r = threadIdx.x >> 4, c = threadIdx.x & 15u;
         if constexpr (NXY > 0)
             if (r < ny && c < nx)
-                ev.template tab_x_xy<Tabs::kPairX>(sample(cx, step, xs0 + x0 + c), sample(cy, step, y0 + r), Tabs{tx + c, ty + r, tz, txy, txz, tyz},
+                ev.template tab_x_xy<Tabs::kPairX>(sample(cx, step, xs0 + x0 + c), sample(cy, step, y0 + r), Tabs{tx + c, ty + r, tz, txy, txz, tyz}, pr,
                                                    txy + (r * Tabs::kRowX + c));
         if constexpr (NXZ > 0)
             if (r < nz && c < nx)
-                ev.template tab_x_xz<Tabs::kPairX>(sample(cx, step, xs0 + x0 + c), sample(cz, step, z0 + r), Tabs{tx + c, ty, tz + r, txy, txz, tyz},
+                ev.template tab_x_xz<Tabs::kPairX>(sample(cx, step, xs0 + x0 + c), sample(cz, step, z0 + r), Tabs{tx + c, ty, tz + r, txy, txz, tyz}, pr,
                                                    txz + (r * Tabs::kRowX + c));
         if constexpr (NYZ > 0)
             if (r < ny && c < nz)
-                ev.template tab_x_yz<Tabs::kPairYZ>(sample(cy, step, y0 + r), sample(cz, step, z0 + c), Tabs{tx, ty + r, tz + c, txy, txz, tyz},
+                ev.template tab_x_yz<Tabs::kPairYZ>(sample(cy, step, y0 + r), sample(cz, step, z0 + c), Tabs{tx, ty + r, tz + c, txy, txz, tyz}, pr,
                                                     tyz + (r * Tabs::kRowYZ + c));
         __syncthreads();
     }
@@ -269,14 +279,16 @@ __device__ __forceinline__ BoxTables box_tables(const E& ev, float4* lds, float 
 
 template <class E, int LAYOUT, int N>
 __device__ __forceinline__ void box_eval(const E& ev, float4* lds, float cx, float cy, float cz, float step, uint32_t xs0,
-                                         uint32_t x0, uint32_t y0, uint32_t z0, const BoxOut& o)
+                                         uint32_t x0, uint32_t y0, uint32_t z0, const BoxOut& o, const uint32_t* __restrict__ masks)
 {
     using T = typename Pack<N>::T;
     using Tabs = sdf::BoxTabs;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t sx = o.sxa, sy = o.sy, sz = o.sz;
     const uint32_t nx = min(16u, o.nx - x0), ny = min(16u, sy - y0), nz = min(16u, sz - z0);
-    const BoxTables t = box_tables(ev, lds, cx, cy, cz, step, xs0, x0, y0, z0, nx, ny, nz);
+    // box pruning: which operands of the tape's selects can win anywhere in this box (k_box_masks ran before this launch)
+    const sdf::Prune<E::kPruneWords> pr = sdf::load_prune<E::kPruneWords>(masks, blockIdx.x);
+    const BoxTables t = box_tables(ev, lds, cx, cy, cz, step, xs0, x0, y0, z0, nx, ny, nz, pr);
     sdf::lds_float* const tx = t.x; sdf::lds_float* const ty = t.y; sdf::lds_float* const tz = t.z;
     sdf::lds_float* const txy = t.xy; sdf::lds_float* const txz = t.xz; sdf::lds_float* const tyz = t.yz;
     // The box's (y, z) columns of bricks, at most eight: a wavefront takes column `wave` and the one four on -- the same
@@ -297,7 +309,7 @@ __device__ __forceinline__ void box_eval(const E& ev, float4* lds, float cx, flo
     for (; yl < ny; yl += 4u * dby) {
         const float py = sample(cy, step, y0 + yl);
         Tabs tb = col;
-        const auto hoisted = ev.hoist_x(py, pz, tb);
+        const auto hoisted = ev.hoist_x(py, walk_coordinate<E>(pz), tb, pr);
         size_t p = at;
 #pragma unroll 1
         for (uint32_t j = 0; j < (nx >> 2); ++j) {
@@ -308,12 +320,13 @@ __device__ __forceinline__ void box_eval(const E& ev, float4* lds, float cx, flo
 #pragma unroll
             for (int i = 0; i < N; ++i) xs[i] = sample(cx, step, xs0 + x0 + j * 4u + xl + 2u * i);
             const T px = pack(xs);
+            const float pyb = walk_coordinate<E>(py), pzb = walk_coordinate<E>(pz);
             if (LAYOUT == 0) {
-                const sdf::V4<T> r = ev.eval_hoisted_x(px, py, pz, hoisted, tb);
+                const sdf::V4<T> r = ev.eval_hoisted_x(px, pyb, pzb, hoisted, tb, pr);
 #pragma unroll
                 for (int i = 0; i < N; ++i) store_voxel(static_cast<float4*>(o.out) + p + (size_t)i * second, sdf::voxel(r, i));
             } else {
-                const T w = ev.dist_hoisted_x(px, py, pz, hoisted, tb);
+                const T w = ev.dist_hoisted_x(px, pyb, pzb, hoisted, tb, pr);
 #pragma unroll
                 for (int i = 0; i < N; ++i) store_voxel(static_cast<float*>(o.out) + p + (size_t)i * second, sdf::get(w, i));
             }
@@ -336,7 +349,7 @@ __device__ __forceinline__ void box_eval(const E& ev, float4* lds, float cx, flo
 template <class E, int LAYOUT, int N>
 __global__ void __launch_bounds__(256) SDF_KERNEL_ATTRS
 k_grid_eval(const E ev, float cx, float cy, float cz, float step, uint32_t sx, Dim dy, Dim dz, uint32_t x0,
-            uint32_t n_cells, uint32_t boxes, void* __restrict__ out)
+            uint32_t n_cells, uint32_t boxes, void* __restrict__ out, const uint32_t* __restrict__ masks)
 {
     const uint32_t sy = dy.n, sz = dz.n;
     using T = typename Pack<N>::T;
@@ -348,10 +361,13 @@ k_grid_eval(const E ev, float cx, float cy, float cz, float step, uint32_t sx, D
             const uint32_t boxes_z = (sz + 15u) >> 4, boxes_y = (sy + 15u) >> 4;
             const uint32_t qz = blockIdx.x % boxes_z, qt = blockIdx.x / boxes_z, qy = qt % boxes_y, qx = qt / boxes_y;
             const BoxOut o{out, 0, sx, sy, sz, LAYOUT == 0 ? 0u : x0, nx_slab};
-            box_eval<E, LAYOUT, N>(ev, lds, cx, cy, cz, step, x0, qx * 16u, qy * 16u, qz * 16u, o);
+            box_eval<E, LAYOUT, N>(ev, lds, cx, cy, cz, step, x0, qx * 16u, qy * 16u, qz * 16u, o, masks);
             return;
         }
     }
+#ifdef SDF_EXP_NO_FALLBACK
+    if constexpr (E::kBricks && N == 2) return;
+#endif
     const uint32_t lin0 = first_cell<N>(blockIdx.x);
     const Cells<N> c(lin0, n_cells, dy, dz, kLaneStride);
     const T px = c.position(cx, step, c.x, x0), py = c.position(cy, step, c.y), pz = c.position(cz, step, c.z);
@@ -380,7 +396,7 @@ template <class E, int LAYOUT, int N>
 __global__ void __launch_bounds__(256) SDF_KERNEL_ATTRS
 k_grid_eval_blocks(const E ev, const int4* __restrict__ blocks, const uint32_t* __restrict__ n_blocks_dev, uint32_t b0,
                    uint32_t chunks, uint32_t bricks, double res, double ox, double oy, double oz, float step, uint32_t sx,
-                   Dim dy, Dim dz, void* __restrict__ out)
+                   Dim dy, Dim dz, void* __restrict__ out, const uint32_t* __restrict__ masks)
 {
     const uint32_t sy = dy.n, sz = dz.n;
     using T = typename Pack<N>::T;
@@ -403,7 +419,7 @@ k_grid_eval_blocks(const E ev, const int4* __restrict__ blocks, const uint32_t* 
             const uint32_t boxes_z = bricks & 0xffffu, boxes_y = bricks >> 16;
             const uint32_t qz = chunk % boxes_z, qt = chunk / boxes_z, qy = qt % boxes_y, qx = qt / boxes_y;
             const BoxOut o{out, (size_t)b * cells, sx, sy, sz, 0u, sx};
-            box_eval<E, LAYOUT, N>(ev, lds, cx, cy, cz, step, 0u, qx * 16u, qy * 16u, qz * 16u, o);
+            box_eval<E, LAYOUT, N>(ev, lds, cx, cy, cz, step, 0u, qx * 16u, qy * 16u, qz * 16u, o, masks);
             return;
         }
     }
@@ -447,6 +463,7 @@ struct ClassifyArgs {
     uint32_t* sums;        // MASS: uint32[10] per parent
     uint32_t scratch_offset;  // bytes of LDS taken by the register file or a box's tables (scratch follows)
     uint32_t boxes;           // per-tape code over boxes (box_classify): boxes along y << 16 | boxes along z; chunks = boxes per parent
+    const uint32_t* masks;    // boxes: the pruning masks of this launch's workgroups (k_box_masks), or NULL
 };
 
 template <class E, bool MASS, bool BATCH, int N>
@@ -495,7 +512,8 @@ __global__ void __launch_bounds__(256) k_classify(const E ev, const ClassifyArgs
             const uint32_t qz = chunk % boxes_z, qt = chunk / boxes_z, qy = qt % boxes_y, qx = qt / boxes_y;
             const uint32_t x0 = qx * 16u, y0 = qy * 16u, z0 = qz * 16u;
             const uint32_t nx = min(16u, a.sx - x0), ny = min(16u, a.sy - y0), nz = min(16u, a.sz - z0);
-            const BoxTables t = box_tables(ev, lds, cx, cy, cz, a.step, 0u, x0, y0, z0, nx, ny, nz);
+            const sdf::Prune<E::kPruneWords> pr = sdf::load_prune<E::kPruneWords>(a.masks, blockIdx.x);
+            const BoxTables t = box_tables(ev, lds, cx, cy, cz, a.step, 0u, x0, y0, z0, nx, ny, nz, pr);
             if (MASS) __syncthreads();   // scratch[8..17] zeroed (a tape without tables has no barrier in box_tables)
             const bool nothing_ambiguous = MASS && a.thr == 0.0f;
             const uint32_t nbz = nz >> 3, bz = nbz == 2u ? (wave & 1u) : 0u, dby = 4u / nbz;
@@ -507,13 +525,13 @@ __global__ void __launch_bounds__(256) k_classify(const E ev, const ClassifyArgs
                 const uint32_t y = y0 + yl;
                 const float py = sample(cy, a.step, y);
                 Tabs tb{t.x + xl, t.y + yl, t.z + zl, t.xy + (yl * Tabs::kRowX + xl), t.xz + (zl * Tabs::kRowX + xl), t.yz + (yl * Tabs::kRowYZ + zl)};
-                const auto hoisted = ev.hoist_x(py, pz, tb);
+                const auto hoisted = ev.hoist_x(py, walk_coordinate<E>(pz), tb, pr);
 #pragma unroll 1
                 for (uint32_t j = 0; j < (nx >> 2); ++j) {
                     asm volatile("" ::: "memory");
                     const uint32_t xv = x0 + j * 4u + xl;
                     const T px = sdf::make_f2(sample(cx, a.step, xv), sample(cx, a.step, xv + 2u));
-                    const T w = ev.dist_hoisted_x(px, py, pz, hoisted, tb);
+                    const T w = ev.dist_hoisted_x(px, walk_coordinate<E>(py), walk_coordinate<E>(pz), hoisted, tb, pr);
                     bool amb[2];
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
@@ -652,6 +670,69 @@ __global__ void __launch_bounds__(256) k_classify(const E ev, const ClassifyArgs
         if (threadIdx.x < 10) {
             const uint32_t v = scratch[8 + threadIdx.x];
             if (v) atomicAdd(&a.sums[(size_t)b * 10 + threadIdx.x], v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// box pruning: the masks of a launch's boxes (specialise.hpp "BOX PRUNING")
+// ------------------------------------------------------------------------------------------
+// Runs BEFORE a launch of k_grid_eval / k_grid_eval_blocks / k_classify over boxes, on the same stream: one LANE per box
+// (= per workgroup of that launch) evaluates the tape's bounded primitives at the box's centre and decides which operands of
+// which selects can win anywhere in the box -> out[box * words ...].  What a box is -- which unit (slab, leaf block, parent)
+// it belongs to, where its first sample lies -- is worked out exactly as the consuming kernel does.
+struct MaskArgs {
+    uint32_t mode;               // 0 dense slab, 1 leaf blocks (int4 rows), 2 one classified grid, 3 / 4 a level's parents (subdivision / mass)
+    uint32_t n_boxes;            // workgroups of the launch this prepares
+    uint32_t chunks;             // boxes per unit
+    uint32_t boxes_y, boxes_z;
+    uint32_t nx, ny, nz;         // a unit's extents in samples
+    uint32_t xs0;                // mode 0: sample index of the slab's first plane
+    uint32_t unit_base;          // first unit of the launch
+    const void* units;           // modes 1, 3: int4[]; mode 4: double4[]
+    const uint32_t* n_units_dev; // optional: the number of units, on the device
+    float cx, cy, cz, step;      // modes 0, 2: the corner sample as given
+    int32_t int_step, dimension; // mode 3
+    double res, ox, oy, oz, s;   // modes 1, 3 (resolution + origin), 4 (cell size)
+    uint32_t* out;
+};
+template <class E> __global__ void __launch_bounds__(64) k_box_masks(const E ev, const MaskArgs a)
+{
+    if constexpr (E::kBricks) {
+        constexpr int W = E::kPruneWords;
+        if constexpr (W > 0) {
+            const uint32_t box = blockIdx.x * blockDim.x + threadIdx.x;
+            if (box >= a.n_boxes) return;
+            const uint32_t unit = a.unit_base + box / a.chunks, chunk = box % a.chunks;
+            sdf::Prune<W> pr;
+#pragma unroll
+            for (int i = 0; i < W; ++i) pr.w[i] = 0xffffffffu;
+            if (!(a.n_units_dev && unit >= *a.n_units_dev)) {
+                float cx = a.cx, cy = a.cy, cz = a.cz;
+                if (a.mode == 1u) {
+                    const int4 ic = static_cast<const int4*>(a.units)[unit];
+                    cx = (float)((double)ic.x * a.res + a.ox); cy = (float)((double)ic.y * a.res + a.oy); cz = (float)((double)ic.z * a.res + a.oz);
+                } else if (a.mode == 3u) {
+                    const int4 ip = static_cast<const int4*>(a.units)[unit];
+                    const double h = (double)a.int_step / 2;
+                    cx = (float)(((double)ip.x + h) * a.res + a.ox); cy = (float)(((double)ip.y + h) * a.res + a.oy);
+                    cz = (float)(((double)ip.z + (a.dimension == 3 ? h : 0.0)) * a.res + a.oz);
+                } else if (a.mode == 4u) {
+                    const double4 pc = static_cast<const double4*>(a.units)[unit];
+                    const double h = a.s / 2;
+                    cx = (float)(pc.x + h); cy = (float)(pc.y + h); cz = (float)(pc.z + h);
+                }
+                const uint32_t qz = chunk % a.boxes_z, qt = chunk / a.boxes_z, qy = qt % a.boxes_y, qx = qt / a.boxes_y;
+                const uint32_t x0 = qx * 16u, y0 = qy * 16u, z0 = qz * 16u;
+                const float ex = 0.5f * (float)(min(16u, a.nx - x0) - 1u), ey = 0.5f * (float)(min(16u, a.ny - y0) - 1u),
+                            ez = 0.5f * (float)(min(16u, a.nz - z0) - 1u);
+                // the box's samples are corner + step * index: its centre and half extents in the same arithmetic
+                const float hx = a.step * ex, hy = a.step * ey, hz = a.step * ez;
+                ev.prune(sample(cx, a.step, a.xs0 + x0) + hx, sample(cy, a.step, y0) + hy, sample(cz, a.step, z0) + hz,
+                         __builtin_fabsf(hx), __builtin_fabsf(hy), __builtin_fabsf(hz), pr);
+            }
+#pragma unroll
+            for (int i = 0; i < W; ++i) a.out[(size_t)box * W + i] = pr.w[i];
         }
     }
 }

@@ -314,6 +314,7 @@ struct Phase1 {
     std::vector<int> dist_of;                 // node -> value id of its distance (RESULT nodes)
     std::vector<int> choice_of_rec;           // record -> value id of its choice mask, or -1
     std::vector<int> keep_w_of_rec;           // record -> value id of the distance that entered it, or -1
+    std::vector<std::pair<int, int>> choice_of_select;   // (a select's value id, the value id of its choice mask)
     int root = -1;
     int px = -1, py = -1, pz = -1;
     int n_phase1 = 0;                         // statements [0, n_phase1) are phase 1's; the rest are directions (phase 2)
@@ -488,16 +489,20 @@ inline bool symbolic_phase1(const SpecProgram& p, const std::vector<Node>& nodes
         switch (nd.role) {
         case LEAF: {
             const Pt& c = pt[a];
-            if (op == OP_RECTANGLE) w = perp(abs_minus(c.c[0], q[0]), abs_minus(c.c[1], q[1]));
+            // (these four are exact distances in their local coordinates: 1-Lipschitz there, so Lipschitz with the point's constant)
+            if (op == OP_RECTANGLE) w = iv_leaf(perp(abs_minus(c.c[0], q[0]), abs_minus(c.c[1], q[1])), c.lip);
             else if (op == OP_CIRCLE)
-                w = bound(e.add("len2_x($0, $1) - " + flit(q[0]), {c.c[0], c.c[1]}), G(c.c[0]) + G(c.c[1]), O(c.c[0]) + O(c.c[1]) + A(q[0]), OK(c.c[0]) && OK(c.c[1]));
+                w = iv_leaf(bound(e.add("len2_x($0, $1) - " + flit(q[0]), {c.c[0], c.c[1]}), G(c.c[0]) + G(c.c[1]), O(c.c[0]) + O(c.c[1]) + A(q[0]), OK(c.c[0]) && OK(c.c[1])), c.lip);
             else if (op == OP_SPHERE)
-                w = bound(e.add("len3_x($0, $1, $2) - " + flit(q[0]), {c.c[0], c.c[1], c.c[2]}), G(c.c[0]) + G(c.c[1]) + G(c.c[2]),
-                          O(c.c[0]) + O(c.c[1]) + O(c.c[2]) + A(q[0]), OK(c.c[0]) && OK(c.c[1]) && OK(c.c[2]));
-            else if (op == OP_HALF_SPACE) w = neg(c.c[1]);
-            else {   // polygons, the gear
-                const int last[4] = {c.c[0], c.c[1], c.c[2], zero};
+                w = iv_leaf(bound(e.add("len3_x($0, $1, $2) - " + flit(q[0]), {c.c[0], c.c[1], c.c[2]}), G(c.c[0]) + G(c.c[1]) + G(c.c[2]),
+                                  O(c.c[0]) + O(c.c[1]) + O(c.c[2]) + A(q[0]), OK(c.c[0]) && OK(c.c[1]) && OK(c.c[2])), c.lip);
+            else if (op == OP_HALF_SPACE) w = iv_leaf(neg(c.c[1]), c.lip);
+            else {   // polygons, the gear: no bound is claimed for them (the gear's distance jumps between teeth)
+                // (2D primitives: they read x and y only -- handing them a zero for z keeps the statement a function of the
+                // two coordinates its frame's x and y depend on, so it can be a column of a pair table)
+                const int last[4] = {c.c[0], c.c[1], zero, zero};
                 w = unknown(e.add("$0.w", {run_record(r, last, none4)}));
+                e.st[w].iv = IV_UNKNOWN;
             }
             break;
         }
@@ -506,11 +511,11 @@ inline bool symbolic_phase1(const SpecProgram& p, const std::vector<Node>& nodes
             if (keep_w[nd.rec]) out.keep_w_of_rec[nd.rec] = in;
             switch (op) {
             case OP_TRANSFORMATION_FROM: case OPX_FROM_SCALE: case OPX_FROM_AXIS_X: case OPX_FROM_AXIS_Y: case OPX_FROM_AXIS_Z:
-                w = bound(e.add("$0 * " + flit(q[5]), {in}), A(q[5]) * G(in), A(q[5]) * O(in), OK(in));
+                w = iv_op(bound(e.add("$0 * " + flit(q[5]), {in}), A(q[5]) * G(in), A(q[5]) * O(in), OK(in)), IV_SCALE, in, -1, q[5]);
                 break;
-            case OPX_FROM_MATRIX: w = bound(e.add("$0 * " + flit(q[9]), {in}), A(q[9]) * G(in), A(q[9]) * O(in), OK(in)); break;
-            case OP_OFFSET: w = bound(e.add("$0 - " + flit(q[0]), {in}), G(in), O(in) + A(q[0]), OK(in)); break;
-            case OP_SHELL: w = bound(e.add("sel(ge($0, 0.0f), $0, -($0)) - " + flit(q[0]), {in}), G(in), O(in) + A(q[0]), OK(in)); break;
+            case OPX_FROM_MATRIX: w = iv_op(bound(e.add("$0 * " + flit(q[9]), {in}), A(q[9]) * G(in), A(q[9]) * O(in), OK(in)), IV_SCALE, in, -1, q[9]); break;
+            case OP_OFFSET: w = iv_op(bound(e.add("$0 - " + flit(q[0]), {in}), G(in), O(in) + A(q[0]), OK(in)), IV_OFFSET, in, -1, q[0]); break;
+            case OP_SHELL: w = iv_op(bound(e.add("sel(ge($0, 0.0f), $0, -($0)) - " + flit(q[0]), {in}), G(in), O(in) + A(q[0]), OK(in)), IV_SHELL, in, -1, q[0]); break;
             case OP_MIRROR: w = in; break;      // (flips the direction's x: the distance stays)
             default: return false;
             }
@@ -520,11 +525,16 @@ inline bool symbolic_phase1(const SpecProgram& p, const std::vector<Node>& nodes
             const int in = out.dist_of[a];
             const Pt& c = pt[nd.b];
             if (keep_w[nd.rec]) out.keep_w_of_rec[nd.rec] = in;
-            if (op == OP_EXTRUSION) w = perp(abs_minus(c.c[2], q[0]), in);
+            if (op == OP_EXTRUSION) {
+                // perp(|z| - h, w): non-decreasing in both operands; the slab's distance is Lipschitz with the point's constant
+                const int slab = iv_leaf(abs_minus(c.c[2], q[0]), c.lip);
+                w = iv_op(perp(slab, in), IV_PERP, slab, in);
+            }
             else if (op == OP_SYMMETRICAL_FROM || op == OP_CIRCULAR_REPETITION_FROM || op == OP_REVOLUTION_FROM) w = in;   // directions only
             else if (op == OP_TWIST_REVOLUTION_FROM) {
                 const int last[4] = {zero, zero, zero, in}, operand[4] = {c.c[0], c.c[1], c.c[2], zero};
                 w = unknown(e.add("$0.w", {run_record(r, last, operand)}));
+                e.st[w].iv = IV_UNKNOWN;
             } else return false;
             break;
         }
@@ -536,8 +546,10 @@ inline bool symbolic_phase1(const SpecProgram& p, const std::vector<Node>& nodes
                 const int ca = op == OP_UNION ? x : neg(x), cb = op == OP_INTERSECTION ? neg(y) : y;
                 out.choice_of_rec[nd.rec] = e.add("lt_x($0, $1)", {ca, cb}, 0, true);
             }
-            w = bound(e.add(std::string(op == OP_UNION ? "min_x" : op == OP_INTERSECTION ? "max_x" : "max_neg_x") + "($0, $1)", {x, y}),
-                      std::max(G(x), G(y)), std::max(O(x), O(y)), OK(x) && OK(y));
+            w = iv_op(bound(e.add(std::string(op == OP_UNION ? "min_x" : op == OP_INTERSECTION ? "max_x" : "max_neg_x") + "($0, $1)", {x, y}),
+                            std::max(G(x), G(y)), std::max(O(x), O(y)), OK(x) && OK(y)),
+                      op == OP_UNION ? IV_MIN : op == OP_INTERSECTION ? IV_MAX : IV_MAXNEG, x, y);
+            if (out.choice_of_rec[nd.rec] >= 0) out.choice_of_select.emplace_back(w, out.choice_of_rec[nd.rec]);
             break;
         }
         default: return false;
@@ -652,6 +664,215 @@ inline std::string table_load(const Stmt& s, int column, bool single = false)
     return std::string("tb.template ") + kTableName[table_slot(s.deps)] + (single && (s.deps & DX) ? "1" : "") + "<" + std::to_string(column) + ">()";
 }
 
+// BOX PRUNING (round 4).  A CAD assembly is a union of many parts, and a 16^3 box of samples is near two or three of them:
+// for most boxes most operands of most min / max cannot win ANYWHERE in the box.  Which ones is decided once per box, before
+// the box's kernel runs (kernels.hpp k_box_masks, one box per lane): the distances are evaluated at the box's centre and
+// bounded over the box --
+//   a primitive that is an exact distance in its local frame (circle, rectangle, sphere, half-space, the slab of an
+//   extrusion) is Lipschitz in the sample point with its frame's constant: centre value +- (constant * the box's radius
+//   over the coordinates it reads + a margin for rounding);
+//   scalings, offsets, shells, extrusions (perp is non-decreasing in both operands), min and max carry bounds through;
+//   what has no bound (gears, polygons, anything behind a repetition or a twist) is (-inf, +inf) -- and is still skipped
+//   where the min / max structure above it decides without it: a gear lives between its root circle and its tip circle.
+// An operand of min whose lower bound lies above the other's upper bound loses in every sample of the box: the hardware
+// minimum then returns the other operand's bits, so dropping the loser -- with everything only it needed -- changes no
+// bit of the result (and its choice mask for the direction phase is constant).  The box's mask has one bit per prunable
+// operand ("scope": alive or not); the generated code tests them with scalar branches.  Tapes in which nothing can be
+// bounded (the sponge: everything sits behind a repetition) get no bits and exactly the code they had.
+struct PruneInfo {
+    int n_bits = 0;
+    std::vector<int> scope_of;                 // per statement: its scope (0 = always evaluated)
+    std::vector<int> parent;                   // per scope
+    std::vector<int> bit;                      // per scope: the mask bit that says it is alive (scope 0: -1)
+    struct Sel { int a_scope = 0, b_scope = 0; };
+    std::vector<Sel> sel;                      // per statement: the scopes of a guarded select's operands (0: that side is never pruned)
+    std::vector<int> select_of_choice;         // per statement: the select whose choice mask it is, or -1
+    std::vector<char> need_iv;                 // the statements the mask function bounds
+    int words() const { return (n_bits + 31) / 32; }
+    bool guarded(int i) const { return i < (int)sel.size() && (sel[i].a_scope || sel[i].b_scope); }
+    std::string alive(int scope) const { return "pr.template alive<" + std::to_string(bit[scope]) + ">()"; }
+    std::vector<int> path(int scope) const
+    {
+        std::vector<int> p;
+        for (int s = scope; s > 0; s = parent[s]) p.push_back(s);
+        std::reverse(p.begin(), p.end());
+        return p;
+    }
+};
+constexpr int kMaxPruneBits = 512;
+
+inline PruneInfo analyse_pruning(const Phase1& ph, int min_cost)
+{
+    const std::vector<Stmt>& st = ph.e.st;
+    const int n = ph.n_phase1;
+    PruneInfo pi;
+    pi.scope_of.assign(st.size(), 0);
+    pi.sel.assign(st.size(), PruneInfo::Sel());
+    pi.select_of_choice.assign(st.size(), -1);
+    pi.need_iv.assign(st.size(), 0);
+    pi.parent.push_back(-1);
+    pi.bit.push_back(-1);
+    if (min_cost <= 0 || ph.root < 0) return pi;
+    // which bounds can be finite at all
+    std::vector<char> lo(st.size(), 0), hi(st.size(), 0);
+    for (int i = 0; i < n; ++i) {
+        const Stmt& s = st[i];
+        const int a = s.iv_a, b = s.iv_b;
+        switch (s.iv) {
+        case IV_LEAF: lo[i] = hi[i] = 1; break;
+        case IV_SCALE: if (s.iv_c > 0.0f) { lo[i] = lo[a]; hi[i] = hi[a]; } else if (s.iv_c < 0.0f) { lo[i] = hi[a]; hi[i] = lo[a]; } else lo[i] = hi[i] = 1; break;
+        case IV_OFFSET: lo[i] = lo[a]; hi[i] = hi[a]; break;
+        case IV_SHELL: lo[i] = 1; hi[i] = lo[a] && hi[a]; break;
+        case IV_PERP: lo[i] = lo[a] || lo[b]; hi[i] = hi[a] && hi[b]; break;
+        case IV_MIN: lo[i] = lo[a] && lo[b]; hi[i] = hi[a] || hi[b]; break;
+        case IV_MAX: lo[i] = lo[a] || lo[b]; hi[i] = hi[a] && hi[b]; break;
+        case IV_MAXNEG: lo[i] = lo[a] || hi[b]; hi[i] = hi[a] && lo[b]; break;
+        default: break;
+        }
+    }
+    auto is_select = [&](int i) { return st[i].iv == IV_MIN || st[i].iv == IV_MAX || st[i].iv == IV_MAXNEG; };
+    for (const auto& sc : ph.choice_of_select) pi.select_of_choice[sc.second] = sc.first;
+    std::vector<int> choice_of(st.size(), -1);
+    for (const auto& sc : ph.choice_of_select) choice_of[sc.first] = sc.second;
+    // the statements the root distance is computed from, and who reads whom
+    std::vector<char> in_graph(st.size(), 0);
+    std::vector<std::vector<int>> users(st.size());
+    {
+        std::vector<int> stack{ph.root};
+        for (const auto& sc : ph.choice_of_select) stack.push_back(sc.second);   // (the comparisons of the direction phase read operands too)
+        while (!stack.empty()) {
+            const int i = stack.back();
+            stack.pop_back();
+            if (in_graph[i]) continue;
+            in_graph[i] = 1;
+            for (int o : st[i].ops) { users[o].push_back(i); stack.push_back(o); }
+        }
+    }
+    const std::vector<int> cost = statement_costs(ph);
+    auto depth_of = [&](int s) { int d = 0; for (; s > 0; s = pi.parent[s]) ++d; return d; };
+    auto lca = [&](int x, int y) {
+        int dx = depth_of(x), dy = depth_of(y);
+        while (dx > dy) { x = pi.parent[x]; --dx; }
+        while (dy > dx) { y = pi.parent[y]; --dy; }
+        while (x != y) { x = pi.parent[x]; y = pi.parent[y]; }
+        return x;
+    };
+    // users have larger ids than what they read -- except that a select's comparison was made just before the select
+    // itself: a comparison lives where its select lives and reads each operand in that operand's scope
+    std::vector<char> placed(st.size(), 0);
+    auto place = [&](int i) {
+        if (!in_graph[i] || placed[i]) return;
+        placed[i] = 1;
+        int scope = -1;
+        if (i == ph.root) scope = 0;
+        if (pi.select_of_choice[i] >= 0) scope = pi.scope_of[pi.select_of_choice[i]];
+        for (int u : users[i]) {
+            int at = pi.scope_of[u];
+            const int sel = is_select(u) ? u : pi.select_of_choice[u];     // (the select u is, or compares for)
+            if (sel >= 0 && pi.guarded(sel) && st[u].ops.size() == 2) {
+                // a select's first operand is its `a`, and so is its comparison's (a itself or -a); the second its `b`
+                const bool on_a = st[u].ops[0] == i, on_b = st[u].ops[1] == i;
+                const int base = pi.scope_of[sel];
+                if (on_a && !on_b) at = pi.sel[sel].a_scope ? pi.sel[sel].a_scope : base;
+                else if (on_b && !on_a) at = pi.sel[sel].b_scope ? pi.sel[sel].b_scope : base;
+                else at = base;
+            }
+            scope = scope < 0 ? at : lca(scope, at);
+        }
+        pi.scope_of[i] = scope < 0 ? 0 : scope;
+        if (is_select(i)) {
+            const int a = st[i].iv_a, b = st[i].iv_b;
+            bool can_a = false, can_b = false;     // "a can be pruned", "b can be pruned"
+            if (st[i].iv == IV_MIN) { can_b = hi[a] && lo[b]; can_a = hi[b] && lo[a]; }
+            else if (st[i].iv == IV_MAX) { can_b = lo[a] && hi[b]; can_a = lo[b] && hi[a]; }
+            else { can_b = lo[a] && lo[b]; can_a = hi[b] && hi[a]; }
+            if (a == b) can_a = can_b = false;
+            auto open = [&](int operand) {
+                if (cost[operand] < min_cost || pi.n_bits >= kMaxPruneBits) return 0;
+                pi.parent.push_back(pi.scope_of[i]);
+                pi.bit.push_back(pi.n_bits++);
+                return (int)pi.parent.size() - 1;
+            };
+            if (can_a) pi.sel[i].a_scope = open(a);
+            if (can_b) pi.sel[i].b_scope = open(b);
+        }
+    };
+    for (int i = (int)st.size() - 1; i >= 0; --i) {
+        if (i < n && is_select(i) && choice_of[i] >= 0) {
+            place(i);                 // the select first, then its comparison (whose id is smaller but not adjacent: negations lie between)
+            place(choice_of[i]);
+        }
+        place(i);
+    }
+    if (pi.n_bits == 0) return pi;
+    // what the mask function has to bound: the operands of the guarded selects, down to the leaves
+    std::vector<int> stack;
+    for (int i = 0; i < n; ++i) if (in_graph[i] && pi.guarded(i)) { stack.push_back(st[i].iv_a); stack.push_back(st[i].iv_b); }
+    while (!stack.empty()) {
+        const int i = stack.back();
+        stack.pop_back();
+        if (i < 0 || pi.need_iv[i]) continue;
+        pi.need_iv[i] = 1;
+        if (st[i].iv != IV_LEAF && st[i].iv != IV_UNKNOWN) { stack.push_back(st[i].iv_a); stack.push_back(st[i].iv_b); }
+    }
+    return pi;
+}
+
+// Statements as guarded assignments (box pruning): every value is declared first (its type taken from its expression, which
+// nothing evaluates), then assigned in statement order inside the `if`s of its scope's path; a scope is entered again
+// when statements of another scope lie between (rare: a subtree's statements are contiguous in tape order).
+struct ScopedItem {
+    int id;
+    std::string decl;      // the expression the type is taken from
+    std::string assign;    // complete statement(s) that give t<id> its value, ending in ";"
+};
+inline std::string emit_scoped(const PruneInfo& pi, const std::vector<ScopedItem>& items, const std::string& pad = "    ")
+{
+    std::ostringstream o;
+    // (declared, NOT initialised: an initial value would be live from here to the assignment in its scope -- every value of the
+    // tape at once, 256 registers and one wavefront per SIMD for planetary's float4 kernel; a value is only ever read under
+    // the condition it was assigned under)
+    for (const ScopedItem& it : items) o << pad << "decltype(" << it.decl << ") t" << it.id << ";\n";
+    std::vector<int> open;
+    auto indent = [&]() { return pad + std::string(4 * open.size(), ' '); };
+    for (const ScopedItem& it : items) {
+        const std::vector<int> want = pi.path(pi.scope_of[it.id]);
+        size_t keep = 0;
+        while (keep < open.size() && keep < want.size() && open[keep] == want[keep]) ++keep;
+        while (open.size() > keep) { open.pop_back(); o << indent() << "}\n"; }
+        while (open.size() < want.size()) {
+            o << indent() << "if (" << pi.alive(want[open.size()]) << ") {\n";
+            open.push_back(want[open.size()]);
+        }
+        o << indent() << it.assign << "\n";
+    }
+    while (!open.empty()) { open.pop_back(); o << indent() << "}\n"; }
+    return o.str();
+}
+// the assignment of a guarded select / of its comparison: the operation where both operands are alive, else the survivor
+inline std::string guarded_select(const PruneInfo& pi, const Stmt& s, int id, const std::function<std::string(int)>& name)
+{
+    const PruneInfo::Sel& g = pi.sel[id];
+    const std::string t = "t" + std::to_string(id), a = name(s.ops[0]), b = name(s.ops[1]);
+    const std::string as = "as<decltype(" + t + ")>(";
+    const std::string only_a = t + " = " + as + a + ");", only_b = t + " = " + as + (s.iv == IV_MAXNEG ? "-(" + b + ")" : b) + ");";
+    const std::string both = t + " = " + render(s, name) + ";";
+    if (g.a_scope && g.b_scope)
+        return "if (" + pi.alive(g.a_scope) + " && " + pi.alive(g.b_scope) + ") " + both + " else if (" + pi.alive(g.a_scope) + ") " + only_a + " else " + only_b;
+    if (g.b_scope) return "if (" + pi.alive(g.b_scope) + ") " + both + " else " + only_a;
+    return "if (" + pi.alive(g.a_scope) + ") " + both + " else " + only_b;
+}
+inline std::string guarded_choice(const PruneInfo& pi, const Stmt& s, int id, int select, const std::function<std::string(int)>& name)
+{
+    const PruneInfo::Sel& g = pi.sel[select];
+    const std::string t = "t" + std::to_string(id), both = t + " = " + render(s, name) + ";";
+    const std::string constant = t + " = mask_const<decltype(" + t + ")>(";       // true: the first operand is the one that is left
+    if (g.a_scope && g.b_scope)
+        return "if (" + pi.alive(g.a_scope) + " && " + pi.alive(g.b_scope) + ") " + both + " else " + constant + pi.alive(g.a_scope) + ");";
+    if (g.b_scope) return "if (" + pi.alive(g.b_scope) + ") " + both + " else " + constant + "true);";
+    return "if (" + pi.alive(g.a_scope) + ") " + both + " else " + constant + "false);";
+}
+
 // `tabc`: the table candidates the walk may read (empty: none); `tab_index` (may be NULL while the columns are still
 // being counted): statement -> its column; `held` (may be empty): the columns that do not change along the walk and are
 // read ONCE, in `pre`, and kept in registers (a table read is not free: the data returning from LDS takes the register
@@ -659,8 +880,9 @@ inline std::string table_load(const Stmt& s, int column, bool single = false)
 // brick ran like 264 --, so a column the walk reads in every brick is worth a register or two once registers are there).
 inline Variant render_variant(const Phase1& ph, const std::vector<char>& hoistable, const std::vector<int>& roots,
                               const std::vector<char>& tabc = std::vector<char>(), const std::vector<int>* tab_index = nullptr,
-                              const std::vector<char>& held = std::vector<char>())
+                              const std::vector<char>& held = std::vector<char>(), const PruneInfo* pi = nullptr)
 {
+    const bool scoped = pi && pi->n_bits > 0;       // box pruning: guarded assignments (emit_scoped)
     const std::vector<Stmt>& st = ph.e.st;
     const int n = (int)st.size();
     auto invariant = [&](int i) { return hoistable[i] != 0; };
@@ -693,11 +915,26 @@ inline Variant render_variant(const Phase1& ph, const std::vector<char>& hoistab
     Variant v;
     auto plain = [&](int i) { return st[i].ops.empty() ? st[i].text : "t" + std::to_string(i); };
     std::ostringstream pre, main;
+    // one statement as a scoped item: a guarded select or its comparison assigns by cases, anything else plainly
+    auto scoped_item = [&](int i, const std::string& rhs, const std::function<std::string(int)>& name) {
+        const std::string t = "t" + std::to_string(i);
+        if (pi->guarded(i) && rhs.compare(0, 3, "tb.") != 0) return ScopedItem{i, rhs, guarded_select(*pi, st[i], i, name)};
+        const int sel = pi->select_of_choice[i];
+        if (sel >= 0 && pi->guarded(sel)) return ScopedItem{i, rhs, guarded_choice(*pi, st[i], i, sel, name)};
+        return ScopedItem{i, rhs, t + " = " + rhs + ";"};
+    };
+    std::vector<ScopedItem> pre_items;
     for (int i = 0; i < n; ++i) {
         if (st[i].ops.empty()) continue;
+        if (scoped) {
+            if (pre_load[i]) pre_items.push_back(ScopedItem{i, column(i), "t" + std::to_string(i) + " = " + column(i) + ";"});
+            else if (in_pre[i]) pre_items.push_back(scoped_item(i, render(st[i], plain), plain));
+            continue;
+        }
         if (pre_load[i]) pre << "    const auto t" << i << " = " << column(i) << ";\n";
         else if (in_pre[i]) pre << "    const auto t" << i << " = " << render(st[i], plain) << ";\n";
     }
+    if (scoped) pre << emit_scoped(*pi, pre_items);
     std::ostringstream members, values;
     for (int i = 0; i < n; ++i)
         if (frontier[i]) {
@@ -722,20 +959,26 @@ inline Variant render_variant(const Phase1& ph, const std::vector<char>& hoistab
         if (st[i].text != "min_x($0, $1)" && st[i].text != "max_x($0, $1)") continue;
         const int j = st[i].ops[0];
         if (!in_main[j] || readers[j] != 1 || st[j].text != st[i].text || fused_inner[j] >= 0) continue;
+        if (scoped && (pi->guarded(i) || pi->guarded(j) || pi->scope_of[i] != pi->scope_of[j])) continue;   // (each keeps its own cases)
         fused_inner[i] = j;
         dead[j] = 1;
     }
+    std::vector<ScopedItem> main_items;
     for (int i = 0; i < n; ++i) {
         if (st[i].ops.empty()) continue;
-        if (tab_read[i]) main << "    const auto t" << i << " = " << column(i) << ";\n";
+        std::string rhs;
+        if (tab_read[i]) rhs = column(i);
         else if (in_main[i] && !dead[i]) {
             if (fused_inner[i] >= 0) {
                 const Stmt& in = st[fused_inner[i]];
-                main << "    const auto t" << i << " = " << (st[i].text[1] == 'i' ? "min3_x(" : "max3_x(") << in_walk(in.ops[0]) << ", " << in_walk(in.ops[1])
-                     << ", " << in_walk(st[i].ops[1]) << ");\n";
-            } else main << "    const auto t" << i << " = " << render(st[i], in_walk) << ";\n";
-        }
+                rhs = std::string(st[i].text[1] == 'i' ? "min3_x(" : "max3_x(") + in_walk(in.ops[0]) + ", " + in_walk(in.ops[1]) + ", " + in_walk(st[i].ops[1]) + ")";
+            } else rhs = render(st[i], in_walk);
+        } else continue;
+        if (!scoped) main << "    const auto t" << i << " = " << rhs << ";\n";
+        else if (tab_read[i] || fused_inner[i] >= 0) main_items.push_back(ScopedItem{i, rhs, "t" + std::to_string(i) + " = " + rhs + ";"});
+        else main_items.push_back(scoped_item(i, rhs, in_walk));
     }
+    if (scoped) main << emit_scoped(*pi, main_items);
     v.main = main.str();
     v.handed = frontier;
     v.tab_read = tab_read;
@@ -748,7 +991,7 @@ inline Variant render_variant(const Phase1& ph, const std::vector<char>& hoistab
 // column stored at out[column * S].  A single-axis table computes everything from its coordinate; a pair table reads the
 // single-axis columns (`tabc`, may be empty; `reads`, may be NULL, collects them) and computes the rest.
 inline std::string render_table_builder(const Phase1& ph, uint8_t deps, const std::vector<int>& tab_index, const std::vector<char>& tabc,
-                                        const std::vector<char>& used, std::vector<char>* reads = nullptr)
+                                        const std::vector<char>& used, std::vector<char>* reads = nullptr, const PruneInfo* pi = nullptr)
 {
     const std::vector<Stmt>& st = ph.e.st;
     const int n = (int)st.size();
@@ -766,13 +1009,106 @@ inline std::string render_table_builder(const Phase1& ph, uint8_t deps, const st
     }
     auto plain = [&](int i) { return st[i].ops.empty() ? st[i].text : "t" + std::to_string(i); };
     std::ostringstream o;
+    // box pruning guards the entries of the PAIR tables (256 evaluations per column and box; an axis table's 16 are not worth a branch)
+    const bool scoped = pi && pi->n_bits > 0 && pair;
+    std::vector<ScopedItem> items;
     for (int i = 0; i < n; ++i) {
         if (st[i].ops.empty()) continue;
-        if (loads[i]) o << "    const auto t" << i << " = " << table_load(st[i], tab_index[i], true) << ";\n";
+        const std::string t = "t" + std::to_string(i);
+        if (loads[i]) {
+            const std::string rhs = table_load(st[i], tab_index[i], true);
+            if (scoped) items.push_back(ScopedItem{i, rhs, t + " = " + rhs + ";"});
+            else o << "    const auto " << t << " = " << rhs << ";\n";
+        }
         if (!in[i]) continue;
-        o << "    const auto t" << i << " = " << render(st[i], plain) << ";\n";
-        if (used[i] && st[i].deps == deps) o << "    out[" << tab_index[i] << " * S] = t" << i << ";\n";
+        const std::string rhs = render(st[i], plain);
+        const std::string store = used[i] && st[i].deps == deps ? "out[" + std::to_string(tab_index[i]) + " * S] = " + t + ";" : std::string();
+        if (scoped) {
+            const int sel = pi->select_of_choice[i];
+            const std::string assign = pi->guarded(i) ? guarded_select(*pi, st[i], i, plain)
+                                       : sel >= 0 && pi->guarded(sel) ? guarded_choice(*pi, st[i], i, sel, plain) : t + " = " + rhs + ";";
+            items.push_back(ScopedItem{i, rhs, assign + (store.empty() ? "" : " " + store)});
+        } else {
+            o << "    const auto " << t << " = " << rhs << ";\n";
+            if (!store.empty()) o << "    " << store << "\n";
+        }
     }
+    if (scoped) o << emit_scoped(*pi, items);
+    return o.str();
+}
+
+// The mask function of a tape (box pruning): one box per call -- its centre (px, py, pz), its half extents (hx, hy, hz: the
+// samples lie within them of the centre) -> out.w[]: bit k set = scope k is alive.  Everything is evaluated in place, in
+// float; the bounds (interp.hpp Iv) are widened outwards at every step, and a leaf's radius carries a margin of 64 ulps of
+// the largest magnitude its arithmetic can see (g * B + o, B = the box's largest |coordinate|), so that rounding in the
+// kernels' evaluation of the same statements cannot carry a value out of its bounds.
+inline std::string render_prune_function(const Phase1& ph, const PruneInfo& pi)
+{
+    const std::vector<Stmt>& st = ph.e.st;
+    const int n = ph.n_phase1;
+    std::ostringstream o;
+    o << "template <class PR> __device__ __forceinline__ void tape_prune(float px, float py, float pz, float hx, float hy, float hz, "
+         "const float* __restrict__ extra, PR& out)\n{\n    using namespace sdf;\n";
+    if (pi.n_bits == 0) { o << "}\n"; return o.str(); }
+    o << "    const uint32_t flags = 0u;\n";
+    // the centre values of the bounded leaves, in place
+    std::vector<char> in(st.size(), 0);
+    std::vector<int> stack;
+    for (int i = 0; i < n; ++i) if (pi.need_iv[i] && st[i].iv == IV_LEAF) stack.push_back(i);
+    while (!stack.empty()) {
+        const int i = stack.back();
+        stack.pop_back();
+        if (in[i]) continue;
+        in[i] = 1;
+        for (int op : st[i].ops) stack.push_back(op);
+    }
+    auto plain = [&](int i) { return st[i].ops.empty() ? st[i].text : "t" + std::to_string(i); };
+    for (int i = 0; i < n; ++i)
+        if (in[i] && !st[i].ops.empty()) o << "    const auto t" << i << " = " << render(st[i], plain) << ";\n";
+    // radii over the coordinates a leaf reads (index = DX | DY | DZ), a hair large; the box's largest |coordinate|
+    o << "    const float kUp = 1.0009765625f;\n"
+      << "    const float rad[8] = {0.0f, hx * kUp, hy * kUp, iv_hypot(hx, hy) * kUp, hz * kUp, iv_hypot(hx, hz) * kUp, iv_hypot(hy, hz) * kUp, "
+         "iv_hypot(iv_hypot(hx, hy), hz) * kUp};\n"
+      << "    const float B = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(px) + hx, __builtin_fabsf(py) + hy), __builtin_fabsf(pz) + hz);\n";
+    auto up = [](double v) { return flit(std::nextafter((float)(v * (1.0 + 1e-6)), HUGE_VALF)); };     // a non-negative constant, rounded up
+    auto iv = [](int i) { return "i" + std::to_string(i); };
+    for (int i = 0; i < n; ++i) {
+        if (!pi.need_iv[i]) continue;
+        const Stmt& s = st[i];
+        o << "    const Iv " << iv(i) << " = ";
+        switch (s.iv) {
+        case IV_LEAF:
+            o << "iv_leaf(" << plain(i) << ", " << up(s.iv_l) << " * rad[" << (int)s.deps << "], (" << up(s.g) << " * B + " << up(s.o) << ") * kIvMargin)";
+            break;
+        case IV_SCALE: o << (s.iv_c == 0.0f ? std::string("iv_zero()") : "iv_scale(" + iv(s.iv_a) + ", " + flit(s.iv_c) + ")"); break;
+        case IV_OFFSET: o << "iv_offset(" << iv(s.iv_a) << ", " << flit(s.iv_c) << ")"; break;
+        case IV_SHELL: o << "iv_shell(" << iv(s.iv_a) << ", " << flit(s.iv_c) << ")"; break;
+        case IV_PERP: o << "iv_perp(" << iv(s.iv_a) << ", " << iv(s.iv_b) << ")"; break;
+        case IV_MIN: o << "iv_min(" << iv(s.iv_a) << ", " << iv(s.iv_b) << ")"; break;
+        case IV_MAX: o << "iv_max(" << iv(s.iv_a) << ", " << iv(s.iv_b) << ")"; break;
+        case IV_MAXNEG: o << "iv_max(" << iv(s.iv_a) << ", iv_neg(" << iv(s.iv_b) << "))"; break;
+        default: o << "iv_unknown()"; break;
+        }
+        o << ";\n";
+    }
+    // the decisions: an operand that loses everywhere in the box is dead
+    const int words = pi.words();
+    for (int w = 0; w < words; ++w) o << "    uint32_t w" << w << " = 0xffffffffu;\n";
+    auto kill = [&](int scope, const std::string& cond) {
+        if (!scope) return;
+        const int b = pi.bit[scope];
+        o << "    if (" << cond << ") w" << (b >> 5) << " &= ~" << (1u << (b & 31)) << "u;\n";
+    };
+    for (int i = 0; i < n; ++i) {
+        if (!pi.guarded(i)) continue;
+        const Stmt& s = st[i];
+        const std::string a = iv(s.iv_a), b = iv(s.iv_b);
+        if (s.iv == IV_MIN) { kill(pi.sel[i].b_scope, a + ".hi < " + b + ".lo"); kill(pi.sel[i].a_scope, b + ".hi < " + a + ".lo"); }
+        else if (s.iv == IV_MAX) { kill(pi.sel[i].b_scope, a + ".lo > " + b + ".hi"); kill(pi.sel[i].a_scope, b + ".lo > " + a + ".hi"); }
+        else { kill(pi.sel[i].b_scope, a + ".lo > -" + b + ".lo"); kill(pi.sel[i].a_scope, "-" + b + ".hi > " + a + ".hi"); }
+    }
+    for (int w = 0; w < words; ++w) o << "    out.w[" << w << "] = w" << w << ";\n";
+    o << "}\n";
     return o.str();
 }
 
@@ -784,12 +1120,19 @@ struct SpecMeta {
     bool deferred = false;
     double coord_limit = 0.0;    // the largest |sample coordinate| for which a launch may set sdf::kFlagInRange (0: never)
     int tabs[6] = {0, 0, 0, 0, 0, 0};   // columns of a box's tables: x, y, z, xy, xz, yz
+    int prune_words = 0;         // 32-bit words of a box's pruning mask (0: the tape has nothing to prune)
+    int prune_bits = 0;
+    bool plain_in_place = false; // the in-place functions (single points: ragged grids, small levels, the ray caster) are the plain form
 };
+// Up to this many (primitive, path) pairs the in-place functions defer directions too; beyond it they are the plain
+// record-by-record form (its second phase in place -- every value two voxels wide, no tables, no pruning -- held 250
+// registers for planetary's 80 pairs and took as long to compile as everything else together)
+constexpr size_t kInPlaceDeferredPaths = 40;
 constexpr int kMaxTableColumns = 48;   // per axis (a column of a 16^3 box is 64 B of LDS)
 constexpr int kMaxPairColumns = 16;    // per pair of axes (a column of a 16^3 box is 1 KiB) ...
 constexpr int kMaxPairTotal = 24;      // ... and in all: the tables of a box stay below 28 KiB, five workgroups to a CU
 
-inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t max_paths = 40, SpecMeta* meta = nullptr)
+inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t max_paths = 400, SpecMeta* meta = nullptr)
 {
     using namespace spec_detail;
     if (p.dist.empty() || p.dist.size() != p.full.size()) return false;
@@ -813,6 +1156,16 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
     if (!symbolic_phase1(p, nodes, root, is_choice, keep_w, ph, &pt)) return false;
     if (meta) meta->coord_limit = coordinate_limit(ph);
     ph.n_phase1 = (int)ph.e.st.size();
+    // box pruning: which operands of which selects can be decided per box (HU_PRUNE=0: none; HU_PRUNE_MIN: what an operand
+    // must cost, in instructions, to be worth a scalar branch)
+    static const int prune_min = [] {
+        const char* off = std::getenv("HU_PRUNE");
+        if (off && off[0] == '0') return 0;
+        const char* e = std::getenv("HU_PRUNE_MIN");
+        return e && *e ? std::atoi(e) : 6;
+    }();
+    const PruneInfo prune = analyse_pruning(ph, prune_min);
+    if (meta) { meta->prune_bits = prune.n_bits; meta->prune_words = prune.words(); }
     std::vector<int> dist_roots{ph.root}, eval_roots{ph.root};
     for (int v : ph.choice_of_rec) if (v >= 0) eval_roots.push_back(v);
     for (int v : ph.keep_w_of_rec) if (v >= 0) eval_roots.push_back(v);
@@ -855,7 +1208,7 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
             } else if (leaf.op == OP_HALF_SPACE) {
                 d[1] = e.add("-1.0f", {});
             } else {
-                const int last[4] = {c[0], c[1], c[2], zero}, none4[4] = {zero, zero, zero, zero};
+                const int last[4] = {c[0], c[1], zero, zero}, none4[4] = {zero, zero, zero, zero};      // (2D primitives: x and y only)
                 const int v = full_record(lr, last, none4);
                 d[0] = e.add("$0.x", {v}); d[1] = e.add("$0.y", {v}); d[2] = e.add("$0.z", {v});
             }
@@ -918,9 +1271,15 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
         }
     }
     // phase 1's values that phase 2 reads where they are (not computed again): the comparisons, the kept distances
-    std::vector<char> lives(e.st.size(), 0);
+    // A kept distance stays in its register(s) from phase 1 to the block that reads it -- for an assembly of extruded
+    // profiles that is two registers per extrusion across the whole second phase (planetary: 35 of them) -- unless the block
+    // can have it again cheaply: from a table column, or by computing a short subtree again (a circle's distance: ten
+    // instructions) that holds nothing decided per box.
+    std::vector<char> lives(e.st.size(), 0), kept_w(e.st.size(), 0);
     for (int v : ph.choice_of_rec) if (v >= 0) lives[v] = 1;
-    for (int v : ph.keep_w_of_rec) if (v >= 0) lives[v] = 1;
+    for (int v : ph.keep_w_of_rec) if (v >= 0) kept_w[v] = 1;
+    const std::vector<int> p1_cost = statement_costs(ph);
+    static const int recompute_limit = [] { const char* e = std::getenv("HU_KEEP_RECOMPUTE"); return e && *e ? std::atoi(e) : 40; }();
     // `tabc` / `tab_index` / `tab_used`: the axis tables (render_variant): a block reads a table column where it would
     // have recomputed the statement; `tab_used` (may be NULL) collects which candidates the blocks read
     auto phase2_for = [&](const std::vector<char>& hoistable, const std::vector<char>& tabc, const std::vector<int>* tab_index,
@@ -928,6 +1287,18 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
         const std::vector<Stmt>& st = e.st;
         auto outer = [&](int id) { return st[id].ops.empty() ? st[id].text : (id < (int)hoistable.size() && hoistable[id] ? "h.t" : "t") + std::to_string(id); };
         auto tabled = [&](int id) { return id < (int)tabc.size() && tabc[id] != 0; };
+        auto handed = [&](int id) { return id < (int)hoistable.size() && hoistable[id] != 0; };
+        // can a block compute statement `id` again: a short subtree, down to table columns / handed values, without a select
+        // that box pruning guards (its operands may be dead), a comparison, or a library record
+        std::function<bool(int)> again = [&](int id) -> bool {
+            if (e.st[id].ops.empty() || tabled(id) || handed(id)) return true;
+            if (e.st[id].mask || prune.guarded(id) || e.st[id].text.compare(0, 10, "run_record") == 0) return false;
+            for (int op : e.st[id].ops) if (!again(op)) return false;
+            return true;
+        };
+        std::vector<char> live_here = lives;
+        for (int i = 0; i < (int)kept_w.size(); ++i)
+            if (kept_w[i] && !handed(i) && !tabled(i) && !(p1_cost[i] <= recompute_limit && again(i))) live_here[i] = 1;
         std::ostringstream o2;
         o2 << "    // ---- phase 2\n"
            << "    const auto qx = opaque(px); const auto qy = opaque(py); const auto qz = opaque(pz);\n";
@@ -944,7 +1315,7 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
             while (!stack.empty()) {
                 const int i = stack.back();
                 stack.pop_back();
-                if (inside[i] || loads[i] || st[i].ops.empty() || lives[i] || (i < (int)hoistable.size() && hoistable[i])) continue;
+                if (inside[i] || loads[i] || st[i].ops.empty() || live_here[i] || (i < (int)hoistable.size() && hoistable[i])) continue;
                 if (tabled(i)) { loads[i] = 1; if (tab_used) (*tab_used)[i] = 1; continue; }
                 inside[i] = 1;
                 for (int op : st[i].ops) stack.push_back(op);
@@ -1013,7 +1384,10 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
     // walks of four bricks along x 0.363 -> 0.356 ms at 8.
     auto knob = [](const char* name, int fallback) { const char* e = std::getenv(name); return e && *e ? std::atoi(e) : fallback; };
     const int tab_min = knob("HU_TAB_MIN", 2);      // what a single-axis value must cost to become a table column (0: no tables)
+    const bool plain_in_place = paths.size() > kInPlaceDeferredPaths;
+    if (meta) meta->plain_in_place = plain_in_place;
     for (const Form& f : forms) {
+        if (f.walk == 0 && plain_in_place) continue;      // (specialised_source emits the plain form under these names)
         const std::vector<char> hoistable = hoistable_set(ph, f.walk, knob("HU_HOIST_MIN_X", 8));
         // ---- axis and pair tables: the candidates this form's walk-dependent code and its direction blocks read become
         // columns; the pair tables are filled from single-axis columns
@@ -1022,6 +1396,7 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
         int n_tab[6] = {0, 0, 0, 0, 0, 0};
         std::vector<char> held, used;
         if (f.walk != 0 && tab_min > 0) {
+            const std::vector<int> tab_cost = statement_costs(ph);
             tabc = table_candidates(ph, tab_min, knob("HU_TAB_PAIR_MIN", 3));
             for (;;) {
                 // the columns the DISTANCES read in every brick and the walk does not change are kept in registers instead
@@ -1047,8 +1422,16 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
                 std::fill(tab_index.begin(), tab_index.end(), -1);
                 std::fill(n_tab, n_tab + 6, 0);
                 bool over = false;
-                for (int i = 0; i < (int)used.size(); ++i) {
-                    if (!used[i]) continue;
+                // (the dearest statements first: when a tape has more two-coordinate statements than pair columns -- an assembly
+                // of extruded profiles --, the columns go to the gears and polygons, not to the circles)
+                std::vector<int> order;
+                for (int i = 0; i < (int)used.size(); ++i) if (used[i]) order.push_back(i);
+                int wanted[6] = {0, 0, 0, 0, 0, 0};
+                for (int i : order) ++wanted[table_slot(ph.e.st[i].deps)];
+                const bool crowded = wanted[0] > kMaxTableColumns || wanted[1] > kMaxTableColumns || wanted[2] > kMaxTableColumns || wanted[3] > kMaxPairColumns ||
+                                     wanted[4] > kMaxPairColumns || wanted[5] > kMaxPairColumns || wanted[3] + wanted[4] + wanted[5] > kMaxPairTotal;
+                if (crowded) std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return tab_cost[x] > tab_cost[y]; });
+                for (int i : order) {
                     const int slot = table_slot(ph.e.st[i].deps);
                     const bool fits = slot < 3 ? n_tab[slot] < kMaxTableColumns
                                                : n_tab[slot] < kMaxPairColumns && n_tab[3] + n_tab[4] + n_tab[5] < kMaxPairTotal;
@@ -1063,15 +1446,17 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
             if (std::accumulate(n_tab, n_tab + 6, 0) == 0) { tabc.clear(); held.clear(); }
         }
         if (meta && f.walk != 0) for (int a = 0; a < 6; ++a) meta->tabs[a] = n_tab[a];
-        const Variant vd = render_variant(ph, hoistable, dist_roots, tabc, &tab_index, held), ve = render_variant(ph, hoistable, eval_roots, tabc, &tab_index, held);
+        const PruneInfo* pi = f.walk != 0 ? &prune : nullptr;      // (the in-place form evaluates single points: nothing to decide per box)
+        const Variant vd = render_variant(ph, hoistable, dist_roots, tabc, &tab_index, held, pi),
+                      ve = render_variant(ph, hoistable, eval_roots, tabc, &tab_index, held, pi);
         // the values handed from `pre`: the union of what the distance and the evaluation read (one struct for both)
         const Variant& pre_of = ve;   // (eval's roots include dist's root: its frontier covers it)
         const bool hoists = f.walk != 0 && pre_of.n_hoisted > 0;
         if (f.walk != 0) {
             o << "// hoisted out of walks along x: " << pre_of.n_hoisted << " values; table columns: "
               << n_tab[0] << " / " << n_tab[1] << " / " << n_tab[2] << " (x / y / z), " << n_tab[3] << " / " << n_tab[4] << " / " << n_tab[5] << " (xy / xz / yz)\n"
-              << "template <class PX, class PY, class PZ, class TB> __device__ __forceinline__ auto tape_pre" << f.suffix
-              << "(PX px, PY py, PZ pz, const float* __restrict__ extra, uint32_t flags, const TB& tb)\n{\n    using namespace sdf;\n";
+              << "template <class PX, class PY, class PZ, class TB, class PR> __device__ __forceinline__ auto tape_pre" << f.suffix
+              << "(PX px, PY py, PZ pz, const float* __restrict__ extra, uint32_t flags, const TB& tb, const PR& pr)\n{\n    using namespace sdf;\n";
             if (hoists) o << pre_of.pre;
             else o << "    struct Hoisted {};\n    return Hoisted{};\n";
             o << "}\n";
@@ -1083,12 +1468,13 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
                   << (n_tab[a] ? render_table_builder(ph, slot_deps[a], tab_index, tabc, used) : std::string()) << "}\n";
             // (a pair table's entry: the two coordinates, and the single-axis tables positioned at it)
             for (int a = 3; a < 6; ++a)
-                o << "template <int S, class TB, class L> __device__ __forceinline__ void tape_tab" << f.suffix << "_" << slot_name[a]
-                  << "(float px, float py, float pz, const float* __restrict__ extra, uint32_t flags, const TB& tb, L out)\n{\n    using namespace sdf;\n"
-                  << (n_tab[a] ? render_table_builder(ph, slot_deps[a], tab_index, tabc, used) : std::string()) << "}\n";
+                o << "template <int S, class TB, class PR, class L> __device__ __forceinline__ void tape_tab" << f.suffix << "_" << slot_name[a]
+                  << "(float px, float py, float pz, const float* __restrict__ extra, uint32_t flags, const TB& tb, const PR& pr, L out)\n{\n    using namespace sdf;\n"
+                  << (n_tab[a] ? render_table_builder(ph, slot_deps[a], tab_index, tabc, used, nullptr, pi) : std::string()) << "}\n";
+            o << render_prune_function(ph, prune);
         }
-        const std::string h_param = f.walk != 0 ? ", const H& h, const TB& tb" : "";
-        const std::string h_tmpl = f.walk != 0 ? ", class H, class TB" : "";
+        const std::string h_param = f.walk != 0 ? ", const H& h, const TB& tb, const PR& pr" : "";
+        const std::string h_tmpl = f.walk != 0 ? ", class H, class TB, class PR" : "";
         const std::string root_name = ph.e.st[ph.root].ops.empty() ? ph.e.st[ph.root].text : ((ve.handed[ph.root] ? "h.t" : "t") + std::to_string(ph.root));
         o << "template <class PX, class PY, class PZ" << h_tmpl << "> __device__ __forceinline__ auto tape_dist" << f.suffix
           << "(PX px, PY py, PZ pz, const float* __restrict__ extra, uint32_t flags" << h_param << ")\n{\n" << head
@@ -1098,7 +1484,8 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
           << ve.main << phase2_for(ve.handed, tabc, &tab_index, nullptr)
           << "    return v4<T>(dir.x, dir.y, dir.z, as<T>(" << root_name << "));\n}\n";
     }
-    o << "// deferred directions: " << paths.size() << " (primitive, path) pairs; " << ph.e.st.size() << " statements in phase 1\n";
+    o << "// deferred directions: " << paths.size() << " (primitive, path) pairs; " << ph.e.st.size() << " statements in phase 1; box pruning: "
+      << prune.n_bits << " scopes\n";
     return true;
 }
 
@@ -1107,42 +1494,56 @@ inline std::string specialised_source(const SpecProgram& p, bool allow_deferred,
 {
     std::ostringstream o, d;
     SpecMeta m;
-    static const size_t max_paths = [] { const char* e = std::getenv("HU_MAX_PATHS"); return e && *e ? (size_t)std::atoi(e) : (size_t)40; }();
+    // (round 3's limit was 40: beyond it the second phase held too many registers.  With box pruning, walk coordinates the
+    // compiler cannot hoist from and kept distances read again from the tables, planetary's 80 pairs run its float4 grid
+    // in 1.0 ms where the plain form takes 4.7)
+    static const size_t max_paths = [] { const char* e = std::getenv("HU_MAX_PATHS"); return e && *e ? (size_t)std::atoi(e) : (size_t)400; }();
     const bool ok = allow_deferred && emit_deferred(d, p, max_paths, &m);
     if (!ok) m = SpecMeta();
     m.deferred = ok;
     if (meta) *meta = m;
     o << "#include \"kernels.hpp\"\nnamespace sdfk {\nusing sdf::Rec;\n";
     if (ok) o << d.str();
-    else emit_plain(o, p);
+    if (!ok || m.plain_in_place) emit_plain(o, p);
     o << "struct JitEval {\n    static constexpr bool kBricks = " << (ok ? "true" : "false") << ";\n"
       << "    const float* extra;\n"
       << "    uint32_t flags;   // sdf::kFlagInRange: the launch's coordinates cannot leave the fast range of sqrt_cr\n";
     if (ok) {
-        o << "    template <class T> __device__ __forceinline__ sdf::V4<T> operator()(T px, T py, T pz, void*) const\n"
-          << "    { return tape_eval(px, py, pz, extra, flags); }\n"
-          << "    template <class T> __device__ __forceinline__ T dist(T px, T py, T pz, void*) const\n"
-          << "    { return tape_dist(px, py, pz, extra, flags); }\n"
+        if (m.plain_in_place)
+            o << "    template <class T> __device__ __forceinline__ sdf::V4<T> operator()(T px, T py, T pz, void*) const\n"
+              << "    { return tape_eval<T>(px, py, pz, extra); }\n"
+              << "    template <class T> __device__ __forceinline__ T dist(T px, T py, T pz, void*) const\n"
+              << "    { return tape_dist<T>(px, py, pz, extra); }\n";
+        else
+            o << "    template <class T> __device__ __forceinline__ sdf::V4<T> operator()(T px, T py, T pz, void*) const\n"
+              << "    { return tape_eval(px, py, pz, extra, flags); }\n"
+              << "    template <class T> __device__ __forceinline__ T dist(T px, T py, T pz, void*) const\n"
+              << "    { return tape_dist(px, py, pz, extra, flags); }\n";
+        o
           // the axis tables of the two walks: columns per axis, and the functions that fill one entry of each table
           << "    static constexpr int kTabXX = " << m.tabs[0] << ", kTabXY = " << m.tabs[1] << ", kTabXZ = " << m.tabs[2]
-          << ", kPairXY = " << m.tabs[3] << ", kPairXZ = " << m.tabs[4] << ", kPairYZ = " << m.tabs[5] << ";\n";
+          << ", kPairXY = " << m.tabs[3] << ", kPairXZ = " << m.tabs[4] << ", kPairYZ = " << m.tabs[5] << ";\n"
+          // box pruning: words of a box's mask, and the function that decides it (kernels.hpp k_box_masks)
+          << "    static constexpr int kPruneWords = " << m.prune_words << ";\n"
+          << "    template <class PR> __device__ __forceinline__ void prune(float cx, float cy, float cz, float hx, float hy, float hz, PR& out) const\n"
+          << "    { tape_prune(cx, cy, cz, hx, hy, hz, extra, out); }\n";
         for (const char* axis : {"x", "y", "z"})
             o << "    template <int S, class L> __device__ __forceinline__ void tab_x_" << axis << "(float p, L out) const\n"
               << "    { tape_tab_x_" << axis << "<S>(p, extra, flags, out); }\n";
         // one entry (a, b) of a pair table
-        o << "    template <int S, class TB, class L> __device__ __forceinline__ void tab_x_xy(float a, float b, const TB& tb, L out) const\n"
-          << "    { tape_tab_x_xy<S>(a, b, 0.0f, extra, flags, tb, out); }\n"
-          << "    template <int S, class TB, class L> __device__ __forceinline__ void tab_x_xz(float a, float b, const TB& tb, L out) const\n"
-          << "    { tape_tab_x_xz<S>(a, 0.0f, b, extra, flags, tb, out); }\n"
-          << "    template <int S, class TB, class L> __device__ __forceinline__ void tab_x_yz(float a, float b, const TB& tb, L out) const\n"
-          << "    { tape_tab_x_yz<S>(0.0f, a, b, extra, flags, tb, out); }\n"
+        o << "    template <int S, class TB, class PR, class L> __device__ __forceinline__ void tab_x_xy(float a, float b, const TB& tb, const PR& pr, L out) const\n"
+          << "    { tape_tab_x_xy<S>(a, b, 0.0f, extra, flags, tb, pr, out); }\n"
+          << "    template <int S, class TB, class PR, class L> __device__ __forceinline__ void tab_x_xz(float a, float b, const TB& tb, const PR& pr, L out) const\n"
+          << "    { tape_tab_x_xz<S>(a, 0.0f, b, extra, flags, tb, pr, out); }\n"
+          << "    template <int S, class TB, class PR, class L> __device__ __forceinline__ void tab_x_yz(float a, float b, const TB& tb, const PR& pr, L out) const\n"
+          << "    { tape_tab_x_yz<S>(0.0f, a, b, extra, flags, tb, pr, out); }\n"
           // what does not change along x, for the walks of a box with y and z fixed (kernels.hpp box_eval)
-          << "    template <class PY, class PZ, class TB> __device__ __forceinline__ auto hoist_x(PY py, PZ pz, const TB& tb) const\n"
-          << "    { return tape_pre_x(0.0f, py, pz, extra, flags, tb); }\n"
-          << "    template <class PX, class PY, class PZ, class H, class TB> __device__ __forceinline__ auto eval_hoisted_x(PX px, PY py, PZ pz, const H& h, const TB& tb) const\n"
-          << "    { return tape_eval_x(px, py, pz, extra, flags, h, tb); }\n"
-          << "    template <class PX, class PY, class PZ, class H, class TB> __device__ __forceinline__ auto dist_hoisted_x(PX px, PY py, PZ pz, const H& h, const TB& tb) const\n"
-          << "    { return tape_dist_x(px, py, pz, extra, flags, h, tb); }\n";
+          << "    template <class PY, class PZ, class TB, class PR> __device__ __forceinline__ auto hoist_x(PY py, PZ pz, const TB& tb, const PR& pr) const\n"
+          << "    { return tape_pre_x(0.0f, py, pz, extra, flags, tb, pr); }\n"
+          << "    template <class PX, class PY, class PZ, class H, class TB, class PR> __device__ __forceinline__ auto eval_hoisted_x(PX px, PY py, PZ pz, const H& h, const TB& tb, const PR& pr) const\n"
+          << "    { return tape_eval_x(px, py, pz, extra, flags, h, tb, pr); }\n"
+          << "    template <class PX, class PY, class PZ, class H, class TB, class PR> __device__ __forceinline__ auto dist_hoisted_x(PX px, PY py, PZ pz, const H& h, const TB& tb, const PR& pr) const\n"
+          << "    { return tape_dist_x(px, py, pz, extra, flags, h, tb, pr); }\n";
     } else {
         o << "    template <class T> __device__ __forceinline__ sdf::V4<T> operator()(T px, T py, T pz, void*) const\n"
           << "    { return tape_eval<T>(px, py, pz, extra); }\n"

@@ -68,6 +68,7 @@ PROTOTYPES = {
     "hu_tape_specialize_cached": [_vp, _c.c_char_p, _c.c_char_p, _i, _c.POINTER(_i)],
     "hu_tape_specialize_groups": [_vp, _c.c_char_p, _c.c_char_p, _i, _u32, _c.POINTER(_i)],
     "hu_tape_specialized": [_vp, _c.POINTER(_i)],
+    "hu_tape_prune_info": [_vp, _c.POINTER(_i), _c.POINTER(_i)],
     "hu_tape_compile_check": [_f4, _sz, _c.c_char_p, _c.POINTER(_sz)],
     "hu_tape_compile_cached": [_f4, _sz, _c.c_char_p, _c.c_char_p, _c.POINTER(_sz), _c.POINTER(_i)],
     "hu_tape_compile_groups": [_f4, _sz, _c.c_char_p, _c.c_char_p, _u32, _c.POINTER(_sz), _c.POINTER(_i)],

@@ -420,12 +420,13 @@ class Tape:
         self._take_background_builds()
         return self.specialized
 
-    def specialize(self):
+    def specialize(self, groups=15):
         """Compile straight-line kernels for this tape with hipRTC (seconds, once) and wait for them; afterwards
         every launch with this tape uses them.  Same results as the interpreter.  Raises
-        RuntimeError (with the compiler log) if hipRTC cannot build it."""
+        RuntimeError (with the compiler log) if hipRTC cannot build it.  `groups`: the kernel families to build
+        (hu_spec_group bits: SPEC_DENSE | SPEC_BLOCKS | SPEC_CLASSIFY | SPEC_RENDER; default all of them)."""
         self._jobs = []
-        self._specialize(only_if_cached=False)
+        self._specialize(only_if_cached=False, groups=int(groups))
         return self
 
     def _specialize(self, only_if_cached, directory=None, groups=15):

@@ -288,6 +288,12 @@ int hu_tape_specialize_groups(hu_tape t, const char* include_dir, const char* ca
                               uint32_t groups, int* from_cache);
 /* *out_flag <- the HU_SPEC_* families whose per-tape kernels are loaded (0: everything is interpreted) */
 int hu_tape_specialized(hu_tape t, int* out_flag);
+/* Box pruning of the tape's per-tape code (no counterpart in the reference, whose kernels evaluate every primitive for
+ * every sample): *bits <- the operands of min / max that can be decided per 16^3 box of a launch (0: nothing in this tape
+ * can be bounded, or it is interpreted), *words <- 32-bit words of a box's mask.  Launches over boxes run the tape's mask
+ * kernel first, on their stream; HU_PRUNE=0 in the environment builds tapes without it, HU_PRUNE_RUN=0 skips the mask
+ * kernel (every operand is then taken as alive).  Results are bit-identical either way. */
+int hu_tape_prune_info(hu_tape t, int* bits, int* words);
 /* The HIP source hu_tape_specialize would compile for this tape (host only, no device needed):
  * `*needed` receives its size including the terminator; it is copied when `capacity` suffices. */
 int hu_tape_source(const float* tape, size_t n_floats, char* buf, size_t capacity, size_t* needed);

@@ -69,10 +69,12 @@ def check_blocks(hip, handle, tape, int_corners, resolution, origin, edge=16):
     blocks_dev.release()
 
 
-def run(hip, tape, grids, block_sets):
+def run(hip, tape, grids, block_sets, inspect=None):
     from codecad_amd import hip_util
     handle = hip_util.Tape(tape)
-    handle.specialize()
+    handle.specialize(hip_util.SPEC_DENSE | hip_util.SPEC_BLOCKS)     # (the families these checks launch)
+    if inspect is not None:
+        inspect(handle)
     for corner, step, dims in grids:
         check_dense(hip, handle, tape, corner, step, dims)
     for block_set in block_sets:

@@ -186,6 +186,66 @@ def test_specialised_source_builds_under_hiprtc_without_a_device():
     assert b"malformed" in lib.hu_last_error()
 
 
+def _source_of(tape, env=None):
+    """hu_tape_source of a tape; with `env`, in a process of its own (the generator reads its knobs once)."""
+    import ctypes
+    import os
+    import subprocess
+    import sys
+    import numpy
+    from codecad_amd.hip_util import _lib
+    if env is None:
+        lib = _lib.load()
+        t, p = _tape_ptr(tape)
+        needed = ctypes.c_size_t(0)
+        assert lib.hu_tape_source(p, t.size, None, 0, ctypes.byref(needed)) == 0
+        buf = ctypes.create_string_buffer(needed.value)
+        assert lib.hu_tape_source(p, t.size, buf, needed.value, ctypes.byref(needed)) == 0
+        return buf.value.decode()
+    code = ("import sys, ctypes, numpy; sys.path.insert(0, %r); from codecad_amd.hip_util import _lib; lib = _lib.load();"
+            "t = numpy.frombuffer(sys.stdin.buffer.read(), dtype=numpy.float32).copy(); n = ctypes.c_size_t(0);"
+            "p = t.ctypes.data_as(ctypes.POINTER(ctypes.c_float)); assert lib.hu_tape_source(p, t.size, None, 0, ctypes.byref(n)) == 0;"
+            "b = ctypes.create_string_buffer(n.value); assert lib.hu_tape_source(p, t.size, b, n.value, ctypes.byref(n)) == 0;"
+            "sys.stdout.write(b.value.decode())" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", code], input=numpy.ascontiguousarray(tape, dtype=numpy.float32).tobytes(), capture_output=True,
+                         env=dict(os.environ, **env), timeout=300)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    return out.stdout.decode()
+
+
+def test_box_pruning_in_the_generated_source():
+    """specialise.hpp "BOX PRUNING": an assembly's tape gets a mask function (bounds of its distances over a box from their
+    values at the centre) and guarded assignments -- scalar bit tests around everything only a prunable operand needs --;
+    the planetary assembly: all 80 (primitive, path) pairs deferred, > 100 prunable operands, its XY-frame gears in the pair
+    table.  A tape in which nothing can be bounded (the sponge: all of it behind a repetition) keeps the code it had, and
+    HU_PRUNE=0 builds any tape without pruning."""
+    import re
+    import codecad_amd as cc
+    planetary = cc.nodes.make_program(cc.examples.planetary())
+    src = _source_of(planetary)
+    m = re.search(r"deferred directions: (\d+) \(primitive, path\) pairs; \d+ statements in phase 1; box pruning: (\d+) scopes", src)
+    assert m and int(m.group(1)) == 80 and int(m.group(2)) > 100, src[-600:]
+    words = int(re.search(r"kPruneWords = (\d+);", src).group(1))
+    assert words == (int(m.group(2)) + 31) // 32
+    prune = src[src.index("void tape_prune("):]
+    prune = prune[:prune.index("\n}\n")]
+    assert "iv_leaf(" in prune and "iv_perp(" in prune and "iv_min(" in prune and "iv_unknown()" in prune
+    assert prune.count("&= ~") == int(m.group(2)) and "out.w[%d] = w%d;" % (words - 1, words - 1) in prune
+    assert "run_record" not in prune          # (no bound is claimed for a gear: the mask function never evaluates one)
+    dist = src[src.index("auto tape_dist_x("):]
+    dist = dist[:dist.index("\n}\n")]
+    assert dist.count("if (pr.template alive<") > 100 and "as<decltype(t" in dist and "{};" not in dist
+    xy = src[src.index("void tape_tab_x_xy("):]
+    xy = xy[:xy.index("\n}\n")]
+    assert xy.count("= run_record<") >= 6 and "if (pr.template alive<" in xy       # the gears of the frames that keep z: 256 evaluations per box
+    assert "mask_const<decltype(t" in src[src.index("auto tape_eval_x("):]
+    # nothing to bound: no scopes, no tests, the statements as they were
+    sponge = _source_of(cc.nodes.make_program(cc.examples.sponge(3)))
+    assert "box pruning: 0 scopes" in sponge and "kPruneWords = 0;" in sponge and "alive<" not in sponge and "const auto t" in sponge
+    off = _source_of(planetary, env={"HU_PRUNE": "0"})
+    assert "box pruning: 0 scopes" in off and "alive<" not in off
+
+
 def test_specialised_code_cache_on_disk(tmp_path):
     """hu_tape_compile_cached (host only): a miss compiles and stores one file, a hit only reads it and gives
     the same code; truncated / bit-flipped / foreign files are ignored, rebuilt and replaced; another tape or other

@@ -115,3 +115,19 @@ def test_tape_shape_roundtrip():
     assert ts.dimension() == 3
     with pytest.raises(TypeError):
         nodes.make_program(ts + ts)
+
+
+def test_the_packaged_planetary_tape_is_the_golden_one():
+    """codecad_amd.examples.planetary() (BASELINE config C4, bench.py --config c4) carries the tape, bounding box and
+    feature size that tests/golden/gen/make_golden.py captured from the reference's examples/planetary.py."""
+    import json
+    import os
+    import numpy as np
+    import codecad_amd as cc
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = {s["name"]: s for s in json.load(open(os.path.join(root, "tests", "golden", "ref_tapes.json")))["shapes"]}["planetary"]
+    shape = cc.examples.planetary()
+    assert np.array_equal(cc.nodes.make_program(shape).view(np.uint32), np.array(g["tape_u32"], dtype=np.uint32))
+    box = shape.bounding_box()
+    assert [box.a.x, box.a.y, box.a.z] == [float(v) for v in g["bbox_a"]] and [box.b.x, box.b.y, box.b.z] == [float(v) for v in g["bbox_b"]]
+    assert shape.feature_size() == float(g["feature_size"])

@@ -1,0 +1,4 @@
+#!/bin/bash
+set -u
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
+python3 -m pytest tests -x -q -m gpu --durations=15 ${1:-} > gpurun_out/r04_gputest.log 2>&1; echo "pytest rc=$?"; tail -25 gpurun_out/r04_gputest.log

@@ -41,10 +41,10 @@ def main():
     os.makedirs(out, exist_ok=True)
     if blocks:
         inst = ("template __global__ void sdfk::k_grid_eval_blocks<sdfk::JitEval, 1, 2>(const sdfk::JitEval, const int4*, const uint32_t*, uint32_t, "
-                "uint32_t, uint32_t, double, double, double, double, float, uint32_t, sdfk::Dim, sdfk::Dim, void*);\n")
+                "uint32_t, uint32_t, double, double, double, double, float, uint32_t, sdfk::Dim, sdfk::Dim, void*, const uint32_t*);\n")
     else:
         inst = ("template __global__ void sdfk::k_grid_eval<sdfk::JitEval, %d, 2>(const sdfk::JitEval, float, float, float, float, uint32_t, "
-                "sdfk::Dim, sdfk::Dim, uint32_t, uint32_t, uint32_t, void*);\n" % layout)
+                "sdfk::Dim, sdfk::Dim, uint32_t, uint32_t, uint32_t, void*, const uint32_t*);\n" % layout)
     src = source_of(tape) + "\n" + inst
     open(out + "/spec.hip", "w").write(src)
     extra = [a for a in sys.argv[3:]]
