@@ -309,8 +309,10 @@ def main():
     torch.cuda.synchronize()                       # setup (default-stream fills and copies) is complete before any stream runs
     # warm-up: the first traversals also settle the list capacities at what the lists need + 12 % (a launch is
     # sized for the capacity, and workgroups past the list's end cost their dispatch: 80 000 spare leaf blocks are 0.2 ms)
-    totals, settled, done = None, False, 0
-    for i in range(n_pipes * max(args.warmup, 1) + 4 * n_pipes):
+    # (tightening may be needed twice: with tight lists the small levels become REPLICATED levels -- every rank classifies them
+    # in full and keeps the cells it owns, dist.py -- and a rank's share of the leaf level is then 1 / N of what it was)
+    totals, settled, done = None, 0, 0
+    for i in range(n_pipes * max(args.warmup, 1) + 8 * n_pipes):
         pipe = pipes[i % n_pipes]
         mine = one_step(warm_events, i)
         try:
@@ -318,11 +320,11 @@ def main():
             tight = [int(v * 1.125) + 16 for v in pipe.needed]
         except dist.Overflow as e:
             totals, tight = None, [int(v * 1.125) + 16 for v in e.needed]
-        if totals is None or (not settled and any(c > t for c, t in zip(pipe.capacities, tight))):
+        if totals is None or (settled < 3 and any(c > t + t // 8 + 64 for c, t in zip(pipe.capacities, tight))):
             barrier()
             pipes[:] = [build_pipeline(tight, j) for j in range(n_pipes)]
             leaf_out[0] = None
-            settled = totals is not None
+            settled += 1 if totals is not None else 0
             totals = None
             done = 0
             continue
@@ -380,7 +382,11 @@ def main():
             unit = min(8, args.steps)
             g_unit = capture_steps(unit)
             g_rest = capture_steps(args.steps % unit) if args.steps % unit else None
-            g_unit.replay()                               # (warm: the first launch of a graph uploads it)
+            # warm: the first launch of a graph uploads it, and the kernel trace (tools/r04/graph_trace.py) shows the first ~16
+            # steps after the capture running ~20 % slower whatever launches them -- the capture and instantiation keep the host
+            # busy for tens of ms while the device idles and clocks down -- so the graph is replayed three times before it is timed
+            for _ in range(3):
+                g_unit.replay()
             if g_rest is not None:
                 g_rest.replay()
             barrier()
@@ -399,7 +405,7 @@ def main():
             graph_leg = {"captured": True, "steps_per_graph": unit, "steps": args.steps,
                          "ms_per_step": round(g_wall / args.steps * 1e3, 4),
                          "host_enqueue_ms_per_step": round(g_enqueue / args.steps * 1e3, 4),
-                         "collectives_in_graph": bool(dist.exchanging())}
+                         "collectives_in_graph": bool(dist.exchanging()) and pipes[0].replicate < len(pipes[0].capacities)}
         except Exception as e:   # (a runtime that cannot capture a collective: said, not hidden)
             graph_leg = {"captured": False, "error": ("%s: %s" % (type(e).__name__, e))[:400]}
 
@@ -475,10 +481,12 @@ def main():
                        "evaluator": evaluator + (" (per-tape straight-line kernels compiled with hipRTC from the same "
                                                   "op library; bit-identical to the interpreter)" if evaluator == "specialised" else ""),
                        "traversals_in_flight": n_pipes,
+                       "replicated_levels": int(pipes[0].replicate),
                        "tape_floats": int(host_tape.size), "tape_instructions": tape.n_instructions,
                        "value_registers": tape.n_registers,
-                       "parallelism": ("x-slabs of the one grid, balanced parent slices + one fixed-size RCCL all-gather of the "
-                                       "survivors per level, leaf blocks balanced over ranks" if world > 1 and not weak else
+                       "parallelism": ("x-slabs of the one grid; the small leading levels of the hierarchy replicated (every rank classifies them "
+                                       "in full, the last one listing the cells the rank owns: no exchange), larger levels: balanced parent slices + "
+                                       "one fixed-size RCCL all-gather of the survivors per level; leaf blocks: the rank's share" if world > 1 and not weak else
                                        "one object per rank; one global parent list per level, re-balanced" if weak else "single GPU")},
             "samples_per_step": {"dense": job_dense, "subdivision": subdivision_samples, "leaf_blocks": leaf_samples,
                                  "survivors_per_level_global": totals, "rank0_dense": dense_voxels,
@@ -486,6 +494,8 @@ def main():
             "adaptive": {"what": "B + C, slowest rank: the whole traversal on its own stream (kernels + all-gathers, overlapping A), "
                                  "then every sample of this rank's leaf blocks",
                          "subdivision_ms": round(b_avg, 4), "leaf_blocks_ms": round(c_avg, 4), "ms": round(adaptive_ms, 4),
+                         # launch-to-launch spread of the leaf-block kernel in THIS run (rank 0, HIP events, free-running)
+                         "leaf_blocks_ms_min_max": [round(min(c_ms), 4), round(max(c_ms), 4)] if c_ms else None,
                          "evaluated_samples": subdivision_samples + leaf_samples,
                          "evaluated_msamples_per_s": round((subdivision_samples + leaf_samples) / adaptive_ms / 1e3, 1),
                          "effective_voxels": n ** 3 * n_objects,
@@ -498,9 +508,10 @@ def main():
                 graph_leg["host_enqueue_ms_per_step_direct"] = line["host_enqueue_ms_per_step"]
             line["graph_replay"] = graph_leg
         if dist.exchanging() and world == 1:
-            line["config"]["forced_collectives"] = ("CODECAD_AMD_FORCE_COLLECTIVES=1: one rank, a real process group (backend %s): every "
-                                                    "level goes through all_gather_into_tensor -> hu_slice_rows -> indirect launches"
-                                                    % torch.distributed.get_backend())
+            line["config"]["forced_collectives"] = ("CODECAD_AMD_FORCE_COLLECTIVES=1: one rank, a real process group (backend %s): the %d leading "
+                                                    "levels are replicated (hu_subdivision_level_owned: every rank classifies them in full and keeps the "
+                                                    "cells it owns, no exchange), every other level goes through all_gather_into_tensor -> hu_slice_rows -> "
+                                                    "indirect launches" % (torch.distributed.get_backend(), int(pipes[0].replicate)))
         if verified is not None:
             line["verified"] = verified
         if interp_ms:

@@ -232,6 +232,9 @@ struct SpecKernels {
     uint32_t groups = 0;                // HU_SPEC_* bits: the kernel families that are loaded
     hipFunction_t dense[2] = {nullptr, nullptr};
     hipFunction_t blocks[2] = {nullptr, nullptr};
+    // tapes with box code: the same over runs of cells, for extents that are no multiples of (4, 4, 8) (kernels.hpp k_grid_eval_ragged)
+    hipFunction_t dense_ragged[2] = {nullptr, nullptr};
+    hipFunction_t blocks_ragged[2] = {nullptr, nullptr};
     hipFunction_t classify[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [MASS][BATCH]
     hipFunction_t ray_caster = nullptr, bitmap = nullptr;
     hipFunction_t box_masks = nullptr;   // k_box_masks (box pruning), part of every family that launches over boxes
@@ -303,19 +306,22 @@ void keep_programs(hu_tape_s* t, const sdf::DecodedTape& d)
 
 struct SpecEval { const float* extra; uint32_t flags; };  // same layout as the generated sdfk::JitEval
 
-constexpr int kSpecKernelCount = 11;
+constexpr int kSpecKernelCount = 15;
 // the family (include/hip_util.h HU_SPEC_*) of each kernel below: a build may hold any subset of the families (the mask
 // kernel of box pruning belongs to every family that launches over boxes)
 constexpr uint32_t kSpecGroupOf[kSpecKernelCount] = {HU_SPEC_DENSE, HU_SPEC_DENSE, HU_SPEC_BLOCKS, HU_SPEC_BLOCKS, HU_SPEC_CLASSIFY, HU_SPEC_CLASSIFY,
                                                       HU_SPEC_CLASSIFY, HU_SPEC_CLASSIFY, HU_SPEC_RENDER, HU_SPEC_RENDER,
-                                                      HU_SPEC_DENSE | HU_SPEC_BLOCKS | HU_SPEC_CLASSIFY};
+                                                      HU_SPEC_DENSE | HU_SPEC_BLOCKS | HU_SPEC_CLASSIFY,
+                                                      HU_SPEC_DENSE, HU_SPEC_DENSE, HU_SPEC_BLOCKS, HU_SPEC_BLOCKS};
 const char* const kSpecKernelNames[kSpecKernelCount] = {
     "sdfk::k_grid_eval<sdfk::JitEval, 0, 2>",           "sdfk::k_grid_eval<sdfk::JitEval, 1, 2>",
     "sdfk::k_grid_eval_blocks<sdfk::JitEval, 0, 2>",    "sdfk::k_grid_eval_blocks<sdfk::JitEval, 1, 2>",
     "sdfk::k_classify<sdfk::JitEval, false, false, 2>", "sdfk::k_classify<sdfk::JitEval, false, true, 2>",
     "sdfk::k_classify<sdfk::JitEval, true, false, 2>",  "sdfk::k_classify<sdfk::JitEval, true, true, 2>",
     "sdfk::k_ray_caster<sdfk::JitEval>",                "sdfk::k_bitmap<sdfk::JitEval>",
-    "sdfk::k_box_masks<sdfk::JitEval>"};
+    "sdfk::k_box_masks<sdfk::JitEval>",
+    "sdfk::k_grid_eval_ragged<sdfk::JitEval, 0, 2>",        "sdfk::k_grid_eval_ragged<sdfk::JitEval, 1, 2>",
+    "sdfk::k_grid_eval_blocks_ragged<sdfk::JitEval, 0, 2>", "sdfk::k_grid_eval_blocks_ragged<sdfk::JitEval, 1, 2>"};
 
 // Box pruning: run the tape's mask kernel for the `m.n_boxes` workgroups of the launch that follows on `stream` and hand
 // back their masks -- or NULL (nothing to prune in this tape, HU_PRUNE_RUN=0, or a buffer that would have to grow while
@@ -594,7 +600,20 @@ int hu_grid_eval_slab(hu_tape t, const float corner[4], float step, const uint32
             // directions) and where the tape has tables to fill; a tape that is bound by its store stream keeps the runs
             // along z (2 KiB contiguous per wavefront: sphere, 512^3 float4: 0.34 ms in runs, 0.42 ms in bricks)
             uint32_t boxes = t->spec->deferred ? brick_tiles(nx, dims[1], dims[2]) : 0u;
-            const uint32_t per_block = kSpecBlock * kSpecVoxelsPerLane;
+            // runs of cells (HU_RUN_BLOCK: 64 / 128 / 256 lanes per workgroup, for measurements: the lanes of a run kernel share
+            // nothing, but single-wavefront workgroups were SLOWER on the store-bound tapes -- box, 512^3 float4: 0.409 against
+            // 0.373 ms, its distance grid 0.265 against 0.180 ms)
+            static const uint32_t run_block = [] { const char* e = getenv("HU_RUN_BLOCK"); const int v = e ? atoi(e) : 0; return (v == 64 || v == 128 || v == 256) ? (uint32_t)v : 256u; }();
+            const uint32_t block = boxes ? kSpecBlock : run_block;
+            // A tape of a primitive or two (a box, a sphere: per-tape code in the plain form, over runs) is bound by its
+            // store stream, and that stream runs FASTER with fewer wavefronts in flight: box, 512^3 float4: 0.373 ms at eight
+            // wavefronts per SIMD (what its 20-odd registers allow), 0.328 ms at four -- the interpreter's rate, whose LDS
+            // register file holds it near there anyway (measured with -DSDF_WAVES_PER_EU: 2 / 4 / 6 / 8 -> 0.382 / 0.328 /
+            // 0.353 / 0.373 ms).  So such a launch asks for 40 KiB of LDS it never touches: four workgroups, sixteen
+            // wavefronts per CU.  (HU_STORE_BOUND_LDS=0: off; longer tapes -- sponge(4): 0.407 -> 0.429 ms at four -- keep all.)
+            static const bool limit_store_bound = [] { const char* e = getenv("HU_STORE_BOUND_LDS"); return !(e && e[0] == '0'); }();
+            const uint32_t idle_lds = (!boxes && !t->spec->deferred && limit_store_bound && t->n_instr <= 16) ? 40u * 1024u : 0u;
+            const uint32_t per_block = block * kSpecVoxelsPerLane;
             uint32_t grid = (n_cells + per_block - 1) / per_block;
             const uint32_t* masks = nullptr;
             if (boxes) {
@@ -604,9 +623,14 @@ int hu_grid_eval_slab(hu_tape t, const float corner[4], float step, const uint32
                 m.nx = nx; m.ny = dims[1]; m.nz = dims[2]; m.xs0 = xs; m.cx = cx; m.cy = cy; m.cz = cz; m.step = step;
                 if ((rc = prepare_masks(t, m, (hipStream_t)stream, &masks))) return rc;
             }
-            void* args[] = {&ev, &cx, &cy, &cz, &step, &sx, &sy, &sz, &xs, &n_cells, &boxes, &o, &masks};
-            HU_HIP(hipModuleLaunchKernel(t->spec->dense[layout], grid, 1, 1, kSpecBlock, 1, 1, boxes ? box_table_bytes(t->spec) : 0u,
-                                         (hipStream_t)stream, args, nullptr));
+            if (t->spec->deferred && !boxes) {      // a tape with box code on a slab that has no boxes: its kernel over runs
+                void* args[] = {&ev, &cx, &cy, &cz, &step, &sx, &sy, &sz, &xs, &n_cells, &o};
+                HU_HIP(hipModuleLaunchKernel(t->spec->dense_ragged[layout], grid, 1, 1, block, 1, 1, 0u, (hipStream_t)stream, args, nullptr));
+            } else {
+                void* args[] = {&ev, &cx, &cy, &cz, &step, &sx, &sy, &sz, &xs, &n_cells, &boxes, &o, &masks};
+                HU_HIP(hipModuleLaunchKernel(t->spec->dense[layout], grid, 1, 1, block, 1, 1, boxes ? box_table_bytes(t->spec) : idle_lds,
+                                             (hipStream_t)stream, args, nullptr));
+            }
             done += nx;
         }
         return HU_OK;
@@ -697,9 +721,14 @@ static int grid_eval_blocks_impl(hu_tape t, const int32_t* blocks_dev, uint32_t 
                 m.res = res; m.ox = ox; m.oy = oy; m.oz = oz;
                 if ((rc = prepare_masks(t, m, (hipStream_t)stream, &masks))) return rc;
             }
-            void* args[] = {&ev, &b, &n_dev, &first, &chunks, &bricks, &res, &ox, &oy, &oz, &step, &sx, &sy, &sz, &out_dev, &masks};
-            HU_HIP(hipModuleLaunchKernel(t->spec->blocks[layout], chunks * count, 1, 1, kSpecBlock, 1, 1,
-                                         bricks ? box_table_bytes(t->spec) : 0u, (hipStream_t)stream, args, nullptr));
+            if (t->spec->deferred && !bricks) {
+                void* args[] = {&ev, &b, &n_dev, &first, &chunks, &res, &ox, &oy, &oz, &step, &sx, &sy, &sz, &out_dev};
+                HU_HIP(hipModuleLaunchKernel(t->spec->blocks_ragged[layout], chunks * count, 1, 1, kSpecBlock, 1, 1, 0u, (hipStream_t)stream, args, nullptr));
+            } else {
+                void* args[] = {&ev, &b, &n_dev, &first, &chunks, &bricks, &res, &ox, &oy, &oz, &step, &sx, &sy, &sz, &out_dev, &masks};
+                HU_HIP(hipModuleLaunchKernel(t->spec->blocks[layout], chunks * count, 1, 1, kSpecBlock, 1, 1,
+                                             bricks ? box_table_bytes(t->spec) : 0u, (hipStream_t)stream, args, nullptr));
+            }
         }
         return HU_OK;
     }
@@ -770,7 +799,7 @@ int launch_classify(hu_tape t, ClassifyArgs& a, uint32_t n_parents, const uint32
         a.boxes = 0;
         // Grids of more than one workgroup's worth of cells go over 16^3 boxes with their tables in LDS (kernels.hpp
         // k_classify / box_eval) where the extents allow it.  (Up to 256 cells the lane-order compaction of ONE workgroup
-        // is what dist.LevelPipeline's replicate_first relies on: that path stays as it is.)
+
         // And only launches that fill the chip several times over: a box is one workgroup where the path below has eight,
         // and a level of a few hundred parents is a latency exercise (measured: C5's 704 parents of 16^3 0.21 -> 0.33 ms
         // over boxes; C3's mass properties at grid 8, 167 000 parents in the last level, 0.94 -> 0.80 ms).
@@ -908,6 +937,48 @@ int hu_subdivision_level_indirect(hu_tape t, const int32_t* parents_dev, const u
     a.step = step; a.thr = threshold;
     a.counter = counter_dev; a.list = children_dev; a.capacity = capacity;
     return launch_classify<false, true>(t, a, max_parents, dims, stream);
+}
+
+// ... and with OWNERSHIP (kernels.hpp ClassifyArgs::own): the launch of a level that `world` ranks classify in full, each keeping
+// the cells it owns
+int hu_subdivision_level_owned(hu_tape t, const int32_t* parents_dev, const uint32_t* n_parents_dev, uint32_t max_parents,
+                               int32_t int_step, const uint32_t dims[3], int dimension, double resolution,
+                               const double origin[3], float step, float threshold, uint32_t* counter_dev,
+                               int32_t* children_dev, uint32_t capacity, uint32_t world, uint32_t rank, void* stream)
+{
+    if (!t || !origin || !counter_dev || !n_parents_dev || (!children_dev && capacity) || (!parents_dev && max_parents))
+        return fail(HU_ERR_BAD_ARG, "NULL argument");
+    if (dimension != 2 && dimension != 3) return fail(HU_ERR_BAD_ARG, "dimension must be 2 or 3");
+    if (world == 0 || rank >= world) return fail(HU_ERR_BAD_ARG, "rank must be below world");
+    ClassifyArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.parents = parents_dev;
+    a.n_parents_dev = n_parents_dev;
+    a.int_step = int_step; a.dimension = dimension;
+    a.res = resolution; a.ox = origin[0]; a.oy = origin[1]; a.oz = origin[2];
+    a.step = step; a.thr = threshold;
+    a.counter = counter_dev; a.list = children_dev; a.capacity = capacity;
+    a.own = make_dim(world); a.own_rank = rank;
+    return launch_classify<false, true>(t, a, max_parents, dims, stream);
+}
+
+int hu_mass_properties_level_owned(hu_tape t, const double* parents_dev, const uint32_t* n_parents_dev, uint32_t max_parents, double s,
+                                   const uint32_t dims[3], float step, float threshold, uint32_t* sums_dev,
+                                   uint32_t* counter_dev, double* children_dev, uint32_t capacity, uint32_t world, uint32_t rank, void* stream)
+{
+    if (!t || !sums_dev || !counter_dev || !n_parents_dev || (!children_dev && capacity) || (!parents_dev && max_parents))
+        return fail(HU_ERR_BAD_ARG, "NULL argument");
+    if (world == 0 || rank >= world) return fail(HU_ERR_BAD_ARG, "rank must be below world");
+    ClassifyArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.parents = parents_dev;
+    a.n_parents_dev = n_parents_dev;
+    a.s = s;
+    a.step = step; a.thr = threshold;
+    a.counter = counter_dev; a.list = children_dev; a.capacity = capacity;
+    a.sums = sums_dev;
+    a.own = make_dim(world); a.own_rank = rank;
+    return launch_classify<true, true>(t, a, max_parents, dims, stream);
 }
 
 int hu_mass_properties_level(hu_tape t, const double* parents_dev, uint32_t n_parents, double s,
@@ -1329,7 +1400,8 @@ int hu_tape_specialize_groups(hu_tape t, const char* include_dir, const char* ca
             SpecKernels* k = t->spec;
             hipFunction_t* slots[kSpecKernelCount] = {&k->dense[0], &k->dense[1], &k->blocks[0], &k->blocks[1],
                                                       &k->classify[0][0], &k->classify[0][1], &k->classify[1][0], &k->classify[1][1],
-                                                      &k->ray_caster, &k->bitmap, &k->box_masks};
+                                                      &k->ray_caster, &k->bitmap, &k->box_masks,
+                                                      &k->dense_ragged[0], &k->dense_ragged[1], &k->blocks_ragged[0], &k->blocks_ragged[1]};
             for (int i = 0; i < kSpecKernelCount; ++i)
                 if (kSpecGroupOf[i] & missing) *slots[i] = loaded[i];
             k->modules.push_back(module);

@@ -340,6 +340,9 @@ template <class T> __device__ __forceinline__ T perp_w(T a, T b)
 // below computes in the wider of its operands' types; a float operand is the same IEEE binary32 value in both
 // halves of the packed form and every packed operation is two IEEE operations, so the bits are those of the all-f2
 // evaluation (tests/test_gpu_bricks.py, test_gpu_random_shapes.py compare them with the oracle).
+template <class X> struct plain { using type = X; };
+template <class X> struct plain<const X> { using type = X; };
+template <class X> using plain_t = typename plain<X>::type;     // decltype of a `const auto` value without its const
 template <class A, class B> struct wider { using type = f2; };
 template <> struct wider<float, float> { using type = float; };
 template <class A, class B> using wider_t = typename wider<A, B>::type;
@@ -1273,6 +1276,7 @@ typedef __attribute__((address_space(3))) float lds_float;
 struct BoxTabs {
     static constexpr int kAxis = 16;                   // entries per column of a single-axis table
     static constexpr int kRowX = 17, kRowYZ = 24;      // floats per row of xy / xz, of yz
+    static constexpr int kPairStep = 2;                // x entries between a lane's two voxels (two x planes apart)
     static constexpr int kPairX = 16 * kRowX, kPairYZ = 16 * kRowYZ;   // floats per column
     const lds_float* x;
     const lds_float* y;
@@ -1280,12 +1284,12 @@ struct BoxTabs {
     const lds_float* xy;
     const lds_float* xz;
     const lds_float* yz;
-    template <int K> __device__ __forceinline__ f2 X() const { return make_f2(x[K * kAxis], x[K * kAxis + 2]); }
+    template <int K> __device__ __forceinline__ f2 X() const { return make_f2(x[K * kAxis], x[K * kAxis + kPairStep]); }
     template <int K> __device__ __forceinline__ float X1() const { return x[K * kAxis]; }
     template <int K> __device__ __forceinline__ float Y() const { return y[K * kAxis]; }
     template <int K> __device__ __forceinline__ float Z() const { return z[K * kAxis]; }
-    template <int K> __device__ __forceinline__ f2 XY() const { return make_f2(xy[K * kPairX], xy[K * kPairX + 2]); }
-    template <int K> __device__ __forceinline__ f2 XZ() const { return make_f2(xz[K * kPairX], xz[K * kPairX + 2]); }
+    template <int K> __device__ __forceinline__ f2 XY() const { return make_f2(xy[K * kPairX], xy[K * kPairX + kPairStep]); }
+    template <int K> __device__ __forceinline__ f2 XZ() const { return make_f2(xz[K * kPairX], xz[K * kPairX + kPairStep]); }
     template <int K> __device__ __forceinline__ float YZ() const { return yz[K * kPairYZ]; }
 };
 

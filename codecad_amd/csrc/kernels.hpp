@@ -346,28 +346,47 @@ __device__ __forceinline__ void box_eval(const E& ev, float4* lds, float cx, flo
 // bricks buy besides the tables: values that are uniform over a wavefront stay uniform far more often -- which primitive
 // of a CSG tree is nearest (sponge(4) at 512^3: 1.8 distinct winners per brick against 3.1 per run; per-tape code
 // computes the direction once per DISTINCT winner), and whether any lane is in the corner region of a rectangle.
+// Evaluators with box code (E::kBricks) have TWO kernels per layout: this one over boxes, and k_grid_eval_ragged over runs for
+// slabs whose extents are no multiples of (4, 4, 8).  One kernel holding both paths is allocated the registers of the
+// hungrier one: planetary's in-place evaluation (256 registers, two wavefronts per SIMD) sat on its box path (175) until they
+// were split -- 1.86 against 1.03 ms for its 256^3 float4 grid.
+template <class E, int LAYOUT, int N>
+__device__ __forceinline__ void grid_eval_runs(const E& ev, float4* lds, float cx, float cy, float cz, float step, uint32_t sx, Dim dy, Dim dz,
+                                               uint32_t x0, uint32_t n_cells, void* __restrict__ out);
+
 template <class E, int LAYOUT, int N>
 __global__ void __launch_bounds__(256) SDF_KERNEL_ATTRS
 k_grid_eval(const E ev, float cx, float cy, float cz, float step, uint32_t sx, Dim dy, Dim dz, uint32_t x0,
             uint32_t n_cells, uint32_t boxes, void* __restrict__ out, const uint32_t* __restrict__ masks)
 {
     const uint32_t sy = dy.n, sz = dz.n;
-    using T = typename Pack<N>::T;
     extern __shared__ float4 lds[];
     if constexpr (E::kBricks && N == 2) {
-        if (boxes) {
-            // boxes along z fastest
-            const uint32_t nx_slab = sx_slab(n_cells, sy, sz);
-            const uint32_t boxes_z = (sz + 15u) >> 4, boxes_y = (sy + 15u) >> 4;
-            const uint32_t qz = blockIdx.x % boxes_z, qt = blockIdx.x / boxes_z, qy = qt % boxes_y, qx = qt / boxes_y;
-            const BoxOut o{out, 0, sx, sy, sz, LAYOUT == 0 ? 0u : x0, nx_slab};
-            box_eval<E, LAYOUT, N>(ev, lds, cx, cy, cz, step, x0, qx * 16u, qy * 16u, qz * 16u, o, masks);
-            return;
-        }
+        // boxes along z fastest (the launchers send anything else to k_grid_eval_ragged)
+        const uint32_t nx_slab = sx_slab(n_cells, sy, sz);
+        const uint32_t boxes_z = (sz + 15u) >> 4, boxes_y = (sy + 15u) >> 4;
+        const uint32_t qz = blockIdx.x % boxes_z, qt = blockIdx.x / boxes_z, qy = qt % boxes_y, qx = qt / boxes_y;
+        const BoxOut o{out, 0, sx, sy, sz, LAYOUT == 0 ? 0u : x0, nx_slab};
+        box_eval<E, LAYOUT, N>(ev, lds, cx, cy, cz, step, x0, qx * 16u, qy * 16u, qz * 16u, o, masks);
+    } else {
+        grid_eval_runs<E, LAYOUT, N>(ev, lds, cx, cy, cz, step, sx, dy, dz, x0, n_cells, out);
     }
-#ifdef SDF_EXP_NO_FALLBACK
-    if constexpr (E::kBricks && N == 2) return;
-#endif
+}
+template <class E, int LAYOUT, int N>
+__global__ void __launch_bounds__(256) SDF_KERNEL_ATTRS
+k_grid_eval_ragged(const E ev, float cx, float cy, float cz, float step, uint32_t sx, Dim dy, Dim dz, uint32_t x0,
+                   uint32_t n_cells, void* __restrict__ out)
+{
+    extern __shared__ float4 lds[];
+    if constexpr (E::kBricks) grid_eval_runs<E, LAYOUT, N>(ev, lds, cx, cy, cz, step, sx, dy, dz, x0, n_cells, out);
+}
+
+template <class E, int LAYOUT, int N>
+__device__ __forceinline__ void grid_eval_runs(const E& ev, float4* lds, float cx, float cy, float cz, float step, uint32_t sx, Dim dy, Dim dz,
+                                               uint32_t x0, uint32_t n_cells, void* __restrict__ out)
+{
+    const uint32_t sy = dy.n, sz = dz.n;
+    using T = typename Pack<N>::T;
     const uint32_t lin0 = first_cell<N>(blockIdx.x);
     const Cells<N> c(lin0, n_cells, dy, dz, kLaneStride);
     const T px = c.position(cx, step, c.x, x0), py = c.position(cy, step, c.y), pz = c.position(cz, step, c.z);
@@ -392,15 +411,13 @@ k_grid_eval(const E ev, float cx, float cy, float cz, float step, uint32_t sx, D
     }
 }
 
-template <class E, int LAYOUT, int N>
-__global__ void __launch_bounds__(256) SDF_KERNEL_ATTRS
-k_grid_eval_blocks(const E ev, const int4* __restrict__ blocks, const uint32_t* __restrict__ n_blocks_dev, uint32_t b0,
-                   uint32_t chunks, uint32_t bricks, double res, double ox, double oy, double oz, float step, uint32_t sx,
-                   Dim dy, Dim dz, void* __restrict__ out, const uint32_t* __restrict__ masks)
+template <class E, int LAYOUT, int N, bool BOXES>
+__device__ __forceinline__ void grid_eval_blocks_body(const E& ev, float4* lds, const int4* __restrict__ blocks, const uint32_t* __restrict__ n_blocks_dev,
+                                                      uint32_t b0, uint32_t chunks, uint32_t bricks, double res, double ox, double oy, double oz, float step,
+                                                      uint32_t sx, Dim dy, Dim dz, void* __restrict__ out, const uint32_t* __restrict__ masks)
 {
     const uint32_t sy = dy.n, sz = dz.n;
     using T = typename Pack<N>::T;
-    extern __shared__ float4 lds[];
     // b0: the first block of this launch (a list too long for one grid is launched in pieces)
     const uint32_t chunk = blockIdx.x % chunks, b = b0 + blockIdx.x / chunks;
     // indirect form: the list length lives on the device (the launch is sized for its capacity), so a
@@ -412,16 +429,14 @@ k_grid_eval_blocks(const E ev, const int4* __restrict__ blocks, const uint32_t* 
     const float cx = (float)((double)ic.x * res + ox);
     const float cy = (float)((double)ic.y * res + oy);
     const float cz = (float)((double)ic.z * res + oz);
-    if constexpr (E::kBricks && N == 2) {
-        if (bricks) {
-            // a workgroup takes one BOX of the block (box_eval): `chunks` = boxes per block, `bricks` = the boxes along y
-            // and z packed as (boxes_y << 16 | boxes_z); a 16^3 block is one box
-            const uint32_t boxes_z = bricks & 0xffffu, boxes_y = bricks >> 16;
-            const uint32_t qz = chunk % boxes_z, qt = chunk / boxes_z, qy = qt % boxes_y, qx = qt / boxes_y;
-            const BoxOut o{out, (size_t)b * cells, sx, sy, sz, 0u, sx};
-            box_eval<E, LAYOUT, N>(ev, lds, cx, cy, cz, step, 0u, qx * 16u, qy * 16u, qz * 16u, o, masks);
-            return;
-        }
+    if constexpr (BOXES) {
+        // a workgroup takes one BOX of the block (box_eval): `chunks` = boxes per block, `bricks` = the boxes along y
+        // and z packed as (boxes_y << 16 | boxes_z); a 16^3 block is one box
+        const uint32_t boxes_z = bricks & 0xffffu, boxes_y = bricks >> 16;
+        const uint32_t qz = chunk % boxes_z, qt = chunk / boxes_z, qy = qt % boxes_y, qx = qt / boxes_y;
+        const BoxOut o{out, (size_t)b * cells, sx, sy, sz, 0u, sx};
+        box_eval<E, LAYOUT, N>(ev, lds, cx, cy, cz, step, 0u, qx * 16u, qy * 16u, qz * 16u, o, masks);
+        return;
     }
     const uint32_t lin0 = first_cell<N>(chunk);
     const Cells<N> c(lin0, cells, dy, dz, kLaneStride);
@@ -439,6 +454,26 @@ k_grid_eval_blocks(const E ev, const int4* __restrict__ blocks, const uint32_t* 
             if (c.active[i])
                 store_voxel(static_cast<float*>(out) + base + (size_t)c.z[i] + ((size_t)c.x[i] + (size_t)(sy - 1u - c.y[i]) * sx) * sz, sdf::get(w, i));
     }
+}
+// (two kernels for evaluators with box code, like k_grid_eval / k_grid_eval_ragged)
+template <class E, int LAYOUT, int N>
+__global__ void __launch_bounds__(256) SDF_KERNEL_ATTRS
+k_grid_eval_blocks(const E ev, const int4* __restrict__ blocks, const uint32_t* __restrict__ n_blocks_dev, uint32_t b0,
+                   uint32_t chunks, uint32_t bricks, double res, double ox, double oy, double oz, float step, uint32_t sx,
+                   Dim dy, Dim dz, void* __restrict__ out, const uint32_t* __restrict__ masks)
+{
+    extern __shared__ float4 lds[];
+    grid_eval_blocks_body<E, LAYOUT, N, (E::kBricks && N == 2)>(ev, lds, blocks, n_blocks_dev, b0, chunks, bricks, res, ox, oy, oz, step, sx, dy, dz, out, masks);
+}
+template <class E, int LAYOUT, int N>
+__global__ void __launch_bounds__(256) SDF_KERNEL_ATTRS
+k_grid_eval_blocks_ragged(const E ev, const int4* __restrict__ blocks, const uint32_t* __restrict__ n_blocks_dev, uint32_t b0,
+                          uint32_t chunks, double res, double ox, double oy, double oz, float step, uint32_t sx, Dim dy, Dim dz,
+                          void* __restrict__ out)
+{
+    extern __shared__ float4 lds[];
+    if constexpr (E::kBricks)
+        grid_eval_blocks_body<E, LAYOUT, N, false>(ev, lds, blocks, n_blocks_dev, b0, chunks, 0u, res, ox, oy, oz, step, sx, dy, dz, out, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -464,7 +499,32 @@ struct ClassifyArgs {
     uint32_t scratch_offset;  // bytes of LDS taken by the register file or a box's tables (scratch follows)
     uint32_t boxes;           // per-tape code over boxes (box_classify): boxes along y << 16 | boxes along z; chunks = boxes per parent
     const uint32_t* masks;    // boxes: the pruning masks of this launch's workgroups (k_box_masks), or NULL
+    // OWNERSHIP (multi-GPU, codecad_amd/dist.py "replicated levels"): several ranks classify the SAME parents, and each keeps
+    // only the cells it owns -- owner = mix(hash of the parent's row, the cell's linear index) mod own.n -- both in the list
+    // and in the moment sums.  A cell's owner depends on what the cell is, not on where its parent stands in anybody's
+    // list, so the ranks' lists partition the level however each rank's atomics ordered its own.  own.n <= 1: keep all.
+    Dim own;
+    uint32_t own_rank;
 };
+__device__ __forceinline__ uint32_t row_hash(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    uint32_t h = a * 0x9e3779b1u;
+    h = (h ^ (h >> 15)) + b * 0x85ebca77u;
+    h = (h ^ (h >> 13)) + c * 0xc2b2ae3du;
+    h = (h ^ (h >> 16)) + d * 0x27d4eb2fu;
+    return h ^ (h >> 15);
+}
+__device__ __forceinline__ bool owned(const ClassifyArgs& a, uint32_t parent_hash, uint32_t cell)
+{
+    // (straight-line: a mix -- plain (hash + cell) mod n would stripe a 16-wide grid over 8 ranks by z alone, and the sponge's
+    // survivors are anything but uniform in z: shares of 3193..4499 where the mix gives 3850 +- 2 % --, then a multiply-high,
+    // two shifts, a multiply; own.n <= 1 decides by a kernel-uniform select)
+    uint32_t v = parent_hash + cell * 0x9e3779b1u;
+    v = (v ^ (v >> 15)) * 0x85ebca77u;
+    v ^= v >> 13;
+    const bool mine = v - div(v, a.own) * a.own.n == a.own_rank;
+    return a.own.n <= 1u ? true : mine;
+}
 
 template <class E, bool MASS, bool BATCH, int N>
 __global__ void __launch_bounds__(256) k_classify(const E ev, const ClassifyArgs a)
@@ -500,6 +560,11 @@ __global__ void __launch_bounds__(256) k_classify(const E ev, const ClassifyArgs
     if (MASS) {
         if (threadIdx.x < 10) scratch[8 + threadIdx.x] = 0u;
     }
+    // what identifies this parent on every rank that classifies it (ownership): its row
+    const uint32_t phash = !BATCH ? 0u
+                           : MASS ? row_hash((uint32_t)__double2loint(pcx) ^ (uint32_t)__double2hiint(pcx), (uint32_t)__double2loint(pcy) ^ (uint32_t)__double2hiint(pcy),
+                                             (uint32_t)__double2loint(pcz) ^ (uint32_t)__double2hiint(pcz), (uint32_t)__double2loint(pcw) ^ (uint32_t)__double2hiint(pcw))
+                                  : row_hash((uint32_t)ipar.x, (uint32_t)ipar.y, (uint32_t)ipar.z, (uint32_t)ipar.w);
 
     if constexpr (E::kBricks && N == 2) {
         if (a.boxes) {
@@ -516,11 +581,60 @@ __global__ void __launch_bounds__(256) k_classify(const E ev, const ClassifyArgs
             const BoxTables t = box_tables(ev, lds, cx, cy, cz, a.step, 0u, x0, y0, z0, nx, ny, nz, pr);
             if (MASS) __syncthreads();   // scratch[8..17] zeroed (a tape without tables has no barrier in box_tables)
             const bool nothing_ambiguous = MASS && a.thr == 0.0f;
+            const uint64_t below = (1ull << lane) - 1ull;
+            uint32_t v[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            constexpr uint32_t kStep = (uint32_t)Tabs::kPairStep;      // x distance of a lane's two voxels
+            // one brick: the lane's two voxels at (xv, y, z) and (xv + kStep, y, z); `live`: the lane's row is inside the box
+            auto brick = [&](uint32_t xv, uint32_t y, uint32_t z, float py, float pz, const Tabs& tb, const auto& hoisted, bool live) {
+                const T px = sdf::make_f2(sample(cx, a.step, xv), sample(cx, a.step, xv + kStep));
+                const T w = ev.dist_hoisted_x(px, walk_coordinate<E>(py), walk_coordinate<E>(pz), hoisted, tb, pr);
+                bool amb[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const float wi = sdf::get(w, i);
+                    const uint32_t x = xv + kStep * (uint32_t)i;
+                    const bool mine = live && owned(a, phash, z + a.sz * (y + a.sy * x));
+                    if (MASS) {
+                        // mass_properties.cl:31-52: inside (w <= -thr) -> moments of the integer cell index; else w < thr -> ambiguous
+                        const bool in = wi <= -a.thr, inside = in && mine;
+                        amb[i] = mine && !in && (wi < a.thr);
+                        const uint32_t m = inside ? 1u : 0u;
+                        const uint32_t xm = inside ? x : 0u, ym = inside ? y : 0u, zm = inside ? z : 0u;
+                        v[0] += __umul24(xm, x); v[1] += __umul24(xm, y); v[2] += __umul24(xm, z); v[3] += xm;
+                        v[4] += __umul24(ym, y); v[5] += __umul24(ym, z); v[6] += ym;
+                        v[7] += __umul24(zm, z); v[8] += zm; v[9] += m;
+                    } else {
+                        amb[i] = mine && (wi > -a.thr) && (wi < a.thr);   // subdivision.cl:25
+                    }
+                }
+                if (!nothing_ambiguous) {
+                    const uint64_t m0 = __ballot(amb[0]), m1 = __ballot(amb[1]);
+                    const uint32_t n0 = __popcll(m0), total = n0 + __popcll(m1);
+                    if (total) {   // wave-uniform
+                        uint32_t base = 0u;
+                        if (lane == 0u) base = atomicAdd(a.counter, total);
+                        base = __builtin_amdgcn_readfirstlane(base);
+                        const uint32_t slot[2] = {base + (uint32_t)__popcll(m0 & below), base + n0 + (uint32_t)__popcll(m1 & below)};
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            if (!(amb[i] && slot[i] < a.capacity)) continue;
+                            const uint32_t x = xv + kStep * (uint32_t)i;
+                            if (!BATCH) {
+                                static_cast<uchar4*>(a.list)[slot[i]] = make_uchar4((unsigned char)x, (unsigned char)y, (unsigned char)z, 0);
+                            } else if (MASS) {
+                                static_cast<double4*>(a.list)[slot[i]] =
+                                    make_double4((double)x * a.s + pcx, (double)y * a.s + pcy, (double)z * a.s + pcz, pcw);
+                            } else {
+                                static_cast<int4*>(a.list)[slot[i]] =
+                                    make_int4(ipar.x + (int)x * a.int_step, ipar.y + (int)y * a.int_step, ipar.z + (int)z * a.int_step, ipar.w);
+                            }
+                        }
+                    }
+                }
+            };
             const uint32_t nbz = nz >> 3, bz = nbz == 2u ? (wave & 1u) : 0u, dby = 4u / nbz;
             const uint32_t zl = bz * 8u + (lane & 7u), z = z0 + zl, xl = lane >> 5;
             const float pz = sample(cz, a.step, z);
-            const uint64_t below = (1ull << lane) - 1ull;
-            uint32_t v[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             for (uint32_t yl = (nbz == 2u ? (wave >> 1) : wave) * 4u + ((lane >> 3) & 3u); yl < ny; yl += 4u * dby) {
                 const uint32_t y = y0 + yl;
                 const float py = sample(cy, a.step, y);
@@ -529,50 +643,7 @@ __global__ void __launch_bounds__(256) k_classify(const E ev, const ClassifyArgs
 #pragma unroll 1
                 for (uint32_t j = 0; j < (nx >> 2); ++j) {
                     asm volatile("" ::: "memory");
-                    const uint32_t xv = x0 + j * 4u + xl;
-                    const T px = sdf::make_f2(sample(cx, a.step, xv), sample(cx, a.step, xv + 2u));
-                    const T w = ev.dist_hoisted_x(px, walk_coordinate<E>(py), walk_coordinate<E>(pz), hoisted, tb, pr);
-                    bool amb[2];
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const float wi = sdf::get(w, i);
-                        if (MASS) {
-                            // mass_properties.cl:31-52: inside (w <= -thr) -> moments of the integer cell index; else w < thr -> ambiguous
-                            const bool inside = wi <= -a.thr;
-                            amb[i] = !inside && (wi < a.thr);
-                            const uint32_t x = xv + 2u * (uint32_t)i, m = inside ? 1u : 0u;
-                            const uint32_t xm = inside ? x : 0u, ym = inside ? y : 0u, zm = inside ? z : 0u;
-                            v[0] += __umul24(xm, x); v[1] += __umul24(xm, y); v[2] += __umul24(xm, z); v[3] += xm;
-                            v[4] += __umul24(ym, y); v[5] += __umul24(ym, z); v[6] += ym;
-                            v[7] += __umul24(zm, z); v[8] += zm; v[9] += m;
-                        } else {
-                            amb[i] = (wi > -a.thr) && (wi < a.thr);   // subdivision.cl:25
-                        }
-                    }
-                    if (!nothing_ambiguous) {
-                        const uint64_t m0 = __ballot(amb[0]), m1 = __ballot(amb[1]);
-                        const uint32_t n0 = __popcll(m0), total = n0 + __popcll(m1);
-                        if (total) {   // wave-uniform
-                            uint32_t base = 0u;
-                            if (lane == 0u) base = atomicAdd(a.counter, total);
-                            base = __builtin_amdgcn_readfirstlane(base);
-                            const uint32_t slot[2] = {base + (uint32_t)__popcll(m0 & below), base + n0 + (uint32_t)__popcll(m1 & below)};
-#pragma unroll
-                            for (int i = 0; i < 2; ++i) {
-                                if (!(amb[i] && slot[i] < a.capacity)) continue;
-                                const uint32_t x = xv + 2u * (uint32_t)i;
-                                if (!BATCH) {
-                                    static_cast<uchar4*>(a.list)[slot[i]] = make_uchar4((unsigned char)x, (unsigned char)y, (unsigned char)z, 0);
-                                } else if (MASS) {
-                                    static_cast<double4*>(a.list)[slot[i]] =
-                                        make_double4((double)x * a.s + pcx, (double)y * a.s + pcy, (double)z * a.s + pcz, pcw);
-                                } else {
-                                    static_cast<int4*>(a.list)[slot[i]] =
-                                        make_int4(ipar.x + (int)x * a.int_step, ipar.y + (int)y * a.int_step, ipar.z + (int)z * a.int_step, ipar.w);
-                                }
-                            }
-                        }
-                    }
+                    brick(x0 + j * 4u + xl, y, z, py, pz, tb, hoisted, true);
                     tb.x += 4; tb.xy += 4; tb.xz += 4;
                 }
             }
@@ -605,8 +676,12 @@ __global__ void __launch_bounds__(256) k_classify(const E ev, const ClassifyArgs
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const float wi = sdf::get(w, i);
-            inside[i] = c.active[i] && (wi <= -a.thr);
-            ambiguous[i] = c.active[i] && !inside[i] && (wi < a.thr);
+            // (no short-circuit around owned(): its division would become a divergent branch, in the unit built with
+            // -structurizecfg-skip-uniform-regions of all places)
+            const bool own = owned(a, phash, lin0 + (uint32_t)i);
+            const bool mine = c.active[i] & own, in = wi <= -a.thr;
+            inside[i] = mine & in;
+            ambiguous[i] = mine & !in & (wi < a.thr);
             any_inside |= inside[i];
         }
         const uint64_t imask = __ballot(any_inside);
@@ -634,7 +709,8 @@ __global__ void __launch_bounds__(256) k_classify(const E ev, const ClassifyArgs
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const float wi = sdf::get(w, i);
-            ambiguous[i] = c.active[i] && (wi > -a.thr) && (wi < a.thr);
+            const bool own = owned(a, phash, lin0 + (uint32_t)i);
+            ambiguous[i] = c.active[i] & own & (wi > -a.thr) & (wi < a.thr);
         }
     }
 

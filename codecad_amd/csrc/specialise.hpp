@@ -938,7 +938,7 @@ inline Variant render_variant(const Phase1& ph, const std::vector<char>& hoistab
     std::ostringstream members, values;
     for (int i = 0; i < n; ++i)
         if (frontier[i]) {
-            members << " decltype(t" << i << ") t" << i << ";";
+            members << " plain_t<decltype(t" << i << ")> t" << i << ";";       // (not const: the walks of a cut box assign the struct)
             values << (v.n_hoisted ? ", " : "") << "t" << i;
             ++v.n_hoisted;
         }
@@ -1406,7 +1406,9 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
                 // (measured, sponge(4), MI355X, single-axis tables only: leaf blocks 0.327 / 0.325 / 0.319 / 0.325 ms holding
                 // 0 / 6 / 12 / 24 registers' worth; walks of sixteen bricks along z, round 3's first form of the dense kernel,
                 // 0.497 / 0.508 / 0.532 / 0.553 ms at 0 / 6 / 9 / 16 -- registers were dearer there than reads)
-                int budget = knob("HU_TAB_HOLD_X", 12);
+                // (a tape with box pruning holds none: most of its columns are dead in any one box, and the registers decide how many
+                // wavefronts hide its scalar branches -- planetary's distance kernels: 122 -> 78 registers, four -> six wavefronts per SIMD)
+                int budget = knob("HU_TAB_HOLD_X", prune.n_bits > 0 ? 0 : 12);
                 for (int i = 0; i < (int)probe.tab_main.size(); ++i) {
                     if (!probe.tab_main[i] || !tabc[i] || (ph.e.st[i].deps & f.walk)) continue;
                     const int regs = (ph.e.st[i].deps & DX) ? 2 : 1;

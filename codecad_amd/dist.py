@@ -196,9 +196,48 @@ def run_levels(top_parents, n_levels, classify_level, hints=None):
     return parents, counts
 
 
-# The largest single top block every rank may classify for itself (LevelPipeline replicate_first): the cells one
-# workgroup of EVERY kernel variant covers -- 64 lanes x 1 voxel is the smallest launch shape there is.
-REPLICATE_FIRST_MAX_CELLS = 64
+# REPLICATED LEVELS.  The first levels of a hierarchy are tiny (the bench's: 27 cells, then 27 parents of 4096 cells): cutting
+# their parent lists into slices, all-gathering the survivors and slicing again costs far more than the work.  Every rank
+# classifies such a level IN FULL instead -- no exchange --, and in the last replicated level keeps only the cells it OWNS
+# (hu_*_level_owned: owner = mix(hash of the parent's row, the cell's linear index) mod world): the ranks' lists then partition
+# that level's survivors evenly -- a cell's owner is as good as random -- whatever order each rank's atomics left its own
+# lists in.  A level is replicated while (parents' capacity x cells) stays below this many samples.
+REPLICATE_MAX_SAMPLES = int(os.environ.get("CODECAD_AMD_REPLICATE_SAMPLES", 4 << 20))
+
+
+def replicated_levels(n_top, capacities, cells, limit=None):
+    """How many leading levels of a hierarchy are replicated: `capacities[i]` = list capacity of level i's survivors,
+    `cells[i]` = cells of a level-i parent.  The same on every rank (capacities are)."""
+    limit = REPLICATE_MAX_SAMPLES if limit is None else limit
+    k, parents = 0, int(n_top)
+    for capacity, c in zip(capacities, cells):
+        if parents * int(c) > limit:
+            break
+        k += 1
+        parents = int(capacity)
+    return k
+
+
+def row_hash(words):
+    """kernels.hpp row_hash over four uint32 words (a subdivision row; for a mass row: lo ^ hi of each double), in numpy."""
+    import numpy
+    m = 0xffffffff
+    a, b, c, d = (int(numpy.uint32(w)) for w in words)
+    h = (a * 0x9e3779b1) & m
+    h = ((h ^ (h >> 15)) + b * 0x85ebca77) & m
+    h = ((h ^ (h >> 13)) + c * 0xc2b2ae3d) & m
+    h = ((h ^ (h >> 16)) + d * 0x27d4eb2f) & m
+    return h ^ (h >> 15)
+
+
+def owner_of(row_words, cell, world):
+    """The rank that owns cell `cell` (linear index z + sz * (y + sy * x)) of the parent with these row words
+    (kernels.hpp owned(): the parent's hash and the cell mixed, so that neighbouring cells scatter over the ranks)."""
+    m = 0xffffffff
+    v = (row_hash(row_words) + int(cell) * 0x9e3779b1) & m
+    v = ((v ^ (v >> 15)) * 0x85ebca77) & m
+    v ^= v >> 13
+    return v % int(world)
 
 
 class Overflow(RuntimeError):
@@ -258,18 +297,16 @@ class LevelPipeline:
     n_parents = the 1-element view of the header holding their count, out = the (capacity + 1, k) buffer to
     count into / append to (header already zeroed).  For the HIP path see `subdivision_pipeline`, `mass_pipeline`."""
 
-    def __init__(self, top_rows, capacities, classify, slice_rows=None, device=None, stream=None, replicate_first=False):
-        """replicate_first: every rank classifies the WHOLE top list itself and takes its share of the result without
-        a collective (slice_rows(..., sharers=world) on its own piece).  Only valid where all ranks compute the identical
-        list in the identical order: ONE top row whose cells fit one workgroup of every kernel variant
-        (<= REPLICATE_FIRST_MAX_CELLS cells) --
-        the compaction order of a single workgroup is the lane order (kernels.hpp wg_compact_slots).  That is the top
-        level of a hierarchy like the bench's (3 x 3 x 3 cells): one all-gather less in a latency-bound step."""
+    def __init__(self, top_rows, capacities, classify, slice_rows=None, device=None, stream=None, replicate=0):
+        """replicate = k: the first k levels are REPLICATED (see REPLICATE_MAX_SAMPLES): every rank classifies all of their
+        parents itself, without an exchange; in the last of them the classification is called with own=(world, rank) and
+        lists only the cells this rank owns, so that from there on every rank holds a share.  `classify` must then take
+        that keyword (the HIP ones do: hu_*_level_owned).  Levels after the replicated ones are exchanged as described above
+        -- there the all-gather re-balances the shares."""
         assert top_rows.dtype == torch.int32, "rows are int32 words (view 32-byte double rows as (n, 8) int32)"
         self.rank, self.world = rank_world()
         self.exchange = exchanging()
-        self.replicate_first = bool(replicate_first) and self.exchange and bool(capacities)
-        assert not self.replicate_first or int(top_rows.shape[0]) == 1
+        self.replicate = min(max(int(replicate), 0), len(capacities)) if self.exchange else 0
         self.classify = classify
         self.slice_rows = slice_rows or slice_rows_reference
         self.capacities = [int(c) for c in capacities]
@@ -277,7 +314,7 @@ class LevelPipeline:
         self.device, self.stream = device, stream
         k = int(top_rows.shape[1])
         begin, end = balanced_slice(int(top_rows.shape[0]), self.rank, self.world)   # the top list is host knowledge
-        if self.replicate_first:
+        if self.replicate:
             begin, end = 0, int(top_rows.shape[0])
         self.top = torch.zeros((max(end - begin, 1) + 1, k), dtype=torch.int32, device=device)
         self.top[0, 0] = end - begin
@@ -320,14 +357,17 @@ class LevelPipeline:
         for level, capacity in enumerate(self.capacities):
             out = self.send[level]
             plan.append(out[:1].zero_)
+            if level < self.replicate:
+                # a replicated level: all of its parents, no exchange; the last one lists what this rank owns
+                own = (self.world, self.rank) if level + 1 == self.replicate else None
+                plan.append(bound(self.classify, level, parents[1:], parents[0, :1], max_parents, out, own=own))
+                parents = out
+                max_parents = capacity
+                continue
             plan.append(bound(self.classify, level, parents[1:], parents[0, :1], max_parents, out))
             if not self.exchange or (capacity == 0 and level + 1 == len(self.capacities)):
                 # (a last level that can list nothing -- the leaf level of mass properties -- has nothing to exchange)
                 parents = out
-            elif level == 0 and self.replicate_first:
-                # every rank holds the whole (identical) list: its share, no collective
-                plan.append(bound(self.slice_rows, out.unsqueeze(0), self.rank, self.mine[level], self.stats[level], sharers=self.world))
-                parents = self.mine[level]
             else:
                 g = self.gathered[level]
                 if g.device.type != "cpu" and _host_staged():     # several ranks on one GPU through gloo: rehearsal only
@@ -359,12 +399,18 @@ class LevelPipeline:
             totals = [int(row[0]) for row in st]
             if self.capacities[-1] == 0:        # (not exchanged, _make_plan: the count is this rank's own, and zero unless it overflowed)
                 totals[-1] = own[-1]
+            for level in range(self.replicate):     # replicated: every rank counted the whole level -- or, in the last one, its own cells
+                totals[level] = own[level]
+            if self.replicate:
+                k = self.replicate - 1
+                totals[k] = int(allreduce_sum(torch.tensor([own[k]], dtype=torch.int64, device=self.send[0].device)).item())
             # hu_slice_rows' truncation flag: set exactly when a gathered piece or a share was cut, i.e. when the counts below
             # say Overflow -- a flag without an overflow would be a protocol error
             truncated = [int(row[1]) != 0 for row in st]
             biggest = allreduce_max(torch.tensor(own, dtype=torch.int64, device=self.send[0].device)).tolist()
             needed = [max(int(b), -(-t // self.world)) for b, t in zip(biggest, totals)]
-            # (a replicated first level: `own` is the whole list on every rank, and that is what its buffer must hold)
+            for level in range(self.replicate):     # (a replicated level's buffer holds what the rank itself listed)
+                needed[level] = int(biggest[level])
         self.needed = needed      # per level: the largest list any rank held (what the capacities must cover)
         if any(n > c for n, c in zip(needed, self.capacities)):
             raise Overflow(needed)
@@ -412,35 +458,37 @@ def subdivision_pipeline(tape, levels, resolution, origin, dimension, capacities
     lib = hip_manager.lib
     o = (ctypes.c_double * 3)(*[float(v) for v in origin])
 
-    def bind(level, parents, n_parents, max_parents, out):
-        """-> the launch without arguments (LevelPipeline._make_plan): pointers, sizes and converted scalars worked out once"""
+    def bind(level, parents, n_parents, max_parents, out, own=None):
+        """-> the launch without arguments (LevelPipeline._make_plan): pointers, sizes and converted scalars worked out once;
+        own = (world, rank): a replicated level of which this rank lists the cells it owns (hu_subdivision_level_owned)"""
         int_step, dims = levels[level]
         d = (ctypes.c_uint32 * 3)(int(dims[0]), int(dims[1]), int(dims[2]))
         box_step = int_step * resolution
         thr = box_step * math.sqrt(dimension) / 2
         args = (tape.device_ptr, parents.data_ptr(), n_parents.data_ptr(), int(max_parents), int(int_step), d, dimension,
                 float(resolution), o, numpy.float32(box_step), numpy.float32(thr), out.data_ptr(), out[1:].data_ptr(),
-                int(out.shape[0]) - 1, stream)
+                int(out.shape[0]) - 1)
         keep = (parents, n_parents, out, d)
-        fn = lib.hu_subdivision_level_indirect
+        if own is None:
+            fn, name, args = lib.hu_subdivision_level_indirect, "hu_subdivision_level_indirect", args + (stream,)
+        else:
+            fn, name, args = lib.hu_subdivision_level_owned, "hu_subdivision_level_owned", args + (int(own[0]), int(own[1]), stream)
 
         def run():
-            check(fn(*args), "hu_subdivision_level_indirect")
+            check(fn(*args), name)
             return keep
         return run
 
-    def classify(level, parents, n_parents, max_parents, out):
-        bind(level, parents, n_parents, max_parents, out)()
+    def classify(level, parents, n_parents, max_parents, out, own=None):
+        bind(level, parents, n_parents, max_parents, out, own)()
     classify.bind = bind
 
     if top_rows is None:
         top_rows = torch.zeros((1, 4), dtype=torch.int32, device=device)
-    # one top block of at most 64 cells: ONE workgroup of every kernel variant -- the interpreter shrinks its workgroups to
-    # 128 or 64 lanes when a lane's register file is large or HU_BLOCK says so (hip_util.hip launch_shape), and with more
-    # than one workgroup the list order depends on which atomic arrives first -- so all ranks classify it themselves
-    top_cells = int(levels[0][1][0]) * int(levels[0][1][1]) * int(levels[0][1][2])
+    # the small leading levels are classified by every rank in full, the last of them with ownership (REPLICATE_MAX_SAMPLES)
+    cells = [int(d[0]) * int(d[1]) * int(d[2]) for _, d in levels]
     return LevelPipeline(top_rows, capacities, classify, _hip_slice_rows(lib, check, stream), device, stream,
-                         replicate_first=int(top_rows.shape[0]) == 1 and top_cells <= REPLICATE_FIRST_MAX_CELLS)
+                         replicate=replicated_levels(int(top_rows.shape[0]), capacities, cells))
 
 
 class MassPipeline:
@@ -472,7 +520,7 @@ class MassPipeline:
             self.pieces.append(torch.zeros((integral_rows(max_parents), 10), dtype=torch.float64, device=device))
             max_parents = max(capacity, 1)
 
-        def classify(level, parents, n_parents, max_parents, out):
+        def classify(level, parents, n_parents, max_parents, out, own=None):
             s, dims = levels[level]
             leaf = level + 1 == len(levels)
             thr = 0.0 if leaf else s * math.sqrt(3) / 2
@@ -483,17 +531,25 @@ class MassPipeline:
             events = (self.timing or {}).get(level)       # bench.py: HIP events around one level's classification launch
             if events:
                 check(lib.hu_event_record(events[0], stream), "hu_event_record")
-            check(lib.hu_mass_properties_level_indirect(tape.device_ptr, parents.data_ptr(), n_parents.data_ptr(), int(max_parents),
-                                                        float(s), d, numpy.float32(s), numpy.float32(thr), sums.data_ptr(),
-                                                        out.data_ptr(), out[1:].data_ptr(), int(out.shape[0]) - 1, stream),
-                  "hu_mass_properties_level_indirect")
+            if own is None:
+                check(lib.hu_mass_properties_level_indirect(tape.device_ptr, parents.data_ptr(), n_parents.data_ptr(), int(max_parents),
+                                                            float(s), d, numpy.float32(s), numpy.float32(thr), sums.data_ptr(),
+                                                            out.data_ptr(), out[1:].data_ptr(), int(out.shape[0]) - 1, stream),
+                      "hu_mass_properties_level_indirect")
+            else:   # a replicated level: this rank's sums and list hold the cells it owns
+                check(lib.hu_mass_properties_level_owned(tape.device_ptr, parents.data_ptr(), n_parents.data_ptr(), int(max_parents),
+                                                         float(s), d, numpy.float32(s), numpy.float32(thr), sums.data_ptr(),
+                                                         out.data_ptr(), out[1:].data_ptr(), int(out.shape[0]) - 1, int(own[0]), int(own[1]), stream),
+                      "hu_mass_properties_level_owned")
             if events:
                 check(lib.hu_event_record(events[1], stream), "hu_event_record")
             check(lib.hu_mass_integrals_indirect(parents.data_ptr(), sums.data_ptr(), n_parents.data_ptr(), int(max_parents), float(s),
                                                  pieces.data_ptr(), int(pieces.shape[0]), stream), "hu_mass_integrals_indirect")
 
+        # (the leaf level lists nothing: it is never worth replicating -- its parents are the work -- and needs no exchange)
+        cells = [int(d[0]) * int(d[1]) * int(d[2]) for _, d in levels]
         self.pipe = LevelPipeline(top.view(torch.int32).reshape(1, 8), capacities, classify, _hip_slice_rows(lib, check, stream),
-                                  device, stream)
+                                  device, stream, replicate=min(replicated_levels(1, capacities, cells), len(levels) - 1))
 
     def enqueue(self):
         self.pipe.enqueue()

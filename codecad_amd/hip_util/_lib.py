@@ -48,12 +48,14 @@ PROTOTYPES = {
     "hu_grid_eval_blocks": [_vp, _vp, _u32, _d, _d3, _f, _u3, _i, _vp, _vp],
     "hu_subdivision_level": [_vp, _vp, _u32, _c.c_int32, _u3, _i, _d, _d3, _f, _f, _vp, _vp, _u32, _vp],
     "hu_subdivision_level_indirect": [_vp, _vp, _vp, _u32, _c.c_int32, _u3, _i, _d, _d3, _f, _f, _vp, _vp, _u32, _vp],
+    "hu_subdivision_level_owned": [_vp, _vp, _vp, _u32, _c.c_int32, _u3, _i, _d, _d3, _f, _f, _vp, _vp, _u32, _u32, _u32, _vp],
     "hu_grid_eval_blocks_indirect": [_vp, _vp, _vp, _u32, _d, _d3, _f, _u3, _i, _vp, _vp],
     "hu_slice_rows": [_vp, _u32, _u32, _u32, _u32, _vp, _u32, _vp, _vp],
     "hu_slice_rows_of": [_vp, _u32, _u32, _u32, _u32, _vp, _u32, _vp, _vp],
     "hu_mass_properties_level": [_vp, _vp, _u32, _d, _u3, _f, _f, _vp, _vp, _vp, _u32, _vp],
     "hu_mass_integrals": [_vp, _vp, _u32, _d, _vp, _u32, _vp],
     "hu_mass_properties_level_indirect": [_vp, _vp, _vp, _u32, _d, _u3, _f, _f, _vp, _vp, _vp, _u32, _vp],
+    "hu_mass_properties_level_owned": [_vp, _vp, _vp, _u32, _d, _u3, _f, _f, _vp, _vp, _vp, _u32, _u32, _u32, _vp],
     "hu_mass_integrals_indirect": [_vp, _vp, _vp, _u32, _d, _vp, _u32, _vp],
     "hu_ray_caster": [_vp, _f4, _f4, _f4, _f4, _f, _f, _f, _f, _f, _u32, _u32, _u32, _vp, _vp],
     "hu_bitmap": [_vp, _f4, _f, _u32, _u32, _vp, _vp],

@@ -178,6 +178,19 @@ int hu_mass_properties_level_indirect(hu_tape t, const double* parents_dev, cons
                                       uint32_t max_parents, double s, const uint32_t dims[3], float step,
                                       float threshold, uint32_t* sums_dev, uint32_t* counter_dev,
                                       double* children_dev, uint32_t capacity, void* stream);
+/* Levels that SEVERAL ranks classify in full (multi-GPU, codecad_amd/dist.py "replicated levels"; the reference has one
+ * device, cl_util/opencl_manager.py:89-98): like the *_indirect forms, but of every parent's cells a rank lists -- and sums --
+ * only those it OWNS: owner = mix(hash of the parent's row, the cell's linear index z + sz * (y + sy * x)) mod world.  The ranks'
+ * lists then partition the level's survivors (their moment sums add up to the level's) without any exchange, whatever order
+ * each rank's parents were in.  world = 1: the *_indirect forms. */
+int hu_subdivision_level_owned(hu_tape t, const int32_t* parents_dev, const uint32_t* n_parents_dev, uint32_t max_parents,
+                               int32_t int_step, const uint32_t dims[3], int dimension, double resolution,
+                               const double origin[3], float step, float threshold, uint32_t* counter_dev,
+                               int32_t* children_dev, uint32_t capacity, uint32_t world, uint32_t rank, void* stream);
+int hu_mass_properties_level_owned(hu_tape t, const double* parents_dev, const uint32_t* n_parents_dev, uint32_t max_parents,
+                                   double s, const uint32_t dims[3], float step, float threshold, uint32_t* sums_dev,
+                                   uint32_t* counter_dev, double* children_dev, uint32_t capacity, uint32_t world,
+                                   uint32_t rank, void* stream);
 int hu_mass_integrals_indirect(const double* parents_dev, const uint32_t* sums_dev, const uint32_t* n_parents_dev,
                                uint32_t max_parents, double s, double* out_dev, uint32_t rows, void* stream);
 

@@ -46,7 +46,7 @@ def _traverse(tape, levels, resolution, origin, n_objects, hints=None):
     return dist.run_levels(top, len(levels) - 1, classify, hints=hints)
 
 
-def _pipeline(tape, levels, resolution, origin, n_objects, capacities, replicate_first=False):
+def _pipeline(tape, levels, resolution, origin, n_objects, capacities, replicate=0):
     """The traversal through dist.LevelPipeline (lists with their lengths in header rows, one fixed-size
     all-gather per level, the balanced share taken without the host looking at any count), classification by
     the CPU oracle.  -> (this rank's share of the leaves, global survivors per level)"""
@@ -54,7 +54,7 @@ def _pipeline(tape, levels, resolution, origin, n_objects, capacities, replicate
     import oracle
     from codecad_amd import dist
 
-    def classify(level, parents, n_parents, max_parents, out):
+    def classify(level, parents, n_parents, max_parents, out, own=None):
         int_step, dims = levels[level]
         k = min(int(n_parents.item()), max_parents)   # an overflowed list holds `capacity` rows: the launch covers no more
         rows = []
@@ -65,7 +65,11 @@ def _pipeline(tape, levels, resolution, origin, n_objects, capacities, replicate
             step = int_step * resolution
             n, cells = oracle.subdivision_step(tape, np.array(corner).astype(np.float32), np.float32(step),
                                                np.float32(step * math.sqrt(3) / 2), dims)
-            rows += [[ix + i * int_step, iy + j * int_step, iz + k_ * int_step, obj] for i, j, k_, _ in cells.tolist()]
+            for i, j, k_, _ in cells.tolist():
+                # a replicated level (hu_subdivision_level_owned): of every parent's cells a rank lists those it owns
+                if own is not None and dist.owner_of([ix, iy, iz, obj], k_ + dims[2] * (j + dims[1] * i), own[0]) != own[1]:
+                    continue
+                rows.append([ix + i * int_step, iy + j * int_step, iz + k_ * int_step, obj])
         capacity = out.shape[0] - 1
         out[0, 0] = len(rows)                       # like the kernel: the counter counts everything ...
         rows = rows[:capacity]                      # ... and only what fits is stored
@@ -74,7 +78,7 @@ def _pipeline(tape, levels, resolution, origin, n_objects, capacities, replicate
 
     top = torch.zeros((n_objects, 4), dtype=torch.int32)
     top[:, 3] = torch.arange(n_objects, dtype=torch.int32)
-    pipe = dist.LevelPipeline(top, capacities, classify, replicate_first=replicate_first)
+    pipe = dist.LevelPipeline(top, capacities, classify, replicate=replicate)
     mine = pipe.enqueue()
     totals = pipe.check()
     return mine[1:1 + int(mine[0, 0])], totals
@@ -110,7 +114,7 @@ def _integrate(tape, box_a, levels):
     return dist.integrate_levels(top, len(levels), level_fn)
 
 
-def _integrate_pipeline(tape, box_a, levels, capacities):
+def _integrate_pipeline(tape, box_a, levels, capacities, replicate=0):
     """The same integration through dist.LevelPipeline as dist.MassPipeline drives it on the GPU: 32-byte rows of four
     doubles seen as eight int32 words, the count in the header's first word, every level (the leaf level too) a
     classify call, nothing looked at by the host until check().  -> the ten integrals, all-reduced."""
@@ -121,16 +125,35 @@ def _integrate_pipeline(tape, box_a, levels, capacities):
 
     partial = torch.zeros(10, dtype=torch.float64)
 
-    def classify(level, parents, n_parents, max_parents, out):
+    def owned_kernel(row_words, shifted, s, thr, dims, own):
+        """hu_mass_properties_level_owned restated over the oracle's distances: the kernel of mass_properties.cl:7-56 with
+        every cell that another rank owns left out of the sums and of the list"""
+        w = oracle.grid_eval(tape, shifted.astype(np.float32), np.float32(s), dims)[..., 3]
+        idx = np.indices(dims).reshape(3, -1).T
+        lin = idx[:, 2] + dims[2] * (idx[:, 1] + dims[1] * idx[:, 0])
+        mine = np.array([dist.owner_of(row_words, c, own[0]) == own[1] for c in lin.tolist()])
+        wf = w.reshape(-1)
+        inside = mine & (wf <= -np.float32(thr))
+        amb = mine & ~(wf <= -np.float32(thr)) & (wf < np.float32(thr))
+        x, y, z = (idx[inside, c].astype(np.uint64) for c in range(3))
+        su = np.array([np.sum(x * x), np.sum(x * y), np.sum(x * z), np.sum(x), np.sum(y * y), np.sum(y * z), np.sum(y), np.sum(z * z),
+                       np.sum(z), inside.sum()], dtype=np.uint64).astype(np.uint32)
+        return su, int(amb.sum()), np.concatenate([idx[amb], np.zeros((int(amb.sum()), 1), dtype=idx.dtype)], axis=1)
+
+    def classify(level, parents, n_parents, max_parents, out, own=None):
         s, dims = levels[level]
         leaf = level + 1 == len(levels)
         thr = 0.0 if leaf else s * math.sqrt(3) / 2
         k = min(int(n_parents.item()), max_parents)
-        rows = parents[:k].contiguous().view(torch.float64).reshape(-1, 4)
+        words = parents[:k].contiguous()
+        rows = words.view(torch.float64).reshape(-1, 4)
         children, corners, sums = [], [], []
-        for cx, cy, cz, tag in rows.tolist():
+        for (cx, cy, cz, tag), rw in zip(rows.tolist(), words.view(torch.int32).reshape(-1, 8).numpy().view(np.uint32)):
             shifted = np.array([cx + s / 2, cy + s / 2, cz + s / 2])
-            su, n, cells = oracle.mass_properties(tape, shifted.astype(np.float32), np.float32(s), np.float32(thr), dims)
+            if own is None:
+                su, n, cells = oracle.mass_properties(tape, shifted.astype(np.float32), np.float32(s), np.float32(thr), dims)
+            else:   # (kernels.hpp k_classify: lo ^ hi of each of the row's four doubles)
+                su, n, cells = owned_kernel([rw[0] ^ rw[1], rw[2] ^ rw[3], rw[4] ^ rw[5], rw[6] ^ rw[7]], shifted, s, thr, tuple(int(v) for v in dims), own)
             corners.append([cx, cy, cz])
             sums.append(su)
             if not leaf:
@@ -145,7 +168,7 @@ def _integrate_pipeline(tape, box_a, levels, capacities):
             out[1:1 + len(children)] = torch.tensor(children, dtype=torch.float64).view(torch.int32).reshape(-1, 8)
 
     top = torch.tensor([[box_a[0], box_a[1], box_a[2], 0.0]], dtype=torch.float64).view(torch.int32).reshape(1, 8)
-    pipe = dist.LevelPipeline(top, list(capacities) + [0], classify)
+    pipe = dist.LevelPipeline(top, list(capacities) + [0], classify, replicate=replicate)
     pipe.enqueue()
     totals = pipe.check()
     return dist.allreduce_sum(partial), totals[:-1]
@@ -211,12 +234,16 @@ def _worker(rank, world, port, queue):
     assert e - b == share.shape[0]
     shares = dist.allgather_rows(share)
     assert sorted(map(tuple, shares.tolist())) == sorted(map(tuple, one.tolist()))
-    # the same with the first level REPLICATED: every rank classifies the one top block itself and takes its share of the
-    # (identical) result without a collective (hu_slice_rows_of) -- same totals, the shares still tile the leaf list
-    share_r, totals_r = _pipeline(tape, levels, res, origin, 1, [max(one_counts) + 3] * len(one_counts), replicate_first=True)
-    assert totals_r == one_counts and share_r.shape[0] == e - b
-    shares_r = dist.allgather_rows(share_r)
-    assert sorted(map(tuple, shares_r.tolist())) == sorted(map(tuple, one.tolist()))
+    # the same with REPLICATED levels: every rank classifies the first k levels in full -- no exchange -- and in the last of
+    # them lists only the cells it owns: same totals, the shares still partition the leaf list; with every level replicated
+    # the traversal needs no collective at all (the bench's hierarchy), and the owners' shares are balanced
+    for k in range(1, len(one_counts) + 1):
+        share_r, totals_r = _pipeline(tape, levels, res, origin, 1, [max(one_counts) + 3] * len(one_counts), replicate=k)
+        assert totals_r == one_counts, (k, totals_r, one_counts)
+        shares_r = dist.allgather_rows(share_r)
+        assert sorted(map(tuple, shares_r.tolist())) == sorted(map(tuple, one.tolist())), k
+        if k == len(one_counts):
+            assert abs(share_r.shape[0] - one.shape[0] / world) <= 0.2 * one.shape[0] / world + 2
     # a list that outgrows its capacity is reported with the sizes that would have sufficed -- on every rank
     try:
         _pipeline(tape, levels, res, origin, 1, [2] * len(one_counts))
@@ -228,6 +255,10 @@ def _worker(rank, world, port, queue):
     # the device-counted form (what dist.mass_properties runs): same integrals, no count seen by the host on the way
     piped, ambiguous = _integrate_pipeline(mtape, box_a, mlevels, [800] * (len(mlevels) - 1))
     assert np.allclose(piped.tolist(), integrals.tolist(), rtol=1e-13, atol=1e-15) and all(a > 0 for a in ambiguous)
+    # ... and with its first levels replicated (the last of them summing and listing owned cells only): no all-gather, same integrals
+    for k in range(1, len(mlevels)):
+        piped_r, ambiguous_r = _integrate_pipeline(mtape, box_a, mlevels, [800] * (len(mlevels) - 1), replicate=k)
+        assert np.allclose(piped_r.tolist(), integrals.tolist(), rtol=1e-13, atol=1e-15) and ambiguous_r == ambiguous, k
     try:
         _integrate_pipeline(mtape, box_a, mlevels, [1] * (len(mlevels) - 1))
         raise AssertionError("overflow went unnoticed")

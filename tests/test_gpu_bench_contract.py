@@ -95,8 +95,11 @@ def test_forced_collectives_walk_the_multi_rank_path_on_one_gpu(hip):
     are launched from the sliced list.  Same counts as the plain single-GPU step; the step is also captured into a
     hipGraph, collectives included, and replayed."""
     plain = run_bench_env({"CODECAD_AMD_FORCE_COLLECTIVES": "0"})
-    forced = run_bench_env({"CODECAD_AMD_FORCE_COLLECTIVES": "1"})
+    # (levels this small are REPLICATED on several ranks -- classified by every rank in full, no exchange, dist.py --: with
+    # CODECAD_AMD_REPLICATE_SAMPLES=0 they are exchanged like large ones, and that is the path this test is about)
+    forced = run_bench_env({"CODECAD_AMD_FORCE_COLLECTIVES": "1", "CODECAD_AMD_REPLICATE_SAMPLES": "0"})
     assert "forced_collectives" in forced["config"] and "nccl" in forced["config"]["forced_collectives"]
+    assert forced["config"]["replicated_levels"] == 0
     assert "forced_collectives" not in plain["config"]
     assert forced["samples_per_step"] == plain["samples_per_step"]
     assert forced["n_gpus"] == 1 and forced["value"] > 0
@@ -105,6 +108,11 @@ def test_forced_collectives_walk_the_multi_rank_path_on_one_gpu(hip):
         assert g["captured"], g
         assert g["steps"] == 4 and g["ms_per_step"] > 0 and g["host_enqueue_ms_per_step"] < line["host_enqueue_ms_per_step"]
     assert forced["graph_replay"]["collectives_in_graph"] is True and plain["graph_replay"]["collectives_in_graph"] is False
+    # the default on several ranks: both levels of this hierarchy replicated, the last with ownership -- no collective in the step
+    owned = run_bench_env({"CODECAD_AMD_FORCE_COLLECTIVES": "1"})
+    # (at this reduced edge the hierarchy has one level above the leaves)
+    assert owned["config"]["replicated_levels"] == 1 and owned["samples_per_step"] == plain["samples_per_step"]
+    assert owned["verified"]["ok"] and owned["graph_replay"]["captured"] and owned["graph_replay"]["collectives_in_graph"] is False
 
 
 def test_step_counts_are_replayed_exactly(hip):

@@ -599,34 +599,106 @@ def test_library_forms_over_a_process_group(hip, forced):
     assert proc.returncode == 0 and "rehearsal ok" in proc.stdout, proc.stdout[-2000:] + proc.stderr[-3000:]
 
 
-def test_a_single_workgroup_compacts_in_lane_order(hip):
-    """What replicating the first level of a multi-rank traversal rests on (dist.LevelPipeline replicate_first): a
-    level with ONE parent whose cells fit one workgroup leaves its survivors in the same order every time, on every
-    rank -- one workgroup's compaction order is the lane order -- and hu_slice_rows_of shares that one piece out like
-    hu_slice_rows shares a gathered set."""
+def test_replicated_levels_partition_by_ownership(hip):
+    """What replicated levels of a multi-rank traversal rest on (dist.LevelPipeline `replicate`, hu_*_level_owned): when
+    `world` ranks classify the same parents, each listing the cells it owns, the lists partition the level -- whatever the
+    order of a rank's parents and of its atomics, whichever evaluator or launch shape serves it -- and a cell's owner is
+    dist.owner_of(parent row, linear cell index); the owned moment sums of mass_properties add up to the level's."""
     import torch
     import codecad_amd as cc
-    from codecad_amd import subdivision, dist
+    from codecad_amd import subdivision, dist, hip_util
     from codecad_amd.hip_util import check
     shape = cc.examples.sponge(4)
-    tape = cc.nodes.make_program_buffer(shape)
     res = 1 / 512
     box = shape.bounding_box().expanded_additive(res / 2)
     levels = subdivision.calculate_block_sizes(box, 3, res, 16, True)
-    assert int(levels[0][1][0]) * int(levels[0][1][1]) * int(levels[0][1][2]) <= dist.REPLICATE_FIRST_MAX_CELLS
     dev = torch.device("cuda", 0)
     stream = torch.cuda.current_stream(dev).cuda_stream
-    lists = []
+    origin = (ctypes.c_double * 3)(box.a.x, box.a.y, box.a.z)
+    tape = hip_util.Tape(cc.nodes.make_program(shape), policy="0")
+
+    def level(parents, lvl, own=None, capacity=40000):
+        int_step, dims = levels[lvl]
+        d = (ctypes.c_uint32 * 3)(int(dims[0]), int(dims[1]), int(dims[2]))
+        n = torch.tensor([parents.shape[0]], dtype=torch.int32, device=dev)
+        out = torch.zeros((capacity + 1, 4), dtype=torch.int32, device=dev)
+        step = np.float32(int_step * res)
+        args = (tape.device_ptr, parents.data_ptr(), n.data_ptr(), int(parents.shape[0]), int(int_step), d, 3, float(res), origin, step,
+                np.float32(float(step) * 3 ** 0.5 / 2), out.data_ptr(), out[1:].data_ptr(), capacity)
+        if own is None:
+            check(hip.lib.hu_subdivision_level_indirect(*args, stream), "level")
+        else:
+            check(hip.lib.hu_subdivision_level_owned(*args, own[0], own[1], stream), "level owned")
+        torch.cuda.synchronize()
+        return out[1:1 + int(out[0, 0])].clone()
+
+    top = torch.zeros((1, 4), dtype=torch.int32, device=dev)
     for evaluator in ("interpreter", "specialised"):
         if evaluator == "specialised":
-            tape.specialize()
-        for _ in range(4):
-            pipe = dist.subdivision_pipeline(tape, levels[:2], res, tuple(box.a), 3, [64], dev, stream)
-            mine = pipe.enqueue()
-            assert pipe.check() == [27]
-            lists.append(mine[1:28].cpu().numpy().copy())
-    for other in lists[1:]:
-        assert np.array_equal(lists[0], other)
+            tape.specialize(hip_util.SPEC_CLASSIFY)
+        l0 = level(top, 0)
+        assert l0.shape[0] == 27
+        whole = level(l0, 1)
+        want = sorted(map(tuple, whole.cpu().tolist()))
+        assert len(want) == 30800
+        int_step, dims = levels[1]
+        for world in (2, 3, 8):
+            shares = []
+            for rank in range(world):
+                parents = l0[torch.randperm(27, device=dev)]          # every rank has its own order of the same parents
+                shares.append(level(parents, 1, own=(world, rank)).cpu().numpy())
+            assert sorted(map(tuple, np.concatenate(shares).tolist())) == want, (evaluator, world)
+            sizes = [len(sh) for sh in shares]
+            assert max(sizes) - min(sizes) <= 0.12 * len(want) / world + 8, sizes      # a cell's owner is as good as random
+            # a cell's owner is the rule of dist.owner_of on its parent's row and its linear index in the parent's grid
+            for rank in (0, world - 1):
+                for row in shares[rank][:: max(1, len(shares[rank]) // 40)]:
+                    cell = [int(row[c]) for c in range(3)]
+                    # the parent is the level-0 survivor whose block holds the cell
+                    for p in l0.cpu().tolist():
+                        rel = [(cell[c] - p[c]) // int(int_step) for c in range(3)]
+                        if all(0 <= rel[c] < int(dims[c]) and (cell[c] - p[c]) % int(int_step) == 0 for c in range(3)):
+                            assert dist.owner_of(p, rel[2] + int(dims[2]) * (rel[1] + int(dims[1]) * rel[0]), world) == rank
+                            break
+                    else:
+                        raise AssertionError("a listed cell belongs to no parent")
+    # mass properties: the owned sums and lists of `world` ranks add up to the level's
+    mlevels = [(res * cell, tuple(int(v) for v in dims)) for cell, dims in subdivision.calculate_block_sizes(shape.bounding_box(), 3, res, 8, overlap=False)]
+    s, dims = mlevels[0]
+    d = (ctypes.c_uint32 * 3)(*dims)
+    parent = torch.zeros((1, 4), dtype=torch.float64, device=dev)
+    parent[0, :3] = torch.tensor([shape.bounding_box().a.x, shape.bounding_box().a.y, shape.bounding_box().a.z], dtype=torch.float64)
+    one = torch.tensor([1], dtype=torch.int32, device=dev)
+
+    def mass(own=None):
+        sums = torch.zeros((1, 10), dtype=torch.int32, device=dev)
+        out = torch.zeros((600, 4), dtype=torch.float64, device=dev)
+        args = (tape.device_ptr, parent.data_ptr(), one.data_ptr(), 1, float(s), d, np.float32(s), np.float32(s * 3 ** 0.5 / 2), sums.data_ptr(),
+                out.data_ptr(), out[1:].data_ptr(), 599)
+        if own is None:
+            check(hip.lib.hu_mass_properties_level_indirect(*args, stream), "mass level")
+        else:
+            check(hip.lib.hu_mass_properties_level_owned(*args, own[0], own[1], stream), "mass level owned")
+        torch.cuda.synchronize()
+        n = int(out.view(torch.int32)[0, 0])
+        return sums.cpu().numpy().astype(np.int64)[0], sorted(map(tuple, out[1:1 + n].cpu().tolist()))
+    all_sums, all_cells = mass()
+    for world in (2, 5):
+        parts = [mass((world, r)) for r in range(world)]
+        assert (sum(p[0] for p in parts) == all_sums).all()
+        assert sorted(c for p in parts for c in p[1]) == all_cells and sum(len(p[1]) for p in parts) == len(all_cells)
+
+
+def test_slice_rows_of_shares_one_piece_out(hip):
+    """hu_slice_rows_of: ONE piece [header | rows] shared out among `world` ranks by dist.balanced_slice -- the shares tile it
+    in order."""
+    import torch
+    from codecad_amd import dist
+    from codecad_amd.hip_util import check
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    rng = np.random.default_rng(5)
+    lists = [rng.integers(-1000, 1000, (27, 4)).astype(np.int32)]
     # the share rule on one replicated piece: the shares of 1..8 ranks tile it in order
     piece = torch.zeros((33, 4), dtype=torch.int32, device=dev)
     piece[0, 0] = 27

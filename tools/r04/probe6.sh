@@ -1,0 +1,18 @@
+#!/bin/bash
+set -u
+cd "$GRAFT_REPO_ROOT"; O=gpurun_out/r04_probe6; rm -rf $O; mkdir -p $O
+python3 -m pytest tests -x -q -m gpu --durations=8 > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -14 $O/pytest.log
+python3 bench.py --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
+HU_RTC_FLAGS="-DSDF_BRICK_Z16=0" python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_oldbricks.json 2> $O/bench_oldbricks.err; echo "bench old rc=$?"
+python3 bench.py --config c5 --steps 5 --warmup 2 --no-cpu-baseline --no-hbm-leg > $O/bench_c5.json 2> $O/bench_c5.err; echo "bench c5 rc=$?"
+HU_RTC_FLAGS="-DSDF_BRICK_Z16=0" python3 bench.py --config c5 --steps 5 --warmup 2 --no-cpu-baseline --no-hbm-leg > $O/bench_c5_old.json 2> $O/bench_c5_old.err; echo "bench c5 old rc=$?"
+python3 bench.py --config c4 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_c4.json 2> $O/bench_c4.err; echo "bench c4 rc=$?"
+HU_RTC_FLAGS="-DSDF_BRICK_Z16=0" python3 bench.py --config c4 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_c4_old.json 2> $O/bench_c4_old.err; echo "bench c4 old rc=$?"
+python3 tools/prof_planetary.py > $O/planetary.txt 2>&1; grep per-tape $O/planetary.txt
+for f in bench bench_oldbricks bench_c5 bench_c5_old bench_c4 bench_c4_old; do python3 -c "
+import json,sys
+d=json.load(open('$O/$f.json'))
+print('$f', d['value'], d['ms_per_step'], d['roofline'].get('kernel_ms'), d['roofline'].get('frac'), d.get('verified',{}).get('ok'), d.get('graph_replay',{}).get('ms_per_step'), d.get('adaptive',{}).get('leaf_blocks_ms'))
+for e in d.get('roofline_hbm',[]):
+    print('    ', e['tape'], e['evaluator'], e['kernel'], e['ms'], e['frac'])
+"; done

@@ -39,7 +39,11 @@ def main():
         tape = np.array({s["name"]: s for s in shapes}[name]["tape_u32"], dtype=np.uint32).view(np.float32)
     out = "/tmp/spec_isa"
     os.makedirs(out, exist_ok=True)
-    if blocks:
+    ragged = "ragged" in sys.argv[3:]
+    if ragged:
+        inst = ("template __global__ void sdfk::k_grid_eval_ragged<sdfk::JitEval, %d, 2>(const sdfk::JitEval, float, float, float, float, uint32_t, "
+                "sdfk::Dim, sdfk::Dim, uint32_t, uint32_t, void*);\n" % layout)
+    elif blocks:
         inst = ("template __global__ void sdfk::k_grid_eval_blocks<sdfk::JitEval, 1, 2>(const sdfk::JitEval, const int4*, const uint32_t*, uint32_t, "
                 "uint32_t, uint32_t, double, double, double, double, float, uint32_t, sdfk::Dim, sdfk::Dim, void*, const uint32_t*);\n")
     else:
@@ -47,7 +51,7 @@ def main():
                 "sdfk::Dim, sdfk::Dim, uint32_t, uint32_t, uint32_t, void*, const uint32_t*);\n" % layout)
     src = source_of(tape) + "\n" + inst
     open(out + "/spec.hip", "w").write(src)
-    extra = [a for a in sys.argv[3:]]
+    extra = [a for a in sys.argv[3:] if a != "ragged"]
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I", ROOT + "/codecad_amd/csrc",
            "--cuda-device-only", "-S", "-o", out + "/spec.s", out + "/spec.hip"] + extra
     subprocess.run(cmd, check=True)
