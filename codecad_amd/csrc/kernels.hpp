@@ -321,12 +321,13 @@ __device__ __forceinline__ void box_eval(const E& ev, float4* lds, float cx, flo
             for (int i = 0; i < N; ++i) xs[i] = sample(cx, step, xs0 + x0 + j * 4u + xl + 2u * i);
             const T px = pack(xs);
             const float pyb = walk_coordinate<E>(py), pzb = walk_coordinate<E>(pz);
+            const auto prb = pr.fresh();
             if (LAYOUT == 0) {
-                const sdf::V4<T> r = ev.eval_hoisted_x(px, pyb, pzb, hoisted, tb, pr);
+                const sdf::V4<T> r = ev.eval_hoisted_x(px, pyb, pzb, hoisted, tb, prb);
 #pragma unroll
                 for (int i = 0; i < N; ++i) store_voxel(static_cast<float4*>(o.out) + p + (size_t)i * second, sdf::voxel(r, i));
             } else {
-                const T w = ev.dist_hoisted_x(px, pyb, pzb, hoisted, tb, pr);
+                const T w = ev.dist_hoisted_x(px, pyb, pzb, hoisted, tb, prb);
 #pragma unroll
                 for (int i = 0; i < N; ++i) store_voxel(static_cast<float*>(o.out) + p + (size_t)i * second, sdf::get(w, i));
             }
@@ -587,7 +588,7 @@ __global__ void __launch_bounds__(256) k_classify(const E ev, const ClassifyArgs
             // one brick: the lane's two voxels at (xv, y, z) and (xv + kStep, y, z); `live`: the lane's row is inside the box
             auto brick = [&](uint32_t xv, uint32_t y, uint32_t z, float py, float pz, const Tabs& tb, const auto& hoisted, bool live) {
                 const T px = sdf::make_f2(sample(cx, a.step, xv), sample(cx, a.step, xv + kStep));
-                const T w = ev.dist_hoisted_x(px, walk_coordinate<E>(py), walk_coordinate<E>(pz), hoisted, tb, pr);
+                const T w = ev.dist_hoisted_x(px, walk_coordinate<E>(py), walk_coordinate<E>(pz), hoisted, tb, pr.fresh());
                 bool amb[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {

@@ -25,7 +25,11 @@ def main():
                                            ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_int)]
     lib.hu_tape_compile_groups.restype = ctypes.c_int
     lib.hu_last_error.restype = ctypes.c_char_p
-    out = sys.stdout
+    # the protocol gets a descriptor of its own: whatever the library, hipRTC or comgr print on fd 1 goes to stderr and
+    # cannot end up between the replies
+    import os
+    out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     for line in sys.stdin:
         line = line.strip()
         if not line:

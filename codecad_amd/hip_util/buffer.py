@@ -231,16 +231,29 @@ def cache_dir():
 
 
 class _BackgroundCompiler:
-    """ONE worker thread that turns tapes into per-tape code objects with hipRTC while the interpreter serves their
-    launches.  The builds themselves run in a PROCESS of their own (_compile_server.py, started at the first request,
-    host only): the HIP runtime and hipRTC share a lock, so a build on a thread of this process would stall a module
-    load or a kernel's first launch for its whole duration.  A finished build sits in the on-disk cache -- or, when that
-    is switched off, in a private directory of this process -- where the tape's next launch finds it in milliseconds.
-    The server's first build also pays hipRTC's one-off start (~1.5 s in a fresh process), so no launch ever waits for
-    that either.  CODECAD_AMD_RTC_SERVER=0 (or a server that cannot be started) builds on the worker thread instead."""
+    """Worker threads that turn tapes into per-tape code objects with hipRTC while the interpreter serves their launches.
+    The builds themselves run in PROCESSES of their own (_compile_server.py, one per worker, started at its first request,
+    host only): the HIP runtime and hipRTC share a lock, so a build on a thread of this process would stall a module load
+    or a kernel's first launch for its whole duration.  A finished build sits in the on-disk cache -- or, when that is
+    switched off, in a private directory of this process -- where the tape's next launch finds it in milliseconds.  A
+    server's first build also pays hipRTC's one-off start (~1.5 s in a fresh process), so no launch ever waits for that.
+    Several workers (CODECAD_AMD_RTC_SERVERS, default: up to four, half the cores) build a tape's kernel FAMILIES side by
+    side: the whole of a tape is ready after its slowest family, not after their sum (planetary: 4.5 s instead of 12 s;
+    the family in use is asked for first).  CODECAD_AMD_RTC_SERVER=0 (or a server that cannot be started) builds on the
+    worker thread instead."""
 
-    def __init__(self):
-        self.queue, self.thread, self.private_dir, self.server = None, None, None, None
+    REPLY_TIMEOUT = 900.0      # seconds a build may take before its server is given up (and replaced at the next job)
+
+    def __init__(self, servers=None):
+        if servers is None:
+            servers = int(os.environ.get("CODECAD_AMD_RTC_SERVERS", "0") or 0) or min(4, max(1, (os.cpu_count() or 2) // 2))
+        self.queue, self.threads, self.private_dir = None, [], None
+        self.slots = [{"server": None} for _ in range(max(1, int(servers)))]
+
+    @property
+    def server(self):
+        """the first worker's server: None (not started yet), a live process, or False (cannot be used: builds run on the thread)"""
+        return self.slots[0]["server"]
 
     def directory(self):
         d = cache_dir()
@@ -259,10 +272,12 @@ class _BackgroundCompiler:
         kernel families it builds (hu_spec_group bits)}"""
         import queue
         import threading
-        if self.thread is None:
+        if not self.threads:
             self.queue = queue.Queue()
-            self.thread = threading.Thread(target=self._run, name="codecad_amd-hiprtc", daemon=True)
-            self.thread.start()
+            for k, slot in enumerate(self.slots):
+                th = threading.Thread(target=self._run, args=(slot,), name="codecad_amd-hiprtc-%d" % k, daemon=True)
+                th.start()
+                self.threads.append(th)
         job = {"done": threading.Event(), "error": None, "directory": self.directory(), "lib": lib, "groups": int(groups),
                "tape": numpy.array(host_tape, dtype=numpy.float32, copy=True), "include": include_dir}
         self.queue.put(job)
@@ -291,33 +306,54 @@ class _BackgroundCompiler:
         atexit.register(stop)
         return server
 
-    def _build_remote(self, job):
-        """-> None (done) / an error string / False (the server is not there: build here)"""
+    @staticmethod
+    def _stop(server):
+        try:
+            server.stdin.close()
+        except Exception:
+            pass
+        try:
+            server.kill()
+            server.wait(10)
+        except Exception:
+            pass
+
+    def _build_remote(self, job, slot):
+        """-> None (done) / an error string / False (no server for this job: build here)"""
         import base64
         import json
-        if self.server is None:
-            self.server = self._start_server(job["lib"]) or False
-        if not self.server:
+        import select
+        if slot["server"] is None:
+            slot["server"] = self._start_server(job["lib"]) or False
+        server = slot["server"]
+        if not server:
             return False
         try:
             req = {"tape": base64.b64encode(job["tape"].tobytes()).decode(), "include": job["include"], "dir": job["directory"],
                    "groups": job["groups"]}
-            self.server.stdin.write(json.dumps(req) + "\n")
-            self.server.stdin.flush()
-            line = self.server.stdout.readline()
+            server.stdin.write(json.dumps(req) + "\n")
+            server.stdin.flush()
+            ready, _, _ = select.select([server.stdout], [], [], self.REPLY_TIMEOUT)
+            if not ready:
+                raise OSError("the compile server did not answer in %d s" % self.REPLY_TIMEOUT)
+            line = server.stdout.readline()
             if not line:
                 raise OSError("the compile server ended")
             reply = json.loads(line)
             return None if reply.get("rc") == 0 else str(reply.get("error") or "hipRTC failed (%s)" % reply.get("rc"))
         except (OSError, ValueError):
-            self.server = False          # gone: from now on build on this thread
+            # gone, hung or talking nonsense: this job is built here; the server is put away and the NEXT job starts a new one
+            # (a permanent fallback to this thread would bring back the stalls the server exists to avoid)
+            self._stop(server)
+            slot["server"] = None if slot.get("restarts", 0) < 3 else False
+            slot["restarts"] = slot.get("restarts", 0) + 1
             return False
 
-    def _run(self):
+    def _run(self, slot):
         while True:
             job = self.queue.get()
             try:
-                result = self._build_remote(job)
+                result = self._build_remote(job, slot)
                 if result is False:
                     t = job["tape"]
                     size, hit = ctypes.c_size_t(0), ctypes.c_int(0)
@@ -334,6 +370,7 @@ class _BackgroundCompiler:
 
 
 _background = _BackgroundCompiler()
+_FAMILIES = (1, 2, 4, 8)     # hu_spec_group bits: dense, blocks, classify, render
 
 
 class Tape:
@@ -368,7 +405,14 @@ class Tape:
         if self._policy == "1":
             self.specialize()
         elif self._policy == "auto":
-            self._specialize(only_if_cached=True)   # a program compiled before costs milliseconds: take it now
+            # a program compiled before costs milliseconds: take it now (an image of all families, or one per family --
+            # what the background builds leave behind)
+            if cache_dir():
+                self._specialize(only_if_cached=True)
+                for family in _FAMILIES:
+                    if self.groups == 15:
+                        break
+                    self._specialize(only_if_cached=True, groups=family)
 
     # The interpreter retires ~2.5e12 (tape instruction x sample) per second whatever the tape (measured on MI355X:
     # sponge(4): 85 x 29e9; planetary: 467 x 6.2e9).  A background build starts once the interpreter has spent
@@ -383,22 +427,24 @@ class Tape:
         if self._policy != "auto" or self.groups == 15:
             return
         if self._jobs:
-            if self._jobs[0]["done"].is_set():
+            if any(job["done"].is_set() for job in self._jobs):
                 self._take_background_builds()
             return
         if self.groups:
             return      # (what was asked for is loaded; the other families follow when they are used)
         self._work += float(n) * self.n_instructions
         if self._work / self._INTERPRETER_RATE >= self._START_SECONDS:
-            # the family in use first (a fraction of the time of all ten kernels), then all of them (that image is
+            # one build per kernel family, the family in use first; the workers build them side by side (their images are
             # also what a later process finds in the on-disk cache at upload)
             from . import builder
-            self._jobs = [_background.submit(self.manager.lib, self.host_tape, builder.CSRC, group),
-                          _background.submit(self.manager.lib, self.host_tape, builder.CSRC, 15)]
+            families = [f for f in _FAMILIES if f & int(group)] + [f for f in _FAMILIES if not f & int(group)]
+            self._jobs = [_background.submit(self.manager.lib, self.host_tape, builder.CSRC, f) for f in families]
 
     def _take_background_builds(self):
-        while self._jobs and self._jobs[0]["done"].is_set():
-            job = self._jobs.pop(0)
+        for job in [j for j in self._jobs if j["done"].is_set()]:      # (in any order: the families are built side by side)
+            if job not in self._jobs:
+                return
+            self._jobs.remove(job)
             if job["error"] is not None:
                 self._policy = "0"      # hipRTC cannot build this tape: stay with the interpreter
                 self.build_error = job["error"]

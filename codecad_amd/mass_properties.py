@@ -92,6 +92,10 @@ def _enqueue_levels(tape, levels, box_a, capacities, queue):
     into the header of its child list, the next launch -- sized for the capacity -- reads its parent count from there
     (`hu_mass_properties_level_indirect`), and the level's ten integrals are reduced on the device from the same count
     (`hu_mass_integrals_indirect`).  The reference waits for the host after every block (mass_properties.py:98-114).
+    What the host wants to see afterwards -- every list's header and every level's rows of integrals -- is gathered in ONE
+    small device buffer (a 32-byte device-to-device copy per level; the integrals are written there directly) and read
+    once, into its pinned shadow.  (Round 3 copied headers and integrals level by level into pageable numpy arrays: such a
+    copy waits for the stream, i.e. once per level.)
     Returns (survivor count per level, [rows x 10 array of integrals per level]) after ONE synchronisation; a count
     above its capacity means "repeat with larger lists"."""
     lib = hip_manager.lib
@@ -100,8 +104,17 @@ def _enqueue_levels(tape, levels, box_a, capacities, queue):
     first.view(numpy.uint32)[0, 0] = 1
     first[1, :3] = box_a
     top.enqueue_write(first)
+    # results: per level [header row: 4 doubles | rows x 10 doubles]
+    rows_of, max_parents = [], 1
+    for i in range(len(levels)):
+        rows_of.append(integral_rows(max_parents))
+        max_parents = 0 if i == len(levels) - 1 else capacities[i]
+    offsets = [0]
+    for r in rows_of:
+        offsets.append(offsets[-1] + 4 + 10 * r)
+    results = hip_util.Buffer(numpy.float64, (offsets[-1],), queue=queue)
     parents, max_parents = top, 1
-    buffers, heads, partials = [top], [], []
+    buffers = [top, results]
     for i, (s, dims) in enumerate(levels):
         leaf = i == len(levels) - 1
         capacity = 0 if leaf else capacities[i]
@@ -109,8 +122,7 @@ def _enqueue_levels(tape, levels, box_a, capacities, queue):
         d = (ctypes.c_uint32 * 3)(int(dims[0]), int(dims[1]), int(dims[2]))
         children = hip_util.Buffer(numpy.float64, (capacity + 1, 4), queue=queue)
         sums = hip_util.Buffer(numpy.uint32, (max_parents, 10), queue=queue)
-        rows = integral_rows(max_parents)
-        out = hip_util.Buffer(numpy.float64, (rows, 10), queue=queue)
+        out_ptr = results.device_ptr + 8 * (offsets[i] + 4)
         check(lib.hu_memset(children.device_ptr, 0, 32, queue.handle), "hu_memset")
         check(lib.hu_memset(sums.device_ptr, 0, max_parents * 40, queue.handle), "hu_memset")
         check(lib.hu_mass_properties_level_indirect(tape.device_ptr, parents.device_ptr + 32, parents.device_ptr, max_parents, float(s), d,
@@ -118,20 +130,18 @@ def _enqueue_levels(tape, levels, box_a, capacities, queue):
                                                     children.device_ptr + 32, capacity, queue.handle),
               "hu_mass_properties_level_indirect")
         check(lib.hu_mass_integrals_indirect(parents.device_ptr + 32, sums.device_ptr, parents.device_ptr, max_parents, float(s),
-                                             out.device_ptr, rows, queue.handle), "hu_mass_integrals_indirect")
-        head, part = numpy.zeros(8, dtype=numpy.uint32), numpy.zeros((rows, 10), dtype=numpy.float64)
-        check(lib.hu_memcpy_d2h(head.ctypes.data, children.device_ptr, 32, queue.handle), "hu_memcpy_d2h")
-        check(lib.hu_memcpy_d2h(part.ctypes.data, out.device_ptr, part.nbytes, queue.handle), "hu_memcpy_d2h")
-        heads.append(head)
-        partials.append(part)
-        buffers += [children, sums, out]
+                                             out_ptr, rows_of[i], queue.handle), "hu_mass_integrals_indirect")
+        check(lib.hu_memcpy_d2d(results.device_ptr + 8 * offsets[i], children.device_ptr, 32, queue.handle), "hu_memcpy_d2d")
+        buffers += [children, sums]
         if leaf:
             break
         parents, max_parents = children, capacity
-    queue.synchronize()
+    got = results.read()            # one copy into the pinned shadow, one synchronisation
+    heads = [int(got[offsets[i]:offsets[i] + 1].view(numpy.uint32)[0]) for i in range(len(levels))]
+    partials = [got[offsets[i] + 4:offsets[i + 1]].reshape(rows_of[i], 10).copy() for i in range(len(levels))]
     for b in buffers:
         b.release()
-    return [int(h[0]) for h in heads], partials
+    return heads, partials
 
 
 def integral_rows(n_parents):

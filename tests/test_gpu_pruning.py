@@ -156,3 +156,50 @@ def test_tapes_without_bounds_have_nothing_to_prune(hip):
         handle.specialize(hip_util.SPEC_DENSE)
         assert prune_info(hip, handle) == (0, 0)
         handle.release()
+
+
+def test_pruned_launches_inside_a_hipgraph(hip):
+    """A launch over boxes with its mask kernel, captured into a hipGraph and replayed: the mask buffer belongs to the tape
+    handle and is only grown outside a capture (hip_util.hip prepare_masks) -- a capture that finds it too small runs that
+    launch unpruned --, so both a capture after a warm launch (masks inside the graph) and a capture on a stream that never
+    launched (no masks) must give the oracle's bits."""
+    import torch
+    import oracle
+    import codecad_amd as cc
+    from codecad_amd import hip_util
+    from codecad_amd.hip_util import check
+    from conftest import same_bits
+    shape = cc.examples.planetary()
+    host_tape = cc.nodes.make_program(shape)
+    tape = hip_util.Tape(host_tape, policy="0")
+    tape.specialize(hip_util.SPEC_DENSE)
+    assert prune_info(hip, tape)[0] > 50
+    n = 32
+    corner = np.array([8.0, -10.0, 18.0, 0.0], np.float32)
+    step = np.float32(0.5)
+    dims = (ctypes.c_uint32 * 3)(n, n, n)
+    fptr = ctypes.POINTER(ctypes.c_float)
+    want = oracle.grid_eval(host_tape, corner[:3], step, (n, n, n), threads=4)
+    dev = torch.device("cuda", 0)
+    for warm in (True, False):
+        stream = torch.cuda.Stream(device=dev)
+        out = torch.full((n, n, n, 4), float("nan"), dtype=torch.float32, device=dev)
+
+        def launch():
+            check(hip.lib.hu_grid_eval_slab(tape.device_ptr, corner.ctypes.data_as(fptr), step, dims, 0, n, 0, out.data_ptr(), stream.cuda_stream), "slab")
+        if warm:
+            launch()
+            stream.synchronize()
+            assert same_bits(out.cpu().numpy(), want)
+            out.fill_(float("nan"))
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            launch()
+        for _ in range(2):
+            out.fill_(float("nan"))
+            torch.cuda.synchronize()
+            g.replay()
+            torch.cuda.synchronize()
+            assert same_bits(out.cpu().numpy(), want), warm
+    tape.release()

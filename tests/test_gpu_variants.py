@@ -115,7 +115,7 @@ def test_tiered_specialisation_policy(hip, monkeypatch):
     t._START_SECONDS = 0.0                                                   # "enough work" from now on
     t0 = time.perf_counter()
     hip.k.grid_eval((24, 24, 24), None, t, c, np.float32(1 / 24), out).wait()
-    assert time.perf_counter() - t0 < 0.5 and len(t._jobs) == 2 and not t.specialized       # interpreted, the builds are under way
+    assert time.perf_counter() - t0 < 0.5 and len(t._jobs) == 4 and not t.specialized       # interpreted, the builds (one per family) are under way
     assert np.array_equal(out.read().view(np.uint32), interpreted.view(np.uint32))
     assert t.wait_specialized(timeout=120) and t.specialized and t.groups == 15 and not t._jobs
     hip.k.grid_eval((24, 24, 24), None, t, c, np.float32(1 / 24), out).wait()
@@ -129,7 +129,8 @@ def test_tiered_specialisation_policy(hip, monkeypatch):
         hip.k.grid_eval((24, 24, 24), None, u, c, np.float32(1 / 24), out).wait()
         first_groups = first_groups or u.groups
         time.sleep(0.02)
-    assert u.groups == 15 and first_groups in (1, 15)     # the family in use (dense grids) came first
+    # (the families are built side by side, the one in use is asked for first: whichever lands first, all four arrive)
+    assert u.groups == 15 and first_groups != 0
 
     monkeypatch.setenv("CODECAD_AMD_SPECIALIZE", "0")
     never = hip_util.Tape(tape)

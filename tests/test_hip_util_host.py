@@ -537,7 +537,7 @@ def test_background_builds_run_in_a_process_of_their_own(tmp_path, monkeypatch):
         assert rc == 0
         return hit.value == 1
 
-    worker = buffer._BackgroundCompiler()
+    worker = buffer._BackgroundCompiler(servers=1)
     job = worker.submit(lib, tape, builder.CSRC, _lib.SPEC_CLASSIFY)
     assert job["done"].wait(120) and job["error"] is None and job["directory"] == str(tmp_path / "cache")
     assert worker.server and worker.server.poll() is None          # a live child process built it
@@ -546,16 +546,27 @@ def test_background_builds_run_in_a_process_of_their_own(tmp_path, monkeypatch):
     bad = worker.submit(lib, [99 * 512.0], builder.CSRC, _lib.SPEC_DENSE)
     assert bad["done"].wait(120) and bad["error"] and "malformed" in bad["error"]
     assert worker.server.poll() is None
-    # the server gone -> the worker builds the next job itself
+    # the server gone -> the worker builds that job itself, and the job after it gets a NEW server (no permanent fallback to
+    # builds on a thread of this process: those stall launches)
     worker.server.kill()
     worker.server.wait(10)
     tape2 = cc.nodes.make_program(cc.shapes.sphere(2) - cc.shapes.box(1.25))
     job = worker.submit(lib, tape2, builder.CSRC, _lib.SPEC_CLASSIFY)
-    assert job["done"].wait(120) and job["error"] is None and worker.server is False
+    assert job["done"].wait(120) and job["error"] is None and worker.server is None
     assert is_hit(tape2, _lib.SPEC_CLASSIFY)
+    tape2b = cc.nodes.make_program(cc.shapes.sphere(2) - cc.shapes.box(1.3))
+    job = worker.submit(lib, tape2b, builder.CSRC, _lib.SPEC_CLASSIFY)
+    assert job["done"].wait(120) and job["error"] is None and worker.server and worker.server.poll() is None
+    assert is_hit(tape2b, _lib.SPEC_CLASSIFY)
+    # several workers build side by side, each with a server of its own
+    pool = buffer._BackgroundCompiler(servers=2)
+    tapes = [cc.nodes.make_program(cc.shapes.sphere(2) - cc.shapes.box(1.0 + 0.01 * k)) for k in range(2)]
+    jobs = [pool.submit(lib, t, builder.CSRC, _lib.SPEC_CLASSIFY) for t in tapes]
+    assert all(j["done"].wait(120) and j["error"] is None for j in jobs) and all(is_hit(t, _lib.SPEC_CLASSIFY) for t in tapes)
+    assert len(pool.slots) == 2 and sum(1 for sl in pool.slots if sl["server"]) >= 1
     # switched off -> never started
     monkeypatch.setenv("CODECAD_AMD_RTC_SERVER", "0")
-    worker = buffer._BackgroundCompiler()
+    worker = buffer._BackgroundCompiler(servers=1)
     tape3 = cc.nodes.make_program(cc.shapes.sphere(2) - cc.shapes.box(1.125))
     job = worker.submit(lib, tape3, builder.CSRC, _lib.SPEC_DENSE)
     assert job["done"].wait(120) and job["error"] is None and worker.server is False and is_hit(tape3, _lib.SPEC_DENSE)
