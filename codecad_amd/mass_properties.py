@@ -165,10 +165,12 @@ def mass_properties(shape, resolution, grid_size=None):
     cells = [int(d[0]) * int(d[1]) * int(d[2]) for _, d in levels]
     # the whole hierarchy is enqueued at once (device-counted lists); it is repeated with the sizes it reported when a
     # list was too short -- the first guesses are generous, so that is rare
-    capacities = subdivision.first_capacities(cells[:-1], row_bytes=32 + 40)
+    memo_key = ("mass_properties", float(resolution), int(grid_size), tuple(box.a), tuple(box.b))
+    capacities = subdivision.remembered_capacities(tape, memo_key, cells[:-1], row_bytes=32 + 40)
     while True:
         counts, partials = _enqueue_levels(tape, levels, (box.a.x, box.a.y, box.a.z), capacities, queue)
         if all(n <= c for n, c in zip(counts, capacities)):
+            subdivision.remember_counts(tape, memo_key, counts[:len(capacities)])
             break
         capacities = [subdivision.checked_capacity(max(c, int(n * 1.125) + 16)) for n, c in zip(counts, capacities)]
     total = {k: util.KahanSummation() for k in _KEYS}

@@ -145,6 +145,24 @@ def first_capacities(cells_per_level, n_top=1, row_bytes=16):
     return capacities
 
 
+def remembered_capacities(tape, key, cells_per_level, n_top=1, row_bytes=16):
+    """Capacities for a traversal of `tape` under `key` (what fixes the hierarchy: driver, resolution, grid, box): what the
+    SAME traversal needed last time, + 12 % -- a launch is sized for its lists' capacities (workgroups past a list's end
+    cost their dispatch, and the launchers choose boxes or runs by it), so a first guess of 110 592 rows for a level of 27
+    costs every call something; the first traversal of a kind starts from first_capacities()."""
+    memo = getattr(tape, "_level_memo", None)
+    if memo is None:
+        memo = tape._level_memo = {}
+    seen = memo.get(key)
+    if seen is not None and len(seen) == len(cells_per_level):
+        return [checked_capacity(int(n * 1.125) + 16) for n in seen]
+    return first_capacities(cells_per_level, n_top, row_bytes)
+
+
+def remember_counts(tape, key, counts):
+    getattr(tape, "_level_memo", {}).__setitem__(key, [int(n) for n in counts])
+
+
 def _level_launch(tape, parents, n_parents, int_step, dims, dimension, resolution, origin, counter, queue,
                   capacity_hint=None):
     """Run one level, growing the child list until everything fits.  Returns (children, count)."""
@@ -226,10 +244,12 @@ def subdivision_device(shape, resolution, overlap_edge_samples=True, grid_size=N
 
     # first sizes as before (every cell while that is small, else the surface estimate); the whole traversal is
     # repeated with the sizes it reported when a list was too short (fractal shapes keep most cells: rare)
-    capacities = first_capacities(cells[:-1])
+    memo_key = ("subdivision", float(resolution), int(grid_size), bool(overlap_edge_samples), tuple(box.a), tuple(box.b))
+    capacities = remembered_capacities(tape, memo_key, cells[:-1])
     while True:
         buffers, counts = _traverse_device_counted(tape, levels, dimension, resolution, box.a, capacities, queue)
         if all(n <= c for n, c in zip(counts, capacities)):
+            remember_counts(tape, memo_key, counts)
             break
         for b in buffers:
             b.release()
