@@ -243,6 +243,7 @@ struct SpecKernels {
     int tabs[6] = {0, 0, 0, 0, 0, 0};   // columns of a box's tables: x, y, z, xy, xz, yz (specialise.hpp)
     int prune_words = 0;     // 32-bit words of a box's pruning mask (0: nothing to prune in this tape)
     int prune_bits = 0;
+    bool prune_all = false;  // the float4 code is guarded too (else only the distance walks: float4 launches skip the mask kernel)
     // the mask buffers of launches over boxes, one per stream that launched any (the mask kernel and the launch it prepares
     // are neighbours on their stream, so a stream's launches can share one buffer); grown when a launch needs more
     struct MaskBuffer { hipStream_t stream; uint32_t* ptr; size_t bytes; };
@@ -621,7 +622,7 @@ int hu_grid_eval_slab(hu_tape t, const float corner[4], float step, const uint32
                 MaskArgs m{};
                 m.mode = 0u; m.n_boxes = grid; m.chunks = grid; m.boxes_y = (dims[1] + 15u) / 16u; m.boxes_z = (dims[2] + 15u) / 16u;
                 m.nx = nx; m.ny = dims[1]; m.nz = dims[2]; m.xs0 = xs; m.cx = cx; m.cy = cy; m.cz = cz; m.step = step;
-                if ((rc = prepare_masks(t, m, (hipStream_t)stream, &masks))) return rc;
+                if ((layout == 1 || t->spec->prune_all) && (rc = prepare_masks(t, m, (hipStream_t)stream, &masks))) return rc;
             }
             if (t->spec->deferred && !boxes) {      // a tape with box code on a slab that has no boxes: its kernel over runs
                 void* args[] = {&ev, &cx, &cy, &cz, &step, &sx, &sy, &sz, &xs, &n_cells, &o};
@@ -719,7 +720,7 @@ static int grid_eval_blocks_impl(hu_tape t, const int32_t* blocks_dev, uint32_t 
                 m.mode = 1u; m.n_boxes = chunks * count; m.chunks = chunks; m.boxes_y = bricks >> 16; m.boxes_z = bricks & 0xffffu;
                 m.nx = dims[0]; m.ny = dims[1]; m.nz = dims[2]; m.unit_base = b0; m.units = b; m.n_units_dev = n_dev; m.step = step;
                 m.res = res; m.ox = ox; m.oy = oy; m.oz = oz;
-                if ((rc = prepare_masks(t, m, (hipStream_t)stream, &masks))) return rc;
+                if ((layout == 1 || t->spec->prune_all) && (rc = prepare_masks(t, m, (hipStream_t)stream, &masks))) return rc;
             }
             if (t->spec->deferred && !bricks) {
                 void* args[] = {&ev, &b, &n_dev, &first, &chunks, &res, &ox, &oy, &oz, &step, &sx, &sy, &sz, &out_dev};
@@ -1410,6 +1411,7 @@ int hu_tape_specialize_groups(hu_tape t, const char* include_dir, const char* ca
             k->coord_limit = meta.coord_limit;
             k->prune_words = meta.prune_words;
             k->prune_bits = meta.prune_bits;
+            k->prune_all = meta.prune_all;
             std::memcpy(k->tabs, meta.tabs, sizeof k->tabs);
             if (from_cache) *from_cache = cached;
             return HU_OK;

@@ -1350,6 +1350,13 @@ __device__ __forceinline__ Iv iv_leaf(float centre, float radius, float margin)
     return Iv{iv_down(centre - e), iv_up(centre + e)};
 }
 __device__ __forceinline__ Iv iv_neg(Iv a) { return Iv{-a.hi, -a.lo}; }
+// does u, known to within +-e over the box, stay inside ONE cell of a repetition (remainder_t: n = rint(u * inv))?  With a
+// margin of 1e-3 cells against the rounding of the product and a tie at the boundary.
+__device__ __forceinline__ bool iv_same_cell(float u, float e, float inv)
+{
+    const float x = u * inv;
+    return __builtin_fabsf(x - __builtin_rintf(x)) + e * __builtin_fabsf(inv) < 0.499f;
+}
 __device__ __forceinline__ Iv iv_scale(Iv a, float c) { return c > 0.0f ? Iv{iv_down(a.lo * c), iv_up(a.hi * c)} : Iv{iv_down(a.hi * c), iv_up(a.lo * c)}; }
 __device__ __forceinline__ Iv iv_offset(Iv a, float c) { return Iv{iv_down(a.lo - c), iv_up(a.hi - c)}; }
 __device__ __forceinline__ Iv iv_shell(Iv a, float c)

@@ -214,10 +214,10 @@ struct BoxOut {
 // from column to column, so everything the tape computes from them alone is loop-invariant to the compiler -- and it hoists
 // ALL of it (the partial sums of every general rotation: planetary's 27 frames held ~80 registers across the whole kernel,
 // one or two wavefronts per SIMD), where the generator hoists what is worth a register (tape_pre_x) and tables the rest.
-// Only for tapes with box pruning (assemblies: many frames, few of them alive in a box); the others keep their code.
+// Only for tapes pruned throughout (assemblies: many frames, few of them alive in a box); the others keep their code.
 template <class E> __device__ __forceinline__ float walk_coordinate(float v)
 {
-    if constexpr (E::kPruneWords > 0) return sdf::opaque(v);
+    if constexpr (E::kPruneAll) return sdf::opaque(v);
     else return v;
 }
 // One workgroup, one BOX: up to 16 x 16 x 16 voxels at (x0, y0, z0) of a slab or block whose corner sample is (cx, cy, cz)

@@ -261,6 +261,7 @@ struct Stmt {
     double iv_l = 0.0;
     float iv_c = 0.0f;
     int iv_a = -1, iv_b = -1;
+    std::vector<int> iv_conds;   // IV_LEAF: the bound holds in a box only where these conditions do (Phase1::conds: repetitions)
 };
 enum : uint8_t { DX = 1, DY = 2, DZ = 4 };
 enum : uint8_t { IV_NONE = 0, IV_LEAF, IV_UNKNOWN, IV_SCALE, IV_OFFSET, IV_SHELL, IV_PERP, IV_MIN, IV_MAX, IV_MAXNEG };
@@ -315,6 +316,11 @@ struct Phase1 {
     std::vector<int> choice_of_rec;           // record -> value id of its choice mask, or -1
     std::vector<int> keep_w_of_rec;           // record -> value id of the distance that entered it, or -1
     std::vector<std::pair<int, int>> choice_of_select;   // (a select's value id, the value id of its choice mask)
+    // A repetition's remainder jumps at its cell boundaries, but in a box that stays inside ONE cell it is a shift: what is
+    // computed from it is then Lipschitz as if the repetition were not there.  cond: "coordinate statement u (Lipschitz constant
+    // lip) stays within one period (1 / inv) over the box" -- decided per box by the mask function.
+    struct Cond { int u; double lip; float inv; };
+    std::vector<Cond> conds;
     int root = -1;
     int px = -1, py = -1, pz = -1;
     int n_phase1 = 0;                         // statements [0, n_phase1) are phase 1's; the rest are directions (phase 2)
@@ -327,7 +333,7 @@ inline bool symbolic_phase1(const SpecProgram& p, const std::vector<Node>& nodes
     Emitter& e = out.e;
     // lip: a Lipschitz constant of the map sample point -> this point (both in the Euclidean norm), < 0: none is known (the
     // map jumps: repetitions, twists); rowx: the first row of a general matrix, parked until its other two rows arrive
-    struct Pt { int c[3] = {-1, -1, -1}; int w = -1; double lip = 1.0; float rowx[3] = {0.0f, 0.0f, 0.0f}; };
+    struct Pt { int c[3] = {-1, -1, -1}; int w = -1; double lip = 1.0; float rowx[3] = {0.0f, 0.0f, 0.0f}; std::vector<int> conds; };
     std::vector<Pt> pt(nodes.size());
     out.dist_of.assign(nodes.size(), -1);
     out.choice_of_rec.assign(p.full.size(), -1);
@@ -370,9 +376,9 @@ inline bool symbolic_phase1(const SpecProgram& p, const std::vector<Node>& nodes
     };
     auto unknown = [&](int id) { return bound(id, 0.0, 0.0, false); };
     // interval annotations (box pruning): a leaf with the Lipschitz constant of its point, an op on bounded operands
-    auto iv_leaf = [&](int id, double lip) {
+    auto iv_leaf = [&](int id, double lip, const std::vector<int>& conds) {
         Stmt& s = e.st[id];
-        if (lip >= 0.0 && std::isfinite(lip) && s.bounded) { s.iv = IV_LEAF; s.iv_l = lip; }
+        if (lip >= 0.0 && std::isfinite(lip) && s.bounded) { s.iv = IV_LEAF; s.iv_l = lip; s.iv_conds = conds; }
         else s.iv = IV_UNKNOWN;
         return id;
     };
@@ -416,6 +422,7 @@ inline bool symbolic_phase1(const SpecProgram& p, const std::vector<Node>& nodes
             Pt in;
             if (nd.a >= 0) in = pt[nd.a];
             Pt o;
+            o.conds = in.conds;      // (what holds for the point an op starts from holds for what it makes of it; INIT ops start afresh)
             switch (op) {
             case OPX_POINT: o.c[0] = out.px; o.c[1] = out.py; o.c[2] = out.pz; o.lip = 1.0; break;
             case OPX_TO_SCALE:
@@ -453,14 +460,21 @@ inline bool symbolic_phase1(const SpecProgram& p, const std::vector<Node>& nodes
                 o.c[1] = row(src.c, q);
                 o.c[2] = row(src.c, q + 4);
                 o.lip = src.lip < 0.0 ? -1.0 : src.lip * matrix_norm(in.rowx, q, q + 4);
+                o.conds = src.conds;
                 break;
             }
             case OP_REPETITION:
                 for (int c = 0; c < 3; ++c)   // remainder_t: inv == 0 (an infinite spacing) returns the coordinate itself
                     o.c[c] = q[3 + c] == 0.0f ? in.c[c] : bound(e.add("remainder_t($0, " + flit(q[c]) + ", " + flit(q[3 + c]) + ")", {in.c[c]}),
                                                                 G(in.c[c]), O(in.c[c]), OK(in.c[c]));   // (|x - n y| <= |x|: safe for huge x too)
-                // (a remainder jumps at the cell boundaries: what is computed from it is not a Lipschitz function of the sample)
-                o.lip = (q[3] == 0.0f && q[4] == 0.0f && q[5] == 0.0f) ? in.lip : -1.0;
+                // (a remainder jumps at the cell boundaries: what is computed from it is Lipschitz only in boxes that stay
+                // inside one cell -- Phase1::conds)
+                o.lip = in.lip;
+                for (int c = 0; c < 3; ++c)
+                    if (q[3 + c] != 0.0f && in.lip >= 0.0 && OK(in.c[c])) {
+                        out.conds.push_back(Phase1::Cond{in.c[c], in.lip, q[3 + c]});
+                        o.conds.push_back((int)out.conds.size() - 1);
+                    } else if (q[3 + c] != 0.0f) o.lip = -1.0;
                 break;
             case OP_MIRROR: o = in; o.c[0] = neg(in.c[0]); break;
             case OP_SYMMETRICAL_TO: o = in; o.c[0] = bound(e.add("abs_($0)", {in.c[0]}), G(in.c[0]), O(in.c[0]), OK(in.c[0])); break;
@@ -490,13 +504,13 @@ inline bool symbolic_phase1(const SpecProgram& p, const std::vector<Node>& nodes
         case LEAF: {
             const Pt& c = pt[a];
             // (these four are exact distances in their local coordinates: 1-Lipschitz there, so Lipschitz with the point's constant)
-            if (op == OP_RECTANGLE) w = iv_leaf(perp(abs_minus(c.c[0], q[0]), abs_minus(c.c[1], q[1])), c.lip);
+            if (op == OP_RECTANGLE) w = iv_leaf(perp(abs_minus(c.c[0], q[0]), abs_minus(c.c[1], q[1])), c.lip, c.conds);
             else if (op == OP_CIRCLE)
-                w = iv_leaf(bound(e.add("len2_x($0, $1) - " + flit(q[0]), {c.c[0], c.c[1]}), G(c.c[0]) + G(c.c[1]), O(c.c[0]) + O(c.c[1]) + A(q[0]), OK(c.c[0]) && OK(c.c[1])), c.lip);
+                w = iv_leaf(bound(e.add("len2_x($0, $1) - " + flit(q[0]), {c.c[0], c.c[1]}), G(c.c[0]) + G(c.c[1]), O(c.c[0]) + O(c.c[1]) + A(q[0]), OK(c.c[0]) && OK(c.c[1])), c.lip, c.conds);
             else if (op == OP_SPHERE)
                 w = iv_leaf(bound(e.add("len3_x($0, $1, $2) - " + flit(q[0]), {c.c[0], c.c[1], c.c[2]}), G(c.c[0]) + G(c.c[1]) + G(c.c[2]),
-                                  O(c.c[0]) + O(c.c[1]) + O(c.c[2]) + A(q[0]), OK(c.c[0]) && OK(c.c[1]) && OK(c.c[2])), c.lip);
-            else if (op == OP_HALF_SPACE) w = iv_leaf(neg(c.c[1]), c.lip);
+                                  O(c.c[0]) + O(c.c[1]) + O(c.c[2]) + A(q[0]), OK(c.c[0]) && OK(c.c[1]) && OK(c.c[2])), c.lip, c.conds);
+            else if (op == OP_HALF_SPACE) w = iv_leaf(neg(c.c[1]), c.lip, c.conds);
             else {   // polygons, the gear: no bound is claimed for them (the gear's distance jumps between teeth)
                 // (2D primitives: they read x and y only -- handing them a zero for z keeps the statement a function of the
                 // two coordinates its frame's x and y depend on, so it can be a column of a pair table)
@@ -527,7 +541,7 @@ inline bool symbolic_phase1(const SpecProgram& p, const std::vector<Node>& nodes
             if (keep_w[nd.rec]) out.keep_w_of_rec[nd.rec] = in;
             if (op == OP_EXTRUSION) {
                 // perp(|z| - h, w): non-decreasing in both operands; the slab's distance is Lipschitz with the point's constant
-                const int slab = iv_leaf(abs_minus(c.c[2], q[0]), c.lip);
+                const int slab = iv_leaf(abs_minus(c.c[2], q[0]), c.lip, c.conds);
                 w = iv_op(perp(slab, in), IV_PERP, slab, in);
             }
             else if (op == OP_SYMMETRICAL_FROM || op == OP_CIRCULAR_REPETITION_FROM || op == OP_REVOLUTION_FROM) w = in;   // directions only
@@ -808,12 +822,31 @@ inline PruneInfo analyse_pruning(const Phase1& ph, int min_cost)
     // what the mask function has to bound: the operands of the guarded selects, down to the leaves
     std::vector<int> stack;
     for (int i = 0; i < n; ++i) if (in_graph[i] && pi.guarded(i)) { stack.push_back(st[i].iv_a); stack.push_back(st[i].iv_b); }
+    int leaves = 0, conditional = 0;
     while (!stack.empty()) {
         const int i = stack.back();
         stack.pop_back();
         if (i < 0 || pi.need_iv[i]) continue;
         pi.need_iv[i] = 1;
+        if (st[i].iv == IV_LEAF) { ++leaves; conditional += st[i].iv_conds.empty() ? 0 : 1; }
         if (st[i].iv != IV_LEAF && st[i].iv != IV_UNKNOWN) { stack.push_back(st[i].iv_a); stack.push_back(st[i].iv_b); }
+    }
+    // A tape that is MOSTLY repetitions (the sponge: twelve of its thirteen primitives sit behind one) is left alone: in a box
+    // its primitives are table reads, three vector instructions each, and the scalar tests cost more than what they skip
+    // (measured: the bench's leaf blocks 0.137 -> 0.187 ms, C5 6.5 -> 8.5 ms with the sponge's 24 scopes guarded in its
+    // distance walks, 0.41 -> 0.66 ms for its float4 grid guarded throughout).  Bounds behind a repetition serve assemblies
+    // that contain one (a bolt circle), not fractals.  HU_PRUNE_COND_SHARE: the share of conditional leaves from which on a
+    // tape gets no scopes (percent, default 50).
+    static const int cond_share = [] { const char* e = std::getenv("HU_PRUNE_COND_SHARE"); return e && *e ? std::atoi(e) : 50; }();
+    if (leaves > 0 && conditional * 100 > leaves * cond_share) {
+        PruneInfo none;
+        none.scope_of.assign(st.size(), 0);
+        none.sel.assign(st.size(), PruneInfo::Sel());
+        none.select_of_choice = pi.select_of_choice;
+        none.need_iv.assign(st.size(), 0);
+        none.parent.push_back(-1);
+        none.bit.push_back(-1);
+        return none;
     }
     return pi;
 }
@@ -1052,9 +1085,13 @@ inline std::string render_prune_function(const Phase1& ph, const PruneInfo& pi)
     if (pi.n_bits == 0) { o << "}\n"; return o.str(); }
     o << "    const uint32_t flags = 0u;\n";
     // the centre values of the bounded leaves, in place
-    std::vector<char> in(st.size(), 0);
+    std::vector<char> in(st.size(), 0), cond_used(ph.conds.size(), 0);
     std::vector<int> stack;
-    for (int i = 0; i < n; ++i) if (pi.need_iv[i] && st[i].iv == IV_LEAF) stack.push_back(i);
+    for (int i = 0; i < n; ++i)
+        if (pi.need_iv[i] && st[i].iv == IV_LEAF) {
+            stack.push_back(i);
+            for (int c : st[i].iv_conds) { cond_used[c] = 1; stack.push_back(ph.conds[c].u); }
+        }
     while (!stack.empty()) {
         const int i = stack.back();
         stack.pop_back();
@@ -1072,14 +1109,26 @@ inline std::string render_prune_function(const Phase1& ph, const PruneInfo& pi)
       << "    const float B = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(px) + hx, __builtin_fabsf(py) + hy), __builtin_fabsf(pz) + hz);\n";
     auto up = [](double v) { return flit(std::nextafter((float)(v * (1.0 + 1e-6)), HUGE_VALF)); };     // a non-negative constant, rounded up
     auto iv = [](int i) { return "i" + std::to_string(i); };
+    // the conditions of the repetitions: does the coordinate that enters the remainder stay inside one cell over the box?
+    for (size_t c = 0; c < ph.conds.size(); ++c) {
+        if (!cond_used[c]) continue;
+        const Phase1::Cond& k = ph.conds[c];
+        const Stmt& u = st[k.u];
+        o << "    const bool same" << c << " = iv_same_cell(" << plain(k.u) << ", " << up(k.lip) << " * rad[" << (int)u.deps << "] + (" << up(u.g)
+          << " * B + " << up(u.o) << ") * kIvMargin, " << flit(k.inv) << ");\n";
+    }
     for (int i = 0; i < n; ++i) {
         if (!pi.need_iv[i]) continue;
         const Stmt& s = st[i];
         o << "    const Iv " << iv(i) << " = ";
         switch (s.iv) {
-        case IV_LEAF:
+        case IV_LEAF: {
+            std::string ok;
+            for (int c : s.iv_conds) ok += (ok.empty() ? "" : " && ") + ("same" + std::to_string(c));
+            if (!ok.empty()) o << "!(" << ok << ") ? iv_unknown() : ";
             o << "iv_leaf(" << plain(i) << ", " << up(s.iv_l) << " * rad[" << (int)s.deps << "], (" << up(s.g) << " * B + " << up(s.o) << ") * kIvMargin)";
             break;
+        }
         case IV_SCALE: o << (s.iv_c == 0.0f ? std::string("iv_zero()") : "iv_scale(" + iv(s.iv_a) + ", " + flit(s.iv_c) + ")"); break;
         case IV_OFFSET: o << "iv_offset(" << iv(s.iv_a) << ", " << flit(s.iv_c) << ")"; break;
         case IV_SHELL: o << "iv_shell(" << iv(s.iv_a) << ", " << flit(s.iv_c) << ")"; break;
@@ -1122,6 +1171,7 @@ struct SpecMeta {
     int tabs[6] = {0, 0, 0, 0, 0, 0};   // columns of a box's tables: x, y, z, xy, xz, yz
     int prune_words = 0;         // 32-bit words of a box's pruning mask (0: the tape has nothing to prune)
     int prune_bits = 0;
+    bool prune_all = false;      // the float4 walks, `pre` and the table builders are guarded too (else: the distance walks only)
     bool plain_in_place = false; // the in-place functions (single points: ragged grids, small levels, the ray caster) are the plain form
 };
 // Up to this many (primitive, path) pairs the in-place functions defer directions too; beyond it they are the plain
@@ -1165,7 +1215,14 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
         return e && *e ? std::atoi(e) : 6;
     }();
     const PruneInfo prune = analyse_pruning(ph, prune_min);
-    if (meta) { meta->prune_bits = prune.n_bits; meta->prune_words = prune.words(); }
+    // Where the guards go.  An assembly (many scopes: planetary 131) gets them everywhere: walks of both kinds, `pre`, the pair
+    // tables' builders.  A tape with a few (the sponge: 24, all behind repetitions) gets them in the DISTANCE walks only -- leaf
+    // blocks, classification, distance grids, where the vector ALU is the bound --: its float4 code, which sits on the store
+    // roof, stays exactly as it was (and its launches skip the mask kernel).  HU_PRUNE_EVAL_MIN: the number of scopes from
+    // which a tape counts as an assembly.
+    static const int prune_eval_min = [] { const char* e = std::getenv("HU_PRUNE_EVAL_MIN"); return e && *e ? std::atoi(e) : 64; }();
+    const bool prune_all = prune.n_bits >= prune_eval_min;
+    if (meta) { meta->prune_bits = prune.n_bits; meta->prune_words = prune.words(); meta->prune_all = prune_all; }
     std::vector<int> dist_roots{ph.root}, eval_roots{ph.root};
     for (int v : ph.choice_of_rec) if (v >= 0) eval_roots.push_back(v);
     for (int v : ph.keep_w_of_rec) if (v >= 0) eval_roots.push_back(v);
@@ -1408,7 +1465,7 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
                 // 0.497 / 0.508 / 0.532 / 0.553 ms at 0 / 6 / 9 / 16 -- registers were dearer there than reads)
                 // (a tape with box pruning holds none: most of its columns are dead in any one box, and the registers decide how many
                 // wavefronts hide its scalar branches -- planetary's distance kernels: 122 -> 78 registers, four -> six wavefronts per SIMD)
-                int budget = knob("HU_TAB_HOLD_X", prune.n_bits > 0 ? 0 : 12);
+                int budget = knob("HU_TAB_HOLD_X", prune_all ? 0 : 12);
                 for (int i = 0; i < (int)probe.tab_main.size(); ++i) {
                     if (!probe.tab_main[i] || !tabc[i] || (ph.e.st[i].deps & f.walk)) continue;
                     const int regs = (ph.e.st[i].deps & DX) ? 2 : 1;
@@ -1448,8 +1505,10 @@ inline bool emit_deferred(std::ostringstream& o, const SpecProgram& p, size_t ma
             if (std::accumulate(n_tab, n_tab + 6, 0) == 0) { tabc.clear(); held.clear(); }
         }
         if (meta && f.walk != 0) for (int a = 0; a < 6; ++a) meta->tabs[a] = n_tab[a];
-        const PruneInfo* pi = f.walk != 0 ? &prune : nullptr;      // (the in-place form evaluates single points: nothing to decide per box)
-        const Variant vd = render_variant(ph, hoistable, dist_roots, tabc, &tab_index, held, pi),
+        // (the in-place form evaluates single points: nothing to decide per box)
+        const PruneInfo* pi_dist = f.walk != 0 ? &prune : nullptr;
+        const PruneInfo* pi = f.walk != 0 && prune_all ? &prune : nullptr;
+        const Variant vd = render_variant(ph, hoistable, dist_roots, tabc, &tab_index, held, pi_dist),
                       ve = render_variant(ph, hoistable, eval_roots, tabc, &tab_index, held, pi);
         // the values handed from `pre`: the union of what the distance and the evaluation read (one struct for both)
         const Variant& pre_of = ve;   // (eval's roots include dist's root: its frontier covers it)
@@ -1527,6 +1586,7 @@ inline std::string specialised_source(const SpecProgram& p, bool allow_deferred,
           << ", kPairXY = " << m.tabs[3] << ", kPairXZ = " << m.tabs[4] << ", kPairYZ = " << m.tabs[5] << ";\n"
           // box pruning: words of a box's mask, and the function that decides it (kernels.hpp k_box_masks)
           << "    static constexpr int kPruneWords = " << m.prune_words << ";\n"
+          << "    static constexpr bool kPruneAll = " << (m.prune_all ? "true" : "false") << ";\n"
           << "    template <class PR> __device__ __forceinline__ void prune(float cx, float cy, float cz, float hx, float hy, float hz, PR& out) const\n"
           << "    { tape_prune(cx, cy, cz, hx, hy, hz, extra, out); }\n";
         for (const char* axis : {"x", "y", "z"})

@@ -4,7 +4,8 @@ it; the box kernels skip them.  Dropping a loser must not change one bit of any 
 lists, moment sums -- so every check here is the oracle's answer, bit for bit, on scenes built to make the pruning bite:
 assemblies of many small parts far apart (most operands dead in most boxes), parts that touch, cut and contain each other
 (boxes in which the decision is close), shells / offsets / scalings / mirrored and rotated frames between the selects, and
-primitives the bounds know nothing about (gears, polygons, twists, repetitions) mixed in.  Both layouts of the dense
+primitives the bounds know nothing about (gears, polygons, twists, circular repetitions) and plates perforated by a
+repetition (bounded only in boxes that stay inside one cell of it) mixed in.  Both layouts of the dense
 kernel, slabs, leaf blocks, the classification kernels over boxes; `hu_tape_prune_info` says whether a tape has anything
 to prune at all (the sponge must not: it keeps the code it had)."""
 import ctypes
@@ -30,7 +31,8 @@ def prune_info(hip, handle):
 def random_part(rng):
     import codecad_amd as cc
     s = cc.shapes
-    kind = rng.choice(["box", "sphere", "cylinder", "tube", "gear", "plate", "polygon", "shell", "capsule", "cone_stack", "twist", "ring_of_pins"])
+    kind = rng.choice(["box", "sphere", "cylinder", "tube", "gear", "plate", "polygon", "shell", "capsule", "cone_stack", "twist", "ring_of_pins",
+                       "perforated"])
     if kind == "box":
         p = s.box(rng.uniform(1, 4), rng.uniform(1, 4), rng.uniform(1, 4))
     elif kind == "sphere":
@@ -51,6 +53,9 @@ def random_part(rng):
         p = s.capsule(-1, 0, 1, 0.5, 0.5).extruded(1).offset(0.2)
     elif kind == "cone_stack":
         p = s.union([s.cylinder(h=0.6, d=3 - 0.5 * i).translated_z(0.6 * i) for i in range(4)])
+    elif kind == "perforated":
+        # a plate with a grid of holes: the holes sit behind a REPETITION -- bounded only in boxes that stay inside one of its cells
+        p = s.box(5, 4, 0.6) - s.unsafe.Repetition(s.cylinder(h=4, d=rng.uniform(0.3, 0.7)), (rng.choice([1.0, 1.5]), rng.choice([1.0, 1.25]), None))
     elif kind == "twist":
         p = s.rectangle(0.5, 1).revolved(r=1.5, twist=rng.choice([90, 180]))
     else:
@@ -148,7 +153,8 @@ def test_planetary_dense_grids_and_blocks(hip, monkeypatch):
 
 
 def test_tapes_without_bounds_have_nothing_to_prune(hip):
-    """Everything in the sponge sits behind a repetition (no Lipschitz bound): no scopes, no mask kernel, the code it had."""
+    """A tape that is mostly repetitions (the sponge: twelve of its thirteen primitives sit behind one) is left alone -- in a box its
+    primitives are table reads, cheaper than the tests that would skip them --: no scopes, no mask kernel, the code it had."""
     import codecad_amd as cc
     from codecad_amd import hip_util
     for shape in (cc.examples.sponge(3), cc.shapes.sphere(3)):

@@ -239,7 +239,17 @@ def test_box_pruning_in_the_generated_source():
     xy = xy[:xy.index("\n}\n")]
     assert xy.count("= run_record<") >= 6 and "if (pr.template alive<" in xy       # the gears of the frames that keep z: 256 evaluations per box
     assert "mask_const<decltype(t" in src[src.index("auto tape_eval_x("):]
-    # nothing to bound: no scopes, no tests, the statements as they were
+    # a repetition inside an assembly: its primitives are bounded in the boxes that stay inside ONE of its cells
+    plate = cc.shapes.box(5, 4, 0.6) - cc.shapes.unsafe.Repetition(cc.shapes.cylinder(h=4, d=0.5), (1.0, 1.25, None))
+    scene = cc.shapes.union([plate.translated(6, 0, 0), cc.shapes.sphere(3).translated(-6, 1, 0), cc.shapes.box(2).translated(0, 7, 0),
+                             cc.shapes.cylinder(h=3, d=1).translated(0, -7, 1)])
+    rep = _source_of(cc.nodes.make_program(scene))
+    rp = rep[rep.index("void tape_prune("):]
+    rp = rp[:rp.index("\n}\n")]
+    assert rp.count("= iv_same_cell(") == 2 and "!(same0 && same1) ? iv_unknown() : iv_leaf(" in rp
+    assert "kPruneAll = false;" in rep and "alive<" in rep[rep.index("auto tape_dist_x("):rep.index("auto tape_eval_x(")]
+    assert "alive<" not in rep[rep.index("auto tape_eval_x("):]          # few scopes: the distance walks only
+    # a tape that is mostly repetitions, or has nothing to bound: no scopes, no tests, the statements as they were
     sponge = _source_of(cc.nodes.make_program(cc.examples.sponge(3)))
     assert "box pruning: 0 scopes" in sponge and "kPruneWords = 0;" in sponge and "alive<" not in sponge and "const auto t" in sponge
     off = _source_of(planetary, env={"HU_PRUNE": "0"})
