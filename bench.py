@@ -612,7 +612,7 @@ def run_c4(args, real_stdout, rank, world, dev):
     mp = finish(dict(zip(_KEYS, dist.allreduce_sum(partial.clone()).tolist())))
     parents = [1] + [int(t) for t in totals]
     samples = sum(p * c for p, c in zip(parents, cells))
-    leaf_parents_here = int((pipe.pipe.mine if pipe.pipe.exchange else pipe.pipe.send)[-2][0, 0].item())
+    leaf_parents_here = int(pipe.pipe.lists[-2][0, 0].item())       # this rank's share of the leaf level's parents
     verified = None
     if not args.no_verify:
         verified = verify_c4(np, torch, host_tape, pipe, levels, leaf_parents_here)
@@ -685,8 +685,7 @@ def verify_c4(np, torch, host_tape, pipe, levels, leaf_parents, blocks=6):
         if level == 0:
             rows, picks = lp.top[1:2].view(torch.float64).cpu().numpy(), [0]
         else:
-            src = lp.mine[level - 1] if lp.exchange else lp.send[level - 1]
-            rows = src[1:1 + leaf_parents].view(torch.float64).cpu().numpy()
+            rows = lp.lists[level - 1][1:1 + leaf_parents].view(torch.float64).cpu().numpy()
             picks = sorted(set(rng.integers(0, leaf_parents, blocks).tolist())) if leaf_parents else []
         sums = pipe.sums[level].cpu().numpy().view(np.uint32)
         for b in picks:

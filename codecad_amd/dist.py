@@ -353,6 +353,7 @@ class LevelPipeline:
             return bind(*args, **kwargs) if bind is not None else functools.partial(fn, *args, **kwargs)
 
         plan = []
+        self.lists = []          # per level: the buffer [header | rows] that holds this rank's survivors of that level
         parents, max_parents = self.top, self.top_max
         for level, capacity in enumerate(self.capacities):
             out = self.send[level]
@@ -362,6 +363,7 @@ class LevelPipeline:
                 own = (self.world, self.rank) if level + 1 == self.replicate else None
                 plan.append(bound(self.classify, level, parents[1:], parents[0, :1], max_parents, out, own=own))
                 parents = out
+                self.lists.append(parents)
                 max_parents = capacity
                 continue
             plan.append(bound(self.classify, level, parents[1:], parents[0, :1], max_parents, out))
@@ -382,6 +384,7 @@ class LevelPipeline:
                     plan.append(functools.partial(dist.all_gather_into_tensor, g, out))
                 plan.append(bound(self.slice_rows, g, self.rank, self.mine[level], self.stats[level]))
                 parents = self.mine[level]
+            self.lists.append(parents)
             max_parents = capacity
         return plan, parents
 
