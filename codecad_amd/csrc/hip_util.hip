@@ -21,8 +21,14 @@
 #include <vector>
 
 #include <dirent.h>
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <spawn.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
+
+extern char** environ;
 
 #include "../../include/hip_util.h"
 #include "kernels.hpp"
@@ -81,6 +87,8 @@ struct hu_tape_s {
     int flags = 0;
     sdf::SpecProgram program;    // both programs on the host, kept for hu_tape_specialize (specialise.hpp)
     struct SpecKernels* spec = nullptr;
+    std::string spec_source;     // the generated per-tape source, once it has been asked for (a tape's kernels are built and
+    sdf::SpecMeta spec_meta;     // probed one by one: planetary's source takes tens of milliseconds to generate)
 };
 
 namespace {
@@ -224,12 +232,15 @@ int check_dims(const uint32_t dims[3], uint64_t& cells)
 // removed by dead-code elimination.  The arithmetic is the interpreter's, operation for
 // operation, so results are identical (tests run the parity suite on specialised tapes).
 // ------------------------------------------------------------------------------------------
-// All per-tape kernels are compiled together in one module: measured, hipRTC spends its time on the
-// shared straight-line tape function, not per kernel (sponge(4): 0.9 s for eight kernels, 0.56 s for one;
-// planetary: 18 s either way), so compiling lazily, kernel by kernel, costs more whenever two are used.
+// A tape's kernels may sit in several modules: a synchronous build (hu_tape_specialize_groups without a cached image)
+// compiles the requested set as ONE module, the background builds (codecad_amd/hip_util/buffer.py) make one image per
+// KERNEL, side by side in several processes.  (Rounds 1-3 built all kernels, then families, together: in the plain form
+// hipRTC spent its time on the one straight-line tape function every kernel shared.  The deferred form over boxes
+// instantiates its own functions per kernel -- sponge(4), family of five: 1.40 s, its kernels one by one: 0.09 + 0.47 +
+// 0.55 + 0.22 + 0.27 s with the precompiled header below -- so a launch's kernel is ready in a third of the time.)
 struct SpecKernels {
     std::vector<hipModule_t> modules;   // one per hu_tape_specialize_groups call that built something
-    uint32_t groups = 0;                // HU_SPEC_* bits: the kernel families that are loaded
+    uint32_t groups = 0;                // the kernels that are loaded (bit i: kernel i of kSpecKernelNames)
     hipFunction_t dense[2] = {nullptr, nullptr};
     hipFunction_t blocks[2] = {nullptr, nullptr};
     // tapes with box code: the same over runs of cells, for extents that are no multiples of (4, 4, 8) (kernels.hpp k_grid_eval_ragged)
@@ -308,12 +319,16 @@ void keep_programs(hu_tape_s* t, const sdf::DecodedTape& d)
 struct SpecEval { const float* extra; uint32_t flags; };  // same layout as the generated sdfk::JitEval
 
 constexpr int kSpecKernelCount = 15;
-// the family (include/hip_util.h HU_SPEC_*) of each kernel below: a build may hold any subset of the families (the mask
+// bit i of a `groups` mask is kernel i below; the families of include/hip_util.h (HU_SPEC_*) are sets of them (the mask
 // kernel of box pruning belongs to every family that launches over boxes)
-constexpr uint32_t kSpecGroupOf[kSpecKernelCount] = {HU_SPEC_DENSE, HU_SPEC_DENSE, HU_SPEC_BLOCKS, HU_SPEC_BLOCKS, HU_SPEC_CLASSIFY, HU_SPEC_CLASSIFY,
-                                                      HU_SPEC_CLASSIFY, HU_SPEC_CLASSIFY, HU_SPEC_RENDER, HU_SPEC_RENDER,
-                                                      HU_SPEC_DENSE | HU_SPEC_BLOCKS | HU_SPEC_CLASSIFY,
-                                                      HU_SPEC_DENSE, HU_SPEC_DENSE, HU_SPEC_BLOCKS, HU_SPEC_BLOCKS};
+constexpr uint32_t spec_bit(int i) { return 1u << i; }
+constexpr uint32_t kSpecGroupOf[kSpecKernelCount] = {spec_bit(0), spec_bit(1), spec_bit(2), spec_bit(3), spec_bit(4), spec_bit(5), spec_bit(6), spec_bit(7),
+                                                      spec_bit(8), spec_bit(9), spec_bit(10), spec_bit(11), spec_bit(12), spec_bit(13), spec_bit(14)};
+static_assert(HU_SPEC_DENSE == (spec_bit(0) | spec_bit(1) | spec_bit(10) | spec_bit(11) | spec_bit(12)), "hip_util.h");
+static_assert(HU_SPEC_BLOCKS == (spec_bit(2) | spec_bit(3) | spec_bit(10) | spec_bit(13) | spec_bit(14)), "hip_util.h");
+static_assert(HU_SPEC_CLASSIFY == (spec_bit(4) | spec_bit(5) | spec_bit(6) | spec_bit(7) | spec_bit(10)), "hip_util.h");
+static_assert(HU_SPEC_RENDER == (spec_bit(8) | spec_bit(9)), "hip_util.h");
+static_assert(HU_SPEC_ALL == (HU_SPEC_DENSE | HU_SPEC_BLOCKS | HU_SPEC_CLASSIFY | HU_SPEC_RENDER) && HU_SPEC_ALL == spec_bit(kSpecKernelCount) - 1u, "hip_util.h");
 const char* const kSpecKernelNames[kSpecKernelCount] = {
     "sdfk::k_grid_eval<sdfk::JitEval, 0, 2>",           "sdfk::k_grid_eval<sdfk::JitEval, 1, 2>",
     "sdfk::k_grid_eval_blocks<sdfk::JitEval, 0, 2>",    "sdfk::k_grid_eval_blocks<sdfk::JitEval, 1, 2>",
@@ -1250,7 +1265,7 @@ static void spec_cache_store(const char* cache_dir, const std::string& path, con
 }
 
 // Keep the cache bounded: beyond kSpecCacheFiles entries the oldest (by modification time) are removed.
-constexpr size_t kSpecCacheFiles = 1024;
+constexpr size_t kSpecCacheFiles = 8192;    // (up to fifteen per tape)
 static void spec_cache_prune(const char* cache_dir)
 {
     DIR* d = opendir(cache_dir);
@@ -1267,6 +1282,140 @@ static void spec_cache_prune(const char* cache_dir)
     if (files.size() <= kSpecCacheFiles) return;
     std::sort(files.begin(), files.end());
     for (size_t i = 0; i + kSpecCacheFiles * 3 / 4 < files.size(); ++i) (void)std::remove(files[i].second.c_str());
+}
+
+// ---- a precompiled header for the per-tape builds --------------------------------------------------------------------
+// A per-tape build parses the same ~16 000 lines every time -- hipRTC's own runtime header (13 000) and the op library
+// (kernels.hpp and what it includes) -- before it sees the first line that depends on the tape: a quarter of a family's
+// build, and most of a single small kernel's.  hipRTC hands its options to clang, `-include-pch` among them; what it cannot
+// do is WRITE one.  So the header is made once per (cache directory, op library, hipRTC installation) by the clang++ that
+// sits next to the hipRTC in use (<lib>/llvm/bin/clang++: same compiler, or the file is refused and the build goes on
+// without -- as it does when there is no such clang, e.g. under the hipRTC a PyTorch wheel brings along), from hipRTC's
+// runtime header (libhiprtc-builtins.so exports its text) and with the options hipRTC itself passes.  Best effort all the
+// way: no clang, no builtins library, a directory that cannot be written, a header another process is just making, a file
+// clang refuses -- the build runs as before.  HU_RTC_PCH=0 switches it off, HU_CLANG names the compiler.
+static bool g_pch_refused = false;          // the compiler in this process refused a header once: do not offer it again
+static bool g_pch_beside_refused = false;   // ... the one beside the library (then: one of its own, in the cache directory)
+
+static std::string dir_of(const std::string& path)
+{
+    const size_t cut = path.rfind('/');
+    return cut == std::string::npos ? std::string(".") : path.substr(0, cut);
+}
+
+static bool run_and_wait(const std::vector<std::string>& argv)
+{
+    std::vector<char*> av;
+    for (const std::string& a : argv) av.push_back(const_cast<char*>(a.c_str()));
+    av.push_back(nullptr);
+    posix_spawn_file_actions_t fa;
+    posix_spawn_file_actions_init(&fa);
+    posix_spawn_file_actions_addopen(&fa, 0, "/dev/null", O_RDONLY, 0);
+    posix_spawn_file_actions_addopen(&fa, 1, "/dev/null", O_WRONLY, 0);   // (a compile server talks on its stdout)
+    posix_spawn_file_actions_addopen(&fa, 2, "/dev/null", O_WRONLY, 0);
+    pid_t pid = 0;
+    const int rc = posix_spawn(&pid, av[0], &fa, nullptr, av.data(), environ);
+    posix_spawn_file_actions_destroy(&fa);
+    if (rc != 0) return false;
+    int status = 0;
+    while (waitpid(pid, &status, 0) < 0)
+        if (errno != EINTR) return false;
+    return WIFEXITED(status) && WEXITSTATUS(status) == 0;
+}
+
+// -> the path of a usable precompiled header, or "" (then the build runs without one): the one the library's build left
+// next to the library (<directory of libhip_util.so>/pch, builder.py), else the one in `dir` (NULL: none), made now if need be
+static std::string spec_pch(const char* include_dir, const char* dir, const std::vector<std::string>& options, bool only_in_dir = false)
+{
+    static const bool off = [] { const char* e = getenv("HU_RTC_PCH"); return e && e[0] == '0'; }();
+    if (off || g_pch_refused) return "";
+    Dl_info where{};
+    if (!dladdr(reinterpret_cast<const void*>(&hiprtcCompileProgram), &where) || !where.dli_fname) return "";
+    const std::string lib_dir = dir_of(where.dli_fname);
+    std::string clang;
+    if (const char* e = getenv("HU_CLANG")) clang = e;
+    else
+        for (const char* rel : {"/llvm/bin/clang++", "/../llvm/bin/clang++", "/../lib/llvm/bin/clang++"})
+            if (clang.empty() && access((lib_dir + rel).c_str(), X_OK) == 0) clang = lib_dir + rel;
+    if (clang.empty() || access(clang.c_str(), X_OK) != 0) return "";
+    // its name: everything it depends on
+    uint64_t h = 0xcbf29ce484222325ull;
+    int version[3] = {0, 0, HIP_VERSION};
+    (void)hiprtcVersion(&version[0], &version[1]);
+    h = fnv1a(h, version, sizeof version);
+    h = fnv1a(h, lib_dir.data(), lib_dir.size());
+    h = fnv1a(h, clang.data(), clang.size());
+    for (const std::string& o : options)
+        if (o.compare(0, 2, "-I") != 0) h = fnv1a(h, o.data(), o.size() + 1);   // (not the include path: the headers' bytes)
+    std::string text;
+    for (const char* name : kSpecHeaders) {
+        if (!read_file(std::string(include_dir) + "/" + name, text)) return "";
+        h = fnv1a(h, text.data(), text.size());
+    }
+    char hex[32];
+    std::snprintf(hex, sizeof hex, "%016llx", (unsigned long long)h);
+    if (!only_in_dir) {
+        Dl_info self{};
+        if (dladdr(reinterpret_cast<const void*>(&hu_last_error), &self) && self.dli_fname) {
+            const std::string beside = dir_of(self.dli_fname) + "/pch/pch_" + hex + ".pch";
+            if (access(beside.c_str(), R_OK) == 0) return beside;
+        }
+    }
+    if (!dir || !*dir) return "";
+    const std::string base = std::string(dir) + "/pch_" + hex, pch = base + ".pch";
+    if (access(pch.c_str(), R_OK) == 0) return pch;
+    static std::string tried;     // one attempt per process and name
+    if (tried == base) return "";
+    tried = base;
+    // one process makes it; the others carry on without it meanwhile (a lock left behind by a crash expires)
+    const std::string lock = base + ".lock";
+    (void)mkdir(dir, 0700);
+    int fd = open(lock.c_str(), O_CREAT | O_EXCL | O_WRONLY, 0600);
+    if (fd < 0) {
+        struct stat st;
+        if (stat(lock.c_str(), &st) == 0 && time(nullptr) - st.st_mtime > 120) (void)unlink(lock.c_str());
+        return "";
+    }
+    close(fd);
+    bool ok = false;
+    do {
+        // hipRTC's runtime header, the text its own builds start from
+        void* builtins = nullptr;
+        for (const std::string& name : {lib_dir + "/libhiprtc-builtins.so", std::string("libhiprtc-builtins.so." + std::to_string(version[0])),
+                                        std::string("libhiprtc-builtins.so")})
+            if (!builtins) builtins = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (!builtins) break;
+        const char* header = static_cast<const char*>(dlsym(builtins, "__hipRTC_header"));
+        const unsigned* header_size = static_cast<const unsigned*>(dlsym(builtins, "__hipRTC_header_size"));
+        if (!header || !header_size || *header_size == 0) break;
+        size_t n = *header_size;
+        while (n > 0 && header[n - 1] == 0) --n;
+        const std::string inc = base + "_include";
+        (void)mkdir(inc.c_str(), 0755);
+        const std::string tmp_tag = ".tmp" + std::to_string((long)getpid());
+        FILE* f = std::fopen((inc + "/hiprtc_runtime.h" + tmp_tag).c_str(), "wb");
+        if (!f) break;
+        const bool wrote = std::fwrite(header, 1, n, f) == n;
+        if ((std::fclose(f) != 0) || !wrote || std::rename((inc + "/hiprtc_runtime.h" + tmp_tag).c_str(), (inc + "/hiprtc_runtime.h").c_str()) != 0) break;
+        f = std::fopen((base + ".hip").c_str(), "wb");
+        if (!f) break;
+        std::fputs("#include \"kernels.hpp\"\n", f);
+        if (std::fclose(f) != 0) break;
+        // the options hipRTC passes for a HIP source (amd_comgr: COMPILE_SOURCE_TO_RELOCATABLE), then ours
+        const std::string v = std::to_string(HIP_VERSION_MAJOR) + "." + std::to_string(HIP_VERSION_MINOR) + "." + std::to_string(HIP_VERSION_PATCH);
+        std::vector<std::string> argv = {clang, "-c", "-fhip-emit-relocatable", "-mllvm", "-amdgpu-internalize-symbols", "-I", inc, "-O3", "-x", "hip",
+                                         "--offload-device-only", "--hip-version=" + v, "-DHIP_VERSION_MAJOR=" + std::to_string(HIP_VERSION_MAJOR),
+                                         "-DHIP_VERSION_MINOR=" + std::to_string(HIP_VERSION_MINOR), "-DHIP_VERSION_PATCH=" + std::to_string(HIP_VERSION_PATCH),
+                                         "-Wno-gnu-line-marker", "-Wno-missing-prototypes", "-D__HIPCC_RTC__", "-nogpuinc", "-include", "hiprtc_runtime.h"};
+        for (const std::string& o : options) argv.push_back(o);
+        for (const char* o : {"-Xclang", "-emit-pch", "-Xclang", "-fno-pch-timestamp", "-o"}) argv.push_back(o);
+        argv.push_back(pch + tmp_tag);
+        argv.push_back(base + ".hip");
+        if (!run_and_wait(argv)) { (void)std::remove((pch + tmp_tag).c_str()); break; }
+        ok = std::rename((pch + tmp_tag).c_str(), pch.c_str()) == 0;
+    } while (false);
+    (void)unlink(lock.c_str());
+    return ok ? pch : "";
 }
 
 // Compile `src` with hipRTC (needs no device) into an image.
@@ -1329,8 +1478,27 @@ static int specialised_image(const std::string& src, const char* include_dir, co
         img.code.clear();
     }
     if (only_if_cached) return HU_OK;
-    int rc;
-    if ((rc = compile_specialised(src, options, groups, img))) return rc;
+    int rc = HU_ERR_UNSUPPORTED;
+    for (int attempt = 0; attempt < 2 && rc != HU_OK; ++attempt) {
+        const std::string pch = spec_pch(include_dir, cache_dir, options, g_pch_beside_refused);
+        if (pch.empty()) break;
+        std::vector<std::string> with = options;
+        with.push_back("-include-pch");
+        with.push_back(pch);
+        if ((rc = compile_specialised(src, with, groups, img))) {
+            // (whatever it was: the plain build below tells.)  The header beside the library may have been made under other
+            // paths (a copied installation): then this process makes its own in the cache directory; one of the cache
+            // directory that this compiler refuses goes, so that the next process makes a new one.
+            const bool in_dir = cache_dir && *cache_dir && pch.compare(0, std::strlen(cache_dir), cache_dir) == 0;
+            if (in_dir) {
+                g_pch_refused = true;
+                (void)std::remove(pch.c_str());
+            } else {
+                g_pch_beside_refused = true;
+            }
+        }
+    }
+    if (rc != HU_OK && (rc = compile_specialised(src, options, groups, img))) return rc;
     if (cached) {
         spec_cache_store(cache_dir, path, key, img);
         spec_cache_prune(cache_dir);
@@ -1362,6 +1530,14 @@ int hu_tape_compile_groups(const float* tape, size_t n, const char* include_dir,
     return HU_OK;
 }
 
+int hu_spec_pch_prepare(const char* include_dir, const char* dir, char* path, size_t capacity)
+{
+    if (!include_dir || !dir) return fail(HU_ERR_BAD_ARG, "NULL argument");
+    const std::string pch = spec_pch(include_dir, dir, spec_options(include_dir), true);
+    if (path && capacity) std::snprintf(path, capacity, "%s", pch.c_str());
+    return HU_OK;
+}
+
 int hu_tape_compile_check(const float* tape, size_t n, const char* include_dir, size_t* code_bytes)
 {
     return hu_tape_compile_cached(tape, n, include_dir, nullptr, code_bytes, nullptr);
@@ -1372,56 +1548,84 @@ int hu_tape_specialize_cached(hu_tape t, const char* include_dir, const char* ca
     return hu_tape_specialize_groups(t, include_dir, cache_dir, only_if_cached, HU_SPEC_ALL, from_cache);
 }
 
+// Load `img` (the kernels of `set`) into the tape: those of them that are still missing take their slots.
+static int load_specialised(hu_tape t, const SpecImage& img, uint32_t set, hipError_t* why)
+{
+    hipModule_t module = nullptr;
+    hipFunction_t loaded[kSpecKernelCount] = {};
+    hipError_t e = hipModuleLoadData(&module, img.code.data());
+    size_t next = 0;
+    for (int i = 0; i < kSpecKernelCount && e == hipSuccess; ++i)
+        if (kSpecGroupOf[i] & set) e = (next < img.lowered.size()) ? hipModuleGetFunction(&loaded[i], module, img.lowered[next++].c_str()) : hipErrorNotFound;
+    if (e != hipSuccess) {
+        if (module) (void)hipModuleUnload(module);
+        (void)hipGetLastError();  // the failed load must not surface at the next launch's error check
+        if (why) *why = e;
+        return HU_ERR_HIP;
+    }
+    if (!t->spec) t->spec = new SpecKernels();
+    SpecKernels* k = t->spec;
+    hipFunction_t* slots[kSpecKernelCount] = {&k->dense[0], &k->dense[1], &k->blocks[0], &k->blocks[1],
+                                              &k->classify[0][0], &k->classify[0][1], &k->classify[1][0], &k->classify[1][1],
+                                              &k->ray_caster, &k->bitmap, &k->box_masks,
+                                              &k->dense_ragged[0], &k->dense_ragged[1], &k->blocks_ragged[0], &k->blocks_ragged[1]};
+    const uint32_t missing = set & ~k->groups;
+    for (int i = 0; i < kSpecKernelCount; ++i)
+        if (kSpecGroupOf[i] & missing) *slots[i] = loaded[i];
+    k->modules.push_back(module);
+    k->groups |= missing;
+    const sdf::SpecMeta& meta = t->spec_meta;
+    k->deferred = meta.deferred;
+    k->coord_limit = meta.coord_limit;
+    k->prune_words = meta.prune_words;
+    k->prune_bits = meta.prune_bits;
+    k->prune_all = meta.prune_all;
+    std::memcpy(k->tabs, meta.tabs, sizeof k->tabs);
+    return HU_OK;
+}
+
 int hu_tape_specialize_groups(hu_tape t, const char* include_dir, const char* cache_dir, int only_if_cached, uint32_t groups, int* from_cache)
 {
     if (from_cache) *from_cache = 0;
     if (!t || !include_dir) return fail(HU_ERR_BAD_ARG, "NULL argument");
     if (groups & ~(uint32_t)HU_SPEC_ALL) return fail(HU_ERR_BAD_ARG, "groups must be a set of HU_SPEC_* bits");
-    // families that are loaded already stay as they are; the image is the one of the REQUESTED set (so that a build of
-    // all ten kernels, made while one family was already running, is found under its own name)
-    const uint32_t missing = t->spec ? (groups & ~t->spec->groups) : groups;
-    if (missing == 0) return HU_OK;
-    sdf::SpecMeta meta;
-    const std::string src = generate_source(t, &meta);
-    int cached = 0;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        SpecImage img;
-        int crc;
-        // second attempt: the cached image did not load (e.g. written by an incompatible runtime): build and replace it
-        if ((crc = specialised_image(src, include_dir, cache_dir, only_if_cached != 0, groups, img, &cached, attempt != 0))) return crc;
-        if (img.code.empty()) return HU_OK;  // only_if_cached and not there: still interpreted
-        hipModule_t module = nullptr;
-        hipFunction_t loaded[kSpecKernelCount] = {};
-        hipError_t e = hipModuleLoadData(&module, img.code.data());
-        size_t next = 0;
-        for (int i = 0; i < kSpecKernelCount && e == hipSuccess; ++i)
-            if (kSpecGroupOf[i] & groups) e = hipModuleGetFunction(&loaded[i], module, img.lowered[next++].c_str());
-        if (e == hipSuccess) {
-            if (!t->spec) t->spec = new SpecKernels();
-            SpecKernels* k = t->spec;
-            hipFunction_t* slots[kSpecKernelCount] = {&k->dense[0], &k->dense[1], &k->blocks[0], &k->blocks[1],
-                                                      &k->classify[0][0], &k->classify[0][1], &k->classify[1][0], &k->classify[1][1],
-                                                      &k->ray_caster, &k->bitmap, &k->box_masks,
-                                                      &k->dense_ragged[0], &k->dense_ragged[1], &k->blocks_ragged[0], &k->blocks_ragged[1]};
+    auto missing = [&] { return t->spec ? (groups & ~t->spec->groups) : groups; };   // kernels that are loaded stay as they are
+    if (missing() == 0) return HU_OK;
+    if (t->spec_source.empty()) t->spec_source = generate_source(t, &t->spec_meta);
+    const std::string& src = t->spec_source;
+    const bool cache = cache_dir && *cache_dir;
+    bool all_cached = true;
+    // 1. the image of exactly this set (what a synchronous build of it left in the cache), 2. the images of its single
+    // kernels (what the background builds leave), both only read; 3. what is still missing, built as one image
+    for (int step = 0; step < 3 && missing(); ++step) {
+        if (step < 2 && !cache) continue;
+        if (step == 2 && only_if_cached) break;
+        std::vector<uint32_t> sets;
+        if (step == 1) {
             for (int i = 0; i < kSpecKernelCount; ++i)
-                if (kSpecGroupOf[i] & missing) *slots[i] = loaded[i];
-            k->modules.push_back(module);
-            k->groups |= missing;
-            k->deferred = meta.deferred;
-            k->coord_limit = meta.coord_limit;
-            k->prune_words = meta.prune_words;
-            k->prune_bits = meta.prune_bits;
-            k->prune_all = meta.prune_all;
-            std::memcpy(k->tabs, meta.tabs, sizeof k->tabs);
-            if (from_cache) *from_cache = cached;
-            return HU_OK;
+                if ((kSpecGroupOf[i] & missing()) && kSpecGroupOf[i] != groups) sets.push_back(kSpecGroupOf[i]);
+        } else {
+            sets.push_back(step == 0 ? groups : missing());
         }
-        if (module) (void)hipModuleUnload(module);
-        (void)hipGetLastError();  // the failed load must not surface at the next launch's error check
-        if (cached && only_if_cached) return HU_OK;  // an unusable cached image is not the caller's problem: still interpreted
-        if (!cached) return fail(HU_ERR_HIP, std::string("loading the specialised module: ") + hipGetErrorString(e));
+        for (uint32_t set : sets) {
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                SpecImage img;
+                int crc, cached = 0;
+                // second attempt (step 3 only): the cached image did not load (e.g. written by an incompatible runtime): build and replace it
+                if ((crc = specialised_image(src, include_dir, cache_dir, step < 2, set, img, &cached, attempt != 0))) return crc;
+                if (img.code.empty()) break;  // not cached: still interpreted
+                hipError_t e = hipSuccess;
+                if (load_specialised(t, img, set, &e) == HU_OK) {
+                    all_cached = all_cached && cached;
+                    break;
+                }
+                if (step < 2) break;       // an unusable cached image is not the caller's problem
+                if (!cached || attempt == 1) return fail(HU_ERR_HIP, std::string("loading the specialised module: ") + hipGetErrorString(e));
+            }
+        }
     }
-    return fail(HU_ERR_HIP, "loading the specialised module failed");
+    if (from_cache) *from_cache = (all_cached && missing() == 0) ? 1 : 0;
+    return HU_OK;
 }
 
 int hu_tape_specialize(hu_tape t, const char* include_dir) { return hu_tape_specialize_cached(t, include_dir, nullptr, 0, nullptr); }

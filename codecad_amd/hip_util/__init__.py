@@ -7,7 +7,7 @@ implemented over the C ABI in include/hip_util.h via ctypes.
 """
 from .manager import instance as manager, HipManager, HipError, Event, Stream, check  # noqa: F401
 from .buffer import Buffer, BufferList, Tape, interleave, interleave2, mem_flags, map_flags  # noqa: F401
-from ._lib import SPEC_DENSE, SPEC_BLOCKS, SPEC_CLASSIFY, SPEC_RENDER, SPEC_ALL  # noqa: F401  (hu_spec_group bits)
+from ._lib import SPEC_DENSE, SPEC_BLOCKS, SPEC_CLASSIFY, SPEC_RENDER, SPEC_ALL, SPEC_KERNELS  # noqa: F401  (hu_spec_group bits)
 from . import _lib  # noqa: F401
 from .builder import build  # noqa: F401
 

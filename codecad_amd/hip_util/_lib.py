@@ -74,6 +74,7 @@ PROTOTYPES = {
     "hu_tape_compile_check": [_f4, _sz, _c.c_char_p, _c.POINTER(_sz)],
     "hu_tape_compile_cached": [_f4, _sz, _c.c_char_p, _c.c_char_p, _c.POINTER(_sz), _c.POINTER(_i)],
     "hu_tape_compile_groups": [_f4, _sz, _c.c_char_p, _c.c_char_p, _u32, _c.POINTER(_sz), _c.POINTER(_i)],
+    "hu_spec_pch_prepare": [_c.c_char_p, _c.c_char_p, _c.c_char_p, _sz],
     "hu_selftest_math": [_c.POINTER(_c.c_uint64)],
     "hu_selftest_minmax3": [_c.POINTER(_c.c_uint64)],
     "hu_tape_source": [_f4, _sz, _c.c_char_p, _sz, _c.POINTER(_sz)],
@@ -81,7 +82,8 @@ PROTOTYPES = {
 }
 
 # hu_spec_group (include/hip_util.h): the kernel families of per-tape code
-SPEC_DENSE, SPEC_BLOCKS, SPEC_CLASSIFY, SPEC_RENDER, SPEC_ALL = 1, 2, 4, 8, 15
+SPEC_DENSE, SPEC_BLOCKS, SPEC_CLASSIFY, SPEC_RENDER, SPEC_ALL = 0x1c03, 0x640c, 0x04f0, 0x0300, 0x7fff   # sets of kernel bits (hip_util.h)
+SPEC_KERNELS = 15
 
 HEADER = os.path.normpath(os.path.join(os.path.dirname(__file__), "..", "..", "include", "hip_util.h"))
 

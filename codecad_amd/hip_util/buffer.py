@@ -237,16 +237,18 @@ class _BackgroundCompiler:
     or a kernel's first launch for its whole duration.  A finished build sits in the on-disk cache -- or, when that is
     switched off, in a private directory of this process -- where the tape's next launch finds it in milliseconds.  A
     server's first build also pays hipRTC's one-off start (~1.5 s in a fresh process), so no launch ever waits for that.
-    Several workers (CODECAD_AMD_RTC_SERVERS, default: up to four, half the cores) build a tape's kernel FAMILIES side by
-    side: the whole of a tape is ready after its slowest family, not after their sum (planetary: 4.5 s instead of 12 s;
-    the family in use is asked for first).  CODECAD_AMD_RTC_SERVER=0 (or a server that cannot be started) builds on the
-    worker thread instead."""
+    Several workers (CODECAD_AMD_RTC_SERVERS, default: up to eight, half the cores) build a tape's KERNELS side by side,
+    one image per kernel (round 3: all ten kernels in one build; round 4 first its four families): the kernel a launch
+    is waiting for is ready after its own compilation, the whole tape after its slowest kernel, and the servers -- which
+    run the hipRTC of the ROCm installation, with its clang next to it -- skip the headers through a precompiled one
+    (hu_spec_pch_prepare).  CODECAD_AMD_RTC_SERVER=0 (or a server that cannot be started) builds on the worker thread
+    instead."""
 
     REPLY_TIMEOUT = 900.0      # seconds a build may take before its server is given up (and replaced at the next job)
 
     def __init__(self, servers=None):
         if servers is None:
-            servers = int(os.environ.get("CODECAD_AMD_RTC_SERVERS", "0") or 0) or min(4, max(1, (os.cpu_count() or 2) // 2))
+            servers = int(os.environ.get("CODECAD_AMD_RTC_SERVERS", "0") or 0) or min(8, max(1, (os.cpu_count() or 2) // 2))
         self.queue, self.threads, self.private_dir = None, [], None
         self.slots = [{"server": None} for _ in range(max(1, int(servers)))]
 
@@ -254,6 +256,10 @@ class _BackgroundCompiler:
     def server(self):
         """the first worker's server: None (not started yet), a live process, or False (cannot be used: builds run on the thread)"""
         return self.slots[0]["server"]
+
+    def remote(self):
+        """may builds run in server processes (CODECAD_AMD_RTC_SERVER, and no worker has given up on its server)?"""
+        return os.environ.get("CODECAD_AMD_RTC_SERVER", "1") != "0" and all(slot["server"] is not False for slot in self.slots)
 
     def directory(self):
         d = cache_dir()
@@ -370,7 +376,14 @@ class _BackgroundCompiler:
 
 
 _background = _BackgroundCompiler()
-_FAMILIES = (1, 2, 4, 8)     # hu_spec_group bits: dense, blocks, classify, render
+from ._lib import SPEC_ALL, SPEC_KERNELS  # noqa: E402
+
+
+def _kernels_of(groups, first=0):
+    """The single kernels (hu_spec_group bits) of the set `groups`, those of the set `first` -- the family in use -- first;
+    within a family in bit order: its box kernels, then the mask kernel, then the kernels for ragged extents."""
+    bits = [1 << i for i in range(SPEC_KERNELS) if (1 << i) & int(groups)]
+    return [b for b in bits if b & int(first)] + [b for b in bits if not b & int(first)]
 
 
 class Tape:
@@ -400,19 +413,15 @@ class Tape:
         self._policy = policy if policy is not None else os.environ.get("CODECAD_AMD_SPECIALIZE", "auto")
         self._work = 0.0
         self._jobs = []          # background builds in flight, in the order they were asked for
-        self.groups = 0          # the kernel families whose per-tape code is loaded (hu_spec_group bits)
+        self.groups = 0          # the kernels whose per-tape code is loaded (hu_spec_group bits)
         self.from_cache = False
         if self._policy == "1":
             self.specialize()
         elif self._policy == "auto":
-            # a program compiled before costs milliseconds: take it now (an image of all families, or one per family --
+            # a program compiled before costs milliseconds: take it now (an image of all kernels, or one per kernel --
             # what the background builds leave behind)
             if cache_dir():
                 self._specialize(only_if_cached=True)
-                for family in _FAMILIES:
-                    if self.groups == 15:
-                        break
-                    self._specialize(only_if_cached=True, groups=family)
 
     # The interpreter retires ~2.5e12 (tape instruction x sample) per second whatever the tape (measured on MI355X:
     # sponge(4): 85 x 29e9; planetary: 467 x 6.2e9).  A background build starts once the interpreter has spent
@@ -424,7 +433,7 @@ class Tape:
     def note_samples(self, n, group=1):
         """Called by the launch wrappers with the number of samples about to be evaluated with this tape and the kernel
         family (hu_spec_group bit) that is about to run."""
-        if self._policy != "auto" or self.groups == 15:
+        if self._policy != "auto" or self.groups == SPEC_ALL:
             return
         if self._jobs:
             if any(job["done"].is_set() for job in self._jobs):
@@ -434,11 +443,10 @@ class Tape:
             return      # (what was asked for is loaded; the other families follow when they are used)
         self._work += float(n) * self.n_instructions
         if self._work / self._INTERPRETER_RATE >= self._START_SECONDS:
-            # one build per kernel family, the family in use first; the workers build them side by side (their images are
+            # one build per KERNEL, those of the family in use first; the workers build them side by side (their images are
             # also what a later process finds in the on-disk cache at upload)
             from . import builder
-            families = [f for f in _FAMILIES if f & int(group)] + [f for f in _FAMILIES if not f & int(group)]
-            self._jobs = [_background.submit(self.manager.lib, self.host_tape, builder.CSRC, f) for f in families]
+            self._jobs = [_background.submit(self.manager.lib, self.host_tape, builder.CSRC, k) for k in _kernels_of(SPEC_ALL, group)]
 
     def _take_background_builds(self):
         for job in [j for j in self._jobs if j["done"].is_set()]:      # (in any order: the families are built side by side)
@@ -450,9 +458,8 @@ class Tape:
                 self.build_error = job["error"]
                 self._jobs = []
                 return
-            before = self.groups
             self._specialize(only_if_cached=True, directory=job["directory"], groups=job["groups"])
-            if self.groups == before:
+            if self.groups & job["groups"] != job["groups"]:
                 self._policy = "0"      # (the image vanished or does not load: do not try again and again)
                 self._jobs = []
                 return
@@ -466,16 +473,31 @@ class Tape:
         self._take_background_builds()
         return self.specialized
 
-    def specialize(self, groups=15):
+    def specialize(self, groups=SPEC_ALL):
         """Compile straight-line kernels for this tape with hipRTC (seconds, once) and wait for them; afterwards
         every launch with this tape uses them.  Same results as the interpreter.  Raises
-        RuntimeError (with the compiler log) if hipRTC cannot build it.  `groups`: the kernel families to build
-        (hu_spec_group bits: SPEC_DENSE | SPEC_BLOCKS | SPEC_CLASSIFY | SPEC_RENDER; default all of them)."""
+        RuntimeError (with the compiler log) if hipRTC cannot build it.  `groups`: the kernels to build
+        (hu_spec_group bits: SPEC_DENSE | SPEC_BLOCKS | SPEC_CLASSIFY | SPEC_RENDER; default all of them).
+        The kernels are built side by side in the compile servers, one image per kernel: the whole tape is there after
+        its slowest kernel (measured on the MI355X box: sponge(4) 0.53 s, planetary 3.6 s; as one image in this process:
+        1.42 s, 10.9 s).  CODECAD_AMD_SPECIALIZE_POOL=0 -- the default under torch.distributed with more than one rank,
+        where every rank would start its own servers for the same tape -- builds the set in this process, as one image."""
         self._jobs = []
-        self._specialize(only_if_cached=False, groups=int(groups))
+        groups = int(groups)
+        directory = None
+        pool = os.environ.get("CODECAD_AMD_SPECIALIZE_POOL") or ("1" if int(os.environ.get("WORLD_SIZE", "1") or 1) <= 1 else "0")
+        if pool == "1" and _background.remote():
+            from . import builder
+            # what the cache holds already is taken first; the rest goes to the servers, one kernel per job
+            self._specialize(only_if_cached=True, groups=groups)
+            jobs = [_background.submit(self.manager.lib, self.host_tape, builder.CSRC, k) for k in _kernels_of(groups & ~self.groups)]
+            for job in jobs:
+                job["done"].wait()
+            directory = _background.directory()     # (a kernel whose job failed is built -- and its error reported -- below)
+        self._specialize(only_if_cached=False, directory=directory, groups=groups)
         return self
 
-    def _specialize(self, only_if_cached, directory=None, groups=15):
+    def _specialize(self, only_if_cached, directory=None, groups=SPEC_ALL):
         if self.groups & groups == groups:
             return
         from . import builder
@@ -487,7 +509,7 @@ class Tape:
                                                          1 if only_if_cached else 0, int(groups), ctypes.byref(hit)), "hu_tape_specialize_groups")
         check(self.manager.lib.hu_tape_specialized(self.device_ptr, ctypes.byref(flag)), "hu_tape_specialized")
         self.groups = int(flag.value)
-        self.specialized = self.groups != 0     # some family runs per-tape code (all of them: groups == 15)
+        self.specialized = self.groups != 0     # some kernel runs per-tape code (all of them: groups == SPEC_ALL)
         self.from_cache = bool(hit.value)
 
     @property

@@ -73,8 +73,54 @@ def build(force=False, verbose=False, extra_flags=(), out_path=None):
     if out_path is not None:
         return _compile(out_path, list(extra_flags), verbose)
     if not force and not is_stale():
+        if not _pch_files():
+            prepare_pch(verbose)
         return LIB_PATH
-    return _compile(LIB_PATH, [], verbose)
+    path = _compile(LIB_PATH, [], verbose)
+    prepare_pch(verbose)
+    return path
+
+
+PCH_DIR = os.path.join(os.path.dirname(LIB_PATH), "pch")
+
+
+def _pch_files():
+    try:
+        return [f for f in os.listdir(PCH_DIR) if f.endswith(".pch")]
+    except OSError:
+        return []
+
+
+def prepare_pch(verbose=False):
+    """The precompiled header of the per-tape builds (hu_spec_pch_prepare, include/hip_util.h), next to the library:
+    made in a process of its own -- host only, and with the hipRTC the compile servers will use (a process that has
+    imported torch runs the hipRTC of the torch wheel, whose clang is not installed).  Best effort: returns the path or
+    None (the per-tape builds then parse their headers as before); older headers in the directory are removed."""
+    import sys
+    code = ("import ctypes, sys\n"
+            "lib = ctypes.CDLL(sys.argv[1])\n"
+            "buf = ctypes.create_string_buffer(4096)\n"
+            "lib.hu_spec_pch_prepare.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]\n"
+            "rc = lib.hu_spec_pch_prepare(sys.argv[2].encode(), sys.argv[3].encode(), buf, 4096)\n"
+            "print(buf.value.decode() if rc == 0 else '')\n")
+    try:
+        os.makedirs(PCH_DIR, exist_ok=True)
+        out = subprocess.run([sys.executable, "-c", code, LIB_PATH, CSRC, PCH_DIR], capture_output=True, text=True, timeout=300)
+        path = out.stdout.strip().splitlines()[-1] if out.returncode == 0 and out.stdout.strip() else ""
+    except (OSError, subprocess.SubprocessError):
+        path = ""
+    if path:
+        keep = os.path.basename(path)[:-len(".pch")]
+        for f in os.listdir(PCH_DIR):
+            if not f.startswith(keep):
+                full = os.path.join(PCH_DIR, f)
+                if os.path.isdir(full):
+                    shutil.rmtree(full, ignore_errors=True)
+                else:
+                    os.unlink(full)
+    if verbose:
+        print("precompiled header:", path or "none (no clang++ next to hipRTC: per-tape builds parse their headers)")
+    return path or None
 
 
 def _compile(LIB_PATH, extra_flags, verbose):

@@ -30,7 +30,7 @@ def check(rc, what=""):
 
 
 # kernel families of per-tape code (include/hip_util.h hu_spec_group)
-from ._lib import SPEC_DENSE, SPEC_BLOCKS, SPEC_CLASSIFY, SPEC_RENDER, SPEC_ALL  # noqa: E402,F401
+from ._lib import SPEC_DENSE, SPEC_BLOCKS, SPEC_CLASSIFY, SPEC_RENDER, SPEC_ALL, SPEC_KERNELS  # noqa: E402,F401
 
 
 def _note(scene, global_size, factor=1, group=SPEC_DENSE):

@@ -287,19 +287,28 @@ int hu_tape_specialize(hu_tape t, const char* include_dir);
  * `*from_cache` (may be NULL) <- 1 if the kernels came from the cache. */
 int hu_tape_specialize_cached(hu_tape t, const char* include_dir, const char* cache_dir,
                               int only_if_cached, int* from_cache);
-/* The same for a subset of the kernel families (any combination of the bits below): compiling only what is about to be
- * used takes a fraction of the time of all ten kernels, and a tape's families may be built one after the other (families
- * that are loaded already are skipped).  A launch of a kernel whose family is not loaded runs the interpreter. */
+/* The same for a subset of the per-tape KERNELS: bit i of `groups` is kernel i of the list below, and the HU_SPEC_*
+ * constants are the sets a kind of launch needs (its FAMILY).  Compiling only what is about to be used takes a fraction
+ * of the time of all fifteen kernels, and a tape's kernels may be built one by one, side by side in several processes
+ * (round 4: a tape's first kernel is ready after its OWN compilation, not after its family's).  Kernels that are loaded
+ * already are skipped; a launch whose kernel is not loaded runs the interpreter (a launch over boxes whose mask kernel is
+ * not loaded yet treats every operand as alive: same bits).
+ *   bit 0, 1    k_grid_eval (float4, float)            bit 10      k_box_masks (box pruning, every launch over boxes)
+ *   bit 2, 3    k_grid_eval_blocks (float4, float)     bit 11, 12  k_grid_eval_ragged (float4, float)
+ *   bit 4..7    k_classify ([MASS][BATCH])             bit 13, 14  k_grid_eval_blocks_ragged (float4, float)
+ *   bit 8, 9    k_ray_caster, k_bitmap
+ * With a cache directory: the image of exactly the requested set is taken when it is there, else the images of its single
+ * kernels (what the background builds leave behind); what is still missing is built as ONE image (only_if_cached = 0). */
 enum hu_spec_group {
-    HU_SPEC_DENSE = 1,     /* hu_grid_eval, hu_grid_eval_pymcubes, hu_grid_eval_slab */
-    HU_SPEC_BLOCKS = 2,    /* hu_grid_eval_blocks[_indirect] */
-    HU_SPEC_CLASSIFY = 4,  /* hu_subdivision_step / _level[_indirect], hu_mass_properties / _level[_indirect] */
-    HU_SPEC_RENDER = 8,    /* hu_ray_caster, hu_bitmap */
-    HU_SPEC_ALL = 15
+    HU_SPEC_DENSE = 0x1c03,     /* hu_grid_eval, hu_grid_eval_pymcubes, hu_grid_eval_slab */
+    HU_SPEC_BLOCKS = 0x640c,    /* hu_grid_eval_blocks[_indirect] */
+    HU_SPEC_CLASSIFY = 0x04f0,  /* hu_subdivision_step / _level[_indirect], hu_mass_properties / _level[_indirect] */
+    HU_SPEC_RENDER = 0x0300,    /* hu_ray_caster, hu_bitmap */
+    HU_SPEC_ALL = 0x7fff
 };
 int hu_tape_specialize_groups(hu_tape t, const char* include_dir, const char* cache_dir, int only_if_cached,
                               uint32_t groups, int* from_cache);
-/* *out_flag <- the HU_SPEC_* families whose per-tape kernels are loaded (0: everything is interpreted) */
+/* *out_flag <- the per-tape kernels that are loaded (hu_spec_group bits; 0: everything is interpreted) */
 int hu_tape_specialized(hu_tape t, int* out_flag);
 /* Box pruning of the tape's per-tape code (no counterpart in the reference, whose kernels evaluate every primitive for
  * every sample): *bits <- the operands of min / max that can be decided per 16^3 box of a launch (0: nothing in this tape
@@ -307,6 +316,14 @@ int hu_tape_specialized(hu_tape t, int* out_flag);
  * kernel first, on their stream; HU_PRUNE=0 in the environment builds tapes without it, HU_PRUNE_RUN=0 skips the mask
  * kernel (every operand is then taken as alive).  Results are bit-identical either way. */
 int hu_tape_prune_info(hu_tape t, int* bits, int* words);
+/* A precompiled header for the per-tape builds (host only): hipRTC's runtime header + the op library of `include_dir`,
+ * made in `dir` by the clang++ that sits next to the hipRTC in use, if there is one; the builds then skip parsing those
+ * ~16 000 lines (a quarter of a family's build, most of a small kernel's).  `path` (may be NULL) <- the file, or "" when
+ * none could be made (no such clang, no libhiprtc-builtins.so, unwritable directory): the builds then run as before.
+ * The per-tape builds look for it in <directory of libhip_util.so>/pch (where the library's build puts it) and in their
+ * cache directory (where they make it themselves when it is missing).  HU_RTC_PCH=0 switches it off.  No counterpart in
+ * the reference (pyopencl's build has no headers to parse). */
+int hu_spec_pch_prepare(const char* include_dir, const char* dir, char* path, size_t capacity);
 /* The HIP source hu_tape_specialize would compile for this tape (host only, no device needed):
  * `*needed` receives its size including the terminator; it is copied when `capacity` suffices. */
 int hu_tape_source(const float* tape, size_t n_floats, char* buf, size_t capacity, size_t* needed);
@@ -322,7 +339,7 @@ int hu_tape_compile_check(const float* tape, size_t n_floats, const char* includ
  * only reads.  `*from_cache` (may be NULL) <- 1 on a hit. */
 int hu_tape_compile_cached(const float* tape, size_t n_floats, const char* include_dir,
                            const char* cache_dir, size_t* code_bytes, int* from_cache);
-/* ... for a subset of the kernel families (hu_spec_group bits) */
+/* ... for a subset of the kernels (hu_spec_group bits), as ONE image named after the set */
 int hu_tape_compile_groups(const float* tape, size_t n_floats, const char* include_dir, const char* cache_dir,
                            uint32_t groups, size_t* code_bytes, int* from_cache);
 

@@ -115,9 +115,9 @@ def test_tiered_specialisation_policy(hip, monkeypatch):
     t._START_SECONDS = 0.0                                                   # "enough work" from now on
     t0 = time.perf_counter()
     hip.k.grid_eval((24, 24, 24), None, t, c, np.float32(1 / 24), out).wait()
-    assert time.perf_counter() - t0 < 0.5 and len(t._jobs) == 4 and not t.specialized       # interpreted, the builds (one per family) are under way
+    assert time.perf_counter() - t0 < 0.5 and len(t._jobs) == hip_util.SPEC_KERNELS and not t.specialized   # interpreted, the builds (one per kernel) are under way
     assert np.array_equal(out.read().view(np.uint32), interpreted.view(np.uint32))
-    assert t.wait_specialized(timeout=120) and t.specialized and t.groups == 15 and not t._jobs
+    assert t.wait_specialized(timeout=120) and t.specialized and t.groups == hip_util.SPEC_ALL and not t._jobs
     hip.k.grid_eval((24, 24, 24), None, t, c, np.float32(1 / 24), out).wait()
     assert np.array_equal(out.read().view(np.uint32), interpreted.view(np.uint32))
     # a second tape: its launches pick the finished build up by themselves
@@ -125,12 +125,12 @@ def test_tiered_specialisation_policy(hip, monkeypatch):
     u._START_SECONDS = 0.0
     deadline = time.perf_counter() + 120
     first_groups = 0
-    while u.groups != 15 and time.perf_counter() < deadline:
+    while u.groups != hip_util.SPEC_ALL and time.perf_counter() < deadline:
         hip.k.grid_eval((24, 24, 24), None, u, c, np.float32(1 / 24), out).wait()
         first_groups = first_groups or u.groups
         time.sleep(0.02)
-    # (the families are built side by side, the one in use is asked for first: whichever lands first, all four arrive)
-    assert u.groups == 15 and first_groups != 0
+    # (the kernels are built side by side, those of the family in use are asked for first: whichever lands first, all arrive)
+    assert u.groups == hip_util.SPEC_ALL and first_groups != 0
 
     monkeypatch.setenv("CODECAD_AMD_SPECIALIZE", "0")
     never = hip_util.Tape(tape)
@@ -346,25 +346,35 @@ def test_kernel_families_are_built_and_loaded_separately(hip, tmp_path):
     t = hip_util.Tape(tape, policy="0")
     check_both(t)
     assert t.groups == 0
-    t._specialize(only_if_cached=False, groups=1)          # the dense kernels only
+    t._specialize(only_if_cached=False, groups=1)          # one kernel: the dense float4 grid over boxes
     assert t.groups == 1 and t.specialized
+    check_both(t)                                          # (ragged extents and everything else: interpreter)
+    t._specialize(only_if_cached=False, groups=hip_util.SPEC_DENSE)     # the dense family: the missing four as one image
+    assert t.groups == hip_util.SPEC_DENSE
     check_both(t)                                          # grid_eval: per-tape code; subdivision_step: interpreter
-    t._specialize(only_if_cached=False, groups=4)
-    assert t.groups == 5
+    t._specialize(only_if_cached=False, groups=hip_util.SPEC_CLASSIFY)
+    assert t.groups == hip_util.SPEC_DENSE | hip_util.SPEC_CLASSIFY
     check_both(t)
     t.specialize()
-    assert t.groups == 15
+    assert t.groups == hip_util.SPEC_ALL
     check_both(t)
-    # the host-only build of one family, and its image found again by the load
+    # the host-only build of a set of kernels, and its image found again by the load -- as a whole, and kernel by kernel
     cache = tmp_path / "cache"
     cache.mkdir()
     size, hit = ctypes.c_size_t(0), ctypes.c_int(-1)
     ptr = t.host_tape.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
-    assert hip.lib.hu_tape_compile_groups(ptr, t.host_tape.size, builder.CSRC.encode(), str(cache).encode(), 2, ctypes.byref(size), ctypes.byref(hit)) == 0
+    blocks = hip_util.SPEC_BLOCKS
+    assert hip.lib.hu_tape_compile_groups(ptr, t.host_tape.size, builder.CSRC.encode(), str(cache).encode(), blocks, ctypes.byref(size), ctypes.byref(hit)) == 0
     assert hit.value == 0 and size.value > 5000
     u = hip_util.Tape(tape, policy="0")
-    u._specialize(only_if_cached=True, directory=str(cache), groups=2)
-    assert u.groups == 2 and u.from_cache
-    u._specialize(only_if_cached=True, directory=str(cache), groups=1)      # nothing cached for that family: stays as it is
-    assert u.groups == 2
-    assert hip.lib.hu_tape_compile_groups(ptr, t.host_tape.size, builder.CSRC.encode(), str(cache).encode(), 16, None, None) != 0
+    u._specialize(only_if_cached=True, directory=str(cache), groups=blocks)
+    assert u.groups == blocks and u.from_cache
+    u._specialize(only_if_cached=True, directory=str(cache), groups=1)      # nothing cached for that kernel: stays as it is
+    assert u.groups == blocks
+    for kernel in (1, 2):                                                   # what the background builds leave: single kernels
+        assert hip.lib.hu_tape_compile_groups(ptr, t.host_tape.size, builder.CSRC.encode(), str(cache).encode(), kernel, None, None) == 0
+    v = hip_util.Tape(tape, policy="0")
+    v._specialize(only_if_cached=True, directory=str(cache), groups=hip_util.SPEC_DENSE)    # no image of the family: its two cached kernels
+    assert v.groups == 3 and not v.from_cache
+    check_both(v)
+    assert hip.lib.hu_tape_compile_groups(ptr, t.host_tape.size, builder.CSRC.encode(), str(cache).encode(), 1 << hip_util.SPEC_KERNELS, None, None) != 0

@@ -308,15 +308,15 @@ def test_specialised_code_cache_on_disk(tmp_path):
     assert compile_(p, t, None)[1] == 0
     assert compile_(p, t, tmp_path / "missing" / "parent")[1] == 0 and not (tmp_path / "missing").exists()
     assert not [f for f in os.listdir(cache) if ".tmp" in f]
-    # the cache is bounded: past 1024 entries the oldest go, the newest stay
-    for i in range(1030):
+    # the cache is bounded: past 8192 entries (a tape leaves up to fifteen) the oldest go, the newest stay
+    for i in range(8200):
         dummy = cache / ("%032x.huspec" % i)
         dummy.write_bytes(b"old")
         os.utime(dummy, (1000 + i, 1000 + i))
     t3, p3 = _tape_ptr(cc.nodes.make_program(cc.shapes.sphere(4) - cc.shapes.box(1)))
     assert compile_(p3, t3, cache)[1] == 0
     left = set(os.listdir(cache))
-    assert len(left) == 768 and "%032x.huspec" % 0 not in left and "%032x.huspec" % 1029 in left
+    assert len(left) == 6144 and "%032x.huspec" % 0 not in left and "%032x.huspec" % 8199 in left
     assert compile_(p3, t3, cache)[1] == 1 and compile_(p, t, cache)[1] == 1
 
 
@@ -521,6 +521,75 @@ def _check_flagged_unit(text):
                 assert not other_exits, "%s: a divergent loop with a second exit under -structurizecfg-skip-uniform-regions" % m.group(1)
                 checked += 1
     assert checked >= 1    # (the gear's bisection, the rounded blend: the check has something to look at)
+
+
+def test_precompiled_header_of_the_per_tape_builds(tmp_path):
+    """hu_spec_pch_prepare makes the header with the clang++ next to hipRTC (skipped where there is none); a per-tape build
+    finds it in its cache directory, a header the compiler refuses is dropped -- the build still succeeds -- and the next
+    process makes a new one.  Run in processes of their own, without torch (whose wheel brings another hipRTC along), on a
+    COPY of the library (the real one has its header beside it: builder.prepare_pch)."""
+    import shutil
+    import subprocess
+    import sys
+    import codecad_amd as cc
+    from codecad_amd.hip_util import _lib, builder
+    lib = _lib.load()
+    copy = tmp_path / "lib" / "libhip_util.so"
+    copy.parent.mkdir()
+    shutil.copy(lib._name, copy)
+    tape = tmp_path / "tape.f32"
+    numpy.ascontiguousarray(cc.nodes.make_program(cc.shapes.sphere(2) - cc.shapes.box(1.5)), dtype=numpy.float32).tofile(tape)
+    cache = tmp_path / "cache"
+    code = """
+import ctypes, os, sys
+lib = ctypes.CDLL(sys.argv[1])
+fp = ctypes.POINTER(ctypes.c_float)
+lib.hu_tape_compile_groups.argtypes = [fp, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_int)]
+lib.hu_spec_pch_prepare.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
+raw = open(sys.argv[2], 'rb').read()
+tape = (ctypes.c_float * (len(raw) // 4)).from_buffer_copy(raw)
+csrc, cache, what = sys.argv[3].encode(), sys.argv[4].encode(), sys.argv[5]
+def build(kernel):
+    size = ctypes.c_size_t(0)
+    rc = lib.hu_tape_compile_groups(tape, len(tape), csrc, cache, kernel, ctypes.byref(size), None)
+    return rc, size.value
+if what == 'prepare':
+    buf = ctypes.create_string_buffer(4096)
+    assert lib.hu_spec_pch_prepare(csrc, cache, buf, 4096) == 0
+    print('PCH', buf.value.decode())
+    print('BUILD', *build(1 << 10))
+elif what == 'refuse':
+    path = sys.argv[6]
+    open(path, 'wb').write(b'not a precompiled header')
+    print('BUILD', *build(1 << 1))
+    print('LEFT', int(os.path.exists(path)))
+else:
+    print('BUILD', *build(1 << int(sys.argv[6])))
+"""
+
+    def run(*what, env=None):
+        e = dict(os.environ, AMD_COMGR_CACHE="0")
+        e.update(env or {})
+        out = subprocess.run([sys.executable, "-c", code, str(copy), str(tape), builder.CSRC, str(cache)] + list(what),
+                             capture_output=True, text=True, timeout=600, env=e)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return dict(line.split(" ", 1) for line in out.stdout.splitlines() if " " in line)
+
+    first = run("prepare")
+    if not first["PCH"]:
+        pytest.skip("no clang++ next to the hipRTC in use: no precompiled header")
+    pch = first["PCH"]
+    assert os.path.dirname(pch) == str(cache) and os.path.getsize(pch) > 100000 and first["BUILD"].split()[0] == "0"
+    with_header = int(first["BUILD"].split()[1])
+    shutil.rmtree(cache)
+    without = run("build", "10", env={"HU_RTC_PCH": "0"})    # the same kernel without: no header appears, the same code
+    assert without["BUILD"].split() == ["0", str(with_header)] and not [f for f in os.listdir(cache) if f.endswith(".pch")]
+    made = run("build", "9")                                  # a build makes the header itself when it is missing
+    assert made["BUILD"].split()[0] == "0" and os.path.exists(pch) and with_header > 1000
+    refused = run("refuse", pch)
+    assert refused["BUILD"].split()[0] == "0" and refused["LEFT"] == "0"
+    again = run("prepare")
+    assert again["PCH"] == pch and os.path.getsize(pch) > 100000
 
 
 def test_background_builds_run_in_a_process_of_their_own(tmp_path, monkeypatch):
