@@ -494,6 +494,9 @@ class Tape:
             for job in jobs:
                 job["done"].wait()
             directory = _background.directory()     # (a kernel whose job failed is built -- and its error reported -- below)
+            self._specialize(only_if_cached=False, directory=directory, groups=groups)
+            self.from_cache = self.from_cache and not jobs      # (from the cache = nothing had to be compiled)
+            return self
         self._specialize(only_if_cached=False, directory=directory, groups=groups)
         return self
 

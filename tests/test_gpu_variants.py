@@ -150,6 +150,7 @@ def test_specialised_code_cache(hip, monkeypatch, tmp_path):
     import numpy as np
     from codecad_amd import hip_util, examples, nodes, grid_eval
     monkeypatch.setenv("CODECAD_AMD_CACHE", str(tmp_path / "cache"))
+    monkeypatch.setenv("CODECAD_AMD_SPECIALIZE_POOL", "0")      # specialize() in this process: ONE image (the servers' form: below)
     tape = nodes.make_program(examples.sponge(2))
     c = np.zeros(4, np.float32)
     c[:3] = -0.5
@@ -205,6 +206,22 @@ def test_specialised_code_cache(hip, monkeypatch, tmp_path):
     quiet.specialize()
     assert quiet.specialized and not quiet.from_cache and np.array_equal(run(quiet), interpreted)
     assert hip_util.Tape(tape).from_cache
+
+    # specialize() through the compile servers (the default): one image per kernel, found again kernel by kernel
+    monkeypatch.setenv("CODECAD_AMD_SPECIALIZE_POOL", "1")
+    other = nodes.make_program(examples.sponge(1))
+    before = len(os.listdir(tmp_path / "cache"))
+    pooled = hip_util.Tape(other)
+    reference = run(pooled)
+    assert not pooled.specialized
+    pooled.specialize()
+    assert pooled.groups == hip_util.SPEC_ALL and not pooled.from_cache
+    assert len([f for f in os.listdir(tmp_path / "cache") if f.endswith(".huspec")]) == before + hip_util.SPEC_KERNELS
+    assert np.array_equal(run(pooled), reference)
+    found = hip_util.Tape(other)
+    assert found.groups == hip_util.SPEC_ALL and found.from_cache and np.array_equal(run(found), reference)
+    part = hip_util.Tape(other, policy="0").specialize(hip_util.SPEC_RENDER)        # a part of them: nothing to compile
+    assert part.groups == hip_util.SPEC_RENDER and part.from_cache
     out.release()
 
 
