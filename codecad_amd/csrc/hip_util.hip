@@ -627,8 +627,11 @@ int hu_grid_eval_slab(hu_tape t, const float corner[4], float step, const uint32
             // register file holds it near there anyway (measured with -DSDF_WAVES_PER_EU: 2 / 4 / 6 / 8 -> 0.382 / 0.328 /
             // 0.353 / 0.373 ms).  So such a launch asks for 40 KiB of LDS it never touches: four workgroups, sixteen
             // wavefronts per CU.  (HU_STORE_BOUND_LDS=0: off; longer tapes -- sponge(4): 0.407 -> 0.429 ms at four -- keep all.)
-            static const bool limit_store_bound = [] { const char* e = getenv("HU_STORE_BOUND_LDS"); return !(e && e[0] == '0'); }();
-            const uint32_t idle_lds = (!boxes && !t->spec->deferred && limit_store_bound && t->n_instr <= 16) ? 40u * 1024u : 0u;
+            static const uint32_t store_bound_kib = [] { const char* e = getenv("HU_STORE_BOUND_LDS"); const int v = e ? atoi(e) : 40; return (uint32_t)((v >= 0 && v <= 64) ? v : 40); }();
+            // (float4 launches only: the float grid of the same tape stores a quarter of the bytes and is slowed by the limit --
+            // box, 512^3: 0.182 -> 0.206 ms; HU_STORE_BOUND_LDS=<KiB>, 0..64: 32-40 are the best, 53 -- three workgroups per CU,
+            // the best for stores ALONE, tools/experiments/store_patterns.hip -- leaves the arithmetic too few wavefronts: 0.38 ms)
+            const uint32_t idle_lds = (layout == 0 && !boxes && !t->spec->deferred && t->n_instr <= 16) ? store_bound_kib * 1024u : 0u;
             const uint32_t per_block = block * kSpecVoxelsPerLane;
             uint32_t grid = (n_cells + per_block - 1) / per_block;
             const uint32_t* masks = nullptr;
