@@ -279,7 +279,8 @@ __device__ __forceinline__ BoxTables box_tables(const E& ev, float4* lds, float 
 
 template <class E, int LAYOUT, int N>
 __device__ __forceinline__ void box_eval(const E& ev, float4* lds, float cx, float cy, float cz, float step, uint32_t xs0,
-                                         uint32_t x0, uint32_t y0, uint32_t z0, const BoxOut& o, const uint32_t* __restrict__ masks)
+                                         uint32_t x0, uint32_t y0, uint32_t z0, const BoxOut& o, const uint32_t* __restrict__ masks,
+                                         uint32_t box = blockIdx.x)
 {
     using T = typename Pack<N>::T;
     using Tabs = sdf::BoxTabs;
@@ -287,7 +288,7 @@ __device__ __forceinline__ void box_eval(const E& ev, float4* lds, float cx, flo
     const uint32_t sx = o.sxa, sy = o.sy, sz = o.sz;
     const uint32_t nx = min(16u, o.nx - x0), ny = min(16u, sy - y0), nz = min(16u, sz - z0);
     // box pruning: which operands of the tape's selects can win anywhere in this box (k_box_masks ran before this launch)
-    const sdf::Prune<E::kPruneWords> pr = sdf::load_prune<E::kPruneWords>(masks, blockIdx.x);
+    const sdf::Prune<E::kPruneWords> pr = sdf::load_prune<E::kPruneWords>(masks, box);
     const BoxTables t = box_tables(ev, lds, cx, cy, cz, step, xs0, x0, y0, z0, nx, ny, nz, pr);
     sdf::lds_float* const tx = t.x; sdf::lds_float* const ty = t.y; sdf::lds_float* const tz = t.z;
     sdf::lds_float* const txy = t.xy; sdf::lds_float* const txz = t.xz; sdf::lds_float* const tyz = t.yz;
@@ -366,9 +367,14 @@ k_grid_eval(const E ev, float cx, float cy, float cz, float step, uint32_t sx, D
         // boxes along z fastest (the launchers send anything else to k_grid_eval_ragged)
         const uint32_t nx_slab = sx_slab(n_cells, sy, sz);
         const uint32_t boxes_z = (sz + 15u) >> 4, boxes_y = (sy + 15u) >> 4;
-        const uint32_t qz = blockIdx.x % boxes_z, qt = blockIdx.x / boxes_z, qy = qt % boxes_y, qx = qt / boxes_y;
+        uint32_t b = blockIdx.x;
+#ifdef SDF_XCD_BOX_ORDER
+        // (experiment: workgroup i runs on XCD i % 8; give every XCD a contiguous eighth of the boxes)
+        if ((gridDim.x & 7u) == 0u) b = (b & 7u) * (gridDim.x >> 3) + (b >> 3);
+#endif
+        const uint32_t qz = b % boxes_z, qt = b / boxes_z, qy = qt % boxes_y, qx = qt / boxes_y;
         const BoxOut o{out, 0, sx, sy, sz, LAYOUT == 0 ? 0u : x0, nx_slab};
-        box_eval<E, LAYOUT, N>(ev, lds, cx, cy, cz, step, x0, qx * 16u, qy * 16u, qz * 16u, o, masks);
+        box_eval<E, LAYOUT, N>(ev, lds, cx, cy, cz, step, x0, qx * 16u, qy * 16u, qz * 16u, o, masks, b);
     } else {
         grid_eval_runs<E, LAYOUT, N>(ev, lds, cx, cy, cz, step, sx, dy, dz, x0, n_cells, out);
     }

@@ -28,5 +28,5 @@ python3 bench.py --config c4 --steps 10 --warmup 2 > gpurun_out/${TAG}_bench_lin
 python3 bench.py --evaluator interpreter --steps 10 --warmup 2 --no-cpu-baseline --no-hbm-leg > gpurun_out/${TAG}_bench_line_interpreter.json 2> gpurun_out/${TAG}_bench_line_interpreter.err; echo "bench interpreter rc=$?"
 python3 tools/prof_hbm.py > gpurun_out/${TAG}_hbm_sweep.jsonl 2> gpurun_out/${TAG}_hbm_sweep.err; echo "hbm rc=$?"
 python3 tools/run_configs.py > gpurun_out/${TAG}_configs.txt 2>&1; echo "configs rc=$?"
-python3 tools/prof_jit.py > gpurun_out/${TAG}_jit.txt 2>&1; echo "jit rc=$?"
+PROF_JIT_POOL=1 python3 tools/prof_jit.py > gpurun_out/${TAG}_jit.txt 2>&1; echo "jit rc=$?"
 cut -c1-300 gpurun_out/${TAG}_bench_line.json
