@@ -29,10 +29,12 @@ for name in ("sponge4", "csg_example", "planetary"):
         print("%-12s specialize() through the compile servers (%d servers, one image per kernel): %.2f s" % (name, len(hip_util.buffer._background.slots), time.perf_counter() - t0), flush=True)
         del os.environ["CODECAD_AMD_SPECIALIZE_POOL"], os.environ["AMD_COMGR_CACHE"]
         os.environ["CODECAD_AMD_CACHE"] = keep
+    os.environ["CODECAD_AMD_SPECIALIZE_POOL"] = "0"      # in this process, as ONE image (the form of rounds 1-3)
     t = hip_util.Tape(tape, policy="0")
     t0 = time.perf_counter()
     t.specialize()
     t1 = time.perf_counter()
+    del os.environ["CODECAD_AMD_SPECIALIZE_POOL"]
     out = hip_util.Buffer(cc.grid_eval.FLOAT4, (32, 32, 32))
     c = np.zeros(4, np.float32)
     hip_util.manager.k.grid_eval((32, 32, 32), None, t, c, np.float32(0.1), out).wait()
