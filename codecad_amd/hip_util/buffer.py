@@ -248,7 +248,9 @@ class _BackgroundCompiler:
 
     def __init__(self, servers=None):
         if servers is None:
-            servers = int(os.environ.get("CODECAD_AMD_RTC_SERVERS", "0") or 0) or min(8, max(1, (os.cpu_count() or 2) // 2))
+            # (under torchrun the ranks of a node share its cores: LOCAL_WORLD_SIZE)
+            ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))
+            servers = int(os.environ.get("CODECAD_AMD_RTC_SERVERS", "0") or 0) or min(8, max(1, (os.cpu_count() or 2) // (2 * ranks)))
         self.queue, self.threads, self.private_dir = None, [], None
         self.slots = [{"server": None} for _ in range(max(1, int(servers)))]
 
