@@ -763,7 +763,7 @@ def hbm_regime(lib, check, hip_util, cc, torch, np, dev, stream, n, evaluator, t
     """The HBM-bound regime, measured in this run: the SAME dense kernels on tapes whose arithmetic fits under the
     store stream (box: 5 instructions; sphere: 3; sphere + box: 9; csg_example: 28), float4 (16 B/voxel) and float (4 B/voxel),
     with the tape interpreter and with per-tape code.  Each entry: algorithmic bytes / average kernel time (HIP
-    events around ten back-to-back launches, after three warm ones) against the 8 TB/s peak."""
+    events around ten back-to-back launches, after forty warm ones) against the 8 TB/s peak."""
     out = []
     fptr = ctypes.POINTER(ctypes.c_float)
     e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
@@ -787,7 +787,9 @@ def hbm_regime(lib, check, hip_util, cc, torch, np, dev, stream, n, evaluator, t
                 def launch():
                     check(lib.hu_grid_eval_slab(t.device_ptr, corner.ctypes.data_as(fptr), step, dims, 0, n, layout, buf.data_ptr(),
                                                 stream), "hu_grid_eval_slab")
-                for _ in range(3):
+                # warm: the build that precedes these launches keeps the host busy for a second while the device idles and
+                # clocks down; three launches did not bring it back (sponge(4): 0.49 ms here against 0.405 in the timed steps)
+                for _ in range(40):
                     launch()
                 check(lib.hu_event_record(e0, stream), "record")
                 for _ in range(reps):

@@ -3,7 +3,7 @@
 of growing length, interpreter and per-tape code -> one JSON line per (tape, evaluator, layout) and a summary of the
 crossover (the first tape whose float4 launch falls below half of the 8 TB/s peak).  Timed exactly like the
 `roofline_hbm` leg of bench.py (it IS bench.hbm_regime, over more tapes): ten back-to-back launches through the C ABI
-between two HIP events after three warm ones -- no Python driver call sits between the launches (round 2 timed
+between two HIP events after forty warm ones -- no Python driver call sits between the launches (round 2 timed
 Python-driven calls here and read up to 10 % slow).
 Usage (GPU box): python tools/prof_hbm.py [n] > gpurun_out/hbm_sweep.jsonl"""
 import json
