@@ -367,10 +367,18 @@ k_grid_eval(const E ev, float cx, float cy, float cz, float step, uint32_t sx, D
         // boxes along z fastest (the launchers send anything else to k_grid_eval_ragged)
         const uint32_t nx_slab = sx_slab(n_cells, sy, sz);
         const uint32_t boxes_z = (sz + 15u) >> 4, boxes_y = (sy + 15u) >> 4;
+        // BOX ORDER.  Workgroup i runs on XCD i % 8, each XCD behind its own L2.  Boxes taken in launch order put neighbours
+        // along z on different XCDs at the same time -- and in the float layout two boxes along z share every 128-byte line of
+        // the output (a box's row is 16 floats): both L2s hold half-written lines.  So every XCD takes a CONTIGUOUS eighth of
+        // the boxes, its workgroups walking it in order: neighbours meet in one L2.  Measured, 512^3, per-tape code over boxes
+        // (profiles/r04_hbm_sweep.jsonl): float grids 0.16-0.18 -> 0.12-0.14 ms (csg_example 0.177 -> 0.116, sponge(4) 0.171 ->
+        // 0.138), float4 grids of light tapes -2...-4 % (whole lines either way), sponge(4)'s unchanged.  -DSDF_BOX_ORDER=0: off.
         uint32_t b = blockIdx.x;
-#ifdef SDF_XCD_BOX_ORDER
-        // (experiment: workgroup i runs on XCD i % 8; give every XCD a contiguous eighth of the boxes)
-        if ((gridDim.x & 7u) == 0u) b = (b & 7u) * (gridDim.x >> 3) + (b >> 3);
+#if !defined(SDF_BOX_ORDER) || SDF_BOX_ORDER
+        {
+            const uint32_t k = b & 7u, q = gridDim.x >> 3, r = gridDim.x & 7u;     // XCD k takes q + (k < r) boxes
+            b = k * q + (k < r ? k : r) + (b >> 3);
+        }
 #endif
         const uint32_t qz = b % boxes_z, qt = b / boxes_z, qy = qt % boxes_y, qx = qt / boxes_y;
         const BoxOut o{out, 0, sx, sy, sz, LAYOUT == 0 ? 0u : x0, nx_slab};
