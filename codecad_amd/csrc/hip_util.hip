@@ -12,10 +12,12 @@
 #include <hip/hiprtc.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -1297,8 +1299,9 @@ static void spec_cache_prune(const char* cache_dir)
 // runtime header (libhiprtc-builtins.so exports its text) and with the options hipRTC itself passes.  Best effort all the
 // way: no clang, no builtins library, a directory that cannot be written, a header another process is just making, a file
 // clang refuses -- the build runs as before.  HU_RTC_PCH=0 switches it off, HU_CLANG names the compiler.
-static bool g_pch_refused = false;          // the compiler in this process refused a header once: do not offer it again
-static bool g_pch_beside_refused = false;   // ... the one beside the library (then: one of its own, in the cache directory)
+static std::atomic<bool> g_pch_refused{false};          // the compiler in this process refused a header once: do not offer it again
+static std::atomic<bool> g_pch_beside_refused{false};   // ... the one beside the library (then: one of its own, in the cache directory)
+static std::mutex g_pch_mutex;                          // builds may run on several threads of a process (buffer.py, servers off)
 
 static std::string dir_of(const std::string& path)
 {
@@ -1367,6 +1370,8 @@ static std::string spec_pch(const char* include_dir, const char* dir, const std:
     if (!dir || !*dir) return "";
     const std::string base = std::string(dir) + "/pch_" + hex, pch = base + ".pch";
     if (access(pch.c_str(), R_OK) == 0) return pch;
+    std::lock_guard<std::mutex> one_at_a_time(g_pch_mutex);
+    if (access(pch.c_str(), R_OK) == 0) return pch;      // (another thread made it meanwhile)
     static std::string tried;     // one attempt per process and name
     if (tried == base) return "";
     tried = base;
