@@ -21,6 +21,7 @@ for CFG in ${CFGS:-c3 c4 c5}; do
   pass pmc_stalls SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD
   pass pmc_write WRITE_SIZE
   pass pmc_fetch FETCH_SIZE
+  pass pmc_icache SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH
 done
 python3 tools/summarize_kernels.py "$OUT" > "$OUT/summary.json"
 cat "$OUT/summary.json"
