@@ -25,6 +25,8 @@ CODECAD_AMD_FORCE_COLLECTIVES=1 CODECAD_AMD_REPLICATE_SAMPLES=0 python3 -m torch
 python3 bench.py --config c5 --steps 5 --warmup 2 --no-cpu-baseline --no-hbm-leg > gpurun_out/${TAG}_bench_line_c5.json 2> gpurun_out/${TAG}_bench_line_c5.err; echo "bench c5 rc=$?"
 CODECAD_AMD_FORCE_COLLECTIVES=1 CODECAD_AMD_REPLICATE_SAMPLES=0 python3 bench.py --config c5 --steps 5 --warmup 2 --no-cpu-baseline --no-hbm-leg > gpurun_out/${TAG}_bench_line_c5_forced_collectives.json 2> gpurun_out/${TAG}_bench_line_c5_forced_collectives.err; echo "bench c5 forced rc=$?"
 python3 bench.py --config c4 --steps 10 --warmup 2 > gpurun_out/${TAG}_bench_line_c4.json 2> gpurun_out/${TAG}_bench_line_c4.err; echo "bench c4 rc=$?"
+CODECAD_AMD_FORCE_COLLECTIVES=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29543 \
+  bench.py --gpus 1 --config c4 --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/${TAG}_bench_line_c4_forced_collectives.json 2> gpurun_out/${TAG}_bench_line_c4_forced_collectives.err; echo "bench c4 forced rc=$?"
 python3 bench.py --evaluator interpreter --steps 10 --warmup 2 --no-cpu-baseline --no-hbm-leg > gpurun_out/${TAG}_bench_line_interpreter.json 2> gpurun_out/${TAG}_bench_line_interpreter.err; echo "bench interpreter rc=$?"
 python3 tools/prof_hbm.py > gpurun_out/${TAG}_hbm_sweep.jsonl 2> gpurun_out/${TAG}_hbm_sweep.err; echo "hbm rc=$?"
 python3 tools/run_configs.py > gpurun_out/${TAG}_configs.txt 2>&1; echo "configs rc=$?"

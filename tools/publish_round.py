@@ -25,7 +25,7 @@ for name in ("mesh", "render", "polygon"):
     stats = glob.glob(os.path.join(consumers, name, "*", "*_kernel_stats.csv"))
     if stats:
         shutil.copy(max(stats, key=os.path.getmtime), os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, name)))
-for name in ("bench_line.json", "bench_line_forced_collectives.json", "bench_line_forced_replicated.json", "bench_line_c4.json", "bench_line_c5.json", "bench_line_c5_forced_collectives.json",
+for name in ("bench_line.json", "bench_line_forced_collectives.json", "bench_line_forced_replicated.json", "bench_line_c4.json", "bench_line_c4_forced_collectives.json", "bench_line_c5.json", "bench_line_c5_forced_collectives.json",
              "bench_line_interpreter.json", "hbm_sweep.jsonl", "configs.txt", "jit.txt"):
     path = os.path.join(src, "%s_%s" % (tag, name))
     if os.path.exists(path) and os.path.getsize(path):
