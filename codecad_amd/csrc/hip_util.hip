@@ -1156,10 +1156,21 @@ static bool read_file(const std::string& path, std::string& out)
     return ok;
 }
 
-static std::vector<std::string> spec_options(const char* include_dir)
+// A source above this size is built with -O1: what takes the time in a kernel of 200 KB is code generation, the straight-line
+// code the generator writes leaves the optimiser little to do, and -O1 spends a third less on it for the same kernels
+// (planetary, 855 KB of source, MI355X box: first per-tape launch 4.0 -> 2.6 s after upload, all kernels 4.4 -> 2.9 s; C4 0.383
+// ms, its 256^3 grids 0.19 / 0.57 ms, C3 and C5 at -O1: all unchanged; the parity tests pass either way).  Small sources gain
+// nothing (sponge(4), 80 KB: 0.26 s either way) and keep -O3.  HU_RTC_BIG_KB: the threshold in KiB (default 256, 0: never).
+static bool spec_source_is_big(size_t bytes)
+{
+    static const size_t limit = [] { const char* e = getenv("HU_RTC_BIG_KB"); const long v = e ? atol(e) : 256; return (size_t)(v > 0 ? v : 0) * 1024u; }();
+    return limit != 0 && bytes > limit;
+}
+
+static std::vector<std::string> spec_options(const char* include_dir, bool big = false)
 {
     // same numerical contract as the ahead-of-time build: no contraction, IEEE sqrt/divide (HIP default)
-    std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+    std::vector<std::string> opts = {"--offload-arch=gfx950", big ? "-O1" : "-O3", "-std=c++17", "-ffp-contract=off",
                                      std::string("-I") + include_dir};
     if (const char* e = getenv("HU_RTC_FLAGS")) {  // extra compiler options, for tuning experiments
         std::istringstream in(e);
@@ -1372,9 +1383,9 @@ static std::string spec_pch(const char* include_dir, const char* dir, const std:
     if (access(pch.c_str(), R_OK) == 0) return pch;
     std::lock_guard<std::mutex> one_at_a_time(g_pch_mutex);
     if (access(pch.c_str(), R_OK) == 0) return pch;      // (another thread made it meanwhile)
-    static std::string tried;     // one attempt per process and name
-    if (tried == base) return "";
-    tried = base;
+    static std::vector<std::string> tried;     // one attempt per process and name
+    if (std::find(tried.begin(), tried.end(), base) != tried.end()) return "";
+    tried.push_back(base);
     // one process makes it; the others carry on without it meanwhile (a lock left behind by a crash expires)
     const std::string lock = base + ".lock";
     (void)mkdir(dir, 0700);
@@ -1473,7 +1484,7 @@ static int specialised_image(const std::string& src, const char* include_dir, co
 {
     if (from_cache) *from_cache = 0;
     img.code.clear();
-    const std::vector<std::string> options = spec_options(include_dir);
+    const std::vector<std::string> options = spec_options(include_dir, spec_source_is_big(src.size()));
     uint64_t key[2];
     std::string path;
     const bool cached = cache_dir && *cache_dir && spec_cache_key(src, include_dir, options, groups, key);
@@ -1541,8 +1552,10 @@ int hu_tape_compile_groups(const float* tape, size_t n, const char* include_dir,
 int hu_spec_pch_prepare(const char* include_dir, const char* dir, char* path, size_t capacity)
 {
     if (!include_dir || !dir) return fail(HU_ERR_BAD_ARG, "NULL argument");
-    const std::string pch = spec_pch(include_dir, dir, spec_options(include_dir), true);
-    if (path && capacity) std::snprintf(path, capacity, "%s", pch.c_str());
+    // one per set of options the builds use: small sources (-O3) and big ones (-O1): clang refuses a header made at another level
+    const std::string pch = spec_pch(include_dir, dir, spec_options(include_dir, false), true);
+    const std::string pch_big = spec_pch(include_dir, dir, spec_options(include_dir, true), true);
+    if (path && capacity) std::snprintf(path, capacity, "%s%s%s", pch.c_str(), (pch.empty() || pch_big.empty()) ? "" : "\n", pch_big.c_str());
     return HU_OK;
 }
 

@@ -106,11 +106,12 @@ def prepare_pch(verbose=False):
     try:
         os.makedirs(PCH_DIR, exist_ok=True)
         out = subprocess.run([sys.executable, "-c", code, LIB_PATH, CSRC, PCH_DIR], capture_output=True, text=True, timeout=300)
-        path = out.stdout.strip().splitlines()[-1] if out.returncode == 0 and out.stdout.strip() else ""
+        paths = [p for p in out.stdout.splitlines() if p.endswith(".pch")] if out.returncode == 0 else []
     except (OSError, subprocess.SubprocessError):
-        path = ""
-    if path:
-        keep = os.path.basename(path)[:-len(".pch")]
+        paths = []
+    path = " ".join(paths)
+    if paths:
+        keep = tuple(os.path.basename(p)[:-len(".pch")] for p in paths)      # (one per optimisation level the builds use)
         for f in os.listdir(PCH_DIR):
             if not f.startswith(keep):
                 full = os.path.join(PCH_DIR, f)

@@ -320,6 +320,8 @@ int hu_tape_prune_info(hu_tape t, int* bits, int* words);
  * made in `dir` by the clang++ that sits next to the hipRTC in use, if there is one; the builds then skip parsing those
  * ~16 000 lines (a quarter of a family's build, most of a small kernel's).  `path` (may be NULL) <- the file, or "" when
  * none could be made (no such clang, no libhiprtc-builtins.so, unwritable directory): the builds then run as before.
+ * Two files, their paths separated by a newline: big sources are built with -O1 (HU_RTC_BIG_KB), and clang takes a header
+ * only at the optimisation level it was made at.
  * The per-tape builds look for it in <directory of libhip_util.so>/pch (where the library's build puts it) and in their
  * cache directory (where they make it themselves when it is missing).  HU_RTC_PCH=0 switches it off.  No counterpart in
  * the reference (pyopencl's build has no headers to parse). */

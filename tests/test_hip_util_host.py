@@ -556,7 +556,9 @@ def build(kernel):
 if what == 'prepare':
     buf = ctypes.create_string_buffer(4096)
     assert lib.hu_spec_pch_prepare(csrc, cache, buf, 4096) == 0
-    print('PCH', buf.value.decode())
+    made = buf.value.decode().split()
+    print('PCH', made[0] if made else '')
+    print('COUNT', len(made))
     print('BUILD', *build(1 << 10))
 elif what == 'refuse':
     path = sys.argv[6]
@@ -579,6 +581,7 @@ else:
     if not first["PCH"]:
         pytest.skip("no clang++ next to the hipRTC in use: no precompiled header")
     pch = first["PCH"]
+    assert first["COUNT"] == "2"        # one per optimisation level the builds use (-O3; -O1 for big sources)
     assert os.path.dirname(pch) == str(cache) and os.path.getsize(pch) > 100000 and first["BUILD"].split()[0] == "0"
     with_header = int(first["BUILD"].split()[1])
     shutil.rmtree(cache)
@@ -590,6 +593,11 @@ else:
     assert refused["BUILD"].split()[0] == "0" and refused["LEFT"] == "0"
     again = run("prepare")
     assert again["PCH"] == pch and os.path.getsize(pch) > 100000
+    # a source above HU_RTC_BIG_KB is built with -O1, from the header of that level: another image of the same kernel
+    images = len([f for f in os.listdir(cache) if f.endswith(".huspec")])
+    big = run("build", "9", env={"HU_RTC_BIG_KB": "1"})
+    assert big["BUILD"].split()[0] == "0" and len([f for f in os.listdir(cache) if f.endswith(".huspec")]) == images + 1
+    assert len([f for f in os.listdir(cache) if f.endswith(".pch")]) == 2
 
 
 def test_background_builds_run_in_a_process_of_their_own(tmp_path, monkeypatch):
