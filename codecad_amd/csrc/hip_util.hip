@@ -825,7 +825,10 @@ int launch_classify(hu_tape t, ClassifyArgs& a, uint32_t n_parents, const uint32
         // and a level of a few hundred parents is a latency exercise (measured: C5's 704 parents of 16^3 0.21 -> 0.33 ms
         // over boxes; C3's mass properties at grid 8, 167 000 parents in the last level, 0.94 -> 0.80 ms).
         const uint64_t bxn = (dims[0] + 15u) / 16u, byn = (dims[1] + 15u) / 16u, bzn = (dims[2] + 15u) / 16u;
-        uint64_t enough = 8192u;
+        // A tape with box pruning is another matter: only the box path prunes, the path below evaluates every primitive for
+        // every sample (planetary, mass properties at grid 64, resolution 0.5: 45 parents = 2880 boxes: 0.93 -> 0.34 ms over boxes;
+        // resolution 1.0: 8 parents, 0.32 -> 0.27 ms; tools/experiments/mass_scale.py): such tapes take the boxes from 64 on.
+        uint64_t enough = t->spec->prune_bits > 0 ? 64u : 8192u;
         if (const char* e = getenv("HU_CLASSIFY_BOX_MIN")) enough = (uint64_t)atoll(e);   // (read per launch: the tests switch it)
         if (t->spec->deferred && cells > 256u && brick_tiles(dims[0], dims[1], dims[2]) && bxn * byn * bzn * n_parents >= enough) {
             a.boxes = ((uint32_t)byn << 16) | (uint32_t)bzn;
