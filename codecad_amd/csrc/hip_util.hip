@@ -198,11 +198,10 @@ int ensure_attrs()
 }
 
 // Launches of per-tape code go over 16^3 boxes of compact 4 x 4 x 8 bricks (kernels.hpp box_eval) when the slab's or the
-// block's extents allow it without ragged bricks.  HU_BRICKS=0: always runs of cells along z.
+// block's extents allow it without ragged bricks (the grid kernels take ragged boxes too: k_grid_eval_ragged).
 uint32_t brick_tiles(uint32_t nx, uint32_t sy, uint32_t sz)
 {
-    static const bool off = [] { const char* e = getenv("HU_BRICKS"); return e && e[0] == '0'; }();
-    return (!off && nx % 4u == 0u && sy % 4u == 0u && sz % 8u == 0u) ? 1u : 0u;
+    return (nx % 4u == 0u && sy % 4u == 0u && sz % 8u == 0u) ? 1u : 0u;
 }
 
 // How many units (blocks / parents) of `chunks` workgroups of `threads` lanes go into one launch: a grid may
@@ -604,8 +603,13 @@ int hu_grid_eval_slab(hu_tape t, const float corner[4], float step, const uint32
     if ((uint64_t)x0 + x_count > dims[0]) return fail(HU_ERR_BAD_ARG, "slab exceeds the grid's x extent");
     const uint64_t plane = (uint64_t)dims[1] * dims[2];
     if (plane >= (1ull << 30)) return fail(HU_ERR_BAD_ARG, "dims[1]*dims[2] must be below 2^30");
-    if (t->spec && t->spec->dense[layout]) {
-        const uint32_t max_x = (uint32_t)((1ull << 30) / plane);
+    // (pieces of a slab too long for one launch start at multiples of 16 planes: they are ragged only where the slab is)
+    const uint32_t spec_max_x = [&] { const uint32_t m = (uint32_t)((1ull << 30) / plane); return m >= 16u ? m & ~15u : m; }();
+    // extents that are no multiples of (4, 4, 8) take the kernel whose boxes may end anywhere: an image of its own -- while it is
+    // still being built the interpreter serves such launches
+    const bool spec_ragged = t->spec && t->spec->deferred && !(brick_tiles(x_count, dims[1], dims[2]) && (x_count <= spec_max_x || spec_max_x % 4u == 0u));
+    if (t->spec && t->spec->dense[layout] && (!spec_ragged || t->spec->dense_ragged[layout])) {
+        const uint32_t max_x = spec_max_x;
         SpecEval ev{t->extra_dev, spec_flags(t, grid_reach(corner, step, dims))};
         float cx = corner[0], cy = corner[1], cz = corner[2];
         uint32_t sx = dims[0];
@@ -617,7 +621,8 @@ int hu_grid_eval_slab(hu_tape t, const float corner[4], float step, const uint32
             // boxes of compact bricks pay where a wavefront's work depends on how many primitives win in it (deferred
             // directions) and where the tape has tables to fill; a tape that is bound by its store stream keeps the runs
             // along z (2 KiB contiguous per wavefront: sphere, 512^3 float4: 0.34 ms in runs, 0.42 ms in bricks)
-            uint32_t boxes = t->spec->deferred ? brick_tiles(nx, dims[1], dims[2]) : 0u;
+            uint32_t boxes = t->spec->deferred ? 1u : 0u;
+            const bool ragged = boxes && !brick_tiles(nx, dims[1], dims[2]);
             // runs of cells (HU_RUN_BLOCK: 64 / 128 / 256 lanes per workgroup, for measurements: the lanes of a run kernel share
             // nothing, but single-wavefront workgroups were SLOWER on the store-bound tapes -- box, 512^3 float4: 0.409 against
             // 0.373 ms, its distance grid 0.265 against 0.180 ms)
@@ -644,14 +649,9 @@ int hu_grid_eval_slab(hu_tape t, const float corner[4], float step, const uint32
                 m.nx = nx; m.ny = dims[1]; m.nz = dims[2]; m.xs0 = xs; m.cx = cx; m.cy = cy; m.cz = cz; m.step = step;
                 if ((layout == 1 || t->spec->prune_all) && (rc = prepare_masks(t, m, (hipStream_t)stream, &masks))) return rc;
             }
-            if (t->spec->deferred && !boxes) {      // a tape with box code on a slab that has no boxes: its kernel over runs
-                void* args[] = {&ev, &cx, &cy, &cz, &step, &sx, &sy, &sz, &xs, &n_cells, &o};
-                HU_HIP(hipModuleLaunchKernel(t->spec->dense_ragged[layout], grid, 1, 1, block, 1, 1, 0u, (hipStream_t)stream, args, nullptr));
-            } else {
-                void* args[] = {&ev, &cx, &cy, &cz, &step, &sx, &sy, &sz, &xs, &n_cells, &boxes, &o, &masks};
-                HU_HIP(hipModuleLaunchKernel(t->spec->dense[layout], grid, 1, 1, block, 1, 1, boxes ? box_table_bytes(t->spec) : idle_lds,
-                                             (hipStream_t)stream, args, nullptr));
-            }
+            void* args[] = {&ev, &cx, &cy, &cz, &step, &sx, &sy, &sz, &xs, &n_cells, &boxes, &o, &masks};
+            HU_HIP(hipModuleLaunchKernel(ragged ? t->spec->dense_ragged[layout] : t->spec->dense[layout], grid, 1, 1, block, 1, 1,
+                                         boxes ? box_table_bytes(t->spec) : idle_lds, (hipStream_t)stream, args, nullptr));
             done += nx;
         }
         return HU_OK;
@@ -713,13 +713,15 @@ static int grid_eval_blocks_impl(hu_tape t, const int32_t* blocks_dev, uint32_t 
     if ((rc = check_dims(dims, cells))) return rc;
     if (cells > (1ull << 24)) return fail(HU_ERR_BAD_ARG, "a block may have at most 2^24 cells (256^3)");
     if (n_blocks == 0) return HU_OK;
-    if (t->spec && t->spec->blocks[layout]) {
+    if (t->spec && t->spec->blocks[layout] &&
+        (!(t->spec->deferred && !brick_tiles(dims[0], dims[1], dims[2])) || t->spec->blocks_ragged[layout])) {
         const uint32_t per_block = kSpecBlock * kSpecVoxelsPerLane;
         uint32_t chunks = (uint32_t)((cells + per_block - 1) / per_block);
         // deferred-direction code over compact bricks (kernels.hpp): a workgroup per box of up to 16^3 voxels of the block,
         // its wavefronts walking 4 x 4 x 8 bricks along x; `bricks` carries the boxes along y and z
         uint32_t bricks = 0u;
-        if (t->spec->deferred && brick_tiles(dims[0], dims[1], dims[2])) {
+        const bool ragged = t->spec->deferred && !brick_tiles(dims[0], dims[1], dims[2]);   // boxes that may end anywhere (k_grid_eval_blocks_ragged)
+        if (t->spec->deferred) {
             const uint32_t bxn = (dims[0] + 15u) / 16u, byn = (dims[1] + 15u) / 16u, bzn = (dims[2] + 15u) / 16u;
             bricks = (byn << 16) | bzn;
             chunks = bxn * byn * bzn;
@@ -742,14 +744,9 @@ static int grid_eval_blocks_impl(hu_tape t, const int32_t* blocks_dev, uint32_t 
                 m.res = res; m.ox = ox; m.oy = oy; m.oz = oz;
                 if ((layout == 1 || t->spec->prune_all) && (rc = prepare_masks(t, m, (hipStream_t)stream, &masks))) return rc;
             }
-            if (t->spec->deferred && !bricks) {
-                void* args[] = {&ev, &b, &n_dev, &first, &chunks, &res, &ox, &oy, &oz, &step, &sx, &sy, &sz, &out_dev};
-                HU_HIP(hipModuleLaunchKernel(t->spec->blocks_ragged[layout], chunks * count, 1, 1, kSpecBlock, 1, 1, 0u, (hipStream_t)stream, args, nullptr));
-            } else {
-                void* args[] = {&ev, &b, &n_dev, &first, &chunks, &bricks, &res, &ox, &oy, &oz, &step, &sx, &sy, &sz, &out_dev, &masks};
-                HU_HIP(hipModuleLaunchKernel(t->spec->blocks[layout], chunks * count, 1, 1, kSpecBlock, 1, 1,
-                                             bricks ? box_table_bytes(t->spec) : 0u, (hipStream_t)stream, args, nullptr));
-            }
+            void* args[] = {&ev, &b, &n_dev, &first, &chunks, &bricks, &res, &ox, &oy, &oz, &step, &sx, &sy, &sz, &out_dev, &masks};
+            HU_HIP(hipModuleLaunchKernel(ragged ? t->spec->blocks_ragged[layout] : t->spec->blocks[layout], chunks * count, 1, 1, kSpecBlock, 1, 1,
+                                         bricks ? box_table_bytes(t->spec) : 0u, (hipStream_t)stream, args, nullptr));
         }
         return HU_OK;
     }

@@ -277,7 +277,12 @@ __device__ __forceinline__ BoxTables box_tables(const E& ev, float4* lds, float 
     return BoxTables{tx, ty, tz, txy, txz, tyz};
 }
 
-template <class E, int LAYOUT, int N>
+// RAGGED (round 4): the box may end anywhere -- a grid whose extents are no multiples of (4, 4, 8) --: the bricks at its rim
+// are walked whole (their lanes beyond the rim read table entries nobody filled and compute on them: every value is per
+// lane, the op library has no data-dependent loop) and only the voxels inside are stored.  Before, one extent of 250
+// instead of 256 sent the WHOLE launch over runs of cells, in the form without tables and without pruning: planetary's
+// float4 grid 0.55 -> 4.7 ms, sponge(4)'s 0.069 -> 0.123 ms (tools/experiments/ragged_time.py).
+template <class E, int LAYOUT, int N, bool RAGGED = false>
 __device__ __forceinline__ void box_eval(const E& ev, float4* lds, float cx, float cy, float cz, float step, uint32_t xs0,
                                          uint32_t x0, uint32_t y0, uint32_t z0, const BoxOut& o, const uint32_t* __restrict__ masks,
                                          uint32_t box = blockIdx.x)
@@ -295,9 +300,10 @@ __device__ __forceinline__ void box_eval(const E& ev, float4* lds, float cx, flo
     // The box's (y, z) columns of bricks, at most eight: a wavefront takes column `wave` and the one four on -- the same
     // bricks along z, two (or, in a box eight voxels deep, four) rows of bricks further along y: what changes from its
     // first column to its second are y and a few pointers, by constants.
-    const uint32_t nbz = nz >> 3;                                  // 1 or 2
+    const uint32_t nbz = RAGGED ? (nz + 7u) >> 3 : nz >> 3;        // 1 or 2
     const uint32_t bz = nbz == 2u ? (wave & 1u) : 0u, dby = 4u / nbz;
     const uint32_t zl = bz * 8u + (lane & 7u), z = z0 + zl, xl = lane >> 5;
+    const bool z_inside = !RAGGED || zl < nz;
     const float pz = sample(cz, step, z);                          // (one number per lane: its voxels differ in x)
     uint32_t yl = (nbz == 2u ? (wave >> 1) : wave) * 4u + ((lane >> 3) & 3u);
     Tabs col{tx + xl, ty + yl, tz + zl, txy + (yl * Tabs::kRowX + xl), txz + (zl * Tabs::kRowX + xl), tyz + (yl * Tabs::kRowYZ + zl)};
@@ -307,13 +313,15 @@ __device__ __forceinline__ void box_eval(const E& ev, float4* lds, float cx, flo
                             : o.base + ((size_t)z + ((size_t)(o.xa + x0 + xl) + (size_t)(sy - 1u - (y0 + yl)) * sx) * sz);
     const size_t second = LAYOUT == 0 ? 2u * plane : 2u * (size_t)sz, brick = 2u * second;
     const size_t rows = (size_t)(4u * dby) * (LAYOUT == 0 ? (size_t)sz : (size_t)sx * sz);   // LAYOUT 1 runs backwards along y
-    for (; yl < ny; yl += 4u * dby) {
+    const uint32_t row_in_brick = (lane >> 3) & 3u, bricks_x = RAGGED ? (nx + 3u) >> 2 : nx >> 2;
+    for (; (RAGGED ? yl - row_in_brick : yl) < ny; yl += 4u * dby) {     // (RAGGED: while the brick's first row is inside -- wave-uniform)
         const float py = sample(cy, step, y0 + yl);
+        const bool row_inside = !RAGGED || (z_inside && yl < ny);
         Tabs tb = col;
         const auto hoisted = ev.hoist_x(py, walk_coordinate<E>(pz), tb, pr);
         size_t p = at;
 #pragma unroll 1
-        for (uint32_t j = 0; j < (nx >> 2); ++j) {
+        for (uint32_t j = 0; j < bricks_x; ++j) {
             // (the columns of y and z that `pre` does not hold are read again in every brick, which the compiler would
             // otherwise undo; unrolling the walk and batching its reads were measured: no gain)
             asm volatile("" ::: "memory");
@@ -326,11 +334,15 @@ __device__ __forceinline__ void box_eval(const E& ev, float4* lds, float cx, flo
             if (LAYOUT == 0) {
                 const sdf::V4<T> r = ev.eval_hoisted_x(px, pyb, pzb, hoisted, tb, prb);
 #pragma unroll
-                for (int i = 0; i < N; ++i) store_voxel(static_cast<float4*>(o.out) + p + (size_t)i * second, sdf::voxel(r, i));
+                for (int i = 0; i < N; ++i)
+                    if (!RAGGED || (row_inside && j * 4u + xl + 2u * (uint32_t)i < nx))
+                        store_voxel(static_cast<float4*>(o.out) + p + (size_t)i * second, sdf::voxel(r, i));
             } else {
                 const T w = ev.dist_hoisted_x(px, pyb, pzb, hoisted, tb, prb);
 #pragma unroll
-                for (int i = 0; i < N; ++i) store_voxel(static_cast<float*>(o.out) + p + (size_t)i * second, sdf::get(w, i));
+                for (int i = 0; i < N; ++i)
+                    if (!RAGGED || (row_inside && j * 4u + xl + 2u * (uint32_t)i < nx))
+                        store_voxel(static_cast<float*>(o.out) + p + (size_t)i * second, sdf::get(w, i));
             }
             tb.x += 4; tb.xy += 4; tb.xz += 4;
             p += brick;
@@ -348,52 +360,61 @@ __device__ __forceinline__ void box_eval(const E& ev, float4* lds, float cx, flo
 // bricks buy besides the tables: values that are uniform over a wavefront stay uniform far more often -- which primitive
 // of a CSG tree is nearest (sponge(4) at 512^3: 1.8 distinct winners per brick against 3.1 per run; per-tape code
 // computes the direction once per DISTINCT winner), and whether any lane is in the corner region of a rectangle.
-// Evaluators with box code (E::kBricks) have TWO kernels per layout: this one over boxes, and k_grid_eval_ragged over runs for
-// slabs whose extents are no multiples of (4, 4, 8).  One kernel holding both paths is allocated the registers of the
-// hungrier one: planetary's in-place evaluation (256 registers, two wavefronts per SIMD) sat on its box path (175) until they
-// were split -- 1.86 against 1.03 ms for its 256^3 float4 grid.
+// Evaluators with box code (E::kBricks) have TWO kernels per layout: this one over whole bricks, and k_grid_eval_ragged for
+// slabs whose extents are no multiples of (4, 4, 8) (until late in round 4 that one went over RUNS, in the in-place form).
+// One kernel holding two paths is allocated the registers of the hungrier one: planetary's in-place evaluation (256
+// registers, two wavefronts per SIMD) sat on its box path (175) until they were split -- 1.86 against 1.03 ms.
 template <class E, int LAYOUT, int N>
 __device__ __forceinline__ void grid_eval_runs(const E& ev, float4* lds, float cx, float cy, float cz, float step, uint32_t sx, Dim dy, Dim dz,
                                                uint32_t x0, uint32_t n_cells, void* __restrict__ out);
+
+// a slab over boxes: workgroup -> box (boxes along z fastest), in the order below
+template <class E, int LAYOUT, int N, bool RAGGED>
+__device__ __forceinline__ void grid_eval_boxes(const E& ev, float4* lds, float cx, float cy, float cz, float step, uint32_t sx, uint32_t sy, uint32_t sz,
+                                                uint32_t x0, uint32_t n_cells, void* __restrict__ out, const uint32_t* __restrict__ masks)
+{
+    const uint32_t nx_slab = sx_slab(n_cells, sy, sz);
+    const uint32_t boxes_z = (sz + 15u) >> 4, boxes_y = (sy + 15u) >> 4;
+    // BOX ORDER.  Workgroup i runs on XCD i % 8, each XCD behind its own L2.  Boxes taken in launch order put neighbours
+    // along z on different XCDs at the same time -- and in the float layout two boxes along z share every 128-byte line of
+    // the output (a box's row is 16 floats): both L2s hold half-written lines.  So every XCD takes a CONTIGUOUS eighth of
+    // the boxes, its workgroups walking it in order: neighbours meet in one L2.  Measured, 512^3, per-tape code over boxes
+    // (profiles/r04_hbm_sweep.jsonl): float grids 0.16-0.18 -> 0.12-0.14 ms (csg_example 0.177 -> 0.116, sponge(4) 0.171 ->
+    // 0.138), float4 grids of light tapes -2...-4 % (whole lines either way), sponge(4)'s unchanged.  -DSDF_BOX_ORDER=0: off.
+    uint32_t b = blockIdx.x;
+#if !defined(SDF_BOX_ORDER) || SDF_BOX_ORDER
+    {
+        const uint32_t k = b & 7u, q = gridDim.x >> 3, r = gridDim.x & 7u;     // XCD k takes q + (k < r) boxes
+        b = k * q + (k < r ? k : r) + (b >> 3);
+    }
+#endif
+    const uint32_t qz = b % boxes_z, qt = b / boxes_z, qy = qt % boxes_y, qx = qt / boxes_y;
+    const BoxOut o{out, 0, sx, sy, sz, LAYOUT == 0 ? 0u : x0, nx_slab};
+    box_eval<E, LAYOUT, N, RAGGED>(ev, lds, cx, cy, cz, step, x0, qx * 16u, qy * 16u, qz * 16u, o, masks, b);
+}
 
 template <class E, int LAYOUT, int N>
 __global__ void __launch_bounds__(256) SDF_KERNEL_ATTRS
 k_grid_eval(const E ev, float cx, float cy, float cz, float step, uint32_t sx, Dim dy, Dim dz, uint32_t x0,
             uint32_t n_cells, uint32_t boxes, void* __restrict__ out, const uint32_t* __restrict__ masks)
 {
-    const uint32_t sy = dy.n, sz = dz.n;
     extern __shared__ float4 lds[];
     if constexpr (E::kBricks && N == 2) {
-        // boxes along z fastest (the launchers send anything else to k_grid_eval_ragged)
-        const uint32_t nx_slab = sx_slab(n_cells, sy, sz);
-        const uint32_t boxes_z = (sz + 15u) >> 4, boxes_y = (sy + 15u) >> 4;
-        // BOX ORDER.  Workgroup i runs on XCD i % 8, each XCD behind its own L2.  Boxes taken in launch order put neighbours
-        // along z on different XCDs at the same time -- and in the float layout two boxes along z share every 128-byte line of
-        // the output (a box's row is 16 floats): both L2s hold half-written lines.  So every XCD takes a CONTIGUOUS eighth of
-        // the boxes, its workgroups walking it in order: neighbours meet in one L2.  Measured, 512^3, per-tape code over boxes
-        // (profiles/r04_hbm_sweep.jsonl): float grids 0.16-0.18 -> 0.12-0.14 ms (csg_example 0.177 -> 0.116, sponge(4) 0.171 ->
-        // 0.138), float4 grids of light tapes -2...-4 % (whole lines either way), sponge(4)'s unchanged.  -DSDF_BOX_ORDER=0: off.
-        uint32_t b = blockIdx.x;
-#if !defined(SDF_BOX_ORDER) || SDF_BOX_ORDER
-        {
-            const uint32_t k = b & 7u, q = gridDim.x >> 3, r = gridDim.x & 7u;     // XCD k takes q + (k < r) boxes
-            b = k * q + (k < r ? k : r) + (b >> 3);
-        }
-#endif
-        const uint32_t qz = b % boxes_z, qt = b / boxes_z, qy = qt % boxes_y, qx = qt / boxes_y;
-        const BoxOut o{out, 0, sx, sy, sz, LAYOUT == 0 ? 0u : x0, nx_slab};
-        box_eval<E, LAYOUT, N>(ev, lds, cx, cy, cz, step, x0, qx * 16u, qy * 16u, qz * 16u, o, masks, b);
+        // (extents that are multiples of (4, 4, 8): the launchers send anything else to k_grid_eval_ragged)
+        grid_eval_boxes<E, LAYOUT, N, false>(ev, lds, cx, cy, cz, step, sx, dy.n, dz.n, x0, n_cells, out, masks);
     } else {
         grid_eval_runs<E, LAYOUT, N>(ev, lds, cx, cy, cz, step, sx, dy, dz, x0, n_cells, out);
     }
 }
+// the same over boxes that may end anywhere (box_eval RAGGED): a kernel of its own, because its predicated stores and its
+// longer live ranges are not for the aligned launches to pay
 template <class E, int LAYOUT, int N>
 __global__ void __launch_bounds__(256) SDF_KERNEL_ATTRS
 k_grid_eval_ragged(const E ev, float cx, float cy, float cz, float step, uint32_t sx, Dim dy, Dim dz, uint32_t x0,
-                   uint32_t n_cells, void* __restrict__ out)
+                   uint32_t n_cells, uint32_t boxes, void* __restrict__ out, const uint32_t* __restrict__ masks)
 {
     extern __shared__ float4 lds[];
-    if constexpr (E::kBricks) grid_eval_runs<E, LAYOUT, N>(ev, lds, cx, cy, cz, step, sx, dy, dz, x0, n_cells, out);
+    if constexpr (E::kBricks && N == 2) grid_eval_boxes<E, LAYOUT, N, true>(ev, lds, cx, cy, cz, step, sx, dy.n, dz.n, x0, n_cells, out, masks);
 }
 
 template <class E, int LAYOUT, int N>
@@ -426,7 +447,7 @@ __device__ __forceinline__ void grid_eval_runs(const E& ev, float4* lds, float c
     }
 }
 
-template <class E, int LAYOUT, int N, bool BOXES>
+template <class E, int LAYOUT, int N, bool BOXES, bool RAGGED = false>
 __device__ __forceinline__ void grid_eval_blocks_body(const E& ev, float4* lds, const int4* __restrict__ blocks, const uint32_t* __restrict__ n_blocks_dev,
                                                       uint32_t b0, uint32_t chunks, uint32_t bricks, double res, double ox, double oy, double oz, float step,
                                                       uint32_t sx, Dim dy, Dim dz, void* __restrict__ out, const uint32_t* __restrict__ masks)
@@ -450,7 +471,7 @@ __device__ __forceinline__ void grid_eval_blocks_body(const E& ev, float4* lds, 
         const uint32_t boxes_z = bricks & 0xffffu, boxes_y = bricks >> 16;
         const uint32_t qz = chunk % boxes_z, qt = chunk / boxes_z, qy = qt % boxes_y, qx = qt / boxes_y;
         const BoxOut o{out, (size_t)b * cells, sx, sy, sz, 0u, sx};
-        box_eval<E, LAYOUT, N>(ev, lds, cx, cy, cz, step, 0u, qx * 16u, qy * 16u, qz * 16u, o, masks);
+        box_eval<E, LAYOUT, N, RAGGED>(ev, lds, cx, cy, cz, step, 0u, qx * 16u, qy * 16u, qz * 16u, o, masks);
         return;
     }
     const uint32_t lin0 = first_cell<N>(chunk);
@@ -483,12 +504,12 @@ k_grid_eval_blocks(const E ev, const int4* __restrict__ blocks, const uint32_t* 
 template <class E, int LAYOUT, int N>
 __global__ void __launch_bounds__(256) SDF_KERNEL_ATTRS
 k_grid_eval_blocks_ragged(const E ev, const int4* __restrict__ blocks, const uint32_t* __restrict__ n_blocks_dev, uint32_t b0,
-                          uint32_t chunks, double res, double ox, double oy, double oz, float step, uint32_t sx, Dim dy, Dim dz,
-                          void* __restrict__ out)
+                          uint32_t chunks, uint32_t bricks, double res, double ox, double oy, double oz, float step, uint32_t sx,
+                          Dim dy, Dim dz, void* __restrict__ out, const uint32_t* __restrict__ masks)
 {
     extern __shared__ float4 lds[];
-    if constexpr (E::kBricks)
-        grid_eval_blocks_body<E, LAYOUT, N, false>(ev, lds, blocks, n_blocks_dev, b0, chunks, 0u, res, ox, oy, oz, step, sx, dy, dz, out, nullptr);
+    if constexpr (E::kBricks && N == 2)     // blocks whose extents are no multiples of (4, 4, 8): boxes that end anywhere (box_eval RAGGED)
+        grid_eval_blocks_body<E, LAYOUT, N, true, true>(ev, lds, blocks, n_blocks_dev, b0, chunks, bricks, res, ox, oy, oz, step, sx, dy, dz, out, masks);
 }
 
 // ------------------------------------------------------------------------------------------

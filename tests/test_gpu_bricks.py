@@ -137,6 +137,50 @@ def test_boxes_cut_by_the_edge_slabs_and_blocks_of_several_boxes(hip, seed):
     handle.release()
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_boxes_that_end_anywhere(hip, seed):
+    """Extents that are no multiples of (4, 4, 8): per-tape code walks the bricks at the rim whole and stores only what is
+    inside (k_grid_eval_ragged / k_grid_eval_blocks_ragged over box_eval RAGGED; before the end of round 4 one such extent
+    sent the whole launch over runs, in the form without tables and pruning).  Grids, slabs and blocks -- 17^3: leaf blocks
+    with overlapping edge samples -- of sponges, random trees and assemblies with pruning bits, against the oracle; a grid
+    that is ragged only in ONE extent; grids smaller than a brick; nothing written outside."""
+    import ctypes as ct
+    import torch
+    from codecad_amd import hip_util, nodes
+    from codecad_amd.hip_util import check
+    import codecad_amd as cc
+    rng = random.Random(9900 + seed)
+    if seed < 2:
+        shape, scale = cc.examples.sponge(2 + seed), 1.0
+    elif seed < 5:
+        from test_gpu_pruning import assembly
+        shape, scale = assembly(rng, 6 + seed, 6.0), 16.0        # (parts scattered over +-6: the grids below span the lot)
+    else:
+        shape, scale = random_3d(rng, rng.choice([2, 3, 4])), 8.0
+    tape = nodes.make_program(shape)
+    dims_list = [(21, 19, 13), (16, 16, 9), (5, 7, 3), (33, 20, 40), (16, 18, 16), (1, 1, 1), (2, 35, 17)]
+    grids = [(np.array([-0.47, -0.51, -0.49]) * scale, np.float32(0.9 * scale / max(d)), d) for d in (dims_list[seed % 3], dims_list[3 + seed % 4])]
+    blocks = [([(-8, -8, -8), (3, -5, 1), (0, 0, 0)], 0.05 * scale, (0.01, -0.02, 0.0), 17),           # leaf blocks with overlapping edges
+              ([(-4, -10, -12)], 0.04 * scale, (0.0, 0.0, 0.0), (9, 20, 30))]
+    run(hip, tape, grids, blocks)
+    handle = hip_util.Tape(tape)
+    handle.specialize(hip_util.SPEC_DENSE)
+    corner, step, dims = np.array([-0.5, -0.52, -0.48]) * scale, np.float32(0.031 * scale), (30, 18, 20)
+    for x0, count in ((7, 13), (0, 30), (29, 1)):
+        check_slab(hip, handle, tape, corner, step, dims, x0, count)
+    # nothing outside the grid: a buffer with a guard plane on either side of a ragged grid
+    d = (21, 19, 13)
+    c4 = np.zeros(4, np.float32)
+    c4[:3] = corner
+    guard = torch.full((d[0] + 2, d[1], d[2], 4), float("nan"), dtype=torch.float32, device="cuda")
+    check(hip.lib.hu_grid_eval_slab(handle.device_ptr, c4.ctypes.data_as(ct.POINTER(ct.c_float)), step, (ct.c_uint32 * 3)(*d), 0, d[0], 0,
+                                    guard[1:].data_ptr(), None), "slab")
+    torch.cuda.synchronize()
+    got = guard.cpu().numpy()
+    assert np.isnan(got[0]).all() and np.isnan(got[-1]).all() and not np.isnan(got[1:-1, :, :, 3]).any()
+    handle.release()
+
+
 @pytest.mark.parametrize("name", ZOO_3D)
 def test_the_zoo_through_the_brick_kernels(hip, name):
     ref = GOLDEN[name]

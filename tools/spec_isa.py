@@ -42,7 +42,7 @@ def main():
     ragged = "ragged" in sys.argv[3:]
     if ragged:
         inst = ("template __global__ void sdfk::k_grid_eval_ragged<sdfk::JitEval, %d, 2>(const sdfk::JitEval, float, float, float, float, uint32_t, "
-                "sdfk::Dim, sdfk::Dim, uint32_t, uint32_t, void*);\n" % layout)
+                "sdfk::Dim, sdfk::Dim, uint32_t, uint32_t, uint32_t, void*, const uint32_t*);\n" % layout)
     elif blocks:
         inst = ("template __global__ void sdfk::k_grid_eval_blocks<sdfk::JitEval, 1, 2>(const sdfk::JitEval, const int4*, const uint32_t*, uint32_t, "
                 "uint32_t, uint32_t, double, double, double, double, float, uint32_t, sdfk::Dim, sdfk::Dim, void*, const uint32_t*);\n")
