@@ -827,7 +827,7 @@ int launch_classify(hu_tape t, ClassifyArgs& a, uint32_t n_parents, const uint32
         // resolution 1.0: 8 parents, 0.32 -> 0.27 ms; tools/experiments/mass_scale.py): such tapes take the boxes from 64 on.
         uint64_t enough = t->spec->prune_bits > 0 ? 64u : 8192u;
         if (const char* e = getenv("HU_CLASSIFY_BOX_MIN")) enough = (uint64_t)atoll(e);   // (read per launch: the tests switch it)
-        if (t->spec->deferred && cells > 256u && brick_tiles(dims[0], dims[1], dims[2]) && bxn * byn * bzn * n_parents >= enough) {
+        if (t->spec->deferred && cells > 256u && bxn * byn * bzn * n_parents >= enough) {     // (any extents: the rims of a box are predicated)
             a.boxes = ((uint32_t)byn << 16) | (uint32_t)bzn;
             a.chunks = (uint32_t)(bxn * byn * bzn);
             a.scratch_offset = box_table_bytes(t->spec);

@@ -621,6 +621,9 @@ __global__ void __launch_bounds__(256) k_classify(const E ev, const ClassifyArgs
             uint32_t v[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             constexpr uint32_t kStep = (uint32_t)Tabs::kPairStep;      // x distance of a lane's two voxels
             // one brick: the lane's two voxels at (xv, y, z) and (xv + kStep, y, z); `live`: the lane's row is inside the box
+            // (a grid that is no multiple of (4, 4, 8): bricks at a box's rim are walked whole, `live` and x_end keep what lies
+            // beyond the rim out of the sums and the lists -- as box_eval RAGGED does for the grid kernels' stores)
+            const uint32_t x_end = x0 + nx;
             auto brick = [&](uint32_t xv, uint32_t y, uint32_t z, float py, float pz, const Tabs& tb, const auto& hoisted, bool live) {
                 const T px = sdf::make_f2(sample(cx, a.step, xv), sample(cx, a.step, xv + kStep));
                 const T w = ev.dist_hoisted_x(px, walk_coordinate<E>(py), walk_coordinate<E>(pz), hoisted, tb, pr.fresh());
@@ -629,7 +632,7 @@ __global__ void __launch_bounds__(256) k_classify(const E ev, const ClassifyArgs
                 for (int i = 0; i < 2; ++i) {
                     const float wi = sdf::get(w, i);
                     const uint32_t x = xv + kStep * (uint32_t)i;
-                    const bool mine = live && owned(a, phash, z + a.sz * (y + a.sy * x));
+                    const bool mine = live & (x < x_end) & owned(a, phash, z + a.sz * (y + a.sy * x));
                     if (MASS) {
                         // mass_properties.cl:31-52: inside (w <= -thr) -> moments of the integer cell index; else w < thr -> ambiguous
                         const bool in = wi <= -a.thr, inside = in && mine;
@@ -668,18 +671,20 @@ __global__ void __launch_bounds__(256) k_classify(const E ev, const ClassifyArgs
                     }
                 }
             };
-            const uint32_t nbz = nz >> 3, bz = nbz == 2u ? (wave & 1u) : 0u, dby = 4u / nbz;
+            const uint32_t nbz = (nz + 7u) >> 3, bz = nbz == 2u ? (wave & 1u) : 0u, dby = 4u / nbz;
             const uint32_t zl = bz * 8u + (lane & 7u), z = z0 + zl, xl = lane >> 5;
             const float pz = sample(cz, a.step, z);
-            for (uint32_t yl = (nbz == 2u ? (wave >> 1) : wave) * 4u + ((lane >> 3) & 3u); yl < ny; yl += 4u * dby) {
+            const uint32_t row_in_brick = (lane >> 3) & 3u;
+            for (uint32_t yl = (nbz == 2u ? (wave >> 1) : wave) * 4u + row_in_brick; yl - row_in_brick < ny; yl += 4u * dby) {   // (wave-uniform)
                 const uint32_t y = y0 + yl;
+                const bool live = (zl < nz) & (yl < ny);
                 const float py = sample(cy, a.step, y);
                 Tabs tb{t.x + xl, t.y + yl, t.z + zl, t.xy + (yl * Tabs::kRowX + xl), t.xz + (zl * Tabs::kRowX + xl), t.yz + (yl * Tabs::kRowYZ + zl)};
                 const auto hoisted = ev.hoist_x(py, walk_coordinate<E>(pz), tb, pr);
 #pragma unroll 1
-                for (uint32_t j = 0; j < (nx >> 2); ++j) {
+                for (uint32_t j = 0; j < ((nx + 3u) >> 2); ++j) {
                     asm volatile("" ::: "memory");
-                    brick(x0 + j * 4u + xl, y, z, py, pz, tb, hoisted, true);
+                    brick(x0 + j * 4u + xl, y, z, py, pz, tb, hoisted, live);
                     tb.x += 4; tb.xy += 4; tb.xz += 4;
                 }
             }

@@ -264,7 +264,8 @@ def check_classify(hip, handle, tape, corner, step, dims, dimension=3):
 @pytest.mark.parametrize("seed", range(16))
 def test_classification_over_boxes(hip, seed, monkeypatch):
     """The classification kernels of per-tape code take the boxes too (kernels.hpp k_classify, grids of more than 256
-    cells with extents in multiples of (4, 4, 8)): full boxes, cut boxes, several boxes per grid."""
+    cells): full boxes, cut boxes, several boxes per grid, and -- since the end of round 4 -- grids whose extents are no
+    multiples of (4, 4, 8): what lies beyond a box's rim stays out of the sums and the lists."""
     from codecad_amd import hip_util, nodes
     import codecad_amd as cc
     rng = random.Random(9400 + seed)
@@ -276,6 +277,9 @@ def test_classification_over_boxes(hip, seed, monkeypatch):
     for corner, step, dims in ((np.array([-0.5, -0.5, -0.5]) * scale, np.float32(scale / 16), (16, 16, 16)),
                                (np.array([-0.47, -0.51, -0.49]) * scale, np.float32(0.033 * scale), (20, 12, 24)),
                                (np.array([-0.52, -0.5, -0.51]) * scale, np.float32(scale / 31), (32, 32, 32)),
-                               (np.array([-0.5, -0.5, -0.25]) * scale, np.float32(scale / 8), (8, 8, 8))):
+                               (np.array([-0.5, -0.5, -0.25]) * scale, np.float32(scale / 8), (8, 8, 8)),
+                               (np.array([-0.49, -0.5, -0.51]) * scale, np.float32(scale / 21), (21, 19, 13)),
+                               (np.array([-0.5, -0.52, -0.5]) * scale, np.float32(scale / 33), (33, 17, 9)),
+                               (np.array([-0.5, -0.5, -0.5]) * scale, np.float32(scale / 25), (25, 25, 25))):
         check_classify(hip, handle, tape, corner, step, dims)
     handle.release()
