@@ -35,3 +35,23 @@ for res in (1.0, 0.5, 0.25):
               % (res, grid, best * 1e3, n, dims, bl, samples / bl / 1e6), flush=True)
         out.release()
         leaves.blocks.release()
+
+# ---- the consumers: the whole mesh (subdivision at feature_size / 2, leaf grids, marching cubes; no download) and a render
+from codecad_amd.rendering import mesh as mesh_mod, ray_caster  # noqa: E402
+for grid in (16, 32):
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        m = mesh_mod.mesh_arrays(shape, subdivision_grid_size=grid, download=False)
+        hip_util.manager.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    print("mesh (feature size %.3f) grid %3d: %.2f ms wall, %.3f ms on the device, %d samples, %d triangles"
+          % (shape.feature_size(), grid, best * 1e3, m.kernel_ms, m.samples if hasattr(m, "samples") else 0, m.n_triangles if hasattr(m, "n_triangles") else 0), flush=True)
+box = shape.bounding_box()
+cam = ray_caster.get_camera_params(box, (1024, 768), None)
+best = 1e9
+for _ in range(3):
+    t0 = time.perf_counter()
+    px = ray_caster.render(shape, *cam, (1024, 768))
+    best = min(best, time.perf_counter() - t0)
+print("ray caster 1024 x 768: %.2f ms wall (with the read-back)" % (best * 1e3), flush=True)
