@@ -203,6 +203,13 @@ uint32_t brick_tiles(uint32_t nx, uint32_t sy, uint32_t sz)
 {
     return (nx % 4u == 0u && sy % 4u == 0u && sz % 8u == 0u) ? 1u : 0u;
 }
+// ... and are boxes worth it: do at least half of the voxels of the bricks they would walk exist?  (A 2D grid is one voxel deep:
+// an eighth.)  Else the launch goes over runs of cells (k_grid_eval_runs).
+bool boxes_worthwhile(uint64_t nx, uint64_t sy, uint64_t sz)
+{
+    const uint64_t padded = ((nx + 3u) & ~3ull) * ((sy + 3u) & ~3ull) * ((sz + 7u) & ~7ull);
+    return padded <= 2u * nx * sy * sz;
+}
 
 // How many units (blocks / parents) of `chunks` workgroups of `threads` lanes go into one launch: a grid may
 // have at most 2^31 - 1 workgroups and 2^32 - 1 work-items; longer lists are launched in pieces.
@@ -247,6 +254,9 @@ struct SpecKernels {
     // tapes with box code: the same over runs of cells, for extents that are no multiples of (4, 4, 8) (kernels.hpp k_grid_eval_ragged)
     hipFunction_t dense_ragged[2] = {nullptr, nullptr};
     hipFunction_t blocks_ragged[2] = {nullptr, nullptr};
+    // ... and over runs of cells, in the in-place form, where boxes would be mostly padding (2D grids: kernels.hpp k_grid_eval_runs)
+    hipFunction_t dense_runs[2] = {nullptr, nullptr};
+    hipFunction_t blocks_runs[2] = {nullptr, nullptr};
     hipFunction_t classify[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [MASS][BATCH]
     hipFunction_t ray_caster = nullptr, bitmap = nullptr;
     hipFunction_t box_masks = nullptr;   // k_box_masks (box pruning), part of every family that launches over boxes
@@ -319,14 +329,15 @@ void keep_programs(hu_tape_s* t, const sdf::DecodedTape& d)
 
 struct SpecEval { const float* extra; uint32_t flags; };  // same layout as the generated sdfk::JitEval
 
-constexpr int kSpecKernelCount = 15;
+constexpr int kSpecKernelCount = 19;
 // bit i of a `groups` mask is kernel i below; the families of include/hip_util.h (HU_SPEC_*) are sets of them (the mask
 // kernel of box pruning belongs to every family that launches over boxes)
 constexpr uint32_t spec_bit(int i) { return 1u << i; }
 constexpr uint32_t kSpecGroupOf[kSpecKernelCount] = {spec_bit(0), spec_bit(1), spec_bit(2), spec_bit(3), spec_bit(4), spec_bit(5), spec_bit(6), spec_bit(7),
-                                                      spec_bit(8), spec_bit(9), spec_bit(10), spec_bit(11), spec_bit(12), spec_bit(13), spec_bit(14)};
-static_assert(HU_SPEC_DENSE == (spec_bit(0) | spec_bit(1) | spec_bit(10) | spec_bit(11) | spec_bit(12)), "hip_util.h");
-static_assert(HU_SPEC_BLOCKS == (spec_bit(2) | spec_bit(3) | spec_bit(10) | spec_bit(13) | spec_bit(14)), "hip_util.h");
+                                                      spec_bit(8), spec_bit(9), spec_bit(10), spec_bit(11), spec_bit(12), spec_bit(13), spec_bit(14),
+                                                      spec_bit(15), spec_bit(16), spec_bit(17), spec_bit(18)};
+static_assert(HU_SPEC_DENSE == (spec_bit(0) | spec_bit(1) | spec_bit(10) | spec_bit(11) | spec_bit(12) | spec_bit(15) | spec_bit(16)), "hip_util.h");
+static_assert(HU_SPEC_BLOCKS == (spec_bit(2) | spec_bit(3) | spec_bit(10) | spec_bit(13) | spec_bit(14) | spec_bit(17) | spec_bit(18)), "hip_util.h");
 static_assert(HU_SPEC_CLASSIFY == (spec_bit(4) | spec_bit(5) | spec_bit(6) | spec_bit(7) | spec_bit(10)), "hip_util.h");
 static_assert(HU_SPEC_RENDER == (spec_bit(8) | spec_bit(9)), "hip_util.h");
 static_assert(HU_SPEC_ALL == (HU_SPEC_DENSE | HU_SPEC_BLOCKS | HU_SPEC_CLASSIFY | HU_SPEC_RENDER) && HU_SPEC_ALL == spec_bit(kSpecKernelCount) - 1u, "hip_util.h");
@@ -338,7 +349,9 @@ const char* const kSpecKernelNames[kSpecKernelCount] = {
     "sdfk::k_ray_caster<sdfk::JitEval>",                "sdfk::k_bitmap<sdfk::JitEval>",
     "sdfk::k_box_masks<sdfk::JitEval>",
     "sdfk::k_grid_eval_ragged<sdfk::JitEval, 0, 2>",        "sdfk::k_grid_eval_ragged<sdfk::JitEval, 1, 2>",
-    "sdfk::k_grid_eval_blocks_ragged<sdfk::JitEval, 0, 2>", "sdfk::k_grid_eval_blocks_ragged<sdfk::JitEval, 1, 2>"};
+    "sdfk::k_grid_eval_blocks_ragged<sdfk::JitEval, 0, 2>", "sdfk::k_grid_eval_blocks_ragged<sdfk::JitEval, 1, 2>",
+    "sdfk::k_grid_eval_runs<sdfk::JitEval, 0, 2>",          "sdfk::k_grid_eval_runs<sdfk::JitEval, 1, 2>",
+    "sdfk::k_grid_eval_blocks_runs<sdfk::JitEval, 0, 2>",   "sdfk::k_grid_eval_blocks_runs<sdfk::JitEval, 1, 2>"};
 
 // Box pruning: run the tape's mask kernel for the `m.n_boxes` workgroups of the launch that follows on `stream` and hand
 // back their masks -- or NULL (nothing to prune in this tape, HU_PRUNE_RUN=0, or a buffer that would have to grow while
@@ -608,7 +621,9 @@ int hu_grid_eval_slab(hu_tape t, const float corner[4], float step, const uint32
     // extents that are no multiples of (4, 4, 8) take the kernel whose boxes may end anywhere: an image of its own -- while it is
     // still being built the interpreter serves such launches
     const bool spec_ragged = t->spec && t->spec->deferred && !(brick_tiles(x_count, dims[1], dims[2]) && (x_count <= spec_max_x || spec_max_x % 4u == 0u));
-    if (t->spec && t->spec->dense[layout] && (!spec_ragged || t->spec->dense_ragged[layout])) {
+    // ... unless boxes would be mostly padding: then over runs of cells, in the in-place form (a third image)
+    const bool spec_runs = spec_ragged && !boxes_worthwhile(x_count < spec_max_x ? x_count : spec_max_x, dims[1], dims[2]);
+    if (t->spec && t->spec->dense[layout] && (!spec_ragged || (spec_runs ? t->spec->dense_runs[layout] : t->spec->dense_ragged[layout]))) {
         const uint32_t max_x = spec_max_x;
         SpecEval ev{t->extra_dev, spec_flags(t, grid_reach(corner, step, dims))};
         float cx = corner[0], cy = corner[1], cz = corner[2];
@@ -621,7 +636,7 @@ int hu_grid_eval_slab(hu_tape t, const float corner[4], float step, const uint32
             // boxes of compact bricks pay where a wavefront's work depends on how many primitives win in it (deferred
             // directions) and where the tape has tables to fill; a tape that is bound by its store stream keeps the runs
             // along z (2 KiB contiguous per wavefront: sphere, 512^3 float4: 0.34 ms in runs, 0.42 ms in bricks)
-            uint32_t boxes = t->spec->deferred ? 1u : 0u;
+            uint32_t boxes = (t->spec->deferred && !spec_runs) ? 1u : 0u;
             const bool ragged = boxes && !brick_tiles(nx, dims[1], dims[2]);
             // runs of cells (HU_RUN_BLOCK: 64 / 128 / 256 lanes per workgroup, for measurements: the lanes of a run kernel share
             // nothing, but single-wavefront workgroups were SLOWER on the store-bound tapes -- box, 512^3 float4: 0.409 against
@@ -649,9 +664,14 @@ int hu_grid_eval_slab(hu_tape t, const float corner[4], float step, const uint32
                 m.nx = nx; m.ny = dims[1]; m.nz = dims[2]; m.xs0 = xs; m.cx = cx; m.cy = cy; m.cz = cz; m.step = step;
                 if ((layout == 1 || t->spec->prune_all) && (rc = prepare_masks(t, m, (hipStream_t)stream, &masks))) return rc;
             }
-            void* args[] = {&ev, &cx, &cy, &cz, &step, &sx, &sy, &sz, &xs, &n_cells, &boxes, &o, &masks};
-            HU_HIP(hipModuleLaunchKernel(ragged ? t->spec->dense_ragged[layout] : t->spec->dense[layout], grid, 1, 1, block, 1, 1,
-                                         boxes ? box_table_bytes(t->spec) : idle_lds, (hipStream_t)stream, args, nullptr));
+            if (spec_runs) {
+                void* args[] = {&ev, &cx, &cy, &cz, &step, &sx, &sy, &sz, &xs, &n_cells, &o};
+                HU_HIP(hipModuleLaunchKernel(t->spec->dense_runs[layout], grid, 1, 1, block, 1, 1, 0u, (hipStream_t)stream, args, nullptr));
+            } else {
+                void* args[] = {&ev, &cx, &cy, &cz, &step, &sx, &sy, &sz, &xs, &n_cells, &boxes, &o, &masks};
+                HU_HIP(hipModuleLaunchKernel(ragged ? t->spec->dense_ragged[layout] : t->spec->dense[layout], grid, 1, 1, block, 1, 1,
+                                             boxes ? box_table_bytes(t->spec) : idle_lds, (hipStream_t)stream, args, nullptr));
+            }
             done += nx;
         }
         return HU_OK;
@@ -713,15 +733,16 @@ static int grid_eval_blocks_impl(hu_tape t, const int32_t* blocks_dev, uint32_t 
     if ((rc = check_dims(dims, cells))) return rc;
     if (cells > (1ull << 24)) return fail(HU_ERR_BAD_ARG, "a block may have at most 2^24 cells (256^3)");
     if (n_blocks == 0) return HU_OK;
-    if (t->spec && t->spec->blocks[layout] &&
-        (!(t->spec->deferred && !brick_tiles(dims[0], dims[1], dims[2])) || t->spec->blocks_ragged[layout])) {
+    const bool blocks_ragged = t->spec && t->spec->deferred && !brick_tiles(dims[0], dims[1], dims[2]);
+    const bool blocks_runs = blocks_ragged && !boxes_worthwhile(dims[0], dims[1], dims[2]);     // (boxes would be mostly padding)
+    if (t->spec && t->spec->blocks[layout] && (!blocks_ragged || (blocks_runs ? t->spec->blocks_runs[layout] : t->spec->blocks_ragged[layout]))) {
         const uint32_t per_block = kSpecBlock * kSpecVoxelsPerLane;
         uint32_t chunks = (uint32_t)((cells + per_block - 1) / per_block);
         // deferred-direction code over compact bricks (kernels.hpp): a workgroup per box of up to 16^3 voxels of the block,
         // its wavefronts walking 4 x 4 x 8 bricks along x; `bricks` carries the boxes along y and z
         uint32_t bricks = 0u;
-        const bool ragged = t->spec->deferred && !brick_tiles(dims[0], dims[1], dims[2]);   // boxes that may end anywhere (k_grid_eval_blocks_ragged)
-        if (t->spec->deferred) {
+        const bool ragged = blocks_ragged && !blocks_runs;      // boxes that may end anywhere (k_grid_eval_blocks_ragged)
+        if (t->spec->deferred && !blocks_runs) {
             const uint32_t bxn = (dims[0] + 15u) / 16u, byn = (dims[1] + 15u) / 16u, bzn = (dims[2] + 15u) / 16u;
             bricks = (byn << 16) | bzn;
             chunks = bxn * byn * bzn;
@@ -744,9 +765,14 @@ static int grid_eval_blocks_impl(hu_tape t, const int32_t* blocks_dev, uint32_t 
                 m.res = res; m.ox = ox; m.oy = oy; m.oz = oz;
                 if ((layout == 1 || t->spec->prune_all) && (rc = prepare_masks(t, m, (hipStream_t)stream, &masks))) return rc;
             }
-            void* args[] = {&ev, &b, &n_dev, &first, &chunks, &bricks, &res, &ox, &oy, &oz, &step, &sx, &sy, &sz, &out_dev, &masks};
-            HU_HIP(hipModuleLaunchKernel(ragged ? t->spec->blocks_ragged[layout] : t->spec->blocks[layout], chunks * count, 1, 1, kSpecBlock, 1, 1,
-                                         bricks ? box_table_bytes(t->spec) : 0u, (hipStream_t)stream, args, nullptr));
+            if (blocks_runs) {
+                void* args[] = {&ev, &b, &n_dev, &first, &chunks, &res, &ox, &oy, &oz, &step, &sx, &sy, &sz, &out_dev};
+                HU_HIP(hipModuleLaunchKernel(t->spec->blocks_runs[layout], chunks * count, 1, 1, kSpecBlock, 1, 1, 0u, (hipStream_t)stream, args, nullptr));
+            } else {
+                void* args[] = {&ev, &b, &n_dev, &first, &chunks, &bricks, &res, &ox, &oy, &oz, &step, &sx, &sy, &sz, &out_dev, &masks};
+                HU_HIP(hipModuleLaunchKernel(ragged ? t->spec->blocks_ragged[layout] : t->spec->blocks[layout], chunks * count, 1, 1, kSpecBlock, 1, 1,
+                                             bricks ? box_table_bytes(t->spec) : 0u, (hipStream_t)stream, args, nullptr));
+            }
         }
         return HU_OK;
     }
@@ -827,7 +853,7 @@ int launch_classify(hu_tape t, ClassifyArgs& a, uint32_t n_parents, const uint32
         // resolution 1.0: 8 parents, 0.32 -> 0.27 ms; tools/experiments/mass_scale.py): such tapes take the boxes from 64 on.
         uint64_t enough = t->spec->prune_bits > 0 ? 64u : 8192u;
         if (const char* e = getenv("HU_CLASSIFY_BOX_MIN")) enough = (uint64_t)atoll(e);   // (read per launch: the tests switch it)
-        if (t->spec->deferred && cells > 256u && bxn * byn * bzn * n_parents >= enough) {     // (any extents: the rims of a box are predicated)
+        if (t->spec->deferred && cells > 256u && bxn * byn * bzn * n_parents >= enough && boxes_worthwhile(dims[0], dims[1], dims[2])) {   // (any extents: the rims of a box are predicated; not where boxes would be mostly padding: 2D)
             a.boxes = ((uint32_t)byn << 16) | (uint32_t)bzn;
             a.chunks = (uint32_t)(bxn * byn * bzn);
             a.scratch_offset = box_table_bytes(t->spec);
@@ -1281,7 +1307,7 @@ static void spec_cache_store(const char* cache_dir, const std::string& path, con
 }
 
 // Keep the cache bounded: beyond kSpecCacheFiles entries the oldest (by modification time) are removed.
-constexpr size_t kSpecCacheFiles = 8192;    // (up to fifteen per tape)
+constexpr size_t kSpecCacheFiles = 8192;    // (up to nineteen per tape)
 static void spec_cache_prune(const char* cache_dir)
 {
     DIR* d = opendir(cache_dir);
@@ -1589,7 +1615,8 @@ static int load_specialised(hu_tape t, const SpecImage& img, uint32_t set, hipEr
     hipFunction_t* slots[kSpecKernelCount] = {&k->dense[0], &k->dense[1], &k->blocks[0], &k->blocks[1],
                                               &k->classify[0][0], &k->classify[0][1], &k->classify[1][0], &k->classify[1][1],
                                               &k->ray_caster, &k->bitmap, &k->box_masks,
-                                              &k->dense_ragged[0], &k->dense_ragged[1], &k->blocks_ragged[0], &k->blocks_ragged[1]};
+                                              &k->dense_ragged[0], &k->dense_ragged[1], &k->blocks_ragged[0], &k->blocks_ragged[1],
+                                              &k->dense_runs[0], &k->dense_runs[1], &k->blocks_runs[0], &k->blocks_runs[1]};
     const uint32_t missing = set & ~k->groups;
     for (int i = 0; i < kSpecKernelCount; ++i)
         if (kSpecGroupOf[i] & missing) *slots[i] = loaded[i];

@@ -417,6 +417,18 @@ k_grid_eval_ragged(const E ev, float cx, float cy, float cz, float step, uint32_
     if constexpr (E::kBricks && N == 2) grid_eval_boxes<E, LAYOUT, N, true>(ev, lds, cx, cy, cz, step, sx, dy.n, dz.n, x0, n_cells, out, masks);
 }
 
+// ... and over RUNS of cells, in the in-place form, for evaluators with box code: slabs in which boxes would be mostly padding
+// (a 2D grid is one voxel deep: seven of a brick's eight z lanes idle -- 2048^2 float4: 0.081 ms over ragged boxes, slower
+// than interpreted; the launchers take this kernel where less than half of the padded bricks' voxels exist)
+template <class E, int LAYOUT, int N>
+__global__ void __launch_bounds__(256) SDF_KERNEL_ATTRS
+k_grid_eval_runs(const E ev, float cx, float cy, float cz, float step, uint32_t sx, Dim dy, Dim dz, uint32_t x0,
+                 uint32_t n_cells, void* __restrict__ out)
+{
+    extern __shared__ float4 lds[];
+    if constexpr (E::kBricks) grid_eval_runs<E, LAYOUT, N>(ev, lds, cx, cy, cz, step, sx, dy, dz, x0, n_cells, out);
+}
+
 template <class E, int LAYOUT, int N>
 __device__ __forceinline__ void grid_eval_runs(const E& ev, float4* lds, float cx, float cy, float cz, float step, uint32_t sx, Dim dy, Dim dz,
                                                uint32_t x0, uint32_t n_cells, void* __restrict__ out)
@@ -510,6 +522,18 @@ k_grid_eval_blocks_ragged(const E ev, const int4* __restrict__ blocks, const uin
     extern __shared__ float4 lds[];
     if constexpr (E::kBricks && N == 2)     // blocks whose extents are no multiples of (4, 4, 8): boxes that end anywhere (box_eval RAGGED)
         grid_eval_blocks_body<E, LAYOUT, N, true, true>(ev, lds, blocks, n_blocks_dev, b0, chunks, bricks, res, ox, oy, oz, step, sx, dy, dz, out, masks);
+}
+
+// (... and over runs of cells, for blocks in which boxes would be mostly padding: k_grid_eval_runs)
+template <class E, int LAYOUT, int N>
+__global__ void __launch_bounds__(256) SDF_KERNEL_ATTRS
+k_grid_eval_blocks_runs(const E ev, const int4* __restrict__ blocks, const uint32_t* __restrict__ n_blocks_dev, uint32_t b0,
+                        uint32_t chunks, double res, double ox, double oy, double oz, float step, uint32_t sx, Dim dy, Dim dz,
+                        void* __restrict__ out)
+{
+    extern __shared__ float4 lds[];
+    if constexpr (E::kBricks)
+        grid_eval_blocks_body<E, LAYOUT, N, false>(ev, lds, blocks, n_blocks_dev, b0, chunks, 0u, res, ox, oy, oz, step, sx, dy, dz, out, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -82,8 +82,8 @@ PROTOTYPES = {
 }
 
 # hu_spec_group (include/hip_util.h): the kernel families of per-tape code
-SPEC_DENSE, SPEC_BLOCKS, SPEC_CLASSIFY, SPEC_RENDER, SPEC_ALL = 0x1c03, 0x640c, 0x04f0, 0x0300, 0x7fff   # sets of kernel bits (hip_util.h)
-SPEC_KERNELS = 15
+SPEC_DENSE, SPEC_BLOCKS, SPEC_CLASSIFY, SPEC_RENDER, SPEC_ALL = 0x19c03, 0x6640c, 0x04f0, 0x0300, 0x7ffff   # sets of kernel bits (hip_util.h)
+SPEC_KERNELS = 19
 
 HEADER = os.path.normpath(os.path.join(os.path.dirname(__file__), "..", "..", "include", "hip_util.h"))
 

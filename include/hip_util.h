@@ -289,22 +289,25 @@ int hu_tape_specialize_cached(hu_tape t, const char* include_dir, const char* ca
                               int only_if_cached, int* from_cache);
 /* The same for a subset of the per-tape KERNELS: bit i of `groups` is kernel i of the list below, and the HU_SPEC_*
  * constants are the sets a kind of launch needs (its FAMILY).  Compiling only what is about to be used takes a fraction
- * of the time of all fifteen kernels, and a tape's kernels may be built one by one, side by side in several processes
+ * of the time of all nineteen kernels, and a tape's kernels may be built one by one, side by side in several processes
  * (round 4: a tape's first kernel is ready after its OWN compilation, not after its family's).  Kernels that are loaded
  * already are skipped; a launch whose kernel is not loaded runs the interpreter (a launch over boxes whose mask kernel is
  * not loaded yet treats every operand as alive: same bits).
  *   bit 0, 1    k_grid_eval (float4, float)            bit 10      k_box_masks (box pruning, every launch over boxes)
  *   bit 2, 3    k_grid_eval_blocks (float4, float)     bit 11, 12  k_grid_eval_ragged (float4, float)
  *   bit 4..7    k_classify ([MASS][BATCH])             bit 13, 14  k_grid_eval_blocks_ragged (float4, float)
- *   bit 8, 9    k_ray_caster, k_bitmap
+ *   bit 8, 9    k_ray_caster, k_bitmap                 bit 15, 16  k_grid_eval_runs (float4, float)
+ *   bit 17, 18  k_grid_eval_blocks_runs (float4, float)
+ * (ragged: boxes that may end anywhere, for extents that are no multiples of (4, 4, 8); runs: the in-place form over runs of
+ * cells, where boxes would be mostly padding -- 2D grids)
  * With a cache directory: the image of exactly the requested set is taken when it is there, else the images of its single
  * kernels (what the background builds leave behind); what is still missing is built as ONE image (only_if_cached = 0). */
 enum hu_spec_group {
-    HU_SPEC_DENSE = 0x1c03,     /* hu_grid_eval, hu_grid_eval_pymcubes, hu_grid_eval_slab */
-    HU_SPEC_BLOCKS = 0x640c,    /* hu_grid_eval_blocks[_indirect] */
+    HU_SPEC_DENSE = 0x19c03,    /* hu_grid_eval, hu_grid_eval_pymcubes, hu_grid_eval_slab */
+    HU_SPEC_BLOCKS = 0x6640c,   /* hu_grid_eval_blocks[_indirect] */
     HU_SPEC_CLASSIFY = 0x04f0,  /* hu_subdivision_step / _level[_indirect], hu_mass_properties / _level[_indirect] */
     HU_SPEC_RENDER = 0x0300,    /* hu_ray_caster, hu_bitmap */
-    HU_SPEC_ALL = 0x7fff
+    HU_SPEC_ALL = 0x7ffff
 };
 int hu_tape_specialize_groups(hu_tape t, const char* include_dir, const char* cache_dir, int only_if_cached,
                               uint32_t groups, int* from_cache);

@@ -308,7 +308,7 @@ def test_specialised_code_cache_on_disk(tmp_path):
     assert compile_(p, t, None)[1] == 0
     assert compile_(p, t, tmp_path / "missing" / "parent")[1] == 0 and not (tmp_path / "missing").exists()
     assert not [f for f in os.listdir(cache) if ".tmp" in f]
-    # the cache is bounded: past 8192 entries (a tape leaves up to fifteen) the oldest go, the newest stay
+    # the cache is bounded: past 8192 entries (a tape leaves up to nineteen) the oldest go, the newest stay
     for i in range(8200):
         dummy = cache / ("%032x.huspec" % i)
         dummy.write_bytes(b"old")

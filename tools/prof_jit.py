@@ -48,7 +48,7 @@ for name in ("sponge4", "csg_example", "planetary"):
     hip_util.manager.k.grid_eval((32, 32, 32), None, again, c, np.float32(0.1), out).wait()
     t6 = time.perf_counter()
     size = sum(os.path.getsize(os.path.join(os.environ["CODECAD_AMD_CACHE"], f)) for f in os.listdir(os.environ["CODECAD_AMD_CACHE"]))
-    print("%-12s %4d instructions: specialize (in this process, fifteen kernels as one image) %.2f s, first float4 launch %.3f s, first float launch %.3f s; "
+    print("%-12s %4d instructions: specialize (in this process, all kernels as one image) %.2f s, first float4 launch %.3f s, first float launch %.3f s; "
           "upload + load from the cache %.1f ms (from_cache=%s), first launch %.1f ms; cache now %.2f MB"
           % (name, t.n_instructions, t1 - t0, t2 - t1, t3 - t2, (t5 - t4) * 1e3, again.from_cache, (t6 - t5) * 1e3, size / 1e6), flush=True)
 
