@@ -132,7 +132,7 @@ def main():
     evaluator = "interpreter"
     if args.evaluator != "interpreter":
         try:
-            tape = hip_util.Tape(host_tape, policy="0").specialize()   # ~1 s of hipRTC (ms from the disk cache), outside the timed region
+            tape = hip_util.Tape(host_tape, policy="0").specialize(hip_util.SPEC_DENSE | hip_util.SPEC_BLOCKS | hip_util.SPEC_CLASSIFY)   # (no renderers in a step) ~0.5 s of hipRTC (ms from the disk cache), outside the timed region
             evaluator = "specialised"
         except RuntimeError as e:
             if args.evaluator == "specialised":
@@ -553,7 +553,7 @@ def run_c4(args, real_stdout, rank, world, dev):
     evaluator = "interpreter"
     if args.evaluator != "interpreter":
         try:
-            tape.specialize()
+            tape.specialize(hip_util.SPEC_CLASSIFY)      # (the kernels a mass_properties step launches)
             evaluator = "specialised"
         except RuntimeError as e:
             if args.evaluator == "specialised":
@@ -782,7 +782,7 @@ def hbm_regime(lib, check, hip_util, cc, torch, np, dev, stream, n, evaluator, t
         for mode in (["interpreter", "specialised"] if evaluator == "specialised" else ["interpreter"]):
             t = hip_util.Tape(host_tape, policy="0")
             if mode == "specialised":
-                t = t.specialize()
+                t = t.specialize(hip_util.SPEC_DENSE)
             for layout, bytes_per_voxel in ((0, 16), (1, 4)):
                 def launch():
                     check(lib.hu_grid_eval_slab(t.device_ptr, corner.ctypes.data_as(fptr), step, dims, 0, n, layout, buf.data_ptr(),
