@@ -382,10 +382,20 @@ from ._lib import SPEC_ALL, SPEC_KERNELS  # noqa: E402
 
 
 def _kernels_of(groups, first=0):
-    """The single kernels (hu_spec_group bits) of the set `groups`, those of the set `first` -- the family in use -- first;
-    within a family in bit order: its box kernels, then the mask kernel, then the kernels for ragged extents."""
-    bits = [1 << i for i in range(SPEC_KERNELS) if (1 << i) & int(groups)]
-    return [b for b in bits if b & int(first)] + [b for b in bits if not b & int(first)]
+    """The single kernels (hu_spec_group bits) of the set `groups` in the order they are built: the kernels of the set `first`
+    -- the family in use -- over whole bricks, the mask kernel, that family's kernels for boxes that end anywhere; then the
+    other families' the same way; the run-form kernels (grids that are mostly padding: 2D) last."""
+    def rank(i):
+        bit, mine = 1 << i, bool((1 << i) & int(first))
+        if i >= 15:
+            return 5                                   # k_grid_eval_runs / k_grid_eval_blocks_runs
+        if i == 10:
+            return 1                                   # k_box_masks
+        if i >= 11:
+            return 2 if mine else 4                    # ..._ragged
+        return 0 if mine else 3
+    bits = [i for i in range(SPEC_KERNELS) if (1 << i) & int(groups)]
+    return [1 << i for i in sorted(bits, key=lambda i: (rank(i), i))]
 
 
 class Tape:
